@@ -1,0 +1,228 @@
+/*
+ * urf.h -- C ABI of the MI355X-native urban_road_filter hot path.
+ *
+ * Drop-in boundary.  The reference processes every LiDAR
+ * sweep inside one C++ callback,
+ *     void Detector::filtered(const pcl::PointCloud<pcl::PointXYZI>& cloud)
+ *         include/urban_road_filter/data_structures.hpp:118
+ *         src/lidar_segmentation.cpp:95-622
+ * fed by a sensor_msgs/PointCloud2 subscription (src/lidar_segmentation.cpp:53)
+ * and answering with the clouds "road", "curb", "roi", "road_probably"
+ * (src/lidar_segmentation.cpp:55-58, 354-367, 605-608, 618-621).
+ *
+ * This library replaces the geometric classification in the middle
+ * (lidar_segmentation.cpp:100-293,353-367,605-608 + star_shaped_search.cpp +
+ * x_zero_method.cpp + z_zero_method.cpp + blind_spots.cpp) by hand-written
+ * gfx950 HIP kernels.  Points go in as PointCloud2-layout bytes (or as SoA
+ * x/y/z device arrays for resident batches); what comes out is ONE BYTE PER
+ * INPUT POINT that encodes the reference's per-point result:
+ *
+ *     bits 0-1  isCurbPoint of the reference (data_structures.hpp:44):
+ *               0 = none, 1 = road (blind_spots.cpp:128,168,237,277),
+ *               2 = curb (star_shaped_search.cpp:146, x_zero_method.cpp:66,
+ *               z_zero_method.cpp:71)
+ *     bit 2     point passed the ROI filter, i.e. is in the "roi" cloud
+ *               (lidar_segmentation.cpp:106-117, 620)
+ *     bit 3     point was assigned to a ring (lidar_segmentation.cpp:226-277);
+ *               only such points can appear in "road"/"curb"
+ *     bit 4     point lies on sorted ring index 10, i.e. is in the
+ *               "road_probably" cloud (lidar_segmentation.cpp:605-608)
+ *
+ * so   road = {i : (label[i] & 3) == 1},  curb = {i : (label[i] & 3) == 2},
+ *      roi  = {i : label[i] & 4},  road_probably = {i : label[i] & 16}.
+ * The C++ adapter (urban_road_filter_amd/csrc/detector.hpp) re-materialises
+ * the four clouds from these sets.  Set membership is the contract; the order
+ * of points inside the reference's published clouds is not.
+ *
+ * All functions return 0 on success, a negative urf_status on error.  One
+ * context owns one device, one HIP stream and all scratch memory; a context is
+ * not thread-safe, any number of contexts may coexist (the reference keeps its
+ * state in globals and allows one Detector per process).
+ */
+#ifndef URF_H
+#define URF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URF_ABI_VERSION 1
+
+/* ---- label byte --------------------------------------------------------- */
+#define URF_LABEL_MASK   0x03u
+#define URF_LABEL_NONE   0u
+#define URF_LABEL_ROAD   1u
+#define URF_LABEL_CURB   2u
+#define URF_FLAG_ROI     0x04u
+#define URF_FLAG_RING    0x08u
+#define URF_FLAG_RING10  0x10u
+
+/* ---- status codes ------------------------------------------------------- */
+typedef enum urf_status {
+    URF_OK = 0,
+    /* per-scan status (positive: not an error) */
+    URF_TOO_FEW_POINTS = 1,      /* < 30 ROI points: the reference returns without
+                                    publishing (lidar_segmentation.cpp:124-126);
+                                    every label of the scan is 0 */
+    /* errors */
+    URF_ERR_INVALID_ARG = -1,
+    URF_ERR_NO_DEVICE = -2,      /* no HIP device / runtime error at create */
+    URF_ERR_HIP = -3,            /* HIP runtime failure, see urf_last_error() */
+    URF_ERR_CAPACITY = -4,       /* scan or batch larger than urf_create() sizes */
+    URF_ERR_OOM = -5,
+    URF_ERR_PARAMS = -6          /* parameter outside the supported range */
+} urf_status;
+
+/* ---- parameters ----------------------------------------------------------
+ * The hot-path subset of the reference's 27 dynamic_reconfigure fields
+ * (cfg/LidarFilters.cfg:10-84 -> src/main.cpp:4-34 -> namespace params,
+ * data_structures.hpp:66-88) plus its three compile-time globals.  Field names
+ * follow namespace params.  Types follow the reference (float/int/bool), so
+ * e.g. interval is 0.18f, not 0.18.
+ */
+typedef struct urf_params {
+    uint32_t size;               /* = sizeof(urf_params); ABI versioning */
+    int32_t  x_zero_method;      /* cfg:16  bool */
+    int32_t  z_zero_method;      /* cfg:17  bool */
+    int32_t  star_shaped_method; /* cfg:18  bool */
+    int32_t  blind_spots;        /* cfg:19  bool */
+    int32_t  xDirection;         /* cfg:27  0 both, 1 +X, 2 -X */
+    float    interval;           /* cfg:30  ring-angle tolerance [deg] */
+    float    curbHeight;         /* cfg:33  curb_height [m] */
+    int32_t  curbPoints;         /* cfg:36  curb_points, 1..30 */
+    float    beamZone;           /* cfg:39  [deg] */
+    float    min_X, max_X;       /* cfg:42-43 */
+    float    min_Y, max_Y;       /* cfg:46-47 */
+    float    min_Z, max_Z;       /* cfg:50-51 */
+    float    angleFilter1;       /* cfg:54  cylinder_deg_x */
+    float    angleFilter2;       /* cfg:57  cylinder_deg_z */
+    float    angleFilter3;       /* cfg:60  curb_slope_deg */
+    float    kdev_param;         /* cfg:63 */
+    float    kdist_param;        /* cfg:66 */
+    int32_t  starbeam_filter;    /* cfg:69  bool */
+    int32_t  dmin_param;         /* cfg:72 */
+    int32_t  channels;           /* lidar_segmentation.cpp:4   (64), 1..128 */
+    int32_t  sectors;            /* star_shaped_search.cpp:8   rep = 360 */
+    float    beam_width;         /* star_shaped_search.cpp:9   width = 0.2 */
+} urf_params;
+
+/* Fills *p with the reference defaults (cfg/LidarFilters.cfg) and the
+ * reference's compile-time globals (channels 64, rep 360, width 0.2). */
+int urf_default_params(urf_params* p);
+
+/* ---- per-scan summary ---------------------------------------------------- */
+typedef struct urf_scan_info {
+    int32_t  status;     /* URF_OK or URF_TOO_FEW_POINTS */
+    uint32_t n_roi;      /* "piece",  lidar_segmentation.cpp:120 */
+    uint32_t n_rings;    /* "index",  lidar_segmentation.cpp:139,194 */
+    uint32_t n_ring_pts; /* points assigned to a ring */
+    uint32_t n_road;     /* size of the "road" cloud */
+    uint32_t n_curb;     /* size of the "curb" cloud */
+    uint32_t n_ring10;   /* size of "road_probably" */
+    uint32_t reserved;
+} urf_scan_info;
+
+typedef struct urf_ctx urf_ctx;
+
+/* ---- lifetime ------------------------------------------------------------
+ * Replaces Detector::Detector (lidar_segmentation.cpp:51-65): allocates every
+ * scratch buffer once (the reference allocates channels x piece x 64 B per
+ * scan, lidar_segmentation.cpp:207) and runs beam_init()
+ * (star_shaped_search.cpp:32-66).  max_points bounds the points of one scan,
+ * max_batch the scans of one batch call. */
+int urf_create(urf_ctx** ctx, int device_id, uint32_t max_points, uint32_t max_batch);
+int urf_destroy(urf_ctx* ctx);
+
+/* Replaces paramsCallback (src/main.cpp:4-34): may be called between scans. */
+int urf_set_params(urf_ctx* ctx, const urf_params* p);
+int urf_get_params(const urf_ctx* ctx, urf_params* p);
+
+/* Run on a caller-owned hipStream_t (e.g. the framework's current stream);
+ * NULL restores the context's own stream. */
+int urf_set_stream(urf_ctx* ctx, void* hip_stream);
+int urf_synchronize(urf_ctx* ctx);
+
+/* ---- single scan, host buffers, PointCloud2 layout ------------------------
+ * Replaces the body of Detector::filtered for one sensor_msgs/PointCloud2:
+ * `data` holds n_points records of point_step bytes; x/y/z are little-endian
+ * FLOAT32 at byte offsets off_x/off_y/off_z (pcl::fromROSMsg resolves the
+ * fields by name; every other field is ignored, as pcl::PointXYZI ignores
+ * them).  labels_out (host, n_points bytes) receives the label bytes, *info
+ * (optional) the summary.  Synchronous.  Returns URF_OK or an error; the
+ * "too few points" condition is reported in info->status. */
+int urf_classify_pc2(urf_ctx* ctx, const uint8_t* data, uint32_t n_points,
+                     uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                     uint8_t* labels_out, urf_scan_info* info);
+
+/* ---- batch of scans, device-resident ---------------------------------------
+ * n_scans independent scans of n_per_scan points each; scan s owns elements
+ * [s*n_per_scan, (s+1)*n_per_scan) of d_x/d_y/d_z (SoA, device memory) and of
+ * d_labels.  d_info (device, n_scans entries) is optional.  Asynchronous on
+ * the context's stream. */
+int urf_classify_batch_soa(urf_ctx* ctx, const float* d_x, const float* d_y, const float* d_z,
+                           uint32_t n_per_scan, uint32_t n_scans,
+                           uint8_t* d_labels, urf_scan_info* d_info);
+
+/* Same with ragged scans: scan s owns [d_offsets[s], d_offsets[s+1]) (device
+ * array of n_scans+1 uint32).  max_len >= the longest scan (host value). */
+int urf_classify_batch_soa_ragged(urf_ctx* ctx, const float* d_x, const float* d_y, const float* d_z,
+                                  const uint32_t* d_offsets, uint32_t max_len, uint32_t n_scans,
+                                  uint8_t* d_labels, urf_scan_info* d_info);
+
+/* Batch of PointCloud2-layout scans in device memory (n_per_scan records of
+ * point_step bytes per scan, scans back to back). */
+int urf_classify_batch_pc2(urf_ctx* ctx, const uint8_t* d_data, uint32_t n_per_scan, uint32_t n_scans,
+                           uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                           uint8_t* d_labels, urf_scan_info* d_info);
+
+/* ---- index-set outputs -----------------------------------------------------
+ * Compacts the label bytes of ONE scan (device) into ascending index lists
+ * (device, each with room for n_points entries; any may be NULL) and writes
+ * the four counts to d_counts[0..3] = {road, curb, roi, road_probably}. */
+int urf_compact_indices(urf_ctx* ctx, const uint8_t* d_labels, uint32_t n_points,
+                        uint32_t* d_road, uint32_t* d_curb, uint32_t* d_roi, uint32_t* d_ring10,
+                        uint32_t* d_counts);
+
+/* ---- stage-wise inspection (parity tests) ----------------------------------
+ * After a classify call, copies one intermediate array of scan `scan` to host
+ * memory.  Arrays indexed by input point have n_points entries; values of
+ * points outside the ROI / not on a ring are unspecified unless noted. */
+typedef enum urf_stage {
+    URF_STAGE_VALPHA = 1,     /* float  per point: vertical angle, lidar_segmentation.cpp:151-166;
+                                 negative for points outside the ROI */
+    URF_STAGE_RING = 2,       /* int16  per point: sorted ring index or -1, lidar_segmentation.cpp:226-233 */
+    URF_STAGE_AZIMUTH = 3,    /* float  per point: azimuth alpha [deg], lidar_segmentation.cpp:248-269 */
+    URF_STAGE_RANGE2D = 4,    /* float  per point: planar d, lidar_segmentation.cpp:245 */
+    URF_STAGE_DETECT = 5,     /* uint8  per point: bit0 star, bit1 x_zero, bit2 z_zero hit */
+    URF_STAGE_SECTOR = 6,     /* int16  per point: star sector or -1, star_shaped_search.cpp:171 */
+    URF_STAGE_ANGLE_TABLE = 7,/* float[channels]: sorted ring-angle table, lidar_segmentation.cpp:205 */
+    URF_STAGE_MAXDIST = 8,    /* float[channels]: maxDistance, lidar_segmentation.cpp:271-274 */
+    URF_STAGE_QUADRANTS = 9,  /* float[4]: q1..q4, blind_spots.cpp:13-57 */
+    URF_STAGE_BEAM_STOP = 10  /* int16[2*361]: first blocked ring per forward / backward beam
+                                 (n_rings = not blocked, -1 = beam not cast) */
+} urf_stage;
+int urf_read_stage(urf_ctx* ctx, urf_stage what, uint32_t scan, void* host_dst, size_t bytes);
+/* URF_STAGE_RANGE2D needs one extra store per point; it is only kept when
+ * capture is on (default off). */
+int urf_enable_stage_capture(urf_ctx* ctx, int on);
+
+/* ---- synthetic sweeps -------------------------------
+ * Host-side generator of the benchmark clouds: `rings` x `cols` rays from a
+ * sensor 1.8 m above ground, scene 0 = flat plane, 1 = street with 0.15 m
+ * curbs at |y| = 4 m; column-major "firing order" (idx = col*rings + ring);
+ * per-sector radial ties removed.  Writes n = rings*cols floats to x, y, z. */
+int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
+                    float* x, float* y, float* z);
+
+/* ---- diagnostics --------------------------------------------------------- */
+const char* urf_strerror(int status);
+const char* urf_last_error(const urf_ctx* ctx);   /* text of the last HIP failure */
+int urf_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* URF_H */

@@ -1,0 +1,21 @@
+/* Stand-in for visualization_msgs/Marker(.h|Array.h); see ros/ros.h.  TEST INFRASTRUCTURE ONLY. */
+#pragma once
+#include <ros/ros.h>
+
+namespace visualization_msgs {
+struct Marker {
+    enum { LINE_STRIP = 4, ADD = 0, DELETE = 2 };
+    std_msgs::Header header;
+    int type = 0, action = 0, id = 0;
+    geometry_msgs::Pose pose;
+    geometry_msgs::Vector3 scale;
+    std_msgs::ColorRGBA color;
+    ros::Duration lifetime;
+    std::vector<geometry_msgs::Point> points;
+};
+struct MarkerArray {
+    std::vector<Marker> markers;
+};
+/* the road_marker polygon is outside the hot path: captured and dropped */
+inline void shim_capture(const std::string&, const MarkerArray&) {}
+}   // namespace visualization_msgs

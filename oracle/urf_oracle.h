@@ -1,0 +1,54 @@
+/*
+ * urf_oracle.h -- CPU oracle ("oracle B") for the urban_road_filter hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker.  The product path
+ * (urban_road_filter_amd/) never links, imports or falls back to it.
+ *
+ * A plain-C restatement of the reference's per-scan classification, statement
+ * by statement in behaviour (see urf_oracle.c for the file:line map).  Pinned
+ * against "oracle A" = the reference's own unmodified sources compiled against
+ * stand-in ROS/PCL/Boost headers (oracle/Makefile -> oracle/_ref/) by
+ * tests/test_oracle_vs_reference.py and the golden vectors in tests/golden/.
+ */
+#ifndef URF_ORACLE_H
+#define URF_ORACLE_H
+
+#include <stdint.h>
+#include "urf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Optional per-stage outputs; every pointer may be NULL.  Arrays "per point"
+ * have n entries and are indexed by INPUT point index. */
+typedef struct urf_oracle_debug {
+    float*   valpha;      /* per point; -1 outside the ROI */
+    int16_t* ring;        /* per point; -1 if not bucketed */
+    float*   azimuth;     /* per point (bucketed points only, else 0) */
+    float*   range2d;     /* per point (bucketed points only, else 0) */
+    uint8_t* detect;      /* per point: bit0 star, bit1 x_zero, bit2 z_zero */
+    int16_t* sector;      /* per point; -1 outside the ROI or star disabled */
+    float*   angle_table; /* [channels] sorted table, zero padded */
+    float*   max_dist;    /* [channels] */
+    float*   quadrants;   /* [4] q1..q4 */
+    int16_t* beam_stop;   /* [2*361] first blocked ring per fwd/bwd beam; n_rings = free; -1 = not cast */
+} urf_oracle_debug;
+
+/* Classifies one scan given as SoA.  labels: n bytes (urf.h label byte).
+ * Returns URF_OK, URF_TOO_FEW_POINTS, or a negative error. */
+int urf_oracle_classify(const float* x, const float* y, const float* z, uint32_t n,
+                        const urf_params* params, uint8_t* labels,
+                        urf_scan_info* info, urf_oracle_debug* dbg);
+
+/* The three libm replacements, exported for tests/test_libm.py. */
+float urf_oracle_acosf(float x);
+float urf_oracle_asinf(float x);
+float urf_oracle_atan2f(float y, float x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

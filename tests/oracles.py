@@ -1,0 +1,151 @@
+"""Test-side access to the two CPU oracles (TEST INFRASTRUCTURE, see oracle/).
+
+oracle B = oracle/liburf_oracle.so   (C restatement, travels to the GPU box)
+oracle A = oracle/_ref/urf_ref       (the reference's own sources; built only where
+                                      /root/reference exists, the binary travels too)
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+
+from urban_road_filter_amd.api import Params, ScanInfo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_B = os.path.join(ORACLE_DIR, "liburf_oracle.so")
+ORACLE_A = os.path.join(ORACLE_DIR, "_ref", "urf_ref")
+REFERENCE = "/root/reference"
+
+
+class OracleDebug(C.Structure):
+    _fields_ = [("valpha", C.c_void_p), ("ring", C.c_void_p), ("azimuth", C.c_void_p),
+                ("range2d", C.c_void_p), ("detect", C.c_void_p), ("sector", C.c_void_p),
+                ("angle_table", C.c_void_p), ("max_dist", C.c_void_p), ("quadrants", C.c_void_p),
+                ("beam_stop", C.c_void_p)]
+
+
+_B = None
+
+
+def ensure_built():
+    """Builds what can be built here (oracle B always; oracle A when the reference is mounted)."""
+    need_b = not os.path.exists(ORACLE_B)
+    need_a = os.path.isdir(REFERENCE) and not os.path.exists(ORACLE_A)
+    if need_b or need_a:
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def oracle_b():
+    global _B
+    if _B is None:
+        ensure_built()
+        L = C.CDLL(ORACLE_B)
+        L.urf_oracle_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(Params),
+                                          C.c_void_p, C.POINTER(ScanInfo), C.POINTER(OracleDebug)]
+        L.urf_oracle_classify.restype = C.c_int
+        for f in ("urf_oracle_acosf", "urf_oracle_asinf"):
+            getattr(L, f).argtypes = [C.c_float]
+            getattr(L, f).restype = C.c_float
+        L.urf_oracle_atan2f.argtypes = [C.c_float, C.c_float]
+        L.urf_oracle_atan2f.restype = C.c_float
+        _B = L
+    return _B
+
+
+def has_oracle_a():
+    ensure_built()
+    return os.path.exists(ORACLE_A)
+
+
+def run_b(x, y, z, params, debug=False):
+    """Returns (labels uint8[n], info dict, stages dict or None)."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    z = np.ascontiguousarray(z, np.float32)
+    n = len(x)
+    labels = np.zeros(n, np.uint8)
+    info = ScanInfo()
+    dbg = None
+    st = None
+    if debug:
+        ch = params.channels
+        st = {"valpha": np.zeros(n, np.float32), "ring": np.zeros(n, np.int16),
+              "azimuth": np.zeros(n, np.float32), "range2d": np.zeros(n, np.float32),
+              "detect": np.zeros(n, np.uint8), "sector": np.zeros(n, np.int16),
+              "angle_table": np.zeros(ch, np.float32), "max_dist": np.zeros(ch, np.float32),
+              "quadrants": np.zeros(4, np.float32), "beam_stop": np.zeros(2 * 361, np.int16)}
+        dbg = OracleDebug(*[st[k].ctypes.data for k, _ in OracleDebug._fields_])
+    rc = oracle_b().urf_oracle_classify(x.ctypes.data, y.ctypes.data, z.ctypes.data, n, C.byref(params),
+                                        labels.ctypes.data, C.byref(info), C.byref(dbg) if dbg else None)
+    if rc < 0:
+        raise RuntimeError("oracle B failed: %d" % rc)
+    return labels, info.as_dict(), st
+
+
+def run_a(scans, params, repeat=1, timeout=1200):
+    """scans: list of (x, y, z) with equal length.  Returns (list of labels, list of info dicts,
+    ms_per_scan_steady, ms_first).  The RING bit is not observable from the reference."""
+    assert has_oracle_a(), "oracle A (reference build) not available"
+    n = len(scans[0][0])
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(b"URFREFIN")
+            f.write(struct.pack("<4I", len(scans), n, repeat, 0))
+            f.write(bytes(params))
+            for x, y, z in scans:
+                assert len(x) == n
+                f.write(np.ascontiguousarray(x, np.float32).tobytes())
+                f.write(np.ascontiguousarray(y, np.float32).tobytes())
+                f.write(np.ascontiguousarray(z, np.float32).tobytes())
+        subprocess.run([ORACLE_A, fin, fout], check=True, timeout=timeout)
+        with open(fout, "rb") as f:
+            blob = f.read()
+    assert blob[:8] == b"URFREFOU"
+    ns, nn = struct.unpack_from("<2I", blob, 8)
+    ms_steady, ms_first = struct.unpack_from("<2d", blob, 16)
+    pos = 32
+    labels, infos = [], []
+    for _ in range(ns):
+        info = ScanInfo.from_buffer_copy(blob[pos:pos + C.sizeof(ScanInfo)])
+        pos += C.sizeof(ScanInfo)
+        labels.append(np.frombuffer(blob, np.uint8, nn, pos).copy())
+        pos += nn
+        infos.append(info.as_dict())
+    return labels, infos, ms_steady, ms_first
+
+
+# ---- workload configurations (BASELINE.json configs / SURVEY.md section 8d) ------------------
+def cfg_params(name):
+    """Parameter sets of the named configurations."""
+    from urban_road_filter_amd import default_params
+    p = default_params().wide_roi()
+    if name == "cfg1":      # 16x1024 flat, z_zero only
+        p.x_zero_method, p.star_shaped_method, p.blind_spots = 0, 0, 0
+    elif name == "cfg2":    # 64x2048 street, all detectors + blind_spots
+        pass
+    elif name == "cfg5":    # 128x4096, channels 128, interval 0.05
+        p.channels, p.interval = 128, 0.05
+    elif name == "default_roi":
+        p = default_params()
+    else:
+        raise KeyError(name)
+    return p
+
+
+def cfg_cloud(name, seed=1):
+    from urban_road_filter_amd import synth_cloud
+    if name == "cfg1":
+        return synth_cloud(16, 1024, 0, seed)
+    if name in ("cfg2", "default_roi"):
+        return synth_cloud(64, 2048, 1, seed)
+    if name == "cfg5":
+        return synth_cloud(128, 4096, 1, seed)
+    raise KeyError(name)
+
+
+MASK_NO_RING = 0xFF & ~0x08   # oracle A cannot report the RING bit

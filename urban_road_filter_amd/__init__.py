@@ -1,0 +1,19 @@
+"""urban_road_filter_amd -- MI355X-native road/curb classification of LiDAR sweeps.
+
+The product is the C-ABI shared library ``liburf_hip.so`` (include/urf.h): hand-written
+gfx950 HIP kernels behind the reference's ``Detector::filtered`` boundary.  This Python
+package is plumbing for tests and the benchmark: a ctypes binding of that ABI.
+"""
+from .api import (  # noqa: F401
+    Context,
+    Params,
+    ScanInfo,
+    UrfError,
+    default_params,
+    lib,
+    lib_path,
+    synth_cloud,
+    LABEL_MASK, LABEL_ROAD, LABEL_CURB, FLAG_ROI, FLAG_RING, FLAG_RING10,
+    STAGE_VALPHA, STAGE_RING, STAGE_AZIMUTH, STAGE_RANGE2D, STAGE_DETECT, STAGE_SECTOR,
+    STAGE_ANGLE_TABLE, STAGE_MAXDIST, STAGE_QUADRANTS, STAGE_BEAM_STOP,
+)

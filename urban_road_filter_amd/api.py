@@ -1,0 +1,265 @@
+"""ctypes binding of include/urf.h.  No compute happens in Python and there is no
+fallback: if ``liburf_hip.so`` is missing the import of :func:`lib` raises."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+LABEL_MASK, LABEL_ROAD, LABEL_CURB = 0x03, 1, 2
+FLAG_ROI, FLAG_RING, FLAG_RING10 = 0x04, 0x08, 0x10
+(STAGE_VALPHA, STAGE_RING, STAGE_AZIMUTH, STAGE_RANGE2D, STAGE_DETECT, STAGE_SECTOR,
+ STAGE_ANGLE_TABLE, STAGE_MAXDIST, STAGE_QUADRANTS, STAGE_BEAM_STOP) = range(1, 11)
+
+OK, TOO_FEW_POINTS = 0, 1
+
+
+class UrfError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        super().__init__("urf error %d (%s) %s" % (code, _strerror(code), what))
+
+
+class Params(C.Structure):
+    """struct urf_params (include/urf.h); field names follow the reference's namespace params."""
+    _fields_ = [
+        ("size", C.c_uint32),
+        ("x_zero_method", C.c_int32), ("z_zero_method", C.c_int32),
+        ("star_shaped_method", C.c_int32), ("blind_spots", C.c_int32),
+        ("xDirection", C.c_int32),
+        ("interval", C.c_float), ("curbHeight", C.c_float),
+        ("curbPoints", C.c_int32),
+        ("beamZone", C.c_float),
+        ("min_X", C.c_float), ("max_X", C.c_float),
+        ("min_Y", C.c_float), ("max_Y", C.c_float),
+        ("min_Z", C.c_float), ("max_Z", C.c_float),
+        ("angleFilter1", C.c_float), ("angleFilter2", C.c_float), ("angleFilter3", C.c_float),
+        ("kdev_param", C.c_float), ("kdist_param", C.c_float),
+        ("starbeam_filter", C.c_int32), ("dmin_param", C.c_int32),
+        ("channels", C.c_int32), ("sectors", C.c_int32),
+        ("beam_width", C.c_float),
+    ]
+
+    def copy(self):
+        p = Params()
+        C.memmove(C.byref(p), C.byref(self), C.sizeof(Params))
+        return p
+
+    def wide_roi(self, half=200.0):
+        """ROI x,y widened to +-half metres (so that every return of a
+        full sweep is classified); z keeps the reference default [-3, -1]."""
+        self.min_X, self.max_X, self.min_Y, self.max_Y = -half, half, -half, half
+        return self
+
+
+class ScanInfo(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_roi", C.c_uint32), ("n_rings", C.c_uint32),
+                ("n_ring_pts", C.c_uint32), ("n_road", C.c_uint32), ("n_curb", C.c_uint32),
+                ("n_ring10", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "liburf_hip.so")
+
+
+def lib():
+    """Loads liburf_hip.so.  When torch is (or will be) in the process it must be imported
+    first so that both share ONE HIP runtime (torch bundles libamdhip64.so.7; ours is
+    resolved by SONAME to whichever copy is already loaded)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError("%s not built: run `python -m urban_road_filter_amd.build`" % path)
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, u8p, u32p, fp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    sig = {
+        "urf_default_params": [C.POINTER(Params)],
+        "urf_create": [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_uint32],
+        "urf_destroy": [vp],
+        "urf_set_params": [vp, C.POINTER(Params)],
+        "urf_get_params": [vp, C.POINTER(Params)],
+        "urf_set_stream": [vp, vp],
+        "urf_synchronize": [vp],
+        "urf_classify_pc2": [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.POINTER(ScanInfo)],
+        "urf_classify_batch_soa": [vp, fp, fp, fp, C.c_uint32, C.c_uint32, u8p, vp],
+        "urf_classify_batch_soa_ragged": [vp, fp, fp, fp, u32p, C.c_uint32, C.c_uint32, u8p, vp],
+        "urf_classify_batch_pc2": [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p, vp],
+        "urf_compact_indices": [vp, u8p, C.c_uint32, u32p, u32p, u32p, u32p, u32p],
+        "urf_read_stage": [vp, C.c_int, C.c_uint32, vp, C.c_size_t],
+        "urf_enable_stage_capture": [vp, C.c_int],
+        "urf_synth_cloud": [C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, fp, fp, fp],
+        "urf_abi_version": [],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    L.urf_strerror.argtypes = [C.c_int]
+    L.urf_strerror.restype = C.c_char_p
+    L.urf_last_error.argtypes = [vp]
+    L.urf_last_error.restype = C.c_char_p
+    _LIB = L
+    return L
+
+
+def _strerror(code):
+    try:
+        return lib().urf_strerror(code).decode()
+    except Exception:  # pragma: no cover
+        return "?"
+
+
+def default_params():
+    p = Params()
+    rc = lib().urf_default_params(C.byref(p))
+    if rc != 0:
+        raise UrfError(rc)
+    return p
+
+
+def synth_cloud(rings, cols, scene=1, seed=1):
+    """SURVEY.md section 8d synthetic sweep: returns float32 arrays x, y, z of rings*cols points in
+    firing order (idx = col*rings + ring).  scene 0 = flat ground, 1 = street with curbs."""
+    n = rings * cols
+    x = np.empty(n, np.float32)
+    y = np.empty(n, np.float32)
+    z = np.empty(n, np.float32)
+    rc = lib().urf_synth_cloud(rings, cols, scene, seed, x.ctypes.data, y.ctypes.data, z.ctypes.data)
+    if rc != 0:
+        raise UrfError(rc, "urf_synth_cloud")
+    return x, y, z
+
+
+def _ptr(obj):
+    """Device pointer of a torch tensor / int / None; host pointer of a numpy array."""
+    if obj is None:
+        return None
+    if isinstance(obj, int):
+        return obj
+    if isinstance(obj, np.ndarray):
+        return obj.ctypes.data
+    if hasattr(obj, "data_ptr"):
+        return obj.data_ptr()
+    raise TypeError(type(obj))
+
+
+class Context:
+    """One urf_ctx: one device, one stream, all scratch memory."""
+
+    def __init__(self, max_points, max_batch=1, device=0, params=None):
+        self._h = C.c_void_p()
+        self._lib = lib()
+        rc = self._lib.urf_create(C.byref(self._h), device, max_points, max_batch)
+        if rc != 0:
+            self._h = None
+            raise UrfError(rc, "urf_create")
+        self.max_points, self.max_batch = max_points, max_batch
+        if params is not None:
+            self.set_params(params)
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise UrfError(rc, what + ": " + self._lib.urf_last_error(self._h).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.urf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_params(self, p):
+        self._check(self._lib.urf_set_params(self._h, C.byref(p)), "urf_set_params")
+
+    def get_params(self):
+        p = Params()
+        self._check(self._lib.urf_get_params(self._h, C.byref(p)), "urf_get_params")
+        return p
+
+    def set_stream(self, stream_handle):
+        self._check(self._lib.urf_set_stream(self._h, stream_handle), "urf_set_stream")
+
+    def synchronize(self):
+        self._check(self._lib.urf_synchronize(self._h), "urf_synchronize")
+
+    def enable_stage_capture(self, on=True):
+        self._check(self._lib.urf_enable_stage_capture(self._h, int(on)), "urf_enable_stage_capture")
+
+    # -- single scan, host, PointCloud2 layout ------------------------------------
+    def classify_pc2(self, data, n_points, point_step, off_x, off_y, off_z):
+        """data: bytes-like / uint8 array of n_points*point_step bytes.  Returns (labels, ScanInfo)."""
+        buf = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8).reshape(-1)
+        assert buf.size >= n_points * point_step
+        buf = np.ascontiguousarray(buf)
+        labels = np.zeros(n_points, np.uint8)
+        info = ScanInfo()
+        self._check(self._lib.urf_classify_pc2(self._h, buf.ctypes.data, n_points, point_step, off_x, off_y, off_z,
+                                               labels.ctypes.data, C.byref(info)), "urf_classify_pc2")
+        return labels, info
+
+    def classify_xyz(self, x, y, z):
+        """Convenience: one scan given as three float32 arrays -> packs x,y,z,intensity records
+        (the pcl::PointXYZI wire layout, point_step 16) and calls classify_pc2."""
+        n = len(x)
+        rec = np.zeros((n, 4), np.float32)
+        rec[:, 0], rec[:, 1], rec[:, 2] = x, y, z
+        return self.classify_pc2(rec, n, 16, 0, 4, 8)
+
+    # -- batches, device resident -------------------------------------------------
+    def classify_batch_soa(self, d_x, d_y, d_z, n_per_scan, n_scans, d_labels, d_info=None):
+        self._check(self._lib.urf_classify_batch_soa(self._h, _ptr(d_x), _ptr(d_y), _ptr(d_z), n_per_scan, n_scans,
+                                                     _ptr(d_labels), _ptr(d_info)), "urf_classify_batch_soa")
+
+    def classify_batch_soa_ragged(self, d_x, d_y, d_z, d_offsets, max_len, n_scans, d_labels, d_info=None):
+        self._check(self._lib.urf_classify_batch_soa_ragged(self._h, _ptr(d_x), _ptr(d_y), _ptr(d_z), _ptr(d_offsets),
+                                                            max_len, n_scans, _ptr(d_labels), _ptr(d_info)),
+                    "urf_classify_batch_soa_ragged")
+
+    def classify_batch_pc2(self, d_data, n_per_scan, n_scans, point_step, off_x, off_y, off_z, d_labels, d_info=None):
+        self._check(self._lib.urf_classify_batch_pc2(self._h, _ptr(d_data), n_per_scan, n_scans, point_step,
+                                                     off_x, off_y, off_z, _ptr(d_labels), _ptr(d_info)),
+                    "urf_classify_batch_pc2")
+
+    def compact_indices(self, d_labels, n_points, d_road, d_curb, d_roi, d_ring10, d_counts):
+        self._check(self._lib.urf_compact_indices(self._h, _ptr(d_labels), n_points, _ptr(d_road), _ptr(d_curb),
+                                                  _ptr(d_roi), _ptr(d_ring10), _ptr(d_counts)), "urf_compact_indices")
+
+    # -- stage-wise inspection ----------------------------------------------------
+    _STAGE_DTYPE = {STAGE_VALPHA: np.float32, STAGE_RING: np.int16, STAGE_AZIMUTH: np.float32,
+                    STAGE_RANGE2D: np.float32, STAGE_DETECT: np.uint8, STAGE_SECTOR: np.int16,
+                    STAGE_ANGLE_TABLE: np.float32, STAGE_MAXDIST: np.float32, STAGE_QUADRANTS: np.float32,
+                    STAGE_BEAM_STOP: np.int16}
+
+    def read_stage(self, what, n_points, scan=0):
+        if what in (STAGE_ANGLE_TABLE, STAGE_MAXDIST):
+            count = self.get_params().channels
+        elif what == STAGE_QUADRANTS:
+            count = 4
+        elif what == STAGE_BEAM_STOP:
+            count = 2 * 361
+        else:
+            count = n_points
+        out = np.zeros(count, self._STAGE_DTYPE[what])
+        self._check(self._lib.urf_read_stage(self._h, what, scan, out.ctypes.data, out.nbytes), "urf_read_stage")
+        return out

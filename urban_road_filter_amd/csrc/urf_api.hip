@@ -1,0 +1,519 @@
+/*
+ * urf_api.hip -- host side of the C ABI (include/urf.h): context, scratch
+ * memory, kernel sequencing.  No CPU fallback: every entry point that
+ * classifies fails with URF_ERR_NO_DEVICE / URF_ERR_HIP when there is no GPU.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "urf.h"
+#include "urf_internal.hpp"
+#include "urf_kernels.hpp"
+
+struct urf_ctx {
+    int device = 0;
+    uint32_t max_points = 0, max_batch = 0;
+    size_t total = 0;               /* max_points * max_batch */
+    uint32_t max_tiles = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    urf_params params;
+    urf_dev_params dp;
+    urf_kargs k;                    /* device pointers (context-owned part) */
+    /* owned device memory */
+    std::vector<void*> allocs;
+    float *sx = nullptr, *sy = nullptr, *sz = nullptr;   /* SoA staging for PointCloud2 input */
+    uint8_t* raw = nullptr;         /* PointCloud2 staging (single scan) */
+    size_t raw_bytes = 0;
+    uint8_t* labels1 = nullptr;     /* labels of the single-scan entry point */
+    float* d_newY = nullptr;
+    urf_beam* d_beams = nullptr;
+    uint32_t beams_cap = 0;
+    bool debug_rd2 = false;
+    /* last call, for urf_read_stage */
+    uint32_t last_scans = 0, last_n = 0, last_max_len = 0;
+    bool last_ragged = false;
+    const uint32_t* last_offsets = nullptr;
+    const uint8_t* last_labels = nullptr;
+    std::string last_error;
+};
+
+#define URF_HIP(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);      \
+            return e_ == hipErrorOutOfMemory ? URF_ERR_OOM : URF_ERR_HIP;               \
+        }                                                                               \
+    } while (0)
+
+template <class T>
+static int dev_alloc(urf_ctx* c, T** p, size_t count)
+{
+    void* v = nullptr;
+    URF_HIP(c, hipMalloc(&v, (count ? count : 1) * sizeof(T)));
+    c->allocs.push_back(v);
+    *p = (T*)v;
+    return URF_OK;
+}
+
+/* star_shaped_search.cpp:32-66 beam_init: per-sector constants of the
+ * rectangular beam; `fi` is a float, so tan/sin/cos(fi) are the float
+ * overloads and tan(0.5*M_PI - fi) is the double one. */
+static void beam_init(std::vector<urf_beam>& beams, int rep, float width)
+{
+    beams.resize((size_t)rep);
+    const float off = (float)(0.5 * (double)width);
+    for (int i = 0; i < rep; i++) {
+        const float fi = (float)((double)(i * 2) * M_PI / (double)rep);
+        if (std::fabs(std::tan(fi)) > 1) {
+            beams[i].yx = 1;
+            beams[i].d = (float)std::tan(0.5 * M_PI - (double)fi);
+            beams[i].o = std::fabs(off / std::sin(fi));
+        } else {
+            beams[i].yx = 0;
+            beams[i].d = std::tan(fi);
+            beams[i].o = std::fabs(off / std::cos(fi));
+        }
+    }
+}
+
+static int upload_params(urf_ctx* c)
+{
+    const urf_params& p = c->params;
+    urf_dev_params& dp = c->dp;
+    dp.p = p;
+    dp.slope_param = (float)((double)p.angleFilter3 * (M_PI / 180));   /* star_shaped_search.cpp:160 */
+    dp.Kfi = (float)((double)p.sectors / (2 * M_PI));                  /* star_shaped_search.cpp:65 */
+    dp.fwd_limit = 360.0f - p.beamZone;                                /* blind_spots.cpp:68 */
+    dp.bwd_limit = 0.0f + p.beamZone;                                  /* blind_spots.cpp:177 */
+    dp.inv_cp = 1.0f / (float)p.curbPoints;                            /* z_zero_method.cpp:52 */
+    dp.sec_keybits = 10;
+    dp.ring_keybits = 8;
+    std::vector<urf_beam> beams;
+    beam_init(beams, p.sectors, p.beam_width);
+    URF_HIP(c, hipMemcpyAsync(c->d_beams, beams.data(), beams.size() * sizeof(urf_beam), hipMemcpyHostToDevice, c->stream));
+    URF_HIP(c, hipStreamSynchronize(c->stream));   /* `beams` is a stack object */
+    return URF_OK;
+}
+
+extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uint32_t max_batch)
+{
+    if (!out || max_points == 0 || max_batch == 0)
+        return URF_ERR_INVALID_ARG;
+    *out = nullptr;
+    if ((unsigned long long)max_points * max_batch >= (1ull << 32))
+        return URF_ERR_CAPACITY;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
+        return URF_ERR_NO_DEVICE;
+    urf_ctx* c = new urf_ctx();
+    c->device = device_id;
+    c->max_points = max_points;
+    c->max_batch = max_batch;
+    c->total = (size_t)max_points * max_batch;
+    c->max_tiles = (max_points + URF_TILE - 1) / URF_TILE;
+    int rc = URF_OK;
+    auto fail = [&](int code) {
+        urf_destroy(c);
+        return code;
+    };
+    if (hipSetDevice(device_id) != hipSuccess)
+        return fail(URF_ERR_NO_DEVICE);
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
+        return fail(URF_ERR_HIP);
+    c->stream = c->own_stream;
+    urf_default_params(&c->params);
+    std::memset(&c->k, 0, sizeof(c->k));
+    urf_kargs& k = c->k;
+    const size_t T = c->total, S = max_batch, tiles = c->max_tiles;
+    const size_t C = URF_MAX_CHANNELS, K = URF_MAX_SECTORS;
+#define A(ptr, count)                                     \
+    if ((rc = dev_alloc(c, &(ptr), (count))) != URF_OK)   \
+        return fail(rc);
+    A(k.valpha, T) A(k.seckey, T) A(k.ringkey, T)
+    A(k.rx, T) A(k.ry, T) A(k.rz, T) A(k.rsrc, T) A(k.raz, T) A(k.rd2, T) A(k.rflag, T)
+    A(k.sr, T) A(k.sz, T) A(k.ssrc, T)
+    A(k.tile_roi, S * tiles) A(k.tile_ring, S * tiles * C) A(k.tile_sec, S * tiles * K)
+    A(k.angle, S * C) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
+    A(k.sec_cnt, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
+    A(k.maxdist, S * C) A(k.quad, S * 4)
+    A(k.sufmin, S * C * URF_DEG_CELLS) A(k.premax, S * C * URF_DEG_CELLS)
+    A(k.stop_f, S * URF_DEG_CELLS) A(k.stop_b, S * URF_DEG_CELLS)
+    A(k.info, S)
+    A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
+    A(c->labels1, (size_t)max_points)
+#undef A
+    /* x_zero_method.cpp:24-27: newY[j] = newY[j-1] + 0.0100 (float += double), a
+     * data-independent table shared by all rings */
+    {
+        std::vector<float> newY(max_points);
+        newY[0] = 0.0f;
+        for (uint32_t j = 1; j < max_points; j++)
+            newY[j] = (float)((double)newY[j - 1] + 0.0100);
+        if (hipMemcpy(c->d_newY, newY.data(), newY.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(URF_ERR_HIP);
+    }
+    k.newY = c->d_newY;
+    k.beams = c->d_beams;
+    if ((rc = upload_params(c)) != URF_OK)
+        return fail(rc);
+    *out = c;
+    return URF_OK;
+}
+
+extern "C" int urf_destroy(urf_ctx* c)
+{
+    if (!c)
+        return URF_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream)
+        (void)hipStreamSynchronize(c->own_stream);
+    for (void* p : c->allocs)
+        (void)hipFree(p);
+    if (c->raw)
+        (void)hipFree(c->raw);
+    if (c->sx) {
+        (void)hipFree(c->sx);
+        (void)hipFree(c->sy);
+        (void)hipFree(c->sz);
+    }
+    if (c->own_stream)
+        (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return URF_OK;
+}
+
+extern "C" int urf_set_params(urf_ctx* c, const urf_params* p)
+{
+    if (!c || !p)
+        return URF_ERR_INVALID_ARG;
+    const int rc = urf_validate_params(p);
+    if (rc != URF_OK)
+        return rc;
+    URF_HIP(c, hipSetDevice(c->device));
+    c->params = *p;
+    return upload_params(c);
+}
+
+extern "C" int urf_get_params(const urf_ctx* c, urf_params* p)
+{
+    if (!c || !p)
+        return URF_ERR_INVALID_ARG;
+    *p = c->params;
+    return URF_OK;
+}
+
+extern "C" int urf_set_stream(urf_ctx* c, void* hip_stream)
+{
+    if (!c)
+        return URF_ERR_INVALID_ARG;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return URF_OK;
+}
+
+extern "C" int urf_synchronize(urf_ctx* c)
+{
+    if (!c)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    URF_HIP(c, hipStreamSynchronize(c->stream));
+    return URF_OK;
+}
+
+extern "C" int urf_enable_stage_capture(urf_ctx* c, int on)
+{
+    if (!c)
+        return URF_ERR_INVALID_ARG;
+    c->debug_rd2 = on != 0;
+    return URF_OK;
+}
+
+extern "C" const char* urf_last_error(const urf_ctx* c) { return c ? c->last_error.c_str() : ""; }
+
+/* ---- the pipeline ---------------------------------------------------------- */
+static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const float* d_z,
+                        const uint32_t* d_offsets, uint32_t n_per_scan, uint32_t max_len, uint32_t n_scans,
+                        uint8_t* d_labels, urf_scan_info* d_info)
+{
+    if (!d_x || !d_y || !d_z || !d_labels)
+        return URF_ERR_INVALID_ARG;
+    if (n_scans == 0)
+        return URF_OK;
+    if (n_scans > c->max_batch || max_len > c->max_points)
+        return URF_ERR_CAPACITY;
+    URF_HIP(c, hipSetDevice(c->device));
+    urf_kargs a = c->k;
+    a.x = d_x;
+    a.y = d_y;
+    a.z = d_z;
+    a.offsets = d_offsets;
+    a.n_per_scan = n_per_scan;
+    a.n_scans = n_scans;
+    a.max_len = max_len;
+    a.tiles = (max_len + URF_TILE - 1) / URF_TILE;
+    if (a.tiles == 0)
+        a.tiles = 1;
+    a.labels = d_labels;
+    if (!c->debug_rd2)
+        a.rd2 = nullptr;
+    const urf_dev_params dp = c->dp;
+    const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
+    const bool star = dp.p.star_shaped_method != 0;
+    hipStream_t st = c->stream;
+    const dim3 g_tiles(a.tiles, n_scans), g_scan(n_scans);
+
+    hipLaunchKernelGGL(k_ingest, g_tiles, dim3(URF_TILE_THREADS), (K + 1) * sizeof(unsigned), st, a, dp);
+    hipLaunchKernelGGL(k_ring_table, g_scan, dim3(256), 0, st, a, dp);
+    hipLaunchKernelGGL(k_ring_assign, g_tiles, dim3(URF_TILE_THREADS), 0, st, a, dp);
+    hipLaunchKernelGGL(k_offsets, g_scan, dim3(256), 0, st, a, dp);
+    {
+        const size_t keys = C + (star ? K : 0);
+        const size_t lds = 4 * keys + 2 * (size_t)URF_TILE_GROUPS * keys + 8;
+        hipLaunchKernelGGL(k_scatter, g_tiles, dim3(URF_TILE_THREADS), lds, st, a, dp);
+    }
+    if (star) {
+        const dim3 g_sec(K, n_scans);
+        hipLaunchKernelGGL((k_star<-1, 512, true>), g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
+        hipLaunchKernelGGL((k_star<512, 2048, true>), g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
+        hipLaunchKernelGGL((k_star<2048, 0, false>), g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
+    }
+    const dim3 g_ring(C, n_scans);
+    hipLaunchKernelGGL(k_ring, g_ring, dim3(URF_RING_THREADS), 0, st, a, dp);
+    hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_LABEL_THREADS), 0, st, a, dp);
+    hipLaunchKernelGGL(k_label, g_ring, dim3(URF_LABEL_THREADS), 0, st, a, dp);
+    URF_HIP(c, hipGetLastError());
+    if (d_info)
+        URF_HIP(c, hipMemcpyAsync(d_info, a.info, (size_t)n_scans * sizeof(urf_scan_info), hipMemcpyDeviceToDevice, st));
+    c->last_scans = n_scans;
+    c->last_n = n_per_scan;
+    c->last_max_len = max_len;
+    c->last_ragged = d_offsets != nullptr;
+    c->last_offsets = d_offsets;
+    c->last_labels = d_labels;
+    return URF_OK;
+}
+
+extern "C" int urf_classify_batch_soa(urf_ctx* c, const float* d_x, const float* d_y, const float* d_z,
+                                      uint32_t n_per_scan, uint32_t n_scans, uint8_t* d_labels, urf_scan_info* d_info)
+{
+    if (!c)
+        return URF_ERR_INVALID_ARG;
+    return run_pipeline(c, d_x, d_y, d_z, nullptr, n_per_scan, n_per_scan, n_scans, d_labels, d_info);
+}
+
+extern "C" int urf_classify_batch_soa_ragged(urf_ctx* c, const float* d_x, const float* d_y, const float* d_z,
+                                             const uint32_t* d_offsets, uint32_t max_len, uint32_t n_scans,
+                                             uint8_t* d_labels, urf_scan_info* d_info)
+{
+    if (!c || !d_offsets)
+        return URF_ERR_INVALID_ARG;
+    return run_pipeline(c, d_x, d_y, d_z, d_offsets, 0, max_len, n_scans, d_labels, d_info);
+}
+
+static int ensure_soa_staging(urf_ctx* c)
+{
+    if (c->sx)
+        return URF_OK;
+    void *px = nullptr, *py = nullptr, *pz = nullptr;
+    URF_HIP(c, hipMalloc(&px, c->total * sizeof(float)));
+    URF_HIP(c, hipMalloc(&py, c->total * sizeof(float)));
+    URF_HIP(c, hipMalloc(&pz, c->total * sizeof(float)));
+    c->sx = (float*)px;
+    c->sy = (float*)py;
+    c->sz = (float*)pz;
+    return URF_OK;
+}
+
+extern "C" int urf_classify_batch_pc2(urf_ctx* c, const uint8_t* d_data, uint32_t n_per_scan, uint32_t n_scans,
+                                      uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                                      uint8_t* d_labels, urf_scan_info* d_info)
+{
+    if (!c || !d_data || point_step < 4 || off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step)
+        return URF_ERR_INVALID_ARG;
+    if (n_scans > c->max_batch || n_per_scan > c->max_points)
+        return URF_ERR_CAPACITY;
+    if (n_scans == 0)
+        return URF_OK;
+    URF_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_soa_staging(c);
+    if (rc != URF_OK)
+        return rc;
+    const unsigned long long total = (unsigned long long)n_per_scan * n_scans;
+    hipLaunchKernelGGL(k_pc2_to_soa, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_data, total,
+                       point_step, off_x, off_y, off_z, c->sx, c->sy, c->sz);
+    return run_pipeline(c, c->sx, c->sy, c->sz, nullptr, n_per_scan, n_per_scan, n_scans, d_labels, d_info);
+}
+
+extern "C" int urf_classify_pc2(urf_ctx* c, const uint8_t* data, uint32_t n_points, uint32_t point_step,
+                                uint32_t off_x, uint32_t off_y, uint32_t off_z, uint8_t* labels_out, urf_scan_info* info)
+{
+    if (!c || !data || !labels_out)
+        return URF_ERR_INVALID_ARG;
+    if (n_points > c->max_points)
+        return URF_ERR_CAPACITY;
+    if (n_points == 0) {
+        if (info) {
+            std::memset(info, 0, sizeof(*info));
+            info->status = URF_TOO_FEW_POINTS;
+        }
+        return URF_OK;
+    }
+    URF_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n_points * point_step;
+    if (bytes > c->raw_bytes) {
+        if (c->raw)
+            (void)hipFree(c->raw);
+        c->raw = nullptr;
+        c->raw_bytes = 0;
+        void* p = nullptr;
+        URF_HIP(c, hipMalloc(&p, bytes));
+        c->raw = (uint8_t*)p;
+        c->raw_bytes = bytes;
+    }
+    URF_HIP(c, hipMemcpyAsync(c->raw, data, bytes, hipMemcpyHostToDevice, c->stream));
+    int rc = urf_classify_batch_pc2(c, c->raw, n_points, 1, point_step, off_x, off_y, off_z, c->labels1, nullptr);
+    if (rc != URF_OK)
+        return rc;
+    URF_HIP(c, hipMemcpyAsync(labels_out, c->labels1, n_points, hipMemcpyDeviceToHost, c->stream));
+    urf_scan_info tmp;
+    URF_HIP(c, hipMemcpyAsync(&tmp, c->k.info, sizeof(tmp), hipMemcpyDeviceToHost, c->stream));
+    URF_HIP(c, hipStreamSynchronize(c->stream));
+    if (info)
+        *info = tmp;
+    return URF_OK;
+}
+
+extern "C" int urf_compact_indices(urf_ctx* c, const uint8_t* d_labels, uint32_t n_points,
+                                   uint32_t* d_road, uint32_t* d_curb, uint32_t* d_roi, uint32_t* d_ring10,
+                                   uint32_t* d_counts)
+{
+    if (!c || !d_labels)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, c->stream, d_labels, n_points, d_road, d_curb, d_roi, d_ring10,
+                       d_counts);
+    URF_HIP(c, hipGetLastError());
+    return URF_OK;
+}
+
+/* ---- stage-wise inspection -------------------------------------------------- */
+template <class T>
+static int fetch(urf_ctx* c, std::vector<T>& dst, const T* src, size_t count)
+{
+    dst.resize(count);
+    URF_HIP(c, hipMemcpy(dst.data(), src, count * sizeof(T), hipMemcpyDeviceToHost));
+    return URF_OK;
+}
+
+extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* host_dst, size_t bytes)
+{
+    if (!c || !host_dst || scan >= c->last_scans)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    URF_HIP(c, hipStreamSynchronize(c->stream));
+    uint32_t off, len;
+    if (c->last_ragged) {
+        uint32_t o2[2];
+        URF_HIP(c, hipMemcpy(o2, c->last_offsets + scan, sizeof(o2), hipMemcpyDeviceToHost));
+        off = o2[0];
+        len = o2[1] - o2[0];
+    } else {
+        off = scan * c->last_n;
+        len = c->last_n;
+    }
+    const unsigned C = (unsigned)c->params.channels, K = (unsigned)c->params.sectors;
+    const urf_kargs& k = c->k;
+    urf_scan_info in;
+    URF_HIP(c, hipMemcpy(&in, k.info + scan, sizeof(in), hipMemcpyDeviceToHost));
+    int rc;
+    switch (what) {
+    case URF_STAGE_VALPHA:
+        if (bytes < len * sizeof(float)) return URF_ERR_INVALID_ARG;
+        URF_HIP(c, hipMemcpy(host_dst, k.valpha + off, len * sizeof(float), hipMemcpyDeviceToHost));
+        return URF_OK;
+    case URF_STAGE_RING: {
+        if (bytes < len * sizeof(int16_t)) return URF_ERR_INVALID_ARG;
+        std::vector<uint8_t> rk;
+        if ((rc = fetch(c, rk, k.ringkey + off, len)) != URF_OK) return rc;
+        int16_t* o = (int16_t*)host_dst;
+        for (uint32_t i = 0; i < len; i++)
+            o[i] = (in.status != URF_OK || rk[i] == URF_RING_NONE) ? (int16_t)-1 : (int16_t)rk[i];
+        return URF_OK;
+    }
+    case URF_STAGE_SECTOR: {
+        if (bytes < len * sizeof(int16_t)) return URF_ERR_INVALID_ARG;
+        std::vector<uint16_t> sk;
+        if ((rc = fetch(c, sk, k.seckey + off, len)) != URF_OK) return rc;
+        int16_t* o = (int16_t*)host_dst;
+        for (uint32_t i = 0; i < len; i++)
+            o[i] = sk[i] == URF_SEC_NONE ? (int16_t)-1 : (int16_t)sk[i];
+        return URF_OK;
+    }
+    case URF_STAGE_AZIMUTH:
+    case URF_STAGE_RANGE2D:
+    case URF_STAGE_DETECT: {
+        if (what == URF_STAGE_RANGE2D && !c->debug_rd2) return URF_ERR_INVALID_ARG;
+        const size_t esz = what == URF_STAGE_DETECT ? 1 : 4;
+        if (bytes < len * esz) return URF_ERR_INVALID_ARG;
+        std::memset(host_dst, 0, len * esz);
+        if (in.status != URF_OK) return URF_OK;
+        std::vector<uint32_t> src, roff;
+        if ((rc = fetch(c, roff, k.ring_off + (size_t)scan * (C + 1), C + 1)) != URF_OK) return rc;
+        const uint32_t nb = roff[C];   /* bucketed points */
+        if ((rc = fetch(c, src, k.rsrc + off, nb)) != URF_OK) return rc;
+        if (what == URF_STAGE_DETECT) {
+            std::vector<uint8_t> fl;
+            if ((rc = fetch(c, fl, k.rflag + off, nb)) != URF_OK) return rc;
+            uint8_t* o = (uint8_t*)host_dst;
+            for (uint32_t p = 0; p < nb; p++)
+                o[src[p]] = fl[p];
+            if (c->params.star_shaped_method) {   /* star hits on points that match no ring */
+                std::vector<int32_t> hit;
+                if ((rc = fetch(c, hit, k.star_hit + (size_t)scan * K, K)) != URF_OK) return rc;
+                for (uint32_t s = 0; s < K; s++)
+                    if (hit[s] >= 0 && (uint32_t)hit[s] < len)
+                        o[hit[s]] |= 1;
+            }
+        } else {
+            std::vector<float> v;
+            if ((rc = fetch(c, v, (what == URF_STAGE_AZIMUTH ? k.raz : k.rd2) + off, nb)) != URF_OK) return rc;
+            float* o = (float*)host_dst;
+            for (uint32_t p = 0; p < nb; p++)
+                o[src[p]] = v[p];
+        }
+        return URF_OK;
+    }
+    case URF_STAGE_ANGLE_TABLE: {
+        if (bytes < C * sizeof(float)) return URF_ERR_INVALID_ARG;
+        std::memset(host_dst, 0, C * sizeof(float));
+        if (in.status != URF_OK) return URF_OK;
+        URF_HIP(c, hipMemcpy(host_dst, k.angle + (size_t)scan * C, in.n_rings * sizeof(float), hipMemcpyDeviceToHost));
+        return URF_OK;
+    }
+    case URF_STAGE_MAXDIST: {
+        if (bytes < C * sizeof(float)) return URF_ERR_INVALID_ARG;
+        std::memset(host_dst, 0, C * sizeof(float));
+        if (in.status != URF_OK) return URF_OK;
+        URF_HIP(c, hipMemcpy(host_dst, k.maxdist + (size_t)scan * C, in.n_rings * sizeof(float), hipMemcpyDeviceToHost));
+        return URF_OK;
+    }
+    case URF_STAGE_QUADRANTS:
+        if (bytes < 4 * sizeof(float)) return URF_ERR_INVALID_ARG;
+        URF_HIP(c, hipMemcpy(host_dst, k.quad + (size_t)scan * 4, 4 * sizeof(float), hipMemcpyDeviceToHost));
+        return URF_OK;
+    case URF_STAGE_BEAM_STOP:
+        if (bytes < 2 * URF_DEG_CELLS * sizeof(int16_t)) return URF_ERR_INVALID_ARG;
+        URF_HIP(c, hipMemcpy(host_dst, k.stop_f + (size_t)scan * URF_DEG_CELLS, URF_DEG_CELLS * sizeof(int16_t), hipMemcpyDeviceToHost));
+        URF_HIP(c, hipMemcpy((int16_t*)host_dst + URF_DEG_CELLS, k.stop_b + (size_t)scan * URF_DEG_CELLS,
+                             URF_DEG_CELLS * sizeof(int16_t), hipMemcpyDeviceToHost));
+        return URF_OK;
+    }
+    return URF_ERR_INVALID_ARG;
+}

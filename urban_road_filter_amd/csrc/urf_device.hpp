@@ -1,0 +1,123 @@
+/*
+ * urf_device.hpp -- device-side helpers: the per-point expressions of the
+ * reference with its exact float/double mix, and the
+ * wave64 primitives the kernels share.  gfx950 only; compile with
+ * -ffp-contract=off (the reference is built without contraction).
+ */
+#ifndef URF_DEVICE_HPP
+#define URF_DEVICE_HPP
+
+#include <hip/hip_runtime.h>
+
+#include "urf_internal.hpp"
+#include "urf_libm.h"
+
+#define URF_WAVE 64
+
+__device__ __forceinline__ unsigned urf_lane() { return __lane_id(); }
+
+/* Mask of the lanes of this wave that hold the same key.  Every lane of the
+ * wave must be active.  nbits = number of key bits that can differ. */
+__device__ __forceinline__ unsigned long long urf_match_any(unsigned key, unsigned nbits)
+{
+    unsigned long long m = ~0ull;
+    for (unsigned b = 0; b < nbits; b++) {
+        const bool bit = (key >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+
+__device__ __forceinline__ unsigned urf_popc_below(unsigned long long m)
+{
+    return __popcll(m & ((1ull << urf_lane()) - 1ull));
+}
+
+__device__ __forceinline__ bool urf_is_leader(unsigned long long m)
+{
+    return (unsigned)__ffsll((long long)m) - 1u == urf_lane();
+}
+
+/* scan s occupies [off, off+len) of every per-point array */
+__device__ __forceinline__ void urf_scan_range(const urf_kargs& a, unsigned s, unsigned& off, unsigned& len)
+{
+    if (a.offsets) {
+        off = a.offsets[s];
+        len = a.offsets[s + 1] - off;
+    } else {
+        off = s * a.n_per_scan;
+        len = a.n_per_scan;
+    }
+}
+
+/* ---- per-point expressions ------------------------------------------------ */
+
+/* lidar_segmentation.cpp:106-113 */
+__device__ __forceinline__ bool urf_in_roi(const urf_params& p, float x, float y, float z)
+{
+    return x >= p.min_X && x <= p.max_X && y >= p.min_Y && y <= p.max_Y &&
+           z >= p.min_Z && z <= p.max_Z && (x + y) + z != 0.0f;
+}
+
+/* lidar_segmentation.cpp:148-166: 3-D range in double, vertical angle in degrees */
+__device__ __forceinline__ float urf_vertical_angle(float x, float y, float z)
+{
+    const float d = (float)__builtin_sqrt((double)x * (double)x + (double)y * (double)y + (double)z * (double)z);
+    float b = __builtin_fabsf(z) / d;
+    if (b < -1.0f)
+        b = -1.0f;
+    else if (b > 1.0f)
+        b = 1.0f;
+    if (z < 0.0f)
+        return (float)((double)(urf_acosf(b) * 180.0f) / URF_PI_D);
+    return (float)((double)(urf_asinf(b) * 180.0f) / URF_PI_D + 90.0);
+}
+
+/* lidar_segmentation.cpp:245-269: planar range and azimuth in degrees
+ * (0 at -y, 90 at +x, 180 at +y, 270 at -x) */
+__device__ __forceinline__ float urf_azimuth(float x, float y, float* d_out)
+{
+    const float d = (float)__builtin_sqrt((double)x * (double)x + (double)y * (double)y);
+    *d_out = d;
+    float b = __builtin_fabsf(x) / d;
+    if (b < -1.0f)
+        b = -1.0f;
+    else if (b > 1.0f)
+        b = 1.0f;
+    const double t = (double)(urf_asinf(b) * 180.0f) / URF_PI_D;
+    if (x >= 0.0f && y <= 0.0f)
+        return (float)t;
+    if (x >= 0.0f && y > 0.0f)
+        return (float)(180.0 - t);
+    if (x < 0.0f && y >= 0.0f)
+        return (float)(180.0 + t);
+    return (float)(360.0 - t);
+}
+
+/* star_shaped_search.cpp:164-171: sector of a point (index == sectors wraps to 0,
+ * where the reference dereferences a null pointer) */
+__device__ __forceinline__ unsigned urf_sector(float x, float y, float Kfi, unsigned sectors)
+{
+    float fi = urf_atan2f(y, x);
+    if (fi < 0.0f)
+        fi = (float)((double)fi + 2.0 * URF_PI_D);
+    const int f = (int)(fi * Kfi);
+    return ((unsigned)f >= sectors) ? 0u : (unsigned)f;
+}
+
+/* star_shaped_search.cpp:73-107: is the point inside the rectangular beam of its sector */
+__device__ __forceinline__ bool urf_in_beam(const urf_beam& b, float x, float y)
+{
+    if (b.yx) {
+        const float c = b.d * y;
+        return (c - b.o) < x && x < (c + b.o);
+    }
+    const float c = b.d * x;
+    return (c - b.o) < y && y < (c + b.o);
+}
+
+/* non-negative floats order like their bit patterns */
+__device__ __forceinline__ unsigned urf_fbits(float f) { return __float_as_uint(f); }
+
+#endif /* URF_DEVICE_HPP */

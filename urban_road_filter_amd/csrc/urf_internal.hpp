@@ -1,0 +1,104 @@
+/*
+ * urf_internal.hpp -- limits, device-side views and the context shared by the
+ * host API (urf_api.hip) and the kernels (urf_kernels.hpp).
+ */
+#ifndef URF_INTERNAL_HPP
+#define URF_INTERNAL_HPP
+
+#include <cstddef>
+#include <cstdint>
+
+#include "urf.h"
+
+/* ---- limits --------------------------------------------------------------- */
+#define URF_MAX_CHANNELS    128    /* ring keys fit 7 bits + "none" */
+#define URF_MAX_SECTORS     1022   /* sector keys fit 10 bits + "none" */
+#define URF_MAX_CURB_POINTS 30     /* cfg/LidarFilters.cfg:36 */
+#define URF_DEG_CELLS       361    /* integer degrees 0..360 (blind_spots.cpp:68,177) */
+
+/* one tile = the unit of the stable multi-split by ring / by sector */
+#define URF_TILE            4096
+#define URF_TILE_THREADS    1024
+#define URF_TILE_GROUPS     (URF_TILE / 64)   /* wave-sized groups per tile */
+
+#define URF_RING_NONE       0xFFu
+#define URF_SEC_NONE        0x3FFu
+
+int urf_validate_params(const urf_params* p);
+
+/* Per-sector constants of the rectangular star beam
+ * (star_shaped_search.cpp:32-66 beam_init). */
+struct urf_beam {
+    int32_t yx;
+    float   d;
+    float   o;
+};
+
+/* Parameters as the kernels see them: the reference's scalars plus the values
+ * the reference derives once per scan or per start-up. */
+struct urf_dev_params {
+    urf_params p;
+    float    slope_param;   /* star_shaped_search.cpp:160 */
+    float    Kfi;           /* star_shaped_search.cpp:65  */
+    float    fwd_limit;     /* 360 - beamZone  (blind_spots.cpp:68)  */
+    float    bwd_limit;     /* 0 + beamZone    (blind_spots.cpp:177) */
+    float    inv_cp;        /* 1 / (float)curbPoints (z_zero_method.cpp:52) */
+    uint32_t sec_keybits;   /* bits needed for sector keys incl. "none" */
+    uint32_t ring_keybits;
+};
+
+/* Everything a kernel needs to find a scan's data.  All pointers are device
+ * memory owned by the context except x/y/z/labels/info (caller's). */
+struct urf_kargs {
+    /* input */
+    const float* x;
+    const float* y;
+    const float* z;
+    const uint32_t* offsets;    /* ragged: [n_scans+1]; else NULL */
+    uint32_t n_per_scan;
+    uint32_t n_scans;
+    uint32_t max_len;
+    uint32_t tiles;             /* tiles per scan = ceil(max_len / URF_TILE) */
+    /* output */
+    uint8_t* labels;
+    urf_scan_info* info;        /* context copy, [n_scans] */
+    /* per point, input order */
+    float*    valpha;
+    uint16_t* seckey;
+    uint8_t*  ringkey;
+    /* per point, ring-major */
+    float*    rx;
+    float*    ry;
+    float*    rz;
+    uint32_t* rsrc;
+    float*    raz;
+    float*    rd2;              /* debug only (may be NULL) */
+    uint8_t*  rflag;
+    /* per point, sector-major */
+    float*    sr;
+    float*    sz;
+    uint32_t* ssrc;
+    /* per scan x tile */
+    uint32_t* tile_roi;         /* [S][tiles] ROI points of the tile */
+    uint32_t* tile_ring;        /* [S][tiles][channels] per-tile ring counts; k_offsets turns them into the
+                                   position of the tile's first point of ring c inside ring c */
+    uint32_t* tile_sec;         /* [S][tiles][sectors]  same for star sectors */
+    /* per scan */
+    float*    angle;            /* [S][channels] sorted ring-angle table */
+    uint32_t* ring_cnt;         /* [S][channels] */
+    uint32_t* ring_off;         /* [S][channels+1] */
+    uint32_t* sec_cnt;          /* [S][sectors] */
+    uint32_t* sec_off;          /* [S][sectors+1] */
+    int32_t*  star_hit;         /* [S][sectors] input index (scan-relative) of the sector's curb point, -1 none */
+    float*    maxdist;          /* [S][channels] */
+    float*    quad;             /* [S][4] */
+    float*    sufmin;           /* [S][channels][361] */
+    float*    premax;           /* [S][channels][361] */
+    int16_t*  stop_f;           /* [S][361] */
+    int16_t*  stop_b;           /* [S][361] */
+    /* tables */
+    const float*    newY;       /* [max_points] x_zero_method.cpp:24-27 */
+    const urf_beam* beams;      /* [sectors] */
+};
+
+#endif /* URF_INTERNAL_HPP */
