@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- scans/sec of the urban_road_filter classification hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scans S]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One STEP = one pass of the whole hot path (all kernels of urf_classify_batch_soa: ROI, ring
+table, ring split, star-shaped search, x_zero, z_zero, blind-spot beam march, label write-back)
+over one HBM-resident batch of S = 1024 independent synthetic 64-ring x 2048-column sweeps
+(BASELINE.json configs[2] "throughput saturation", the configuration the scans/sec metric is
+quoted on).  With N GPUs every rank owns its own batch of S sweeps (weak
+scaling, no collective on the data path; RCCL only reduces timing and counters -- SURVEY.md 8e).
+
+Prints ONE JSON line (rank 0).  value = N*S*K / t, t = max over ranks of the wall time of exactly
+K steps bracketed by barrier + device synchronize.  Inputs are resident in HBM before the timed
+region; the PCIe-inclusive rate is reported separately as `h2d_inclusive_scans_per_s`.
+"""
+import argparse
+import concurrent.futures as cf
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+RINGS, COLS = 64, 2048
+N_PTS = RINGS * COLS
+ALG_BYTES_PER_SCAN = 13 * N_PTS          # 12 B x,y,z read + 1 B label written per point
+HBM_PEAK_GBS = 8000.0                    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def gen_batch(n_scans, seed0):
+    """n_scans distinct street sweeps (seeds seed0..), generated on a thread pool
+    (urf_synth_cloud releases the GIL)."""
+    import urban_road_filter_amd as u
+    X = np.empty((n_scans, N_PTS), np.float32)
+    Y = np.empty_like(X)
+    Z = np.empty_like(X)
+
+    def one(s):
+        x, y, z = u.synth_cloud(RINGS, COLS, 1, seed0 + s)
+        X[s], Y[s], Z[s] = x, y, z
+
+    with cf.ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        list(ex.map(one, range(n_scans)))
+    return X, Y, Z
+
+
+def cpu_baseline(params, budget_scans=6):
+    """The reference's own CPU path (oracle/_ref, built from its unmodified sources) timed on the
+    host cores of this box: single process, and P = min(cores, 16) independent processes (the
+    reference is single-threaded and keeps its state in globals).  A bounded sample: each process
+    classifies `budget_scans` sweeps after one excluded warm-up call (first-touch of its 512 MiB
+    scratch).  Falls back to the C restatement (kind "port") when the binary is absent."""
+    import oracles as O
+    cores_avail = os.cpu_count() or 1
+    scans = [O.cfg_cloud("cfg2", 1 + s) for s in range(2)]
+    if O.has_oracle_a():
+        kind = "reference"
+        _, _, ms1, _ = O.run_a(scans, params, repeat=1 + budget_scans // 2)
+        single = 1000.0 / ms1
+        P = min(cores_avail, 16)
+        # P concurrent processes
+        with tempfile.TemporaryDirectory() as td:
+            import struct
+            fin = os.path.join(td, "in.bin")
+            with open(fin, "wb") as f:
+                f.write(b"URFREFIN")
+                f.write(struct.pack("<4I", len(scans), N_PTS, 1 + budget_scans // 2, 0))
+                f.write(bytes(params))
+                for x, y, z in scans:
+                    f.write(x.tobytes()); f.write(y.tobytes()); f.write(z.tobytes())
+            procs = [subprocess.Popen([O.ORACLE_A, fin, os.path.join(td, "o%d.bin" % i)]) for i in range(P)]
+            for pr in procs:
+                pr.wait()
+            rates = []
+            for i in range(P):
+                blob = open(os.path.join(td, "o%d.bin" % i), "rb").read()
+                rates.append(1000.0 / struct.unpack_from("<d", blob, 16)[0])
+        multi = float(sum(rates))
+        sample = ("%d x 64x2048 street sweeps per process after 1 excluded warm-up call; "
+                  "value = sum over %d concurrent single-threaded processes" % (2 * (1 + budget_scans // 2) - 1, P))
+        return {"value": round(multi, 3), "unit": "scans/s", "cores": P, "kind": kind, "sample": sample,
+                "single_core_value": round(single, 3), "host_cores_available": cores_avail}
+    kind = "port"
+    t0 = time.perf_counter()
+    k = 0
+    while k < 3 * budget_scans:
+        O.run_b(*scans[k % 2], params)
+        k += 1
+    single = k / (time.perf_counter() - t0)
+    return {"value": round(single, 3), "unit": "scans/s", "cores": 1, "kind": kind,
+            "sample": "%d x 64x2048 street sweeps, oracle/urf_oracle.c, one thread" % k,
+            "host_cores_available": cores_avail}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scans", type=int, default=1024, help="sweeps per GPU per step (BASELINE cfg3: 1024)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-scans", type=int, default=4)
+    args = ap.parse_args()
+
+    import torch   # first: the HIP runtime torch bundles is the one the C-ABI library binds to
+    import torch.distributed as dist
+    import oracles as O
+    import urban_road_filter_amd as u
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        # convenience: re-launch ourselves under torch.distributed.run
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the classification has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    S = args.scans
+    params = O.cfg_params("cfg2")   # reference defaults, ROI widened to +-200 m
+    t_gen = time.perf_counter()
+    X, Y, Z = gen_batch(S, 1 + rank * S)          # seeds 1..S on rank 0, S+1..2S on rank 1, ...
+    t_gen = time.perf_counter() - t_gen
+
+    stream = torch.cuda.current_stream()
+    t_h2d = time.perf_counter()
+    dx = torch.from_numpy(X).to(dev)
+    dy = torch.from_numpy(Y).to(dev)
+    dz = torch.from_numpy(Z).to(dev)
+    torch.cuda.synchronize()
+    t_h2d = time.perf_counter() - t_h2d
+    dl = torch.empty((S, N_PTS), dtype=torch.uint8, device=dev)
+    di = torch.zeros((S, 8), dtype=torch.int32, device=dev)
+
+    ctx = u.Context(N_PTS, S, device=local_rank, params=params)
+    ctx.set_stream(stream.cuda_stream)
+
+    def step():
+        ctx.classify_batch_soa(dx, dy, dz, N_PTS, S, dl, di)
+
+    # parity gate: no number is reported for a batch whose labels differ from the CPU oracle
+    step()
+    torch.cuda.synchronize()
+    L = dl[:args.parity_scans].cpu().numpy()
+    for s in range(min(args.parity_scans, S)):
+        lb, _, _ = O.run_b(X[s], Y[s], Z[s], params)
+        if not np.array_equal(L[s], lb):
+            raise SystemExit("parity failure on scan %d of rank %d: %d labels differ" % (s, rank, int((L[s] != lb).sum())))
+
+    for _ in range(args.warmup):
+        step()
+    ctx.enable_kernel_timing(True)
+    ctx.kernel_timing()                     # reset
+    ctx.enable_kernel_timing(True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kms, kcalls = ctx.kernel_timing()
+    ctx.enable_kernel_timing(False)
+
+    info = di.cpu().numpy().astype(np.int64)
+    counters = torch.tensor([S * args.steps, int(info[:, 1].sum()), int(info[:, 4].sum()), int(info[:, 5].sum()),
+                             int((info[:, 0] == 0).sum())], dtype=torch.int64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+    elapsed_max = float(tmax.item())
+    counters = counters.cpu().numpy()
+
+    if rank == 0:
+        total_scans = int(counters[0])
+        value = total_scans / elapsed_max
+        ms_step = 1e3 * elapsed_max / args.steps
+        dom = max(kms, key=lambda k: kms[k])
+        dom_ms = kms[dom] / max(kcalls, 1)
+        alg_bytes_launch = ALG_BYTES_PER_SCAN * S
+        achieved = alg_bytes_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        whole = ALG_BYTES_PER_SCAN * S / (ms_step * 1e-3) / 1e9
+        out = {
+            "metric": "scans/sec (64-ring x 2048-column cloud)",
+            "value": round(value, 2),
+            "unit": "scans/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32+f64",
+            "data": "synthetic",
+            "config": {"workload": "cfg3: batch of %d independent 64x2048 street sweeps per GPU, all three detectors "
+                                   "+ blind_spots, reference default parameters with ROI x,y widened to +-200 m, "
+                                   "inputs resident in HBM (SoA x/y/z)" % S,
+                       "scans_per_gpu": S, "points_per_scan": N_PTS, "sharding": "one batch per GPU, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": dom, "kernel_ms": round(dom_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         "whole_pipeline_achieved": round(whole, 2), "whole_pipeline_frac": round(whole / HBM_PEAK_GBS, 5)},
+            "kernel_ms": {k: round(v / max(kcalls, 1), 4) for k, v in kms.items()},
+            "counters": {"scans": total_scans, "roi_points_last_step": int(counters[1]), "road_last_step": int(counters[2]),
+                         "curb_last_step": int(counters[3]), "ok_scans_last_step": int(counters[4])},
+            "parity_checked_scans": min(args.parity_scans, S),
+            "h2d_inclusive_scans_per_s": round(S / (ms_step * 1e-3 + t_h2d), 2),
+            "h2d_seconds_per_batch": round(t_h2d, 4),
+            "gen_seconds": round(t_gen, 2),
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file))
+                if tr.get("kernel") == dom and tr.get("scans_per_launch") == S:
+                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc, corrected per MI355X_MICROARCH.md)"
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

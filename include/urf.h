@@ -209,10 +209,22 @@ int urf_read_stage(urf_ctx* ctx, urf_stage what, uint32_t scan, void* host_dst, 
  * capture is on (default off). */
 int urf_enable_stage_capture(urf_ctx* ctx, int on);
 
+/* ---- per-kernel timing (benchmark) ------------------------------------------
+ * With timing on, every classify call brackets each kernel of the pipeline
+ * with hipEvents on the context's stream.  urf_kernel_timing() synchronises,
+ * adds the elapsed milliseconds of all calls since the last query to
+ * ms_sum[0..URF_NUM_KERNELS) and the number of calls to *n_calls, then resets. */
+#define URF_NUM_KERNELS 9
+int urf_enable_kernel_timing(urf_ctx* ctx, int on);
+int urf_kernel_timing(urf_ctx* ctx, double* ms_sum, uint32_t* n_calls);
+const char* urf_kernel_name(int index);
+
 /* ---- synthetic sweeps -------------------------------
  * Host-side generator of the benchmark clouds: `rings` x `cols` rays from a
  * sensor 1.8 m above ground, scene 0 = flat plane, 1 = street with 0.15 m
- * curbs at |y| = 4 m; column-major "firing order" (idx = col*rings + ring);
+ * curbs at |y| = 4 m, 2 = narrow street (curbs at |y| = 3 m, inside the reach
+ * of the innermost rings, so that the blind-spot logic of blind_spots.cpp:17-99
+ * engages); column-major "firing order" (idx = col*rings + ring);
  * per-sector radial ties removed.  Writes n = rings*cols floats to x, y, z. */
 int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
                     float* x, float* y, float* z);

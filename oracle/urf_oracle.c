@@ -108,7 +108,7 @@ static void beam_init(box* beams, int rep, float width)
 }
 
 /* star_shaped_search.cpp:68-153 beamfunc */
-static void beamfunc(box* bm, pt3* array2D, const urf_params* prm, float slope_param)
+static void beamfunc(box* bm, pt3* array2D, const urf_params* prm, float slope_param, int16_t* dbg_sector)
 {
     int i = 0, s = bm->n;
     float c;
@@ -127,6 +127,8 @@ static void beamfunc(box* bm, pt3* array2D, const urf_params* prm, float slope_p
             }
             if (keep)
                 bm->p[w++] = bm->p[i];   /* erase() keeps the order of the survivors */
+            else if (dbg_sector)
+                dbg_sector[q->src] = -1; /* stage output: sector of the points that take part */
         }
         s = bm->n = w;
     }
@@ -192,7 +194,7 @@ static void star_shaped_search(pt3* array2D, int s, const urf_params* prm, int16
             dbg_sector[array2D[i].src] = (int16_t)f;
     }
     for (int i = 0; i < rep; i++)
-        beamfunc(&beams[i], array2D, prm, slope_param);                       /* :177-180 */
+        beamfunc(&beams[i], array2D, prm, slope_param, dbg_sector);                     /* :177-180 */
     for (int i = 0; i < rep; i++)
         free(beams[i].p);
     free(beams);

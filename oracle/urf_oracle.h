@@ -30,7 +30,7 @@ typedef struct urf_oracle_debug {
     float*   azimuth;     /* per point (bucketed points only, else 0) */
     float*   range2d;     /* per point (bucketed points only, else 0) */
     uint8_t* detect;      /* per point: bit0 star, bit1 x_zero, bit2 z_zero */
-    int16_t* sector;      /* per point; -1 outside the ROI or star disabled */
+    int16_t* sector;      /* per point; -1 outside the ROI, star disabled, or removed by the beam filter */
     float*   angle_table; /* [channels] sorted table, zero padded */
     float*   max_dist;    /* [channels] */
     float*   quadrants;   /* [4] q1..q4 */

@@ -126,7 +126,7 @@ def cfg_params(name):
     p = default_params().wide_roi()
     if name == "cfg1":      # 16x1024 flat, z_zero only
         p.x_zero_method, p.star_shaped_method, p.blind_spots = 0, 0, 0
-    elif name == "cfg2":    # 64x2048 street, all detectors + blind_spots
+    elif name in ("cfg2", "narrow"):    # 64x2048 street, all detectors + blind_spots
         pass
     elif name == "cfg5":    # 128x4096, channels 128, interval 0.05
         p.channels, p.interval = 128, 0.05
@@ -143,6 +143,8 @@ def cfg_cloud(name, seed=1):
         return synth_cloud(16, 1024, 0, seed)
     if name in ("cfg2", "default_roi"):
         return synth_cloud(64, 2048, 1, seed)
+    if name == "narrow":   # curbs within reach of ring 1: blind-spot quadrants engage
+        return synth_cloud(64, 2048, 2, seed)
     if name == "cfg5":
         return synth_cloud(128, 4096, 1, seed)
     raise KeyError(name)

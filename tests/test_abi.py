@@ -1,0 +1,71 @@
+"""The C-ABI library loads without a GPU and exports every function include/urf.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import urban_road_filter_amd as u
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "urf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(urf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported():
+    names = declared_functions()
+    assert len(names) >= 18
+    L = ctypes.CDLL(u.lib_path())
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_abi_version_and_struct_size():
+    assert u.lib().urf_abi_version() == 1
+    p = u.default_params()
+    assert p.size == ctypes.sizeof(u.Params) == 104
+    assert ctypes.sizeof(u.ScanInfo) == 32
+
+
+def test_defaults_are_the_reference_defaults():
+    """cfg/LidarFilters.cfg:10-84 + lidar_segmentation.cpp:4 + star_shaped_search.cpp:8-9."""
+    p = u.default_params()
+    got = {k: getattr(p, k) for k, _ in u.Params._fields_ if k != "size"}
+    f = lambda v: ctypes.c_float(v).value  # noqa: E731
+    want = dict(x_zero_method=1, z_zero_method=1, star_shaped_method=1, blind_spots=1, xDirection=0,
+                interval=f(0.18), curbHeight=f(0.05), curbPoints=5, beamZone=30.0,
+                min_X=0.0, max_X=30.0, min_Y=-10.0, max_Y=10.0, min_Z=-3.0, max_Z=-1.0,
+                angleFilter1=150.0, angleFilter2=140.0, angleFilter3=50.0,
+                kdev_param=f(1.225), kdist_param=2.0, starbeam_filter=0, dmin_param=10,
+                channels=64, sectors=360, beam_width=f(0.2))
+    assert got == want
+
+
+def test_strerror_covers_all_codes():
+    L = u.lib()
+    for code in (0, 1, -1, -2, -3, -4, -5, -6):
+        assert L.urf_strerror(code) and b"unknown" not in L.urf_strerror(code)
+    assert b"unknown" in L.urf_strerror(-99)
+
+
+def test_no_cpu_fallback_without_gpu():
+    """The product path must fail loudly when there is no device -- it never routes to the oracle."""
+    from conftest import gpu_available
+    if gpu_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(u.UrfError) as e:
+        u.Context(1024, 1)
+    assert e.value.code == -2
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "urban_road_filter_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in txt.lower(), fn

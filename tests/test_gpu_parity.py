@@ -1,0 +1,335 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/urf.h), against
+  - the golden label vectors produced by the reference's own sources (tests/golden/),
+  - oracle B on the same seeded inputs (labels, per-scan counts and every intermediate stage),
+  - size-independent properties at the benchmark's full batch size.
+Bar: integer labels / ring / sector ids bit-exact; floats (vertical angle, azimuth, planar range)
+within 1e-5 relative -- they are in fact bit-identical because host and device share
+include/urf_libm.h and every other operation is an IEEE basic operation."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracles as O
+import urban_road_filter_amd as u
+from golden.make_golden import CASES, case_params, cloud_sha
+from hipmem import DevBuf
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FTOL = 1e-5
+
+
+def close(a, b):
+    return np.abs(a.astype(np.float64) - b) <= FTOL * np.maximum(1.0, np.abs(b))
+
+
+@pytest.fixture(scope="module")
+def ctx_big():
+    c = u.Context(128 * 4096, 1)
+    yield c
+    c.close()
+
+
+def info_equal(ig, ib):
+    return all(getattr(ig, k) == ib[k] for k in ("status", "n_roi", "n_rings", "n_ring_pts", "n_road", "n_curb", "n_ring10"))
+
+
+@pytest.mark.parametrize("name,cfg,seed,tweak", CASES, ids=[c[0] for c in CASES])
+def test_golden_cases(ctx_big, name, cfg, seed, tweak):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    p = case_params(cfg, tweak)
+    x, y, z = O.cfg_cloud(cfg, seed)
+    assert cloud_sha(x, y, z) == str(g["cloud_sha"])
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(lg & O.MASK_NO_RING, g["labels"]), "differs from the reference's labels"
+    lb, ib, _ = O.run_b(x, y, z, p)
+    assert np.array_equal(lg, lb)
+    assert info_equal(ig, ib)
+
+
+@pytest.mark.parametrize("cfg,seed,tweak", [("cfg2", 2, {}), ("narrow", 3, {"xDirection": 2}),
+                                            ("cfg5", 2, {}), ("default_roi", 3, {"starbeam_filter": 1}),
+                                            ("cfg1", 4, {})])
+def test_every_stage(ctx_big, cfg, seed, tweak):
+    p = case_params(cfg, tweak)
+    x, y, z = O.cfg_cloud(cfg, seed)
+    n = len(x)
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    ctx_big.set_params(p)
+    ctx_big.enable_stage_capture(True)
+    try:
+        lg, ig = ctx_big.classify_xyz(x, y, z)
+        roi = (lb & u.FLAG_ROI) != 0
+        ring = (lb & u.FLAG_RING) != 0
+        va = ctx_big.read_stage(u.STAGE_VALPHA, n)
+        assert close(va[roi], st["valpha"][roi]).all() and (va[~roi] < 0).all()
+        assert np.array_equal(va[roi], st["valpha"][roi])                      # in fact bit-identical
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_ANGLE_TABLE, n), st["angle_table"])
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_RING, n), st["ring"])
+        if p.star_shaped_method:
+            assert np.array_equal(ctx_big.read_stage(u.STAGE_SECTOR, n), st["sector"])
+        az = ctx_big.read_stage(u.STAGE_AZIMUTH, n)
+        d2 = ctx_big.read_stage(u.STAGE_RANGE2D, n)
+        assert close(az[ring], st["azimuth"][ring]).all() and close(d2[ring], st["range2d"][ring]).all()
+        assert np.array_equal(az[ring], st["azimuth"][ring]) and np.array_equal(d2[ring], st["range2d"][ring])
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, n), st["detect"])
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_MAXDIST, n), st["max_dist"])
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_QUADRANTS, n), st["quadrants"])
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_BEAM_STOP, n), st["beam_stop"])
+        assert np.array_equal(lg, lb) and info_equal(ig, ib)
+    finally:
+        ctx_big.enable_stage_capture(False)
+
+
+def run_batch(ctx, scans, p, ragged=False):
+    """Device-resident batch through urf_classify_batch_soa(_ragged); returns labels per scan + infos."""
+    lens = [len(s[0]) for s in scans]
+    X = np.concatenate([s[0] for s in scans]) if scans else np.zeros(0, np.float32)
+    Y = np.concatenate([s[1] for s in scans]) if scans else np.zeros(0, np.float32)
+    Z = np.concatenate([s[2] for s in scans]) if scans else np.zeros(0, np.float32)
+    dx, dy, dz = DevBuf.from_numpy(X), DevBuf.from_numpy(Y), DevBuf.from_numpy(Z)
+    dl = DevBuf(len(X))
+    dl.fill(0xEE)
+    di = DevBuf(32 * len(scans))
+    ctx.set_params(p)
+    if ragged:
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        do = DevBuf.from_numpy(offs)
+        ctx.classify_batch_soa_ragged(dx, dy, dz, do, max(lens), len(scans), dl, di)
+    else:
+        assert len(set(lens)) == 1
+        ctx.classify_batch_soa(dx, dy, dz, lens[0], len(scans), dl, di)
+    ctx.synchronize()
+    L = dl.to_numpy(np.uint8)
+    infos = di.to_numpy(np.uint32).reshape(len(scans), 8)
+    out, pos = [], 0
+    for n in lens:
+        out.append(L[pos:pos + n])
+        pos += n
+    return out, infos
+
+
+def check_against_b(labels, infos, scans, p):
+    for k, (x, y, z) in enumerate(scans):
+        lb, ib, _ = O.run_b(x, y, z, p)
+        assert np.array_equal(labels[k], lb), "scan %d" % k
+        got = dict(zip(("status", "n_roi", "n_rings", "n_ring_pts", "n_road", "n_curb", "n_ring10"), infos[k][:7]))
+        assert got == ib, "scan %d" % k
+
+
+def test_uniform_batch_of_distinct_scans():
+    p = O.cfg_params("cfg2")
+    scans = [O.cfg_cloud("cfg2" if s % 2 else "narrow", 10 + s) for s in range(6)]
+    with u.Context(64 * 2048, 6) as ctx:
+        labels, infos = run_batch(ctx, scans, p)
+        check_against_b(labels, infos, scans, p)
+
+
+def test_ragged_batch_with_empty_tiny_and_partial_scans():
+    p = O.cfg_params("cfg2")
+    full = O.cfg_cloud("cfg2", 21)
+    part = tuple(a[:50000].copy() for a in O.cfg_cloud("cfg2", 22))
+    odd = tuple(a[:4097].copy() for a in O.cfg_cloud("narrow", 23))     # one point into the second tile
+    tiny = tuple(a[:29].copy() for a in full)                          # < 30 ROI points
+    empty = tuple(np.zeros(0, np.float32) for _ in range(3))
+    flat16 = O.cfg_cloud("cfg1", 24)                                    # 16 rings with channels = 64
+    scans = [part, empty, full, tiny, odd, flat16]
+    with u.Context(64 * 2048, len(scans)) as ctx:
+        labels, infos = run_batch(ctx, scans, p, ragged=True)
+        check_against_b(labels, infos, scans, p)
+        assert infos[1][0] == 1 and infos[3][0] == 1 and not labels[3].any()   # URF_TOO_FEW_POINTS, nothing published
+
+
+def test_pointcloud2_layouts(ctx_big):
+    p = O.cfg_params("cfg2")
+    x, y, z = O.cfg_cloud("cfg2", 31)
+    n = len(x)
+    lb, ib, _ = O.run_b(x, y, z, p)
+    ctx_big.set_params(p)
+    # Ouster-like record: x y z pad intensity t reflectivity ring ... point_step 48
+    rec = np.zeros((n, 48), np.uint8)
+    rec[:, 0:4] = x.view(np.uint8).reshape(n, 4)
+    rec[:, 4:8] = y.view(np.uint8).reshape(n, 4)
+    rec[:, 8:12] = z.view(np.uint8).reshape(n, 4)
+    rec[:, 16:48] = 0xAB
+    lg, ig = ctx_big.classify_pc2(rec, n, 48, 0, 4, 8)
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+    # permuted, unaligned fields: point_step 23, z at 1, x at 9, y at 17
+    rec = np.full((n, 23), 0x5A, np.uint8)
+    rec[:, 1:5] = z.view(np.uint8).reshape(n, 4)
+    rec[:, 9:13] = x.view(np.uint8).reshape(n, 4)
+    rec[:, 17:21] = y.view(np.uint8).reshape(n, 4)
+    lg, ig = ctx_big.classify_pc2(rec, n, 23, 9, 17, 1)
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+
+
+def test_roi_edge_cases(ctx_big):
+    p = O.cfg_params("cfg2")
+    x, y, z = [a.copy() for a in O.cfg_cloud("cfg2", 41)]
+    x[100] = np.nan
+    y[101] = np.inf
+    x[200] = y[200] = z[200] = 0.0                 # "no return"
+    x[300], y[300], z[300] = 1.0, 1.0, -2.0        # x + y + z == 0 is dropped (lidar_segmentation.cpp:111)
+    z[400:500] = 0.5                               # above the z ROI
+    lb, ib, _ = O.run_b(x, y, z, p)
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+    assert not lg[[100, 101, 200, 300]].any() and not lg[400:500].any()
+    # everything outside the ROI
+    lg, ig = ctx_big.classify_xyz(x, y, np.full_like(z, 10.0))
+    assert ig.status == 1 and ig.n_roi == 0 and not lg.any()
+
+
+def test_thirty_point_threshold(ctx_big):
+    p = O.cfg_params("cfg2")
+    x, y, z = [a[:4096].copy() for a in O.cfg_cloud("cfg2", 1)]
+    z[29:] = 5.0
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert ig.status == 1 and ig.n_roi == 29 and not lg.any()
+    z[29] = -1.8
+    lb, ib, _ = O.run_b(x, y, z, p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert ig.status == 0 and ig.n_roi == 30 and np.array_equal(lg, lb) and info_equal(ig, ib)
+
+
+@pytest.mark.parametrize("tweak", [{"channels": 32}, {"channels": 7, "interval": 0.5}, {"interval": 0.4},
+                                   {"curbPoints": 1}, {"curbPoints": 30}, {"beamZone": 100.0}, {"beamZone": 10.25},
+                                   {"x_zero_method": 0, "star_shaped_method": 0}, {"z_zero_method": 0, "x_zero_method": 0},
+                                   {"dmin_param": 3, "kdist_param": 0.4, "angleFilter3": 5.0},
+                                   {"angleFilter1": 179.0, "angleFilter2": 10.0, "curbHeight": 0.01}])
+def test_parameter_corners(ctx_big, tweak):
+    """Ring table overflow (more rings than channels, lidar_segmentation.cpp:191), merged rings,
+    extreme curb_points / beamZone, detectors switched off one by one."""
+    p = case_params("narrow", tweak)
+    x, y, z = O.cfg_cloud("narrow", 51)
+    lb, ib, _ = O.run_b(x, y, z, p)
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+
+
+def crowded_cloud(n_pts, rings=3, seed=5):
+    """All points in a handful of sectors and rings: sector sizes far beyond one LDS tile
+    (exercises the 512 < n <= 2048 and the global-memory sort paths) and rings longer than a tile."""
+    rng = np.random.default_rng(seed)
+    elev = np.deg2rad(-20.0 + 4.0 * (np.arange(n_pts) % rings))
+    az = np.deg2rad(10.3 + 0.4 * rng.random(n_pts))          # inside sectors 10 / 11
+    t = 1.8 / -np.sin(elev) * (1 + 0.02 * rng.random(n_pts))
+    x = (t * np.cos(elev) * np.cos(az)).astype(np.float32)
+    y = (t * np.cos(elev) * np.sin(az)).astype(np.float32)
+    z = (t * np.sin(elev)).astype(np.float32)
+    # make the planar ranges unique (ties are unspecified in the reference)
+    r = np.sqrt(x * x + y * y)
+    _, first = np.unique(r, return_index=True)
+    keep = np.sort(first)
+    return x[keep], y[keep], z[keep]
+
+
+@pytest.mark.parametrize("n_pts", [1500, 6000, 40000])
+def test_crowded_sectors(ctx_big, n_pts):
+    p = O.cfg_params("cfg2")
+    p.interval = 1.0
+    x, y, z = crowded_cloud(n_pts)
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, len(x)), st["detect"])
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+
+
+def test_ring_table_zero_sentinel(ctx_big):
+    """A point straight below the sensor has vertical angle exactly 0, which the reference's ring
+    table treats as its end-of-table mark (lidar_segmentation.cpp:176).  Ring assignment must
+    follow the reference even then (labels are not compared: that point's azimuth is NaN, see
+    DESIGN.md 'deviations')."""
+    p = O.cfg_params("cfg2")
+    x, y, z = [a[:8192].copy() for a in O.cfg_cloud("cfg2", 61)]
+    x[3] = y[3] = 0.0
+    z[3] = -1.8
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_ANGLE_TABLE, len(x)), st["angle_table"])
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_RING, len(x)), st["ring"])
+    assert ig.n_rings == ib["n_rings"] and (lg[3] & 3) != 1
+
+
+def test_storage_order_invariance(ctx_big):
+    p = O.cfg_params("cfg2")
+    x, y, z = O.cfg_cloud("cfg2", 71)
+    perm = np.arange(64 * 2048).reshape(2048, 64).T.reshape(-1)
+    ctx_big.set_params(p)
+    l1, _ = ctx_big.classify_xyz(x, y, z)
+    l2, _ = ctx_big.classify_xyz(x[perm], y[perm], z[perm])
+    assert np.array_equal(l1[perm], l2)
+
+
+def test_index_lists(ctx_big):
+    p = O.cfg_params("cfg2")
+    x, y, z = O.cfg_cloud("cfg2", 81)
+    n = len(x)
+    ctx_big.set_params(p)
+    lg, _ = ctx_big.classify_xyz(x, y, z)
+    dl = DevBuf.from_numpy(lg)
+    bufs = [DevBuf(4 * n) for _ in range(4)]
+    dc = DevBuf(16)
+    ctx_big.compact_indices(dl, n, *bufs, dc)
+    ctx_big.synchronize()
+    cnt = dc.to_numpy(np.uint32)
+    want = [np.nonzero((lg & 3) == 1)[0], np.nonzero((lg & 3) == 2)[0], np.nonzero(lg & 4)[0], np.nonzero(lg & 16)[0]]
+    for k in range(4):
+        assert cnt[k] == len(want[k])
+        assert np.array_equal(bufs[k].to_numpy(np.uint32, int(cnt[k])), want[k])
+
+
+def test_full_size_batch_properties():
+    """BASELINE cfg3 size (1024 scans of 64x2048): 64 distinct sweeps repeated 16 times.
+    Properties: every copy of a sweep gets identical labels wherever it sits in the batch;
+    a second pass over the batch is idempotent; the 64 distinct results equal oracle B; the
+    per-scan counters add up to the label histogram."""
+    S, R = 1024, 64
+    p = O.cfg_params("cfg2")
+    uniq = [O.cfg_cloud("cfg2" if s % 4 else "narrow", 100 + s) for s in range(R)]
+    n = 64 * 2048
+    X = np.concatenate([c[0] for c in uniq])
+    Y = np.concatenate([c[1] for c in uniq])
+    Z = np.concatenate([c[2] for c in uniq])
+    reps = S // R
+    dx, dy, dz = (DevBuf.from_numpy(np.tile(a, reps)) for a in (X, Y, Z))
+    dl, di = DevBuf(S * n), DevBuf(32 * S)
+    with u.Context(n, S, params=p) as ctx:
+        ctx.classify_batch_soa(dx, dy, dz, n, S, dl, di)
+        L1 = dl.to_numpy(np.uint8).reshape(S, n)
+        I1 = di.to_numpy(np.uint32).reshape(S, 8)
+        ctx.classify_batch_soa(dx, dy, dz, n, S, dl, di)
+        L2 = dl.to_numpy(np.uint8).reshape(S, n)
+    assert np.array_equal(L1, L2)
+    for r in range(1, reps):
+        assert np.array_equal(L1[r * R:(r + 1) * R], L1[:R])
+        assert np.array_equal(I1[r * R:(r + 1) * R], I1[:R])
+    assert np.array_equal((L1[:R] & 3 == 1).sum(1), I1[:R, 4]) and np.array_equal((L1[:R] & 3 == 2).sum(1), I1[:R, 5])
+    for s in range(R):
+        lb, ib, _ = O.run_b(*uniq[s], p)
+        assert np.array_equal(L1[s], lb), "scan %d" % s
+
+
+def test_capacity_and_argument_errors():
+    with u.Context(4096, 2) as ctx:
+        x, y, z = [a[:8192] for a in O.cfg_cloud("cfg2", 1)]
+        with pytest.raises(u.UrfError) as e:
+            ctx.classify_xyz(x, y, z)
+        assert e.value.code == -4
+        p = u.default_params()
+        p.channels = 500
+        with pytest.raises(u.UrfError) as e:
+            ctx.set_params(p)
+        assert e.value.code == -6
+        p = u.default_params()
+        p.size = 8
+        with pytest.raises(u.UrfError):
+            ctx.set_params(p)

@@ -1,0 +1,69 @@
+"""include/urf_libm.h (the shared acosf/asinf/atan2f) through oracle B's exports:
+correctly rounded w.r.t. a binary64 evaluation and within 1 ulp of the host libm."""
+import ctypes
+
+import numpy as np
+
+import oracles as O
+
+
+def _vec(fn, *args):
+    L = O.oracle_b()
+    f = getattr(L, fn)
+    return np.array([f(*[ctypes.c_float(float(a)) for a in t]) for t in zip(*args)], np.float32)
+
+
+_M = ctypes.CDLL("libm.so.6")
+for _f in ("asinf", "acosf"):
+    getattr(_M, _f).argtypes = [ctypes.c_float]
+    getattr(_M, _f).restype = ctypes.c_float
+_M.atan2f.argtypes = [ctypes.c_float, ctypes.c_float]
+_M.atan2f.restype = ctypes.c_float
+
+
+def _libm(fn, *args):
+    """glibc's float functions -- what the reference itself calls on this host."""
+    f = getattr(_M, fn)
+    return np.array([f(*[float(a) for a in t]) for t in zip(*args)], np.float32)
+
+
+def _ulps(a, b):
+    ia = a.view(np.int32).astype(np.int64)
+    ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7fffffff), ia)
+    ib = np.where(ib < 0, -(ib & 0x7fffffff), ib)
+    return np.abs(ia - ib)
+
+
+def test_asin_acos_match_rounded_double():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-1, 1, 20000), [0, 1, -1, 0.5, -0.5, 1e-20, 0.99999994, -0.99999994]]).astype(np.float32)
+    a = _vec("urf_oracle_asinf", x)
+    c = _vec("urf_oracle_acosf", x)
+    assert np.array_equal(a, np.arcsin(x.astype(np.float64)).astype(np.float32))
+    assert np.array_equal(c, np.arccos(x.astype(np.float64)).astype(np.float32))
+    # within 1 ulp of the host's float libm (what the reference calls)
+    assert _ulps(a, _libm('asinf', x)).max() <= 1
+    assert _ulps(c, _libm('acosf', x)).max() <= 1
+
+
+def test_atan2_matches_rounded_double():
+    rng = np.random.default_rng(1)
+    y = rng.uniform(-100, 100, 20000).astype(np.float32)
+    x = rng.uniform(-100, 100, 20000).astype(np.float32)
+    r = _vec("urf_oracle_atan2f", y, x)
+    assert np.array_equal(r, np.arctan2(y.astype(np.float64), x.astype(np.float64)).astype(np.float32))
+    assert _ulps(r, _libm('atan2f', y, x)).max() <= 1
+
+
+def test_special_values():
+    L = O.oracle_b()
+    assert L.urf_oracle_acosf(1.0) == 0.0
+    assert L.urf_oracle_asinf(0.0) == 0.0
+    assert np.isnan(L.urf_oracle_acosf(1.5)) and np.isnan(L.urf_oracle_asinf(float("nan")))
+    pi = np.float32(np.pi)
+    assert np.float32(L.urf_oracle_acosf(-1.0)) == pi
+    assert np.float32(L.urf_oracle_atan2f(0.0, -1.0)) == pi
+    assert np.float32(L.urf_oracle_atan2f(-0.0, -1.0)) == -pi
+    assert L.urf_oracle_atan2f(0.0, 0.0) == 0.0
+    assert np.float32(L.urf_oracle_atan2f(1.0, 0.0)) == np.float32(np.pi / 2)

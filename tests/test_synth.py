@@ -1,0 +1,63 @@
+"""Properties the synthetic sweeps must have to be usable as parity fixtures."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import urban_road_filter_amd as u
+
+
+def sectors_of(x, y):
+    fi = np.arctan2(y.astype(np.float64), x.astype(np.float64)).astype(np.float32)
+    fi = np.where(fi < 0, (fi.astype(np.float64) + 2 * np.pi).astype(np.float32), fi)
+    return (fi * np.float32(360 / (2 * np.pi))).astype(np.int32)
+
+
+@pytest.mark.parametrize("rings,cols,scene", [(16, 1024, 0), (64, 2048, 1), (64, 2048, 2), (128, 4096, 1)])
+def test_tie_free_and_safe(rings, cols, scene):
+    x, y, z = u.synth_cloud(rings, cols, scene, 7)
+    assert len(x) == rings * cols and np.isfinite(x).all()
+    assert not ((x == 0) & (y == 0)).any()          # no NaN azimuth
+    sec = sectors_of(x, y)
+    assert sec.min() >= 0 and sec.max() <= 359      # never the sector-360 band
+    r = np.sqrt(x * x + y * y)                       # float32 arithmetic like star_shaped_search.cpp:164
+    key = sec.astype(np.int64) << 32 | r.view(np.uint32).astype(np.int64)
+    assert len(np.unique(key)) == len(key)          # no radial tie inside a sector
+    assert (z < -1.0).all() and (z > -3.0).all()    # inside the default z ROI
+
+
+def test_deterministic_and_seed_dependent():
+    a = u.synth_cloud(64, 2048, 1, 1)
+    b = u.synth_cloud(64, 2048, 1, 1)
+    c = u.synth_cloud(64, 2048, 1, 2)
+    assert all(np.array_equal(p, q) for p, q in zip(a, b))
+    assert not np.array_equal(a[0], c[0])
+
+
+def test_generator_is_pinned():
+    """The golden label files belong to exactly these bytes."""
+    h = hashlib.sha256()
+    for a in u.synth_cloud(16, 1024, 0, 1):
+        h.update(a.tobytes())
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "cfg1_s1.npz"))
+    assert h.hexdigest() == str(g["cloud_sha"])
+
+
+def test_firing_order_and_geometry():
+    rings, cols = 64, 2048
+    x, y, z = u.synth_cloud(rings, cols, 0, 3)
+    X = x.reshape(cols, rings)
+    Y = y.reshape(cols, rings)
+    r = np.hypot(X, Y)
+    assert (np.diff(r, axis=1) > 0).all()           # ring 0 is the steepest beam
+    az = np.arctan2(Y[:, 0], X[:, 0])
+    az = np.where(az < 0, az + 2 * np.pi, az)
+    assert (np.diff(az) > 0).all()                  # columns sweep the azimuth once
+    assert np.allclose(z, -1.8, atol=2e-3)          # flat ground 1.8 m below the sensor
+
+
+def test_bad_arguments():
+    L = u.lib()
+    assert L.urf_synth_cloud(0, 10, 0, 1, None, None, None) == -1
+    buf = np.zeros(8, np.float32)
+    assert L.urf_synth_cloud(2, 4, 5, 1, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data) == -1

@@ -97,6 +97,8 @@ def lib():
         "urf_compact_indices": [vp, u8p, C.c_uint32, u32p, u32p, u32p, u32p, u32p],
         "urf_read_stage": [vp, C.c_int, C.c_uint32, vp, C.c_size_t],
         "urf_enable_stage_capture": [vp, C.c_int],
+        "urf_enable_kernel_timing": [vp, C.c_int],
+        "urf_kernel_timing": [vp, C.c_void_p, C.c_void_p],
         "urf_synth_cloud": [C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, fp, fp, fp],
         "urf_abi_version": [],
     }
@@ -106,6 +108,8 @@ def lib():
         f.restype = C.c_int
     L.urf_strerror.argtypes = [C.c_int]
     L.urf_strerror.restype = C.c_char_p
+    L.urf_kernel_name.argtypes = [C.c_int]
+    L.urf_kernel_name.restype = C.c_char_p
     L.urf_last_error.argtypes = [vp]
     L.urf_last_error.restype = C.c_char_p
     _LIB = L
@@ -205,6 +209,19 @@ class Context:
 
     def enable_stage_capture(self, on=True):
         self._check(self._lib.urf_enable_stage_capture(self._h, int(on)), "urf_enable_stage_capture")
+
+    NUM_KERNELS = 9
+
+    def enable_kernel_timing(self, on=True):
+        self._check(self._lib.urf_enable_kernel_timing(self._h, int(on)), "urf_enable_kernel_timing")
+
+    def kernel_timing(self):
+        """-> ({kernel name: summed ms}, number of classify calls) since the last query."""
+        ms = (C.c_double * self.NUM_KERNELS)()
+        n = C.c_uint32(0)
+        self._check(self._lib.urf_kernel_timing(self._h, ms, C.byref(n)), "urf_kernel_timing")
+        names = [self._lib.urf_kernel_name(i).decode() for i in range(self.NUM_KERNELS)]
+        return dict(zip(names, list(ms))), n.value
 
     # -- single scan, host, PointCloud2 layout ------------------------------------
     def classify_pc2(self, data, n_points, point_step, off_x, off_y, off_z):

@@ -1,7 +1,6 @@
 """Builds the in-tree native libraries (gfx950 HIP kernels + C ABI).
 
     python -m urban_road_filter_amd.build            # liburf_hip.so
-    python -m urban_road_filter_amd.build --oracle   # also oracle/ (test infrastructure)
 
 The shared library is written next to this file so that it travels with a
 snapshot of the repository; nothing is installed into site-packages.
@@ -53,13 +52,5 @@ def build(force=False, verbose=True):
     return LIB
 
 
-def build_oracle(verbose=True):
-    """oracle/ is test infrastructure; building it here is not using it."""
-    odir = os.path.join(ROOT, "oracle")
-    subprocess.check_call(["make", "-C", odir] + ([] if verbose else ["-s"]))
-
-
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
-    if "--oracle" in sys.argv:
-        build_oracle()

@@ -100,10 +100,10 @@ inline int sector_of(float x, float y)
 extern "C" int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
                                float* x, float* y, float* z)
 {
-    if (!x || !y || !z || rings == 0 || cols == 0 || (scene != 0 && scene != 1))
+    if (!x || !y || !z || rings == 0 || cols == 0 || scene < 0 || scene > 2)
         return URF_ERR_INVALID_ARG;
     const double h = 1.8;             /* sensor height above the road */
-    const double curb_y = 4.0;        /* |y| of the curb faces */
+    const double curb_y = scene == 2 ? 3.0 : 4.0;   /* |y| of the curb faces */
     const double curb_h = 0.15;       /* curb height */
     const double max_range = 120.0;   /* beyond: no return -> (0,0,0) */
     const double deg = URF_PI_D / 180.0;
@@ -121,7 +121,7 @@ extern "C" int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_
             det_sincos(e, &se, &ce);
             const double dx = ce * ct, dy = ce * st, dz = se;
             double t = -h / dz;   /* ground hit */
-            if (scene == 1) {
+            if (scene != 0) {
                 const double yg = t * dy;
                 if (std::fabs(yg) >= curb_y) {
                     const double tc = curb_y / std::fabs(dy);   /* reaches the curb plane first */

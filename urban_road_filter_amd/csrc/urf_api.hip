@@ -36,6 +36,8 @@ struct urf_ctx {
     urf_beam* d_beams = nullptr;
     uint32_t beams_cap = 0;
     bool debug_rd2 = false;
+    bool timing = false;
+    std::vector<std::vector<hipEvent_t>> timing_events;   /* one set of URF_NUM_KERNELS+1 events per call */
     /* last call, for urf_read_stage */
     uint32_t last_scans = 0, last_n = 0, last_max_len = 0;
     bool last_ragged = false;
@@ -175,6 +177,9 @@ extern "C" int urf_destroy(urf_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->own_stream)
         (void)hipStreamSynchronize(c->own_stream);
+    for (auto& set : c->timing_events)
+        for (hipEvent_t e : set)
+            (void)hipEventDestroy(e);
     for (void* p : c->allocs)
         (void)hipFree(p);
     if (c->raw)
@@ -235,6 +240,41 @@ extern "C" int urf_enable_stage_capture(urf_ctx* c, int on)
     return URF_OK;
 }
 
+extern "C" int urf_enable_kernel_timing(urf_ctx* c, int on)
+{
+    if (!c)
+        return URF_ERR_INVALID_ARG;
+    c->timing = on != 0;
+    return URF_OK;
+}
+
+extern "C" const char* urf_kernel_name(int i)
+{
+    static const char* names[URF_NUM_KERNELS] = { "k_ingest", "k_ring_table", "k_ring_assign", "k_offsets", "k_scatter",
+                                                  "k_star", "k_ring", "k_beams", "k_label" };
+    return (i >= 0 && i < URF_NUM_KERNELS) ? names[i] : "";
+}
+
+extern "C" int urf_kernel_timing(urf_ctx* c, double* ms_sum, uint32_t* n_calls)
+{
+    if (!c || !ms_sum || !n_calls)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    URF_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& set : c->timing_events) {
+        for (int k = 0; k < URF_NUM_KERNELS; k++) {
+            float ms = 0.f;
+            URF_HIP(c, hipEventElapsedTime(&ms, set[k], set[k + 1]));
+            ms_sum[k] += (double)ms;
+        }
+        for (hipEvent_t e : set)
+            (void)hipEventDestroy(e);
+        (*n_calls)++;
+    }
+    c->timing_events.clear();
+    return URF_OK;
+}
+
 extern "C" const char* urf_last_error(const urf_ctx* c) { return c ? c->last_error.c_str() : ""; }
 
 /* ---- the pipeline ---------------------------------------------------------- */
@@ -269,25 +309,48 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     hipStream_t st = c->stream;
     const dim3 g_tiles(a.tiles, n_scans), g_scan(n_scans);
 
+    std::vector<hipEvent_t>* ev = nullptr;
+    if (c->timing) {
+        c->timing_events.emplace_back(URF_NUM_KERNELS + 1);
+        ev = &c->timing_events.back();
+        for (hipEvent_t& e : *ev)
+            URF_HIP(c, hipEventCreate(&e));
+    }
+    int stage = 0;
+    auto mark = [&]() {
+        if (ev)
+            (void)hipEventRecord((*ev)[stage], st);
+        stage++;
+    };
+    mark();
     hipLaunchKernelGGL(k_ingest, g_tiles, dim3(URF_TILE_THREADS), (K + 1) * sizeof(unsigned), st, a, dp);
+    mark();
     hipLaunchKernelGGL(k_ring_table, g_scan, dim3(256), 0, st, a, dp);
+    mark();
     hipLaunchKernelGGL(k_ring_assign, g_tiles, dim3(URF_TILE_THREADS), 0, st, a, dp);
+    mark();
     hipLaunchKernelGGL(k_offsets, g_scan, dim3(256), 0, st, a, dp);
+    mark();
     {
         const size_t keys = C + (star ? K : 0);
         const size_t lds = 4 * keys + 2 * (size_t)URF_TILE_GROUPS * keys + 8;
         hipLaunchKernelGGL(k_scatter, g_tiles, dim3(URF_TILE_THREADS), lds, st, a, dp);
     }
+    mark();
     if (star) {
         const dim3 g_sec(K, n_scans);
         hipLaunchKernelGGL((k_star<-1, 512, true>), g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
         hipLaunchKernelGGL((k_star<512, 2048, true>), g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
         hipLaunchKernelGGL((k_star<2048, 0, false>), g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
     }
+    mark();
     const dim3 g_ring(C, n_scans);
     hipLaunchKernelGGL(k_ring, g_ring, dim3(URF_RING_THREADS), 0, st, a, dp);
+    mark();
     hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_LABEL_THREADS), 0, st, a, dp);
+    mark();
     hipLaunchKernelGGL(k_label, g_ring, dim3(URF_LABEL_THREADS), 0, st, a, dp);
+    mark();
     URF_HIP(c, hipGetLastError());
     if (d_info)
         URF_HIP(c, hipMemcpyAsync(d_info, a.info, (size_t)n_scans * sizeof(urf_scan_info), hipMemcpyDeviceToDevice, st));
