@@ -115,6 +115,7 @@ def main():
     import torch.distributed as dist
     import oracles as O
     import urban_road_filter_amd as u
+    from urban_road_filter_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -137,7 +138,7 @@ def main():
     S = args.scans
     params = O.cfg_params("cfg2")   # reference defaults, ROI widened to +-200 m
     t_gen = time.perf_counter()
-    X, Y, Z = gen_batch(S, 1 + rank * S)          # seeds 1..S on rank 0, S+1..2S on rank 1, ...
+    X, Y, Z = gen_batch(S, sharding.shard_seeds(S, rank)[0])   # seeds 1..S on rank 0, S+1..2S on rank 1, ...
     t_gen = time.perf_counter() - t_gen
 
     stream = torch.cuda.current_stream()
@@ -185,15 +186,10 @@ def main():
     kms, kcalls = ctx.kernel_timing()
     ctx.enable_kernel_timing(False)
 
-    info = di.cpu().numpy().astype(np.int64)
-    counters = torch.tensor([S * args.steps, int(info[:, 1].sum()), int(info[:, 4].sum()), int(info[:, 5].sum()),
-                             int((info[:, 0] == 0).sum())], dtype=torch.int64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
-    elapsed_max = float(tmax.item())
-    counters = counters.cpu().numpy()
+    # bookkeeping only: all-reduce(SUM) of six 64-bit counters + all-reduce(MAX) of the elapsed time
+    # over RCCL; no point data ever crosses xGMI
+    counters = sharding.local_counters(di.cpu().numpy(), N_PTS, steps=args.steps)
+    counters, elapsed_max = sharding.reduce_run(counters, elapsed, device=dev)
 
     if rank == 0:
         total_scans = int(counters[0])
@@ -227,8 +223,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "whole_pipeline_achieved": round(whole, 2), "whole_pipeline_frac": round(whole / HBM_PEAK_GBS, 5)},
             "kernel_ms": {k: round(v / max(kcalls, 1), 4) for k, v in kms.items()},
-            "counters": {"scans": total_scans, "roi_points_last_step": int(counters[1]), "road_last_step": int(counters[2]),
-                         "curb_last_step": int(counters[3]), "ok_scans_last_step": int(counters[4])},
+            "counters": dict(zip(sharding.COUNTER_NAMES, [int(v) for v in counters])),
             "parity_checked_scans": min(args.parity_scans, S),
             "h2d_inclusive_scans_per_s": round(S / (ms_step * 1e-3 + t_h2d), 2),
             "h2d_seconds_per_batch": round(t_h2d, 4),

@@ -1,0 +1,93 @@
+/*
+ * detector.hpp -- C++ host adapter with the shape of the reference's Detector
+ * (include/urban_road_filter/data_structures.hpp:110-141), on top of the C ABI.
+ *
+ *   reference                                        here
+ *   ------------------------------------------------ -----------------------------------------
+ *   Detector::Detector(ros::NodeHandle*)             urf::Detector::Detector(device, max_points)
+ *     subscribe + advertise + beam_init()              urf_create(): scratch + beam_init tables
+ *     (lidar_segmentation.cpp:51-65)
+ *   paramsCallback(config, level) (main.cpp:4-34)    urf::Detector::setParams(const urf_params&)
+ *   void filtered(const pcl::PointCloud<PointXYZI>&) bool filtered(const PointCloud&)
+ *     (lidar_segmentation.cpp:95)                      false <=> the reference returns without
+ *                                                      publishing (< 30 ROI points, :124-126)
+ *   pub_road/pub_high/pub_box/pub_pobroad.publish    road() curb() roi() road_probably()
+ *     (lidar_segmentation.cpp:612-621)                 clouds carrying the input header
+ *
+ * A ROS node keeps its subscriber/publishers and calls this class from its
+ * callback; see INTEGRATION.md.  Points keep their intensity; the order inside
+ * the output clouds is input order (the reference emits ring-major,
+ * azimuth-ascending; consumers of these topics treat them as unordered sets).
+ */
+#ifndef URF_DETECTOR_HPP
+#define URF_DETECTOR_HPP
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "urf.h"
+
+namespace urf {
+
+/* layout of pcl::PointXYZI: 32 bytes, x y z at 0/4/8, intensity at 16 */
+struct alignas(16) PointXYZI {
+    float x = 0, y = 0, z = 0, pad0 = 1.0f;
+    float intensity = 0;
+    float pad1[3] = { 0, 0, 0 };
+};
+
+struct Header {
+    uint32_t seq = 0;
+    uint64_t stamp = 0;
+    std::string frame_id;
+};
+
+struct PointCloud {
+    Header header;
+    std::vector<PointXYZI> points;
+};
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+class Detector {
+public:
+    explicit Detector(int device = 0, uint32_t max_points = 1u << 20);
+    ~Detector();
+    Detector(const Detector&) = delete;
+    Detector& operator=(const Detector&) = delete;
+
+    /* main.cpp:4-34 paramsCallback: callable between scans */
+    void setParams(const urf_params& p);
+    urf_params params() const;
+
+    /* lidar_segmentation.cpp:95 Detector::filtered.  Returns false when nothing is published. */
+    bool filtered(const PointCloud& cloud);
+    /* The same for a raw sensor_msgs/PointCloud2 payload (data, point_step and the byte offsets of
+     * the x/y/z FLOAT32 fields); the output clouds then carry x,y,z and intensity = input index. */
+    bool filtered(const uint8_t* data, uint32_t n_points, uint32_t point_step,
+                  uint32_t off_x, uint32_t off_y, uint32_t off_z, const Header& header = Header());
+
+    const PointCloud& road() const { return road_; }                    /* topic "road" */
+    const PointCloud& curb() const { return curb_; }                    /* topic "curb" */
+    const PointCloud& roi() const { return roi_; }                      /* topic "roi" */
+    const PointCloud& road_probably() const { return road_probably_; }  /* topic "road_probably" */
+    const std::vector<uint8_t>& labels() const { return labels_; }      /* one urf.h label byte per input point */
+    const urf_scan_info& info() const { return info_; }
+
+private:
+    void check(int rc, const char* what) const;
+    void split(const PointXYZI* pts, uint32_t n, const Header& h);
+    urf_ctx* ctx_ = nullptr;
+    uint32_t max_points_ = 0;
+    std::vector<uint8_t> labels_;
+    urf_scan_info info_{};
+    PointCloud road_, curb_, roi_, road_probably_;
+};
+
+}   // namespace urf
+#endif
