@@ -230,6 +230,10 @@ int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
                     float* x, float* y, float* z);
 
 /* ---- diagnostics --------------------------------------------------------- */
+/* Device self test of the arithmetic shortcuts the kernels take (currently: the
+ * 3-operation division by pi against the IEEE division, exhaustively over all
+ * floats in [0, 600]).  *n_mismatches must come back 0.  Synchronous. */
+int urf_selftest(urf_ctx* ctx, uint64_t* n_mismatches);
 const char* urf_strerror(int status);
 const char* urf_last_error(const urf_ctx* ctx);   /* text of the last HIP failure */
 int urf_abi_version(void);

@@ -318,6 +318,12 @@ def test_full_size_batch_properties():
         assert np.array_equal(L1[s], lb), "scan %d" % s
 
 
+def test_device_arithmetic_selftest(ctx_big):
+    """The kernels divide by pi with three fma-class operations instead of an f64 division; that
+    must equal the IEEE quotient for EVERY float the path can produce (exhaustive over [0, 600])."""
+    assert ctx_big.selftest() == 0
+
+
 def test_capacity_and_argument_errors():
     with u.Context(4096, 2) as ctx:
         x, y, z = [a[:8192] for a in O.cfg_cloud("cfg2", 1)]

@@ -98,6 +98,7 @@ def lib():
         "urf_read_stage": [vp, C.c_int, C.c_uint32, vp, C.c_size_t],
         "urf_enable_stage_capture": [vp, C.c_int],
         "urf_enable_kernel_timing": [vp, C.c_int],
+        "urf_selftest": [vp, C.c_void_p],
         "urf_kernel_timing": [vp, C.c_void_p, C.c_void_p],
         "urf_synth_cloud": [C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, fp, fp, fp],
         "urf_abi_version": [],
@@ -211,6 +212,11 @@ class Context:
         self._check(self._lib.urf_enable_stage_capture(self._h, int(on)), "urf_enable_stage_capture")
 
     NUM_KERNELS = 9
+
+    def selftest(self):
+        n = C.c_uint64(0)
+        self._check(self._lib.urf_selftest(self._h, C.byref(n)), "urf_selftest")
+        return n.value
 
     def enable_kernel_timing(self, on=True):
         self._check(self._lib.urf_enable_kernel_timing(self._h, int(on)), "urf_enable_kernel_timing")

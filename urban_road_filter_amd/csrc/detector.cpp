@@ -5,7 +5,7 @@
 
 namespace urf {
 
-Detector::Detector(int device, uint32_t max_points) : max_points_(max_points)
+Detector::Detector(int device, uint32_t max_points)
 {
     const int rc = urf_create(&ctx_, device, max_points, 1);
     if (rc != URF_OK)

@@ -83,7 +83,6 @@ private:
     void check(int rc, const char* what) const;
     void split(const PointXYZI* pts, uint32_t n, const Header& h);
     urf_ctx* ctx_ = nullptr;
-    uint32_t max_points_ = 0;
     std::vector<uint8_t> labels_;
     urf_scan_info info_{};
     PointCloud road_, curb_, roi_, road_probably_;

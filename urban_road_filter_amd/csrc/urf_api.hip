@@ -21,6 +21,7 @@ struct urf_ctx {
     uint32_t max_points = 0, max_batch = 0;
     size_t total = 0;               /* max_points * max_batch */
     uint32_t max_tiles = 0;
+    unsigned n_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     urf_params params;
@@ -33,6 +34,7 @@ struct urf_ctx {
     size_t raw_bytes = 0;
     uint8_t* labels1 = nullptr;     /* labels of the single-scan entry point */
     float* d_newY = nullptr;
+    float* d_inv_i = nullptr;
     urf_beam* d_beams = nullptr;
     uint32_t beams_cap = 0;
     bool debug_rd2 = false;
@@ -98,6 +100,7 @@ static int upload_params(urf_ctx* c)
     dp.inv_cp = 1.0f / (float)p.curbPoints;                            /* z_zero_method.cpp:52 */
     dp.sec_keybits = 10;
     dp.ring_keybits = 8;
+    dp.exp_flags = std::getenv("URF_EXP") ? (uint32_t)std::strtoul(std::getenv("URF_EXP"), nullptr, 0) : 0u;
     std::vector<urf_beam> beams;
     beam_init(beams, p.sectors, p.beam_width);
     URF_HIP(c, hipMemcpyAsync(c->d_beams, beams.data(), beams.size() * sizeof(urf_beam), hipMemcpyHostToDevice, c->stream));
@@ -131,6 +134,14 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
         return fail(URF_ERR_HIP);
     c->stream = c->own_stream;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+            c->n_cus = (unsigned)prop.multiProcessorCount;
+    }
+    /* k_scatter stages a whole tile in LDS (> 64 KiB of the CU's 160 KiB) */
+    if (hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+        return fail(URF_ERR_HIP);
     urf_default_params(&c->params);
     std::memset(&c->k, 0, sizeof(c->k));
     urf_kargs& k = c->k;
@@ -141,15 +152,16 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
         return fail(rc);
     A(k.valpha, T) A(k.seckey, T) A(k.ringkey, T)
     A(k.rx, T) A(k.ry, T) A(k.rz, T) A(k.rsrc, T) A(k.raz, T) A(k.rd2, T) A(k.rflag, T)
-    A(k.sr, T) A(k.sz, T) A(k.ssrc, T)
+    A(k.sr, T) A(k.sz, T) A(k.ssrc, T) A(k.ssrt, T)
     A(k.tile_roi, S * tiles) A(k.tile_ring, S * tiles * C) A(k.tile_sec, S * tiles * K)
     A(k.angle, S * C) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
+    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 2)
     A(k.maxdist, S * C) A(k.quad, S * 4)
     A(k.sufmin, S * C * URF_DEG_CELLS) A(k.premax, S * C * URF_DEG_CELLS)
     A(k.stop_f, S * URF_DEG_CELLS) A(k.stop_b, S * URF_DEG_CELLS)
     A(k.info, S)
-    A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
+    A(c->d_newY, (size_t)max_points) A(c->d_inv_i, (size_t)max_points) A(c->d_beams, K)
     A(c->labels1, (size_t)max_points)
 #undef A
     /* x_zero_method.cpp:24-27: newY[j] = newY[j-1] + 0.0100 (float += double), a
@@ -162,7 +174,16 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
         if (hipMemcpy(c->d_newY, newY.data(), newY.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
             return fail(URF_ERR_HIP);
     }
+    {
+        std::vector<float> inv(max_points);
+        inv[0] = 0.0f;
+        for (uint32_t j = 1; j < max_points; j++)
+            inv[j] = 1.0f / (float)j;   /* star_shaped_search.cpp:137,140 with nan == 0 */
+        if (hipMemcpy(c->d_inv_i, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(URF_ERR_HIP);
+    }
     k.newY = c->d_newY;
+    k.inv_i = c->d_inv_i;
     k.beams = c->d_beams;
     if ((rc = upload_params(c)) != URF_OK)
         return fail(rc);
@@ -237,6 +258,25 @@ extern "C" int urf_enable_stage_capture(urf_ctx* c, int on)
     if (!c)
         return URF_ERR_INVALID_ARG;
     c->debug_rd2 = on != 0;
+    return URF_OK;
+}
+
+extern "C" int urf_selftest(urf_ctx* c, uint64_t* n_mismatches)
+{
+    if (!c || !n_mismatches)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    URF_HIP(c, hipMalloc((void**)&d, sizeof(*d)));
+    URF_HIP(c, hipMemsetAsync(d, 0, sizeof(*d), c->stream));
+    hipLaunchKernelGGL(k_selftest_div_pi, dim3(c->n_cus * 8), dim3(256), 0, c->stream, d);
+    unsigned long long h = 0;
+    hipError_t e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    URF_HIP(c, e);
+    *n_mismatches = h;
     return URF_OK;
 }
 
@@ -325,23 +365,26 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     mark();
     hipLaunchKernelGGL(k_ingest, g_tiles, dim3(URF_TILE_THREADS), (K + 1) * sizeof(unsigned), st, a, dp);
     mark();
-    hipLaunchKernelGGL(k_ring_table, g_scan, dim3(256), 0, st, a, dp);
+    hipLaunchKernelGGL(k_ring_table, g_scan, dim3(64), 0, st, a, dp);
     mark();
     hipLaunchKernelGGL(k_ring_assign, g_tiles, dim3(URF_TILE_THREADS), 0, st, a, dp);
     mark();
+    if (star)
+        URF_HIP(c, hipMemsetAsync(a.star_count, 0, 2 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_offsets, g_scan, dim3(256), 0, st, a, dp);
     mark();
     {
-        const size_t keys = C + (star ? K : 0);
-        const size_t lds = 4 * keys + 2 * (size_t)URF_TILE_GROUPS * keys + 8;
+        const size_t lds = urf_scatter_lds_bytes(C, K, star);
         hipLaunchKernelGGL(k_scatter, g_tiles, dim3(URF_TILE_THREADS), lds, st, a, dp);
     }
     mark();
     if (star) {
         const dim3 g_sec(K, n_scans);
-        hipLaunchKernelGGL((k_star<-1, 512, true>), g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
-        hipLaunchKernelGGL((k_star<512, 2048, true>), g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
-        hipLaunchKernelGGL((k_star<2048, 0, false>), g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
+        hipLaunchKernelGGL(k_star_sort_small, g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
+        /* persistent workgroups over the (normally empty) work lists of oversized sectors */
+        hipLaunchKernelGGL(k_star_sort_mid, dim3(c->n_cus * 4), dim3(URF_STAR_MID_THREADS), 0, st, a, dp);
+        hipLaunchKernelGGL(k_star_sort_big, dim3(c->n_cus * 2), dim3(256), 0, st, a, dp);
+        hipLaunchKernelGGL(k_star_walk, dim3((K + 255) / 256, n_scans), dim3(256), 0, st, a, dp);
     }
     mark();
     const dim3 g_ring(C, n_scans);

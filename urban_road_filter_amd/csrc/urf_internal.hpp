@@ -45,6 +45,7 @@ struct urf_dev_params {
     float    inv_cp;        /* 1 / (float)curbPoints (z_zero_method.cpp:52) */
     uint32_t sec_keybits;   /* bits needed for sector keys incl. "none" */
     uint32_t ring_keybits;
+    uint32_t exp_flags;     /* experiments (env URF_EXP), 0 in production */
 };
 
 /* Everything a kernel needs to find a scan's data.  All pointers are device
@@ -78,6 +79,7 @@ struct urf_kargs {
     float*    sr;
     float*    sz;
     uint32_t* ssrc;
+    uint32_t* ssrt;             /* input index of the i-th point of the sector in sorted order */
     /* per scan x tile */
     uint32_t* tile_roi;         /* [S][tiles] ROI points of the tile */
     uint32_t* tile_ring;        /* [S][tiles][channels] per-tile ring counts; k_offsets turns them into the
@@ -90,6 +92,10 @@ struct urf_kargs {
     uint32_t* sec_cnt;          /* [S][sectors] */
     uint32_t* sec_off;          /* [S][sectors+1] */
     int32_t*  star_hit;         /* [S][sectors] input index (scan-relative) of the sector's curb point, -1 none */
+    uint32_t* star_first;       /* [S][sectors] last sorted index the walk may visit */
+    uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 513..2048 points */
+    uint32_t* star_list_big;    /* [S*sectors] ... with more than 2048 points */
+    uint32_t* star_count;       /* [2] lengths of the two lists (zeroed per call) */
     float*    maxdist;          /* [S][channels] */
     float*    quad;             /* [S][4] */
     float*    sufmin;           /* [S][channels][361] */
@@ -98,6 +104,7 @@ struct urf_kargs {
     int16_t*  stop_b;           /* [S][361] */
     /* tables */
     const float*    newY;       /* [max_points] x_zero_method.cpp:24-27 */
+    const float*    inv_i;      /* [max_points] 1.0f / (float)i, star_shaped_search.cpp:137 */
     const urf_beam* beams;      /* [sectors] */
 };
 

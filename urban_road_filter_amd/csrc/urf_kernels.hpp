@@ -33,6 +33,7 @@
 #define URF_RING_THREADS 256
 #define URF_LABEL_THREADS 384
 #define URF_STAR_THREADS 64
+#define URF_STAR_MID_CAP_ 2048
 
 /* ------------------------------------------------------------------------- */
 /* PointCloud2 records -> SoA                                                  */
@@ -129,58 +130,33 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_ingest(urf_kargs a, urf_de
 /* ------------------------------------------------------------------------- */
 /* k_ring_table                                                                */
 /* ------------------------------------------------------------------------- */
-__device__ __forceinline__ unsigned urf_block_min_256(unsigned v, unsigned* sh4)
-{
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned w = __shfl_xor(v, o);
-        v = w < v ? w : v;
-    }
-    __syncthreads();
-    if (urf_lane() == 0)
-        sh4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    unsigned r = sh4[0];
-    for (int w = 1; w < 4; w++)
-        r = sh4[w] < r ? sh4[w] : r;
-    return r;
-}
-
 /* The reference walks the ROI points in order and appends a point's vertical
  * angle to the table when no earlier entry lies within `interval`
  * (lidar_segmentation.cpp:168-196).  Equivalent formulation used here: leader
- * k+1 is the first point after leader k that matches none of the leaders
- * 0..k; the search for it is a parallel min-reduction over 1024 points per
- * step, restarted behind every new leader.  The `angle[j] == 0` end-of-table
+ * k+1 is the first point after leader k that matches none of the leaders 0..k.
+ * One wave per scan walks the points 64 at a time; the leaders live in
+ * registers (leader j in lane j & 63) and are broadcast with readlane, so a
+ * chunk without new leaders costs one compare per leader, and a new leader is
+ * found with one ballot.  The walk ends as soon as the table is full (after
+ * the first firing of an organised sweep).  The `angle[j] == 0` end-of-table
  * sentinel (:176) is honoured: once a leader equal to 0 has been stored, only
  * the leaders in front of it take part in matching. */
-__global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params dp)
+__global__ __launch_bounds__(64) void k_ring_table(urf_kargs a, urf_dev_params dp)
 {
-    __shared__ float L[URF_MAX_CHANNELS];
-    __shared__ unsigned sh4[4];
-    __shared__ unsigned sh_n, sh_nmatch, sh_zero;
-    const unsigned s = blockIdx.x, tid = threadIdx.x;
+    const unsigned s = blockIdx.x, lane = threadIdx.x;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned C = (unsigned)dp.p.channels;
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
 
     /* piece = number of ROI points (lidar_segmentation.cpp:120) */
-    unsigned cnt = 0;
-    for (unsigned t = tid; t < ntiles; t += 256)
-        cnt += a.tile_roi[(size_t)s * a.tiles + t];
+    unsigned piece = 0;
+    for (unsigned t = lane; t < ntiles; t += 64)
+        piece += a.tile_roi[(size_t)s * a.tiles + t];
     for (int o = 32; o > 0; o >>= 1)
-        cnt += __shfl_xor(cnt, o);
-    if (urf_lane() == 0)
-        sh4[tid >> 6] = cnt;
-    if (tid == 0) {
-        sh_n = 0;
-        sh_nmatch = 0;
-        sh_zero = 0;
-    }
-    __syncthreads();
-    const unsigned piece = sh4[0] + sh4[1] + sh4[2] + sh4[3];
+        piece += __shfl_xor(piece, o);
     const bool too_few = piece < 30;   /* lidar_segmentation.cpp:124 */
-    if (tid == 0) {
+    if (lane == 0) {
         urf_scan_info in;
         in.status = too_few ? URF_TOO_FEW_POINTS : URF_OK;
         in.n_roi = piece;
@@ -196,63 +172,61 @@ __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params 
         return;
 
     const float interval = dp.p.interval;
-    unsigned base = 0;
-    while (base < len) {
-        const unsigned nmatch = sh_nmatch;
-        unsigned first = 0xffffffffu;
-        for (unsigned q = 0; q < 4 && first == 0xffffffffu; q++) {
-            const unsigned i = base + q * 256 + tid;
-            if (i < len) {
-                const float v = a.valpha[off + i];
-                if (v >= 0.0f) {   /* ROI point */
-                    bool matched = false;
-                    for (unsigned j = 0; j < nmatch; j++) {
-                        if (__builtin_fabsf(L[j] - v) <= interval) {
-                            matched = true;
-                            break;
-                        }
-                    }
-                    if (!matched)
-                        first = i;
+    float L0 = 0.f, L1 = 0.f;      /* leader j lives in lane j & 63 of L0 (j < 64) or L1 */
+    unsigned nL = 0, nmatch = 0;
+    bool zero_seen = false;
+    for (unsigned base = 0; base < len && nL < C; base += 64) {
+        const unsigned i = base + lane;
+        const float v = i < len ? a.valpha[off + i] : -1.0f;
+        bool un = v >= 0.0f;       /* ROI point, not yet matched */
+        for (unsigned j = 0; j < nmatch; j++) {
+            const float lj = __shfl(j < 64 ? L0 : L1, (int)(j & 63));
+            if (__builtin_fabsf(lj - v) <= interval)
+                un = false;
+        }
+        unsigned long long m;
+        while ((m = __ballot(un)) != 0 && nL < C) {
+            const unsigned f = (unsigned)__ffsll((long long)m) - 1u;
+            const float lv = __shfl(v, (int)f);
+            if (lane == (nL & 63)) {
+                if (nL < 64)
+                    L0 = lv;
+                else
+                    L1 = lv;
+            }
+            bool matchable = false;
+            if (!zero_seen) {
+                if (lv == 0.0f)
+                    zero_seen = true;
+                else {
+                    nmatch = nL + 1;
+                    matchable = true;
                 }
             }
+            nL++;
+            if (lane <= f)
+                un = false;
+            else if (matchable && __builtin_fabsf(lv - v) <= interval)
+                un = false;
         }
-        const unsigned m = urf_block_min_256(first, sh4);
-        if (m == 0xffffffffu) {
-            base += 1024;
-        } else {
-            if (tid == 0) {
-                const float v = a.valpha[off + m];
-                const unsigned n = sh_n;
-                L[n] = v;
-                sh_n = n + 1;
-                if (!sh_zero) {
-                    if (v == 0.0f)
-                        sh_zero = 1;
-                    else
-                        sh_nmatch = n + 1;
-                }
-            }
-            base = m + 1;
-        }
-        __syncthreads();
-        if (sh_n >= C)
-            break;
     }
 
     /* std::sort(angle, angle + index), lidar_segmentation.cpp:205 (rank sort) */
-    const unsigned n = sh_n;
-    if (tid < n) {
-        const float v = L[tid];
+    for (unsigned h = 0; h < 2; h++) {
+        const unsigned me = h * 64 + lane;
+        if (h * 64 >= nL)
+            break;
+        const float v = h == 0 ? L0 : L1;
         unsigned rank = 0;
-        for (unsigned j = 0; j < n; j++) {
-            const float w = L[j];
-            rank += (w < v) || (w == v && j < tid);
+        for (unsigned j = 0; j < nL; j++) {
+            const float w = __shfl(j < 64 ? L0 : L1, (int)(j & 63));
+            rank += (w < v) || (w == v && j < me);
         }
-        a.angle[(size_t)s * C + rank] = v;
+        if (me < nL)
+            a.angle[(size_t)s * C + rank] = v;
     }
-    if (tid == 0)
-        a.info[s].n_rings = n;
+    if (lane == 0)
+        a.info[s].n_rings = nL;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -398,6 +372,27 @@ __global__ __launch_bounds__(256) void k_offsets(urf_kargs a, urf_dev_params dp)
     }
     __syncthreads();
     urf_scan_keys_256(&a.sec_cnt[(size_t)s * K], &a.sec_off[(size_t)s * (K + 1)], K, sh);
+    /* sectors too large for one wave's LDS tile go on the work lists of k_star_mid / k_star_big
+     * (one atomic per wave, not per sector) */
+    for (unsigned k0 = 0; k0 < K; k0 += 256) {
+        const unsigned k = k0 + tid;
+        const unsigned c = k < K ? a.sec_cnt[(size_t)s * K + k] : 0;
+        const bool mid = c > 512 && c <= URF_STAR_MID_CAP_, big = c > URF_STAR_MID_CAP_;
+        const unsigned long long bm = __ballot(mid), bb = __ballot(big);
+        unsigned pm = 0, pb = 0;
+        if (urf_lane() == 0) {
+            if (bm)
+                pm = atomicAdd(&a.star_count[0], (unsigned)__popcll(bm));
+            if (bb)
+                pb = atomicAdd(&a.star_count[1], (unsigned)__popcll(bb));
+        }
+        pm = __shfl(pm, 0);
+        pb = __shfl(pb, 0);
+        if (mid)
+            a.star_list_mid[pm + urf_popc_below(bm)] = s * K + k;
+        if (big)
+            a.star_list_big[pb + urf_popc_below(bb)] = s * K + k;
+    }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -408,7 +403,25 @@ __global__ __launch_bounds__(256) void k_offsets(urf_kargs a, urf_dev_params dp)
  * + (in earlier wave-sized groups of this tile: LDS matrix gcnt[group][key])
  * + (in lower lanes of its own group: match_any + popcount).  Input order is
  * preserved inside every ring, which x_zero / z_zero rely on
- * (lidar_segmentation.cpp:280-283 run before the azimuth sort :289). */
+ * (lidar_segmentation.cpp:280-283 run before the azimuth sort :289).
+ *
+ * Ring-major stores: in firing order the 64 lanes of a wave belong to 64
+ * different rings, i.e. 64 different cache lines per store.  The tile is
+ * therefore transposed through LDS first (slot = position of the point in the
+ * tile's ring-sorted order, row-padded against bank conflicts) and written out
+ * slot by slot, so that a wave stores runs of consecutive ring-major elements.
+ * Sector-major stores are already contiguous (a firing shares one sector). */
+#define URF_SLOT(lp) ((lp) + ((lp) >> 6))
+#define URF_SLOTS (URF_TILE + URF_TILE / 64)
+
+__host__ __device__ inline size_t urf_scatter_lds_bytes(unsigned C, unsigned K, bool star)
+{
+    const size_t keys = C + (star ? K : 0);
+    const size_t gcnt = 2 * (size_t)URF_TILE_GROUPS * keys + 8;   /* uint16 matrices */
+    const size_t stage = 4 * (size_t)URF_SLOTS * 4;                /* x y z src staging, aliases gcnt */
+    return 4 * (keys + 2 * C) + (gcnt > stage ? gcnt : stage) + URF_TILE;
+}
+
 __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_dev_params dp)
 {
     extern __shared__ unsigned sh_dyn[];
@@ -422,11 +435,19 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
         return;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
-    /* LDS carve: base_r[C] base_s[K] (uint32) | gcnt_r[G][C] gcnt_s[G][K] (uint16) */
+    constexpr unsigned Q = URF_TILE / URF_TILE_THREADS;
+    /* LDS carve: base_r[C] koff[C] tot_r[C] base_s[K] (uint32) | union { gcnt_r[G][C] gcnt_s[G][K] (uint16),
+     * stage x y z src [URF_SLOTS] (uint32) } | keyL[URF_TILE] (uint8) */
     unsigned* base_r = sh_dyn;
-    unsigned* base_s = base_r + C;
-    uint16_t* gcnt_r = (uint16_t*)(base_s + (star ? K : 0));
+    unsigned* koff = base_r + C;
+    unsigned* tot_r = koff + C;
+    unsigned* base_s = tot_r + C;
+    unsigned* un = base_s + (star ? K : 0);
+    uint16_t* gcnt_r = (uint16_t*)un;
     uint16_t* gcnt_s = gcnt_r + (size_t)URF_TILE_GROUPS * C;
+    const size_t keys = C + (star ? K : 0);
+    const size_t gbytes = 2 * (size_t)URF_TILE_GROUPS * keys + 8, sbytes = 4 * (size_t)URF_SLOTS * 4;
+    uint8_t* keyL = (uint8_t*)un + (gbytes > sbytes ? gbytes : sbytes);
     const size_t row = (size_t)s * a.tiles + t;
 
     for (unsigned k = tid; k < C; k += URF_TILE_THREADS)
@@ -435,18 +456,16 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
         for (unsigned k = tid; k < K; k += URF_TILE_THREADS)
             base_s[k] = off + a.sec_off[(size_t)s * (K + 1) + k] + a.tile_sec[row * K + k];
     {
-        const unsigned tot = URF_TILE_GROUPS * (C + (star ? K : 0));
-        unsigned* z32 = (unsigned*)gcnt_r;
+        const unsigned tot = URF_TILE_GROUPS * (unsigned)keys;
         for (unsigned k = tid; k < (tot + 1) / 2; k += URF_TILE_THREADS)
-            z32[k] = 0;
+            un[k] = 0;
     }
     __syncthreads();
 
-    unsigned rkey[URF_TILE / URF_TILE_THREADS], skey[URF_TILE / URF_TILE_THREADS];
-    unsigned rrank[URF_TILE / URF_TILE_THREADS], srank[URF_TILE / URF_TILE_THREADS];
+    unsigned rkey[Q], skey[Q], rrank[Q], srank[Q];
     const unsigned wave = tid >> 6;
 #pragma unroll
-    for (unsigned q = 0; q < URF_TILE / URF_TILE_THREADS; q++) {
+    for (unsigned q = 0; q < Q; q++) {
         const unsigned i = tbase + q * URF_TILE_THREADS + tid;
         const bool valid = i < len;
         const unsigned g = q * (URF_TILE_THREADS / 64) + wave;
@@ -474,6 +493,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
             gcnt_r[g * C + k] = (uint16_t)run;
             run += c;
         }
+        tot_r[k] = run;
     }
     if (star)
         for (unsigned k = tid; k < K; k += URF_TILE_THREADS) {
@@ -485,166 +505,397 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
             }
         }
     __syncthreads();
+    /* offset of every ring's run inside the tile's ring-sorted order */
+    if (tid < C) {
+        unsigned run = 0;
+        for (unsigned k = 0; k < tid; k++)
+            run += tot_r[k];
+        koff[tid] = run;
+    }
+    __syncthreads();
+    const unsigned tile_ring_pts = koff[C - 1] + tot_r[C - 1];
+
+    /* positions: ring slot inside the tile (lp), sector-major destination (sdst) */
+    unsigned lp[Q], sdst[Q];
 #pragma unroll
-    for (unsigned q = 0; q < URF_TILE / URF_TILE_THREADS; q++) {
-        const unsigned i = tbase + q * URF_TILE_THREADS + tid;
+    for (unsigned q = 0; q < Q; q++) {
         const unsigned g = q * (URF_TILE_THREADS / 64) + wave;
-        if (rkey[q] == URF_RING_NONE && skey[q] == URF_SEC_NONE)
+        lp[q] = rkey[q] != URF_RING_NONE ? koff[rkey[q]] + gcnt_r[g * C + rkey[q]] + rrank[q] : 0xffffffffu;
+        sdst[q] = skey[q] != URF_SEC_NONE ? base_s[skey[q]] + gcnt_s[g * K + skey[q]] + srank[q] : 0xffffffffu;
+    }
+    __syncthreads();   /* gcnt is dead: its memory becomes the staging buffers */
+    unsigned* stx = un;
+    unsigned* sty = stx + URF_SLOTS;
+    unsigned* stz = sty + URF_SLOTS;
+    unsigned* sts = stz + URF_SLOTS;
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned i = tbase + q * URF_TILE_THREADS + tid;
+        if (lp[q] == 0xffffffffu && sdst[q] == 0xffffffffu)
             continue;
         const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
-        if (rkey[q] != URF_RING_NONE) {
-            const unsigned dst = base_r[rkey[q]] + gcnt_r[g * C + rkey[q]] + rrank[q];
-            a.rx[dst] = x;
-            a.ry[dst] = y;
-            a.rz[dst] = z;
-            a.rsrc[dst] = i;
+        if (lp[q] != 0xffffffffu) {
+            const unsigned sl = URF_SLOT(lp[q]);
+            stx[sl] = __float_as_uint(x);
+            sty[sl] = __float_as_uint(y);
+            stz[sl] = __float_as_uint(z);
+            sts[sl] = i;
+            keyL[lp[q]] = (uint8_t)rkey[q];
         }
-        if (skey[q] != URF_SEC_NONE) {
-            const unsigned dst = base_s[skey[q]] + gcnt_s[g * K + skey[q]] + srank[q];
-            a.sr[dst] = __builtin_sqrtf(x * x + y * y);   /* star_shaped_search.cpp:164 */
-            a.sz[dst] = z;
-            a.ssrc[dst] = i;
+        if (sdst[q] != 0xffffffffu) {
+            a.sr[sdst[q]] = __builtin_sqrtf(x * x + y * y);   /* star_shaped_search.cpp:164 */
+            a.sz[sdst[q]] = z;
+            a.ssrc[sdst[q]] = i;
         }
+    }
+    __syncthreads();
+    for (unsigned j = tid; j < tile_ring_pts; j += URF_TILE_THREADS) {
+        const unsigned k = keyL[j];
+        const unsigned dst = base_r[k] + (j - koff[k]);
+        const unsigned sl = URF_SLOT(j);
+        a.rx[dst] = __uint_as_float(stx[sl]);
+        a.ry[dst] = __uint_as_float(sty[sl]);
+        a.rz[dst] = __uint_as_float(stz[sl]);
+        a.rsrc[dst] = sts[sl];
     }
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_star                                                                      */
+/* k_star_*                                                                    */
 /* ------------------------------------------------------------------------- */
-/* star_shaped_search.cpp:123-149: walk the sector outwards, return the position
- * (in sorted order) of the first point whose slope gives the curb away. */
-template <class GetR, class GetZ>
-__device__ __forceinline__ int urf_slope_scan(unsigned n, const urf_dev_params& dp, GetR get_r, GetZ get_z)
+/* One sector = star_shaped_search.cpp:109-150: order the sector's points by planar
+ * range, walk outwards, stop at the first point whose slope gives the curb away.
+ *
+ * Split in two so that neither half idles 63 of 64 lanes:
+ *   k_star_sort_*  one wave (or workgroup) per sector: sort, then ALL lanes compute
+ *                  what the walk needs and does not depend on the running mean:
+ *                    slp[i] = (z_i - z_{i-1}) / (r_i - r_{i-1})            (:129)
+ *                    g[i]   = (r_i - r_{i-1}) * kdist                      (:143)
+ *                    first i with slp[i] > slope_param (walk stops there)  (:142)
+ *                  written over the sector-major arrays in sorted order.
+ *   k_star_walk    one LANE per sector: the sequential running mean /
+ *                  mean-absolute-deviation recurrence (:135-140), 64 sectors
+ *                  per wave.
+ *
+ * Sort key = (range bits << 32 | position in the sector-major array); the
+ * position grows with the input index (the split is stable), so the order is
+ * total where the reference's std::sort leaves ties unspecified (:109).
+ * Small sectors (<= 512 points, <= 8 per lane): every 64-element block is
+ * sorted in registers by an in-wave bitonic network (shuffles, no LDS traffic),
+ * then each element finds its final rank by binary search in the other blocks
+ * (multiway merge by ranking).  Larger sectors: bitonic network in LDS
+ * ("normalised": all comparators ascending, so slots >= n act as +inf and need no
+ * padding), or in global memory for sizes beyond LDS. */
+
+/* 64 keys, one per lane, ascending by lane */
+__device__ __forceinline__ unsigned long long urf_wave_sort64(unsigned long long key)
 {
-    const float kdev = dp.p.kdev_param, kdist = dp.p.kdist_param, slope_param = dp.slope_param;
-    const int dmin = dp.p.dmin_param;
-    float avg = 0.f, dev = 0.f, nan = 0.f;
-    float bx = get_r(0), by = get_z(0);
-    for (unsigned i = 1; i < n; i++) {
-        const float ax = bx, ay = by;
-        bx = get_r(i);
-        by = get_z(i);
-        const float slp = (by - ay) / (bx - ax);
-        if (slp != slp) {
-            nan += 1.0f;
-        } else {
-            const float w = (float)(int)i - nan - 1.0f;
-            const float u = 1.0f / ((float)(int)i - nan);
-            avg *= w;
-            avg += slp;
-            avg *= u;
-            dev *= w;
-            dev += __builtin_fabsf(slp - avg);
-            dev *= u;
+    const unsigned lane = urf_lane();
+#pragma unroll
+    for (unsigned kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (unsigned j = kk >> 1; j > 0; j >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)key, (int)j);
+            const unsigned hi = __shfl_xor((unsigned)(key >> 32), (int)j);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            const bool lower = (lane & j) == 0;
+            const bool up = (lane & kk) == 0 || kk == 64;
+            const bool take_min = lower == up;
+            const bool other_less = other < key;
+            key = (take_min == other_less) ? other : key;
         }
-        if (slp > slope_param ||
-            ((int)i > dmin && (slp * slp - avg * avg) * kdev * ((bx - ax) * kdist) > dev))
-            return (int)i;
     }
-    return -1;
+    return key;
 }
 
-/* One wave per (sector, scan).  MODE 0: sector fits CAP entries of LDS.
- * MODE 1: any size, sorted in place in global memory (adversarial inputs).
- * Sort key = (range bits, input index): unique, so the order is total where
- * the reference's std::sort leaves ties unspecified (star_shaped_search.cpp:109).
- * The network is the "normalised" bitonic sorter: every comparator orders
- * (lower index, higher index) ascending, so slots >= n behave as +inf padding
- * and comparators touching them are skipped. */
-template <int CAP_LO, int CAP_HI, bool IN_LDS>
-__global__ __launch_bounds__(URF_STAR_THREADS) void k_star(urf_kargs a, urf_dev_params dp)
+/* number of entries of the sorted 64-entry block `blk` that are < key */
+__device__ __forceinline__ unsigned urf_count_less64(const unsigned long long* blk, unsigned long long key)
 {
-    __shared__ unsigned long long keys[IN_LDS ? CAP_HI : 1];
-    __shared__ float zs[IN_LDS ? CAP_HI : 1];
+    unsigned pos = 0;
+#pragma unroll
+    for (unsigned step = 32; step > 0; step >>= 1)
+        if (blk[pos + step - 1] < key)
+            pos += step;
+    if (blk[pos] < key)   /* pos <= 63 */
+        pos++;
+    return pos;
+}
+
+/* Common tail: `fin[0..n)` holds the sorted keys, zs[pos] the heights.  Writes
+ * slopes / distance terms / sorted input indices to global memory and returns
+ * (all threads) the index of the first "static" hit, or n. */
+template <int NT>
+__device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_dev_params& dp, unsigned base, unsigned n,
+                                                  const unsigned long long* fin, const float* zs, unsigned* sh_first)
+{
+    const unsigned tid = threadIdx.x;
+    const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
+    unsigned first = n;
+    for (unsigned i = tid; i < n; i += NT) {
+        const unsigned long long kb = fin[i];
+        const unsigned pb = (unsigned)kb;
+        float slp = 0.f, g = 0.f;
+        if (i >= 1) {
+            const unsigned long long ka = fin[i - 1];
+            const float ax = __uint_as_float((unsigned)(ka >> 32)), bx = __uint_as_float((unsigned)(kb >> 32));
+            const float ay = zs[(unsigned)ka], by = zs[pb];
+            slp = (by - ay) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
+            g = (bx - ax) * kdist;
+            if (slp > slope_param && i < first)
+                first = i;
+        }
+        a.ssrt[base + i] = a.ssrc[base + pb];
+        a.sr[base + i] = slp;              /* the ranges are dead: reuse their storage */
+        a.sz[base + i] = g;
+    }
+    atomicMin(sh_first, first);
+    __syncthreads();
+    return *sh_first;
+}
+
+/* sectors with at most 512 points: one wave per (sector, scan) */
+__global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs a, urf_dev_params dp)
+{
+    constexpr unsigned MAXB = 8;
+    __shared__ unsigned long long blk[MAXB * 64];
+    __shared__ unsigned long long fin[MAXB * 64];
+    __shared__ float zs[MAXB * 64];
+    __shared__ unsigned sh_first;
     const unsigned k = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
     if (a.info[s].status != URF_OK)
         return;
     const unsigned K = (unsigned)dp.p.sectors;
     const unsigned n = a.sec_cnt[(size_t)s * K + k];
-    if ((int)n <= CAP_LO || (IN_LDS && (int)n > CAP_HI))
-        return;   /* another instantiation owns this sector */
+    if (n > 512)
+        return;   /* on a work list (k_offsets) */
+    if (n < 2) {
+        if (lane == 0)
+            a.star_first[(size_t)s * K + k] = 0;   /* nothing to walk */
+        return;
+    }
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
-    int hit = -1;
-    if (n >= 2) {
+    const unsigned B = (n + 63) >> 6;
+    if (lane == 0)
+        sh_first = n;
+
+    unsigned long long key[MAXB];
+#pragma unroll
+    for (unsigned q = 0; q < MAXB; q++) {
+        const unsigned i = q * 64 + lane;
+        key[q] = ~0ull;
+        if (q < B && i < n) {
+            key[q] = ((unsigned long long)urf_fbits(a.sr[base + i]) << 32) | i;
+            zs[i] = a.sz[base + i];
+        }
+    }
+#pragma unroll
+    for (unsigned q = 0; q < MAXB; q++)
+        if (q < B) {
+            key[q] = urf_wave_sort64(key[q]);
+            blk[q * 64 + lane] = key[q];
+        }
+    __syncthreads();
+#pragma unroll
+    for (unsigned q = 0; q < MAXB; q++)
+        if (q < B && key[q] != ~0ull) {
+            unsigned rank = lane;
+            for (unsigned p = 0; p < B; p++)
+                if (p != q)
+                    rank += urf_count_less64(blk + p * 64, key[q]);
+            fin[rank] = key[q];
+        }
+    __syncthreads();
+    const unsigned first = urf_star_emit<URF_STAR_THREADS>(a, dp, base, n, fin, zs, &sh_first);
+    if (lane == 0)
+        a.star_first[(size_t)s * K + k] = first < n - 1 ? first : n - 1;   /* last index the walk may visit */
+}
+
+template <int NT>
+__device__ __forceinline__ void urf_bitonic_keys(unsigned long long* keys, unsigned n)
+{
+    unsigned P = 1;
+    while (P < n)
+        P <<= 1;
+    for (unsigned kk = 2; kk <= P; kk <<= 1) {
+        for (unsigned j = kk >> 1; j > 0; j >>= 1) {
+            const bool flip = (j == (kk >> 1));
+            for (unsigned tt = threadIdx.x; tt < (P >> 1); tt += NT) {
+                const unsigned lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
+                /* flip step: partner of lo inside its block of size kk is block_end - (lo - block_start) */
+                const unsigned hi = flip ? ((lo & ~(kk - 1)) + (kk - 1) - (lo & (kk - 1))) : lo + j;
+                if (hi < n) {
+                    const unsigned long long ka = keys[lo], kb = keys[hi];
+                    if (ka > kb) {
+                        keys[lo] = kb;
+                        keys[hi] = ka;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+/* sectors with 513..2048 points (e.g. 128 rings x 4096 columns): persistent
+ * workgroups of 256 threads walk the work list built by k_offsets */
+#define URF_STAR_MID_THREADS 256
+#define URF_STAR_MID_CAP 2048
+__global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_kargs a, urf_dev_params dp)
+{
+    __shared__ unsigned long long keys[URF_STAR_MID_CAP];
+    __shared__ float zs[URF_STAR_MID_CAP];
+    __shared__ unsigned sh_first;
+    const unsigned K = (unsigned)dp.p.sectors;
+    const unsigned count = a.star_count[0];
+    for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
+        const unsigned sk = a.star_list_mid[w];
+        const unsigned s = sk / K, k = sk % K;
+        unsigned off, len;
+        urf_scan_range(a, s, off, len);
+        const unsigned n = a.sec_cnt[(size_t)s * K + k];
+        const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
+        for (unsigned i = threadIdx.x; i < n; i += URF_STAR_MID_THREADS) {
+            keys[i] = ((unsigned long long)urf_fbits(a.sr[base + i]) << 32) | i;
+            zs[i] = a.sz[base + i];
+        }
+        if (threadIdx.x == 0)
+            sh_first = n;
+        __syncthreads();
+        urf_bitonic_keys<URF_STAR_MID_THREADS>(keys, n);
+        const unsigned first = urf_star_emit<URF_STAR_MID_THREADS>(a, dp, base, n, keys, zs, &sh_first);
+        if (threadIdx.x == 0)
+            a.star_first[sk] = first < n - 1 ? first : n - 1;
+        __syncthreads();
+    }
+}
+
+/* sectors with more than 2048 points (adversarial clouds): sorted in place in
+ * global memory by one workgroup each, same network, keys (range, input index);
+ * then slopes in a second sweep (reads complete before the in-place writes). */
+__global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_params dp)
+{
+    __shared__ unsigned sh_first;
+    const unsigned K = (unsigned)dp.p.sectors;
+    const unsigned count = a.star_count[1];
+    const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
+    for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
+        const unsigned sk = a.star_list_big[w];
+        const unsigned s = sk / K, k = sk % K;
+        unsigned off, len;
+        urf_scan_range(a, s, off, len);
+        const unsigned n = a.sec_cnt[(size_t)s * K + k];
+        const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
+        float* R = a.sr + base;
+        float* Z = a.sz + base;
+        unsigned* I = a.ssrc + base;
+        if (threadIdx.x == 0)
+            sh_first = n;
         unsigned P = 1;
         while (P < n)
             P <<= 1;
-        if (IN_LDS) {
-            for (unsigned i = lane; i < n; i += URF_STAR_THREADS) {
-                keys[i] = ((unsigned long long)urf_fbits(a.sr[base + i]) << 32) | a.ssrc[base + i];
-                zs[i] = a.sz[base + i];
+        for (unsigned kk = 2; kk <= P; kk <<= 1) {
+            for (unsigned j = kk >> 1; j > 0; j >>= 1) {
+                const bool flip = (j == (kk >> 1));
+                for (unsigned tt = threadIdx.x; tt < (P >> 1); tt += 256) {
+                    const unsigned lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
+                    const unsigned hi = flip ? ((lo & ~(kk - 1)) + (kk - 1) - (lo & (kk - 1))) : lo + j;
+                    if (hi < n) {
+                        const unsigned long long ka = ((unsigned long long)urf_fbits(R[lo]) << 32) | I[lo];
+                        const unsigned long long kb = ((unsigned long long)urf_fbits(R[hi]) << 32) | I[hi];
+                        if (ka > kb) {
+                            const float r0 = R[lo], z0 = Z[lo];
+                            const unsigned i0 = I[lo];
+                            R[lo] = R[hi]; Z[lo] = Z[hi]; I[lo] = I[hi];
+                            R[hi] = r0; Z[hi] = z0; I[hi] = i0;
+                        }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+        }
+        /* slopes: chunks from the back, so that element i-1 is still a range when i is computed */
+        unsigned first = n;
+        for (unsigned hi = n; hi > 0;) {
+            const unsigned lo = hi > 256 ? hi - 256 : 0;
+            const unsigned i = lo + threadIdx.x;
+            float slp = 0.f, g = 0.f;
+            if (i >= 1 && i < hi) {
+                slp = (Z[i] - Z[i - 1]) / (R[i] - R[i - 1]);
+                g = (R[i] - R[i - 1]) * kdist;
+                if (slp > slope_param && i < first)
+                    first = i;
             }
             __syncthreads();
-            for (unsigned kk = 2; kk <= P; kk <<= 1) {
-                for (unsigned j = kk >> 1; j > 0; j >>= 1) {
-                    const bool flip = (j == (kk >> 1));
-                    for (unsigned tt = lane; tt < (P >> 1); tt += URF_STAR_THREADS) {
-                        const unsigned lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
-                        /* flip step: partner of lo inside its block of size kk is block_end - (lo - block_start) */
-                        const unsigned hi2 = flip ? ((lo & ~(kk - 1)) + (kk - 1) - (lo & (kk - 1))) : lo + j;
-                        if (hi2 < n) {
-                            const unsigned long long ka = keys[lo], kb = keys[hi2];
-                            if (ka > kb) {
-                                keys[lo] = kb;
-                                keys[hi2] = ka;
-                                const float za = zs[lo];
-                                zs[lo] = zs[hi2];
-                                zs[hi2] = za;
-                            }
-                        }
-                    }
-                    __syncthreads();
+            if (i < hi) {
+                R[i] = slp;
+                Z[i] = g;
+                a.ssrt[base + i] = I[i];
+            }
+            __threadfence_block();
+            __syncthreads();
+            hi = lo;
+        }
+        atomicMin(&sh_first, first);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            a.star_first[sk] = sh_first < n - 1 ? sh_first : n - 1;
+        __syncthreads();
+    }
+}
+
+/* star_shaped_search.cpp:123-149, one lane per (sector, scan).  sr = slopes, sz =
+ * distance terms, both in sorted order; the walk visits i = 1..last. */
+__global__ __launch_bounds__(256) void k_star_walk(urf_kargs a, urf_dev_params dp)
+{
+    const unsigned K = (unsigned)dp.p.sectors;
+    const unsigned s = blockIdx.y;
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K || a.info[s].status != URF_OK)
+        return;
+    unsigned off, len;
+    urf_scan_range(a, s, off, len);
+    const unsigned n = a.sec_cnt[(size_t)s * K + k];
+    int hit = -1;
+    if (n >= 2 && !(dp.exp_flags & 2u)) {
+        const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
+        const unsigned last = a.star_first[(size_t)s * K + k];
+        const float* S = a.sr + base;
+        const float* G = a.sz + base;
+        const float kdev = dp.p.kdev_param, slope_param = dp.slope_param;
+        const int dmin = dp.p.dmin_param;
+        float avg = 0.f, dev = 0.f, nan = 0.f;
+        for (unsigned i = 1; i <= last; i++) {
+            const float slp = S[i];
+            if (slp != slp) {
+                nan += 1.0f;                                   /* :131-132 */
+            } else {
+                float w, u;
+                if (nan == 0.0f) {
+                    w = (float)(int)(i - 1);                   /* == (float)i - 0 - 1, exact */
+                    u = a.inv_i[i];                            /* 1.0f / (float)i */
+                } else {
+                    w = (float)(int)i - nan - 1.0f;
+                    u = 1.0f / ((float)(int)i - nan);
                 }
+                avg *= w;                                      /* :135-140 */
+                avg += slp;
+                avg *= u;
+                dev *= w;
+                dev += __builtin_fabsf(slp - avg);
+                dev *= u;
             }
-            if (lane == 0) {
-                const int pos = urf_slope_scan(
-                    n, dp, [&](unsigned i) { return __uint_as_float((unsigned)(keys[i] >> 32)); },
-                    [&](unsigned i) { return zs[i]; });
-                if (pos >= 0)
-                    hit = (int)(unsigned)(keys[pos] & 0xffffffffull);
-            }
-        } else {
-            float* R = a.sr + base;
-            float* Z = a.sz + base;
-            unsigned* I = a.ssrc + base;
-            for (unsigned kk = 2; kk <= P; kk <<= 1) {
-                for (unsigned j = kk >> 1; j > 0; j >>= 1) {
-                    const bool flip = (j == (kk >> 1));
-                    for (unsigned tt = lane; tt < (P >> 1); tt += URF_STAR_THREADS) {
-                        const unsigned lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
-                        const unsigned hi2 = flip ? ((lo & ~(kk - 1)) + (kk - 1) - (lo & (kk - 1))) : lo + j;
-                        if (hi2 < n) {
-                            const unsigned long long ka = ((unsigned long long)urf_fbits(R[lo]) << 32) | I[lo];
-                            const unsigned long long kb = ((unsigned long long)urf_fbits(R[hi2]) << 32) | I[hi2];
-                            if (ka > kb) {
-                                const float r0 = R[lo], z0 = Z[lo];
-                                const unsigned i0 = I[lo];
-                                R[lo] = R[hi2]; Z[lo] = Z[hi2]; I[lo] = I[hi2];
-                                R[hi2] = r0; Z[hi2] = z0; I[hi2] = i0;
-                            }
-                        }
-                    }
-                    __threadfence_block();
-                    __syncthreads();
-                }
-            }
-            if (lane == 0) {
-                const int pos = urf_slope_scan(
-                    n, dp, [&](unsigned i) { return R[i]; }, [&](unsigned i) { return Z[i]; });
-                if (pos >= 0)
-                    hit = (int)I[pos];
+            if (slp > slope_param ||                           /* :142-143 */
+                ((int)i > dmin && (slp * slp - avg * avg) * kdev * G[i] > dev)) {
+                hit = (int)a.ssrt[base + i];                   /* :146 */
+                break;
             }
         }
     }
-    if (lane == 0)
-        a.star_hit[(size_t)s * K + k] = hit;
+    a.star_hit[(size_t)s * K + k] = hit;
 }
-
-/* Instantiations (each sector is owned by exactly one): <-1,512,LDS> for
- * n <= 512 (also writes "no hit" for sectors with 0 or 1 point), <512,2048,LDS>
- * and <2048,-,global> for everything larger. */
 
 /* ------------------------------------------------------------------------- */
 /* k_ring                                                                      */
@@ -737,7 +988,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
                             br = -1.0f;
                         else if (br > 1.0f)
                             br = 1.0f;
-                        const float alpha = (float)((double)(urf_acosf(br) * 180.0f) / URF_PI_D);
+                        const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));
                         if (alpha <= dp.p.angleFilter1 &&
                             (__builtin_fabsf(zj - pz) >= dp.p.curbHeight || __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
                             (double)__builtin_fabsf(zj - z3) >= 0.05)
@@ -780,7 +1031,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
                             br = -1.0f;
                         else if (br > 1.0f)
                             br = 1.0f;
-                        const float alpha = (float)((double)(urf_acosf(br) * 180.0f) / URF_PI_D);
+                        const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));
                         if (alpha <= dp.p.angleFilter2 &&
                             (max1 - az >= dp.p.curbHeight || max2 - az >= dp.p.curbHeight) &&
                             (double)__builtin_fabsf(max1 - max2) >= 0.05)
@@ -831,16 +1082,42 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
     if (want_quad && tid < 4)
         a.quad[(size_t)s * 4 + tid] = __uint_as_float((unsigned)sh_q[tid]);
 
-    /* sufmin[i] = min curb azimuth >= i ; premax[i] = max curb azimuth <= i ; NaN = none */
+    /* sufmin[i] = min curb azimuth >= i ; premax[i] = max curb azimuth <= i ; NaN = none.
+     * Six 64-cell segments: suffix-min / prefix-max inside a segment by wave
+     * shuffles, then combined with the totals of the segments behind / in front. */
+    __shared__ int segmin[6], segmax[6];
+    __syncthreads();
+    const unsigned wave = tid >> 6, lane = tid & 63;
+    for (unsigned seg = wave; seg < 6; seg += URF_RING_THREADS / 64) {
+        const unsigned cidx = seg * 64 + lane;
+        int mn = cidx < URF_DEG_CELLS ? cmin[cidx] : URF_INT_NONE_MIN;
+        int mx = cidx < URF_DEG_CELLS ? cmax[cidx] : -1;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int wmn = __shfl_down(mn, o), wmx = __shfl_up(mx, o);
+            if ((int)lane + o < 64)
+                mn = wmn < mn ? wmn : mn;
+            if ((int)lane >= o)
+                mx = wmx > mx ? wmx : mx;
+        }
+        if (cidx < URF_DEG_CELLS) {
+            cmin[cidx] = mn;
+            cmax[cidx] = mx;
+        }
+        if (lane == 0)
+            segmin[seg] = mn;
+        if (lane == 63)
+            segmax[seg] = mx;
+    }
+    __syncthreads();
     float* sm = a.sufmin + ((size_t)s * C + c) * URF_DEG_CELLS;
     float* pm = a.premax + ((size_t)s * C + c) * URF_DEG_CELLS;
     for (unsigned i = tid; i < URF_DEG_CELLS; i += URF_RING_THREADS) {
-        int mn = URF_INT_NONE_MIN;
-        for (unsigned j = i; j < URF_DEG_CELLS; j++)
-            mn = cmin[j] < mn ? cmin[j] : mn;
-        int mx = -1;
-        for (int j = (int)i; j >= 0; j--)
-            mx = cmax[j] > mx ? cmax[j] : mx;
+        const unsigned seg = i >> 6;
+        int mn = cmin[i], mx = cmax[i];
+        for (unsigned g = seg + 1; g < 6; g++)
+            mn = segmin[g] < mn ? segmin[g] : mn;
+        for (unsigned g = 0; g < seg; g++)
+            mx = segmax[g] > mx ? segmax[g] : mx;
         sm[i] = mn == URF_INT_NONE_MIN ? __builtin_nanf("") : __uint_as_float((unsigned)mn);
         pm[i] = mx < 0 ? __builtin_nanf("") : __uint_as_float((unsigned)mx);
     }
@@ -1086,6 +1363,24 @@ __global__ __launch_bounds__(1024) void k_compact(const uint8_t* __restrict__ la
     }
     if (tid < 4 && counts)
         counts[tid] = run[tid];
+}
+
+/* ------------------------------------------------------------------------- */
+/* self test                                                                   */
+/* ------------------------------------------------------------------------- */
+/* urf_div_pi(a) == a / M_PI for every float a in [0, 600] (bit patterns 0..0x44160000) */
+__global__ __launch_bounds__(256) void k_selftest_div_pi(unsigned long long* mismatches)
+{
+    const unsigned top = 0x44160000u;   /* 600.0f */
+    unsigned long long bad = 0;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= top;
+         b += (unsigned long long)gridDim.x * blockDim.x) {
+        const double a = (double)__uint_as_float((unsigned)b);
+        if (urf_div_pi(a) != a / URF_PI_D)
+            bad++;
+    }
+    if (bad)
+        atomicAdd(mismatches, bad);
 }
 
 #endif /* URF_KERNELS_HPP */
