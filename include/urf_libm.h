@@ -77,15 +77,16 @@ static inline URF_HD double urf__atan_poly(double t)
     return __builtin_fma(tv, q, t);
 }
 
-/* asin on [0,1] in binary64. */
+/* asin on [0,1] in binary64.  One polynomial evaluation serves both ranges
+ * (a <= 0.5 directly, else through asin(a) = pi/2 - 2 asin(sqrt((1-a)/2))), so a
+ * wave whose lanes fall on both sides does not pay for two. */
 static inline URF_HD double urf__asin01(double a)
 {
-    if (a <= 0.5)
-        return urf__asin_poly(a, a * a);
-    double w = (1.0 - a) * 0.5;          /* exact */
-    double s = __builtin_sqrt(w);
-    double r = urf__asin_poly(s, w);     /* asin(sqrt((1-a)/2)) */
-    return __builtin_fma(-2.0, r, URF_PIO2_D);
+    const int small = a <= 0.5;
+    const double w = small ? a * a : (1.0 - a) * 0.5;   /* (1-a)/2 is exact */
+    const double s = small ? a : __builtin_sqrt(w);
+    const double r = urf__asin_poly(s, w);
+    return small ? r : __builtin_fma(-2.0, r, URF_PIO2_D);
 }
 
 /* replaces glibc asinf (float overload of asin) */
@@ -101,17 +102,18 @@ static inline URF_HD float urf_asinf(float x)
 /* replaces glibc acosf (float overload of acos) */
 static inline URF_HD float urf_acosf(float x)
 {
-    double a = __builtin_fabs((double)x);
+    const double a = __builtin_fabs((double)x);
     if (!(a <= 1.0))
         return __builtin_nanf("");
+    const int small = a <= 0.5;
+    const double w = small ? a * a : (1.0 - a) * 0.5;   /* exact */
+    const double s = small ? a : __builtin_sqrt(w);
+    const double p = urf__asin_poly(s, w);
     double r;
-    if (a <= 0.5) {
-        double as = urf__asin_poly(a, a * a);
-        r = x < 0.0f ? URF_PIO2_D + as : URF_PIO2_D - as;
-    } else {
-        double w = (1.0 - a) * 0.5;      /* exact */
-        double s = __builtin_sqrt(w);
-        double t = 2.0 * urf__asin_poly(s, w);
+    if (small)
+        r = x < 0.0f ? URF_PIO2_D + p : URF_PIO2_D - p;   /* pi/2 -+ asin(|x|) */
+    else {
+        const double t = 2.0 * p;                         /* acos(|x|) = 2 asin(sqrt((1-|x|)/2)) */
         r = x < 0.0f ? URF_PI_D - t : t;
     }
     return (float)r;
@@ -128,17 +130,19 @@ static inline URF_HD float urf_atan2f(float y, float x)
     if (mx == 0.0) {
         r = 0.0;
     } else {
-        double t;
-        if (mx > 0x1.fffffffffffffp+1023)          /* infinite operand */
-            t = (mn > 0x1.fffffffffffffp+1023) ? 1.0 : 0.0;
-        else
-            t = mn / mx;                            /* in [0,1] */
-        if (t > URF_SQRT2M1_D) {
-            double tr = (t - 1.0) / (t + 1.0);      /* atan(t) = pi/4 + atan(tr) */
-            r = URF_PIO4_D + urf__atan_poly(tr);
-        } else {
-            r = urf__atan_poly(t);
+        if (mx > 0x1.fffffffffffffp+1023) {              /* infinite operand */
+            mn = (mn > 0x1.fffffffffffffp+1023) ? 1.0 : 0.0;
+            mx = 1.0;
         }
+        /* one division either way: atan(mn/mx) directly, or, above tan(pi/8),
+         * pi/4 + atan((mn-mx)/(mn+mx)) */
+        const int big = mn > mx * URF_SQRT2M1_D;
+        const double num = big ? mn - mx : mn;
+        const double den = big ? mn + mx : mx;
+        const double t = num / den;
+        r = urf__atan_poly(t);
+        if (big)
+            r = URF_PIO4_D + r;
         if (ay > ax)
             r = URF_PIO2_D - r;
     }

@@ -98,8 +98,13 @@ static int upload_params(urf_ctx* c)
     dp.fwd_limit = 360.0f - p.beamZone;                                /* blind_spots.cpp:68 */
     dp.bwd_limit = 0.0f + p.beamZone;                                  /* blind_spots.cpp:177 */
     dp.inv_cp = 1.0f / (float)p.curbPoints;                            /* z_zero_method.cpp:52 */
-    dp.sec_keybits = 10;
-    dp.ring_keybits = 8;
+    /* keys 0..K-1 plus "none" (mapped to K) must be distinguishable */
+    dp.sec_keybits = 1;
+    while ((1u << dp.sec_keybits) <= (unsigned)p.sectors)
+        dp.sec_keybits++;
+    dp.ring_keybits = 1;
+    while ((1u << dp.ring_keybits) <= (unsigned)p.channels)
+        dp.ring_keybits++;
     dp.exp_flags = std::getenv("URF_EXP") ? (uint32_t)std::strtoul(std::getenv("URF_EXP"), nullptr, 0) : 0u;
     std::vector<urf_beam> beams;
     beam_init(beams, p.sectors, p.beam_width);
@@ -384,7 +389,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         /* persistent workgroups over the (normally empty) work lists of oversized sectors */
         hipLaunchKernelGGL(k_star_sort_mid, dim3(c->n_cus * 4), dim3(URF_STAR_MID_THREADS), 0, st, a, dp);
         hipLaunchKernelGGL(k_star_sort_big, dim3(c->n_cus * 2), dim3(256), 0, st, a, dp);
-        hipLaunchKernelGGL(k_star_walk, dim3((K + 255) / 256, n_scans), dim3(256), 0, st, a, dp);
+        hipLaunchKernelGGL(k_star_walk, dim3((K + 63) / 64, n_scans), dim3(64), 0, st, a, dp);
     }
     mark();
     const dim3 g_ring(C, n_scans);

@@ -30,6 +30,10 @@
 #include "urf_device.hpp"
 
 #define URF_INT_NONE_MIN 0x7fffffff
+/* (float)sqrt(s) < 5.0 (x_zero_method.cpp:35-40, z_zero_method.cpp:23-28) holds exactly for the
+ * doubles s below this one: sqrt and the rounding to float are monotone, the threshold is the
+ * smallest double whose rounded root reaches 5.0f (found by bisection, tools/check_dist5.c). */
+#define URF_DIST5_SQ 0x1.8ffffd800000fp+4
 #define URF_RING_THREADS 256
 #define URF_LABEL_THREADS 384
 #define URF_STAR_THREADS 64
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_ingest(urf_kargs a, urf_de
             a.seckey[off + i] = (uint16_t)key;
         }
         if (star) {
-            const unsigned long long m = urf_match_any(key, dp.sec_keybits);
+            const unsigned long long m = urf_match_any(key == URF_SEC_NONE ? K : key, dp.sec_keybits);
             if (key != URF_SEC_NONE && urf_is_leader(m))
                 atomicAdd(&sh_hist[key], (unsigned)__popcll(m));
         }
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_ring_assign(urf_kargs a, u
             a.ringkey[off + i] = (uint8_t)key;
             a.labels[off + i] = lab;
         }
-        const unsigned long long m = urf_match_any(key, dp.ring_keybits);
+        const unsigned long long m = urf_match_any(key == URF_RING_NONE ? C : key, dp.ring_keybits);
         if (key != URF_RING_NONE && urf_is_leader(m))
             atomicAdd(&hist[key], (unsigned)__popcll(m));
     }
@@ -398,11 +402,14 @@ __global__ __launch_bounds__(256) void k_offsets(urf_kargs a, urf_dev_params dp)
 /* ------------------------------------------------------------------------- */
 /* k_scatter                                                                   */
 /* ------------------------------------------------------------------------- */
-/* Stable multi-split of one tile by ring and by sector.  A point's rank
- * inside its key = (points of that key in earlier tiles: tile_ring/tile_sec)
- * + (in earlier wave-sized groups of this tile: LDS matrix gcnt[group][key])
- * + (in lower lanes of its own group: match_any + popcount).  Input order is
- * preserved inside every ring, which x_zero / z_zero rely on
+/* Stable multi-split of one tile by ring and by sector.  Wave w of the
+ * workgroup owns the 256 consecutive points [w*256, w*256+256) of the tile and
+ * walks them 64 at a time.  A point's rank inside its key =
+ *     points of that key in earlier tiles                 (tile_ring / tile_sec, k_offsets)
+ *   + ... in earlier waves of this tile                   (LDS matrix wcnt[wave][key], scanned per key)
+ *   + ... in earlier 64-point steps of its own wave       (running value of wcnt[wave][key])
+ *   + ... in lower lanes of its own step                  (match_any + popcount).
+ * Input order is preserved inside every ring, which x_zero / z_zero rely on
  * (lidar_segmentation.cpp:280-283 run before the azimuth sort :289).
  *
  * Ring-major stores: in firing order the 64 lanes of a wave belong to 64
@@ -413,13 +420,14 @@ __global__ __launch_bounds__(256) void k_offsets(urf_kargs a, urf_dev_params dp)
  * Sector-major stores are already contiguous (a firing shares one sector). */
 #define URF_SLOT(lp) ((lp) + ((lp) >> 6))
 #define URF_SLOTS (URF_TILE + URF_TILE / 64)
+#define URF_TILE_WAVES (URF_TILE_THREADS / 64)
 
 __host__ __device__ inline size_t urf_scatter_lds_bytes(unsigned C, unsigned K, bool star)
 {
     const size_t keys = C + (star ? K : 0);
-    const size_t gcnt = 2 * (size_t)URF_TILE_GROUPS * keys + 8;   /* uint16 matrices */
-    const size_t stage = 4 * (size_t)URF_SLOTS * 4;                /* x y z src staging, aliases gcnt */
-    return 4 * (keys + 2 * C) + (gcnt > stage ? gcnt : stage) + URF_TILE;
+    const size_t wcnt = 2 * (size_t)URF_TILE_WAVES * keys + 8;   /* uint16 matrices */
+    const size_t stage = 4 * (size_t)URF_SLOTS * 4;               /* x y z src staging, aliases wcnt */
+    return 4 * (keys + 2 * C) + (wcnt > stage ? wcnt : stage);
 }
 
 __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_dev_params dp)
@@ -435,62 +443,72 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
         return;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
-    constexpr unsigned Q = URF_TILE / URF_TILE_THREADS;
-    /* LDS carve: base_r[C] koff[C] tot_r[C] base_s[K] (uint32) | union { gcnt_r[G][C] gcnt_s[G][K] (uint16),
-     * stage x y z src [URF_SLOTS] (uint32) } | keyL[URF_TILE] (uint8) */
+    constexpr unsigned Q = 256 / 64;
+    /* LDS carve: base_r[C] koff[C] tot_r[C] base_s[K] (uint32) |
+     * union { wcnt_r[W][C] wcnt_s[W][K] (uint16), stage x y z src [URF_SLOTS] (uint32) } */
     unsigned* base_r = sh_dyn;
     unsigned* koff = base_r + C;
     unsigned* tot_r = koff + C;
     unsigned* base_s = tot_r + C;
     unsigned* un = base_s + (star ? K : 0);
-    uint16_t* gcnt_r = (uint16_t*)un;
-    uint16_t* gcnt_s = gcnt_r + (size_t)URF_TILE_GROUPS * C;
-    const size_t keys = C + (star ? K : 0);
-    const size_t gbytes = 2 * (size_t)URF_TILE_GROUPS * keys + 8, sbytes = 4 * (size_t)URF_SLOTS * 4;
-    uint8_t* keyL = (uint8_t*)un + (gbytes > sbytes ? gbytes : sbytes);
+    uint16_t* wcnt_r = (uint16_t*)un;
+    uint16_t* wcnt_s = wcnt_r + (size_t)URF_TILE_WAVES * C;
+    const unsigned keys = C + (star ? K : 0);
     const size_t row = (size_t)s * a.tiles + t;
+    const unsigned wave = tid >> 6, lane = tid & 63;
 
     for (unsigned k = tid; k < C; k += URF_TILE_THREADS)
         base_r[k] = off + a.ring_off[(size_t)s * (C + 1) + k] + a.tile_ring[row * C + k];
     if (star)
         for (unsigned k = tid; k < K; k += URF_TILE_THREADS)
             base_s[k] = off + a.sec_off[(size_t)s * (K + 1) + k] + a.tile_sec[row * K + k];
-    {
-        const unsigned tot = URF_TILE_GROUPS * (unsigned)keys;
-        for (unsigned k = tid; k < (tot + 1) / 2; k += URF_TILE_THREADS)
-            un[k] = 0;
-    }
+    for (unsigned k = tid; k < (URF_TILE_WAVES * keys + 1) / 2; k += URF_TILE_THREADS)
+        un[k] = 0;
     __syncthreads();
 
+    /* step 1: ranks inside the wave's own 256 points (LDS read-modify-write by the key's
+     * leader lane; one wave touches only its own row, in program order) */
     unsigned rkey[Q], skey[Q], rrank[Q], srank[Q];
-    const unsigned wave = tid >> 6;
+    uint16_t* my_r = wcnt_r + wave * C;
+    uint16_t* my_s = wcnt_s + wave * K;
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned i = tbase + q * URF_TILE_THREADS + tid;
+        const unsigned i = tbase + wave * 256 + q * 64 + lane;
         const bool valid = i < len;
-        const unsigned g = q * (URF_TILE_THREADS / 64) + wave;
         rkey[q] = valid ? (unsigned)a.ringkey[off + i] : URF_RING_NONE;
-        const unsigned long long mr = urf_match_any(rkey[q], dp.ring_keybits);
-        rrank[q] = urf_popc_below(mr);
-        if (rkey[q] != URF_RING_NONE && urf_is_leader(mr))
-            gcnt_r[g * C + rkey[q]] = (uint16_t)__popcll(mr);
+        {
+            const unsigned mk = rkey[q] == URF_RING_NONE ? C : rkey[q];
+            const unsigned long long m = urf_match_any(mk, dp.ring_keybits);
+            const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
+            unsigned old = 0;
+            if (rkey[q] != URF_RING_NONE && leader == lane) {
+                old = my_r[rkey[q]];
+                my_r[rkey[q]] = (uint16_t)(old + (unsigned)__popcll(m));
+            }
+            rrank[q] = (unsigned)__shfl((int)old, (int)leader) + urf_popc_below(m);
+        }
         skey[q] = URF_SEC_NONE;
         srank[q] = 0;
         if (star) {
             skey[q] = valid ? (unsigned)a.seckey[off + i] : URF_SEC_NONE;
-            const unsigned long long ms = urf_match_any(skey[q], dp.sec_keybits);
-            srank[q] = urf_popc_below(ms);
-            if (skey[q] != URF_SEC_NONE && urf_is_leader(ms))
-                gcnt_s[g * K + skey[q]] = (uint16_t)__popcll(ms);
+            const unsigned mk = skey[q] == URF_SEC_NONE ? K : skey[q];
+            const unsigned long long m = urf_match_any(mk, dp.sec_keybits);
+            const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
+            unsigned old = 0;
+            if (skey[q] != URF_SEC_NONE && leader == lane) {
+                old = my_s[skey[q]];
+                my_s[skey[q]] = (uint16_t)(old + (unsigned)__popcll(m));
+            }
+            srank[q] = (unsigned)__shfl((int)old, (int)leader) + urf_popc_below(m);
         }
     }
     __syncthreads();
-    /* exclusive scan over the groups, one thread per key */
+    /* step 2: exclusive scan over the waves, one thread per key */
     for (unsigned k = tid; k < C; k += URF_TILE_THREADS) {
         unsigned run = 0;
-        for (unsigned g = 0; g < URF_TILE_GROUPS; g++) {
-            const unsigned c = gcnt_r[g * C + k];
-            gcnt_r[g * C + k] = (uint16_t)run;
+        for (unsigned w = 0; w < URF_TILE_WAVES; w++) {
+            const unsigned c = wcnt_r[w * C + k];
+            wcnt_r[w * C + k] = (uint16_t)run;
             run += c;
         }
         tot_r[k] = run;
@@ -498,39 +516,49 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
     if (star)
         for (unsigned k = tid; k < K; k += URF_TILE_THREADS) {
             unsigned run = 0;
-            for (unsigned g = 0; g < URF_TILE_GROUPS; g++) {
-                const unsigned c = gcnt_s[g * K + k];
-                gcnt_s[g * K + k] = (uint16_t)run;
+            for (unsigned w = 0; w < URF_TILE_WAVES; w++) {
+                const unsigned c = wcnt_s[w * K + k];
+                wcnt_s[w * K + k] = (uint16_t)run;
                 run += c;
             }
         }
     __syncthreads();
-    /* offset of every ring's run inside the tile's ring-sorted order */
-    if (tid < C) {
-        unsigned run = 0;
-        for (unsigned k = 0; k < tid; k++)
-            run += tot_r[k];
-        koff[tid] = run;
+    /* step 3: offset of every ring's run inside the tile's ring-sorted order (C <= 128) */
+    if (tid < 64) {
+        const unsigned v0 = tid < C ? tot_r[tid] : 0, v1 = tid + 64 < C ? tot_r[tid + 64] : 0;
+        unsigned i0 = v0, i1 = v1;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned w0 = __shfl_up(i0, o), w1 = __shfl_up(i1, o);
+            if ((int)tid >= o) {
+                i0 += w0;
+                i1 += w1;
+            }
+        }
+        const unsigned total0 = __shfl(i0, 63);
+        if (tid < C)
+            koff[tid] = i0 - v0;
+        if (tid + 64 < C)
+            koff[tid + 64] = total0 + i1 - v1;
     }
     __syncthreads();
     const unsigned tile_ring_pts = koff[C - 1] + tot_r[C - 1];
 
-    /* positions: ring slot inside the tile (lp), sector-major destination (sdst) */
+    /* step 4: ring slot inside the tile (lp), sector-major destination (sdst) */
     unsigned lp[Q], sdst[Q];
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned g = q * (URF_TILE_THREADS / 64) + wave;
-        lp[q] = rkey[q] != URF_RING_NONE ? koff[rkey[q]] + gcnt_r[g * C + rkey[q]] + rrank[q] : 0xffffffffu;
-        sdst[q] = skey[q] != URF_SEC_NONE ? base_s[skey[q]] + gcnt_s[g * K + skey[q]] + srank[q] : 0xffffffffu;
+        lp[q] = rkey[q] != URF_RING_NONE ? koff[rkey[q]] + my_r[rkey[q]] + rrank[q] : 0xffffffffu;
+        sdst[q] = skey[q] != URF_SEC_NONE ? base_s[skey[q]] + my_s[skey[q]] + srank[q] : 0xffffffffu;
     }
-    __syncthreads();   /* gcnt is dead: its memory becomes the staging buffers */
+    __syncthreads();   /* wcnt is dead: its memory becomes the staging buffers */
     unsigned* stx = un;
     unsigned* sty = stx + URF_SLOTS;
     unsigned* stz = sty + URF_SLOTS;
     unsigned* sts = stz + URF_SLOTS;
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned i = tbase + q * URF_TILE_THREADS + tid;
+        const unsigned li = wave * 256 + q * 64 + lane;   /* index inside the tile, < 4096 */
+        const unsigned i = tbase + li;
         if (lp[q] == 0xffffffffu && sdst[q] == 0xffffffffu)
             continue;
         const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
@@ -539,8 +567,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
             stx[sl] = __float_as_uint(x);
             sty[sl] = __float_as_uint(y);
             stz[sl] = __float_as_uint(z);
-            sts[sl] = i;
-            keyL[lp[q]] = (uint8_t)rkey[q];
+            sts[sl] = (rkey[q] << 12) | li;
         }
         if (sdst[q] != 0xffffffffu) {
             a.sr[sdst[q]] = __builtin_sqrtf(x * x + y * y);   /* star_shaped_search.cpp:164 */
@@ -550,13 +577,14 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
     }
     __syncthreads();
     for (unsigned j = tid; j < tile_ring_pts; j += URF_TILE_THREADS) {
-        const unsigned k = keyL[j];
-        const unsigned dst = base_r[k] + (j - koff[k]);
         const unsigned sl = URF_SLOT(j);
+        const unsigned pk = sts[sl];
+        const unsigned k = pk >> 12;
+        const unsigned dst = base_r[k] + (j - koff[k]);
         a.rx[dst] = __uint_as_float(stx[sl]);
         a.ry[dst] = __uint_as_float(sty[sl]);
         a.rz[dst] = __uint_as_float(stz[sl]);
-        a.rsrc[dst] = sts[sl];
+        a.rsrc[dst] = tbase + (pk & 0xfffu);
     }
 }
 
@@ -657,8 +685,7 @@ __device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_
 __global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs a, urf_dev_params dp)
 {
     constexpr unsigned MAXB = 8;
-    __shared__ unsigned long long blk[MAXB * 64];
-    __shared__ unsigned long long fin[MAXB * 64];
+    __shared__ unsigned long long blk[MAXB * 64];   /* sorted blocks, then the fully sorted sector */
     __shared__ float zs[MAXB * 64];
     __shared__ unsigned sh_first;
     const unsigned k = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
@@ -697,16 +724,22 @@ __global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs 
             blk[q * 64 + lane] = key[q];
         }
     __syncthreads();
+    unsigned rank[MAXB];
 #pragma unroll
-    for (unsigned q = 0; q < MAXB; q++)
-        if (q < B && key[q] != ~0ull) {
-            unsigned rank = lane;
+    for (unsigned q = 0; q < MAXB; q++) {
+        rank[q] = lane;
+        if (q < B && key[q] != ~0ull)
             for (unsigned p = 0; p < B; p++)
                 if (p != q)
-                    rank += urf_count_less64(blk + p * 64, key[q]);
-            fin[rank] = key[q];
-        }
+                    rank[q] += urf_count_less64(blk + p * 64, key[q]);
+    }
+    __syncthreads();   /* every lane has its ranks: the blocks may be overwritten */
+#pragma unroll
+    for (unsigned q = 0; q < MAXB; q++)
+        if (q < B && key[q] != ~0ull)
+            blk[rank[q]] = key[q];
     __syncthreads();
+    const unsigned long long* fin = blk;
     const unsigned first = urf_star_emit<URF_STAR_THREADS>(a, dp, base, n, fin, zs, &sh_first);
     if (lane == 0)
         a.star_first[(size_t)s * K + k] = first < n - 1 ? first : n - 1;   /* last index the walk may visit */
@@ -846,55 +879,93 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
     }
 }
 
-/* star_shaped_search.cpp:123-149, one lane per (sector, scan).  sr = slopes, sz =
- * distance terms, both in sorted order; the walk visits i = 1..last. */
-__global__ __launch_bounds__(256) void k_star_walk(urf_kargs a, urf_dev_params dp)
+/* star_shaped_search.cpp:123-149, one LANE per (sector, scan), one wave per 64
+ * sectors.  sr = slopes, sz = distance terms, both in sorted order; the walk of
+ * a sector visits i = 1..star_first.  A lane reading its own sector directly
+ * would touch 64 different cache lines per load, so the wave fetches the next
+ * 16 steps of all its sectors cooperatively (16 consecutive floats = one line
+ * per sector) into LDS and every lane then reads its own row. */
+#define URF_WALK_CHUNK 16
+__global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp)
 {
+    __shared__ float tS[64][URF_WALK_CHUNK + 1], tG[64][URF_WALK_CHUNK + 1];
+    __shared__ unsigned sbase[64], slast[64];
     const unsigned K = (unsigned)dp.p.sectors;
-    const unsigned s = blockIdx.y;
-    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K || a.info[s].status != URF_OK)
+    const unsigned s = blockIdx.y, lane = threadIdx.x;
+    const unsigned k = blockIdx.x * 64 + lane;
+    if (a.info[s].status != URF_OK)
         return;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
-    const unsigned n = a.sec_cnt[(size_t)s * K + k];
+    const bool have = k < K;
+    const unsigned n = have ? a.sec_cnt[(size_t)s * K + k] : 0;
+    const unsigned base = have ? off + a.sec_off[(size_t)s * (K + 1) + k] : 0;
+    unsigned last = (n >= 2 && !(dp.exp_flags & 2u)) ? a.star_first[(size_t)s * K + k] : 0;
+    sbase[lane] = base;
+    slast[lane] = last;
+    unsigned maxlast = last;
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned w = __shfl_xor(maxlast, o);
+        maxlast = w > maxlast ? w : maxlast;
+    }
+    __syncthreads();
+
+    const float kdev = dp.p.kdev_param, slope_param = dp.slope_param;
+    const int dmin = dp.p.dmin_param;
+    float avg = 0.f, dev = 0.f, nan = 0.f;
     int hit = -1;
-    if (n >= 2 && !(dp.exp_flags & 2u)) {
-        const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
-        const unsigned last = a.star_first[(size_t)s * K + k];
-        const float* S = a.sr + base;
-        const float* G = a.sz + base;
-        const float kdev = dp.p.kdev_param, slope_param = dp.slope_param;
-        const int dmin = dp.p.dmin_param;
-        float avg = 0.f, dev = 0.f, nan = 0.f;
-        for (unsigned i = 1; i <= last; i++) {
-            const float slp = S[i];
-            if (slp != slp) {
-                nan += 1.0f;                                   /* :131-132 */
-            } else {
-                float w, u;
-                if (nan == 0.0f) {
-                    w = (float)(int)(i - 1);                   /* == (float)i - 0 - 1, exact */
-                    u = a.inv_i[i];                            /* 1.0f / (float)i */
-                } else {
-                    w = (float)(int)i - nan - 1.0f;
-                    u = 1.0f / ((float)(int)i - nan);
-                }
-                avg *= w;                                      /* :135-140 */
-                avg += slp;
-                avg *= u;
-                dev *= w;
-                dev += __builtin_fabsf(slp - avg);
-                dev *= u;
-            }
-            if (slp > slope_param ||                           /* :142-143 */
-                ((int)i > dmin && (slp * slp - avg * avg) * kdev * G[i] > dev)) {
-                hit = (int)a.ssrt[base + i];                   /* :146 */
-                break;
+    bool running = last >= 1;
+    for (unsigned c0 = 0; c0 <= maxlast; c0 += URF_WALK_CHUNK) {
+        if (!__any(running))
+            break;
+        for (unsigned r = 0; r < 64; r += 4) {
+            const unsigned sec = r + (lane >> 4), e = c0 + (lane & 15);
+            if (e >= 1 && e <= slast[sec]) {
+                tS[sec][lane & 15] = a.sr[sbase[sec] + e];
+                tG[sec][lane & 15] = a.sz[sbase[sec] + e];
             }
         }
+        __syncthreads();
+        if (running) {
+            for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
+                const unsigned i = c0 + j;
+                if (i < 1)
+                    continue;
+                if (i > last) {
+                    running = false;
+                    break;
+                }
+                const float slp = tS[lane][j];
+                if (slp != slp) {
+                    nan += 1.0f;                                   /* :131-132 */
+                } else {
+                    float w, u;
+                    if (nan == 0.0f) {
+                        w = (float)(int)(i - 1);                   /* == (float)i - 0 - 1, exact */
+                        u = a.inv_i[i];                            /* 1.0f / (float)i */
+                    } else {
+                        w = (float)(int)i - nan - 1.0f;
+                        u = 1.0f / ((float)(int)i - nan);
+                    }
+                    avg *= w;                                      /* :135-140 */
+                    avg += slp;
+                    avg *= u;
+                    dev *= w;
+                    dev += __builtin_fabsf(slp - avg);
+                    dev *= u;
+                }
+                if (slp > slope_param ||                           /* :142-143 */
+                    ((int)i > dmin && (slp * slp - avg * avg) * kdev * tG[lane][j] > dev)) {
+                    hit = (int)a.ssrt[base + i];                   /* :146 */
+                    running = false;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
     }
-    a.star_hit[(size_t)s * K + k] = hit;
+    if (have)
+        a.star_hit[(size_t)s * K + k] = hit;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -965,77 +1036,85 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
                     flag |= 1u;
             }
 
+            /* Both detectors are an && of an angle test (f64 sqrt/div, acos) and cheap float
+             * height tests.  The height tests run first: on road surface they fail for
+             * whole waves, which then skip the expensive part.  (Reordering an && chain of
+             * side-effect-free tests does not change its value.) */
             if (dp.p.x_zero_method) {   /* x_zero_method.cpp:30-68, evaluated for the point it marks */
                 const int j = p - cp / 2;
                 if (j >= cp && j <= (n - 1) - cp) {
                     const int lj = lp - cp / 2, l3 = lj + cp;
-                    const double dx = (double)(xs[l3] - xs[lj]), dy = (double)(ys[l3] - ys[lj]);
-                    const float d = (float)__builtin_sqrt(dx * dx + dy * dy);
-                    if ((double)d < 5.0) {
-                        const float nyj = a.newY[j], ny2 = a.newY[p], ny3 = a.newY[j + cp];
-                        const float zj = zs[lj], z3 = zs[l3];
-                        double u, v;
-                        u = (double)(ny2 - nyj); v = (double)(pz - zj);
-                        const float x1 = (float)__builtin_sqrt(u * u + v * v);
-                        u = (double)(ny3 - ny2); v = (double)(z3 - pz);
-                        const float x2 = (float)__builtin_sqrt(u * u + v * v);
-                        u = (double)(ny3 - nyj); v = (double)(z3 - zj);
-                        const float x3 = (float)__builtin_sqrt(u * u + v * v);
-                        const double num = (double)x3 * (double)x3 - (double)x1 * (double)x1 - (double)x2 * (double)x2;
-                        const float den = (-2.0f * x1) * x2;
-                        float br = (float)(num / (double)den);
-                        if (br < -1.0f)
-                            br = -1.0f;
-                        else if (br > 1.0f)
-                            br = 1.0f;
-                        const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));
-                        if (alpha <= dp.p.angleFilter1 &&
-                            (__builtin_fabsf(zj - pz) >= dp.p.curbHeight || __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
-                            (double)__builtin_fabsf(zj - z3) >= 0.05)
-                            flag |= 2u;
+                    const float zj = zs[lj], z3 = zs[l3];
+                    const bool heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight ||
+                                          __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
+                                         (double)__builtin_fabsf(zj - z3) >= 0.05;          /* :62-64 */
+                    if (heights) {
+                        const double dx = (double)(xs[l3] - xs[lj]), dy = (double)(ys[l3] - ys[lj]);
+                        if (dx * dx + dy * dy < URF_DIST5_SQ) {                             /* :35-40 */
+                            const float nyj = a.newY[j], ny2 = a.newY[p], ny3 = a.newY[j + cp];
+                            double u, v;
+                            u = (double)(ny2 - nyj); v = (double)(pz - zj);
+                            const float x1 = (float)__builtin_sqrt(u * u + v * v);
+                            u = (double)(ny3 - ny2); v = (double)(z3 - pz);
+                            const float x2 = (float)__builtin_sqrt(u * u + v * v);
+                            u = (double)(ny3 - nyj); v = (double)(z3 - zj);
+                            const float x3 = (float)__builtin_sqrt(u * u + v * v);
+                            const double num = (double)x3 * (double)x3 - (double)x1 * (double)x1 - (double)x2 * (double)x2;
+                            const float den = (-2.0f * x1) * x2;
+                            float br = (float)(num / (double)den);                          /* :52 */
+                            if (br < -1.0f)
+                                br = -1.0f;
+                            else if (br > 1.0f)
+                                br = 1.0f;
+                            const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));   /* :58 */
+                            if (alpha <= dp.p.angleFilter1)                                 /* :61 */
+                                flag |= 2u;
+                        }
                     }
                 }
             }
 
             if (dp.p.z_zero_method) {   /* z_zero_method.cpp:21-72 */
                 if (p >= cp && p <= (n - 1) - cp) {
-                    const double dx = (double)(xs[lp + cp] - xs[lp - cp]), dy = (double)(ys[lp + cp] - ys[lp - cp]);
-                    const float d = (float)__builtin_sqrt(dx * dx + dy * dy);
-                    if ((double)d < 5.0) {
-                        const float az = __builtin_fabsf(pz);
-                        float max1 = az, max2 = az;
-                        float va1 = 0.f, va2 = 0.f, vb1 = 0.f, vb2 = 0.f;
-                        for (int k = 1; k <= cp; k++) {
-                            va1 = va1 + (xs[lp - k] - px);
-                            va2 = va2 + (ys[lp - k] - py);
-                            const float zk = __builtin_fabsf(zs[lp - k]);
-                            if (zk > max1)
-                                max1 = zk;
+                    const float az = __builtin_fabsf(pz);
+                    float max1 = az, max2 = az;
+                    for (int k = 1; k <= cp; k++) {                                         /* :39-40, :48-49 */
+                        const float za = __builtin_fabsf(zs[lp - k]), zb = __builtin_fabsf(zs[lp + k]);
+                        if (za > max1)
+                            max1 = za;
+                        if (zb > max2)
+                            max2 = zb;
+                    }
+                    const bool heights = (max1 - az >= dp.p.curbHeight || max2 - az >= dp.p.curbHeight) &&
+                                         (double)__builtin_fabsf(max1 - max2) >= 0.05;      /* :67-69 */
+                    if (heights) {
+                        const double dx = (double)(xs[lp + cp] - xs[lp - cp]), dy = (double)(ys[lp + cp] - ys[lp - cp]);
+                        if (dx * dx + dy * dy < URF_DIST5_SQ) {                             /* :23-28 */
+                            float va1 = 0.f, va2 = 0.f, vb1 = 0.f, vb2 = 0.f;
+                            for (int k = 1; k <= cp; k++) {                                 /* :35-38 */
+                                va1 = va1 + (xs[lp - k] - px);
+                                va2 = va2 + (ys[lp - k] - py);
+                            }
+                            for (int k = 1; k <= cp; k++) {                                 /* :44-47 */
+                                vb1 = vb1 + (xs[lp + k] - px);
+                                vb2 = vb2 + (ys[lp + k] - py);
+                            }
+                            va1 = dp.inv_cp * va1;                                          /* :52-55 */
+                            va2 = dp.inv_cp * va2;
+                            vb1 = dp.inv_cp * vb1;
+                            vb2 = dp.inv_cp * vb2;
+                            const float num = va1 * vb1 + va2 * vb2;
+                            const double na = __builtin_sqrt((double)va1 * (double)va1 + (double)va2 * (double)va2);
+                            const double nb = __builtin_sqrt((double)vb1 * (double)vb1 + (double)vb2 * (double)vb2);
+                            float br = (float)((double)num / (na * nb));                    /* :57 */
+                            if (br < -1.0f)
+                                br = -1.0f;
+                            else if (br > 1.0f)
+                                br = 1.0f;
+                            const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));   /* :63 */
+                            if (alpha <= dp.p.angleFilter2)                                 /* :66 */
+                                flag |= 4u;
                         }
-                        for (int k = 1; k <= cp; k++) {
-                            vb1 = vb1 + (xs[lp + k] - px);
-                            vb2 = vb2 + (ys[lp + k] - py);
-                            const float zk = __builtin_fabsf(zs[lp + k]);
-                            if (zk > max2)
-                                max2 = zk;
-                        }
-                        va1 = dp.inv_cp * va1;
-                        va2 = dp.inv_cp * va2;
-                        vb1 = dp.inv_cp * vb1;
-                        vb2 = dp.inv_cp * vb2;
-                        const float num = va1 * vb1 + va2 * vb2;
-                        const double na = __builtin_sqrt((double)va1 * (double)va1 + (double)va2 * (double)va2);
-                        const double nb = __builtin_sqrt((double)vb1 * (double)vb1 + (double)vb2 * (double)vb2);
-                        float br = (float)((double)num / (na * nb));
-                        if (br < -1.0f)
-                            br = -1.0f;
-                        else if (br > 1.0f)
-                            br = 1.0f;
-                        const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));
-                        if (alpha <= dp.p.angleFilter2 &&
-                            (max1 - az >= dp.p.curbHeight || max2 - az >= dp.p.curbHeight) &&
-                            (double)__builtin_fabsf(max1 - max2) >= 0.05)
-                            flag |= 4u;
                     }
                 }
             }
