@@ -242,6 +242,43 @@ def test_crowded_sectors(ctx_big, n_pts):
     assert np.array_equal(lg, lb) and info_equal(ig, ib)
 
 
+def test_star_sort_paths(ctx_big, monkeypatch):
+    """k_star_sort_small has a distribution-sort fast path and a general path (in-register block
+    sorts merged by ranking).  (a) force the general path on a normal sweep; (b) a cloud whose
+    ranges are so clustered that buckets overflow and the kernel falls back by itself."""
+    p = O.cfg_params("cfg2")
+    x, y, z = O.cfg_cloud("narrow", 91)
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    monkeypatch.setenv("URF_EXP", "4")
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    monkeypatch.delenv("URF_EXP")
+    ctx_big.set_params(p)
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, len(x)), st["detect"])
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+    # (b) 3 rings; in sector 10: 300 points packed within a few hundred ulps of r = 10 m plus two far
+    # outliers, so that one of the 512 range buckets receives far more than 64 keys
+    rng = np.random.default_rng(3)
+    n = 400
+    az = np.deg2rad(10.2 + 0.6 * rng.random(n))
+    r = (10.0 + 1e-5 * rng.random(n)).astype(np.float32)
+    r[:2] = [3.0, 60.0]
+    elev = np.deg2rad(-20.0 + 4.0 * (np.arange(n) % 3))
+    xs = (r * np.cos(az)).astype(np.float32)
+    ys = (r * np.sin(az)).astype(np.float32)
+    zs = (-1.8 + 0.3 * rng.random(n) * (np.arange(n) % 7 == 0)).astype(np.float32)
+    rr = np.sqrt(xs * xs + ys * ys)
+    _, first = np.unique(rr, return_index=True)
+    keep = np.sort(first)
+    xs, ys, zs = xs[keep], ys[keep], zs[keep]
+    p.interval = 5.0
+    lb, ib, st = O.run_b(xs, ys, zs, p, debug=True)
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(xs, ys, zs)
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, len(xs)), st["detect"])
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+
+
 def test_ring_table_zero_sentinel(ctx_big):
     """A point straight below the sensor has vertical angle exactly 0, which the reference's ring
     table treats as its end-of-table mark (lidar_segmentation.cpp:176).  Ring assignment must

@@ -165,6 +165,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.maxdist, S * C) A(k.quad, S * 4)
     A(k.sufmin, S * C * URF_DEG_CELLS) A(k.premax, S * C * URF_DEG_CELLS)
     A(k.stop_f, S * URF_DEG_CELLS) A(k.stop_b, S * URF_DEG_CELLS)
+    A(k.act_f, S * C * 6) A(k.act_b, S * C * 6)
     A(k.info, S)
     A(c->d_newY, (size_t)max_points) A(c->d_inv_i, (size_t)max_points) A(c->d_beams, K)
     A(c->labels1, (size_t)max_points)
@@ -397,7 +398,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     mark();
     hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_LABEL_THREADS), 0, st, a, dp);
     mark();
-    hipLaunchKernelGGL(k_label, g_ring, dim3(URF_LABEL_THREADS), 0, st, a, dp);
+    hipLaunchKernelGGL(k_label, g_tiles, dim3(URF_TILE_THREADS), 0, st, a, dp);
     mark();
     URF_HIP(c, hipGetLastError());
     if (d_info)

@@ -102,6 +102,8 @@ struct urf_kargs {
     float*    premax;           /* [S][channels][361] */
     int16_t*  stop_f;           /* [S][361] */
     int16_t*  stop_b;           /* [S][361] */
+    unsigned long long* act_f;  /* [S][channels][6] bit i: forward beam i reached beyond the ring */
+    unsigned long long* act_b;  /* [S][channels][6] same for backward beams */
     /* tables */
     const float*    newY;       /* [max_points] x_zero_method.cpp:24-27 */
     const float*    inv_i;      /* [max_points] 1.0f / (float)i, star_shaped_search.cpp:137 */

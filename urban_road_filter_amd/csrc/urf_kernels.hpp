@@ -30,6 +30,8 @@
 #include "urf_device.hpp"
 
 #define URF_INT_NONE_MIN 0x7fffffff
+#define URF_HTAB 2048   /* >= 2 x URF_MAX_SECTORS */
+__device__ __forceinline__ unsigned urf_hash_slot(unsigned v) { return (v * 2654435761u) >> 21; }
 /* (float)sqrt(s) < 5.0 (x_zero_method.cpp:35-40, z_zero_method.cpp:23-28) holds exactly for the
  * doubles s below this one: sqrt and the rounding to float are monotone, the threshold is the
  * smallest double whose rounded root reaches 5.0f (found by bisection, tools/check_dist5.c). */
@@ -681,11 +683,23 @@ __device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_
     return *sh_first;
 }
 
-/* sectors with at most 512 points: one wave per (sector, scan) */
+/* sectors with at most 512 points: one wave per (sector, scan).
+ * Fast path: distribution sort.  The range bits are quantised monotonically
+ * into 512 buckets ((bits - min) >> shift), a counting sort by bucket places
+ * every key next to the few keys sharing its bucket, and each key then counts
+ * the smaller keys inside its own bucket -- exact for any input, and about five
+ * times fewer instructions than a comparison network when the ranges are
+ * spread out (they are: a sector holds ~6 firings x 64 rings; the firings of
+ * one ring share a bucket, a curb face puts a dozen keys into one).  If some
+ * bucket collects more than 64 keys (heavily clustered ranges) the wave falls back to the
+ * general path: every 64-key block is sorted in registers by an in-wave
+ * bitonic network and the blocks are merged by ranking. */
 __global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs a, urf_dev_params dp)
 {
     constexpr unsigned MAXB = 8;
-    __shared__ unsigned long long blk[MAXB * 64];   /* sorted blocks, then the fully sorted sector */
+    constexpr unsigned NB = 512;                    /* buckets */
+    __shared__ unsigned long long A[MAXB * 64];     /* keys by bucket, then the fully sorted sector */
+    __shared__ unsigned cnt[NB + 1];                /* bucket counts, then exclusive offsets */
     __shared__ float zs[MAXB * 64];
     __shared__ unsigned sh_first;
     const unsigned k = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
@@ -708,38 +722,115 @@ __global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs 
         sh_first = n;
 
     unsigned long long key[MAXB];
+    unsigned rmin = 0xffffffffu, rmax = 0;
 #pragma unroll
     for (unsigned q = 0; q < MAXB; q++) {
         const unsigned i = q * 64 + lane;
         key[q] = ~0ull;
         if (q < B && i < n) {
-            key[q] = ((unsigned long long)urf_fbits(a.sr[base + i]) << 32) | i;
+            const unsigned rb = urf_fbits(a.sr[base + i]);
+            key[q] = ((unsigned long long)rb << 32) | i;
             zs[i] = a.sz[base + i];
+            rmin = rb < rmin ? rb : rmin;
+            rmax = rb > rmax ? rb : rmax;
         }
     }
-#pragma unroll
-    for (unsigned q = 0; q < MAXB; q++)
-        if (q < B) {
-            key[q] = urf_wave_sort64(key[q]);
-            blk[q * 64 + lane] = key[q];
-        }
+    for (unsigned c = lane; c <= NB; c += 64)
+        cnt[c] = 0;
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor(rmin, o), hi = __shfl_xor(rmax, o);
+        rmin = lo < rmin ? lo : rmin;
+        rmax = hi > rmax ? hi : rmax;
+    }
+    const unsigned range = rmax - rmin;
+    const unsigned sh = range < NB ? 0u : (unsigned)(32 - __clz((int)range)) - 9u;   /* (range >> sh) < 512 */
     __syncthreads();
-    unsigned rank[MAXB];
+
+    unsigned bkt[MAXB], wq[MAXB];
 #pragma unroll
     for (unsigned q = 0; q < MAXB; q++) {
-        rank[q] = lane;
-        if (q < B && key[q] != ~0ull)
-            for (unsigned p = 0; p < B; p++)
-                if (p != q)
-                    rank[q] += urf_count_less64(blk + p * 64, key[q]);
+        bkt[q] = 0;
+        wq[q] = 0;
+        if (q < B && key[q] != ~0ull) {
+            bkt[q] = ((unsigned)(key[q] >> 32) - rmin) >> sh;
+            wq[q] = atomicAdd(&cnt[bkt[q]], 1u);   /* arrival order inside the bucket: resolved below */
+        }
     }
-    __syncthreads();   /* every lane has its ranks: the blocks may be overwritten */
+    __syncthreads();
+    /* exclusive scan of the 512 counts: 8 consecutive counters per lane */
+    unsigned maxc = 0;
+    {
+        unsigned c8[8], sum = 0;
+#pragma unroll
+        for (unsigned e = 0; e < 8; e++) {
+            c8[e] = cnt[lane * 8 + e];
+            sum += c8[e];
+            maxc = c8[e] > maxc ? c8[e] : maxc;
+        }
+        unsigned inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned w = __shfl_up(inc, o);
+            if ((int)lane >= o)
+                inc += w;
+        }
+        unsigned run = inc - sum;
+#pragma unroll
+        for (unsigned e = 0; e < 8; e++) {
+            cnt[lane * 8 + e] = run;
+            run += c8[e];
+        }
+        if (lane == 63)
+            cnt[NB] = run;   /* == n */
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned w = __shfl_xor(maxc, o);
+            maxc = w > maxc ? w : maxc;
+        }
+    }
+    __syncthreads();
+
+    unsigned rank[MAXB];
+    if (maxc <= 64 && !(dp.exp_flags & 4u)) {
+#pragma unroll
+        for (unsigned q = 0; q < MAXB; q++)
+            if (q < B && key[q] != ~0ull)
+                A[cnt[bkt[q]] + wq[q]] = key[q];
+        __syncthreads();
+#pragma unroll
+        for (unsigned q = 0; q < MAXB; q++) {
+            rank[q] = 0;
+            if (q < B && key[q] != ~0ull) {
+                const unsigned b0 = cnt[bkt[q]], b1 = cnt[bkt[q] + 1];
+                unsigned r = b0;
+                for (unsigned t = b0; t < b1; t++)
+                    r += A[t] < key[q];
+                rank[q] = r;
+            }
+        }
+    } else {
+        /* general path: in-register block sorts + multiway merge by ranking */
+#pragma unroll
+        for (unsigned q = 0; q < MAXB; q++)
+            if (q < B) {
+                key[q] = urf_wave_sort64(key[q]);
+                A[q * 64 + lane] = key[q];
+            }
+        __syncthreads();
+#pragma unroll
+        for (unsigned q = 0; q < MAXB; q++) {
+            rank[q] = lane;
+            if (q < B && key[q] != ~0ull)
+                for (unsigned p = 0; p < B; p++)
+                    if (p != q)
+                        rank[q] += urf_count_less64(A + p * 64, key[q]);
+        }
+    }
+    __syncthreads();   /* every lane has its ranks: A may be overwritten */
 #pragma unroll
     for (unsigned q = 0; q < MAXB; q++)
         if (q < B && key[q] != ~0ull)
-            blk[rank[q]] = key[q];
+            A[rank[q]] = key[q];
     __syncthreads();
-    const unsigned long long* fin = blk;
+    const unsigned long long* fin = A;
     const unsigned first = urf_star_emit<URF_STAR_THREADS>(a, dp, base, n, fin, zs, &sh_first);
     if (lane == 0)
         a.star_first[(size_t)s * K + k] = first < n - 1 ? first : n - 1;   /* last index the walk may visit */
@@ -985,6 +1076,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
     __shared__ int cmin[URF_DEG_CELLS], cmax[URF_DEG_CELLS];
     __shared__ int sh_q[4];
     __shared__ int sh_maxd;
+    __shared__ unsigned htab[URF_HTAB];
     const unsigned c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
     const urf_scan_info in = a.info[s];
     if (in.status != URF_OK || c >= in.n_rings)
@@ -1001,6 +1093,21 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
     for (unsigned i = tid; i < URF_DEG_CELLS; i += URF_RING_THREADS) {
         cmin[i] = URF_INT_NONE_MIN;
         cmax[i] = -1;
+    }
+    if (star) {
+        /* the scan's <= `sectors` star-shaped hits (input indices) as an open-addressing
+         * hash set: one LDS probe per point instead of a sector-key gather from HBM */
+        for (unsigned i = tid; i < URF_HTAB; i += URF_RING_THREADS)
+            htab[i] = 0xffffffffu;
+        __syncthreads();
+        for (unsigned k = tid; k < K; k += URF_RING_THREADS) {
+            const int h = a.star_hit[(size_t)s * K + k];
+            if (h >= 0) {
+                unsigned slot = urf_hash_slot((unsigned)h);
+                while (atomicCAS(&htab[slot], 0xffffffffu, (unsigned)h) != 0xffffffffu)
+                    slot = (slot + 1) & (URF_HTAB - 1);
+            }
+        }
     }
     if (tid == 0) {
         sh_q[0] = (int)urf_fbits(0.f);
@@ -1031,9 +1138,12 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
 
             if (star) {   /* lidar_segmentation.cpp:241-242: carry the star-shaped hit over */
                 const unsigned src = a.rsrc[base + p];
-                const unsigned sk = a.seckey[off + src];
-                if (sk != URF_SEC_NONE && a.star_hit[(size_t)s * K + sk] == (int)src)
-                    flag |= 1u;
+                unsigned slot = urf_hash_slot(src);
+                for (unsigned v; (v = htab[slot]) != 0xffffffffu; slot = (slot + 1) & (URF_HTAB - 1))
+                    if (v == src) {
+                        flag |= 1u;
+                        break;
+                    }
             }
 
             /* Both detectors are an && of an angle test (f64 sqrt/div, acos) and cheap float
@@ -1268,10 +1378,9 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     if (tid < 4 && !(dp.p.blind_spots && nR > 1))
         a.quad[(size_t)s * 4 + tid] = q[tid];
     const int i = (int)tid;
-    if (i > 360)
-        return;
+    const bool inrange = i <= 360;
     const float fi = (float)i;
-    const bool blind = urf_blind(dp.p, q, i);
+    const bool blind = !inrange || urf_blind(dp.p, q, i);
     int sf = -1, sb = -1;
     if (fi <= dp.fwd_limit && !blind) {   /* blind_spots.cpp:68 */
         sf = (int)nR;
@@ -1293,8 +1402,24 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
             }
         }
     }
-    a.stop_f[(size_t)s * URF_DEG_CELLS + i] = (int16_t)sf;
-    a.stop_b[(size_t)s * URF_DEG_CELLS + i] = (int16_t)sb;
+    if (inrange) {
+        a.stop_f[(size_t)s * URF_DEG_CELLS + i] = (int16_t)sf;
+        a.stop_b[(size_t)s * URF_DEG_CELLS + i] = (int16_t)sb;
+    }
+    /* per ring: bit i set <=> the beam starting at degree i reached beyond that ring
+     * (six 64-bit words per ring and direction, consumed by k_label) */
+    for (unsigned k = 0; k < nR; k++) {
+        const unsigned long long bf = __ballot(sf > (int)k), bb = __ballot(sb > (int)k);
+        if (urf_lane() == 0) {
+            a.act_f[((size_t)s * C + k) * 6 + (tid >> 6)] = bf;
+            a.act_b[((size_t)s * C + k) * 6 + (tid >> 6)] = bb;
+        }
+    }
+    if (tid == 0) {   /* lidar_segmentation.cpp:605-608: road_probably = every point of sorted ring 10 */
+        urf_scan_info* o = &a.info[s];
+        o->n_ring_pts = a.ring_off[(size_t)s * (C + 1) + C];
+        o->n_ring10 = nR > 10 ? a.ring_cnt[(size_t)s * C + 10] : 0;
+    }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1303,60 +1428,113 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
 /* A point of ring k is road iff it is no curb point and lies in the window of
  * a beam that reached beyond ring k.  Windows [i, hi_k(i)] grow with i, so it
  * suffices to test the largest such forward beam with i <= azimuth (and the
- * smallest such backward beam with i >= azimuth). */
-__global__ __launch_bounds__(URF_LABEL_THREADS) void k_label(urf_kargs a, urf_dev_params dp)
+ * smallest such backward beam with i >= azimuth).
+ *
+ * One workgroup per input tile, so that the label bytes leave as whole cache
+ * lines: the ring-major runs that belong to the tile (the split is stable, so
+ * each ring contributes one contiguous run: tile_ring) are read run by run,
+ * the labels are placed by input index into an LDS image of the tile and the
+ * image is written out in input order. */
+/* byte image of the tile's labels; consecutive ring-major slots of an organised sweep lie 64
+ * bytes apart in input order, so the row (i >> 6) rotates the column (i & 63) to spread the
+ * byte stores over the LDS banks */
+#define URF_IMG(i) (((i) & ~63u) | ((((i) & 63u) + ((i) >> 6)) & 63u))
+__global__ __launch_bounds__(URF_TILE_THREADS) void k_label(urf_kargs a, urf_dev_params dp)
 {
-    __shared__ unsigned long long actf[6], actb[6];
+    __shared__ unsigned long long actf[URF_MAX_CHANNELS * 6], actb[URF_MAX_CHANNELS * 6];
+    __shared__ double qk[URF_MAX_CHANNELS];
+    __shared__ unsigned base_r[URF_MAX_CHANNELS], koff[URF_MAX_CHANNELS + 1];
+    __shared__ uint8_t img[URF_TILE];
     __shared__ unsigned cnt_road, cnt_curb;
-    const unsigned c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
-    const urf_scan_info in = a.info[s];
-    if (in.status != URF_OK || c >= in.n_rings)
-        return;
+    const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
-    const unsigned C = (unsigned)dp.p.channels;
-    const unsigned n = a.ring_cnt[(size_t)s * C + c];
-    const unsigned base = off + a.ring_off[(size_t)s * (C + 1) + c];
-    {
-        const int i = (int)tid;
-        const bool af = i <= 360 && (int)a.stop_f[(size_t)s * URF_DEG_CELLS + i] > (int)c;
-        const bool ab = i <= 360 && (int)a.stop_b[(size_t)s * URF_DEG_CELLS + i] > (int)c;
-        const unsigned long long bf = __ballot(af), bb = __ballot(ab);
-        if (urf_lane() == 0) {
-            actf[tid >> 6] = bf;
-            actb[tid >> 6] = bb;
-        }
-        if (tid == 0) {
-            cnt_road = 0;
-            cnt_curb = 0;
-        }
+    const unsigned tbase = t * URF_TILE;
+    if (tbase >= len)
+        return;
+    const urf_scan_info in = a.info[s];
+    if (in.status != URF_OK)
+        return;
+    const unsigned C = (unsigned)dp.p.channels, nR = in.n_rings;
+    const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
+    const size_t row = (size_t)s * a.tiles + t;
+    const float* maxd = a.maxdist + (size_t)s * C;
+
+    if (tid < C) {
+        /* run of ring `tid` that belongs to this tile: [first, first + n) inside the ring */
+        const unsigned first = a.tile_ring[row * C + tid];
+        const unsigned next = t + 1 < ntiles ? a.tile_ring[(row + 1) * C + tid] : a.ring_cnt[(size_t)s * C + tid];
+        base_r[tid] = off + a.ring_off[(size_t)s * (C + 1) + tid] + first;
+        koff[tid] = next - first;   /* count, scanned below */
+        qk[tid] = tid < nR ? urf_arc_ratio(dp, maxd[0], maxd[tid]) : 0.0;
+    }
+    for (unsigned w = tid; w < nR * 6; w += URF_TILE_THREADS) {
+        actf[w] = a.act_f[(size_t)s * C * 6 + w];
+        actb[w] = a.act_b[(size_t)s * C * 6 + w];
+    }
+    for (unsigned i = tid; i < URF_TILE / 4; i += URF_TILE_THREADS)
+        ((unsigned*)img)[i] = 0xffffffffu;
+    if (tid == 0) {
+        cnt_road = 0;
+        cnt_curb = 0;
     }
     __syncthreads();
-    const float* maxd = a.maxdist + (size_t)s * C;
-    const double qk = urf_arc_ratio(dp, maxd[0], maxd[c]);
-    const uint8_t lab0 = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0);
+    if (tid < 64) {   /* exclusive scan of the run lengths (C <= 128) */
+        const unsigned v0 = tid < C ? koff[tid] : 0, v1 = tid + 64 < C ? koff[tid + 64] : 0;
+        unsigned i0 = v0, i1 = v1;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned w0 = __shfl_up(i0, o), w1 = __shfl_up(i1, o);
+            if ((int)tid >= o) {
+                i0 += w0;
+                i1 += w1;
+            }
+        }
+        const unsigned total0 = __shfl(i0, 63), total1 = __shfl(i1, 63);
+        if (tid < C)
+            koff[tid] = i0 - v0;
+        if (tid + 64 < C)
+            koff[tid + 64] = total0 + i1 - v1;
+        if (tid == 0)
+            koff[C] = total0 + total1;
+    }
+    __syncthreads();
+    const unsigned npts = koff[C];
+
     unsigned my_road = 0, my_curb = 0;
-    for (unsigned p = tid; p < n; p += URF_LABEL_THREADS) {
-        const unsigned flag = a.rflag[base + p];
-        const float az = a.raz[base + p];
-        const unsigned src = a.rsrc[base + p];
-        uint8_t lab = lab0;
+    for (unsigned j = tid; j < npts; j += URF_TILE_THREADS) {
+        /* ring of slot j: last k with koff[k] <= j */
+        unsigned lo = 0, hi = C;
+        while (hi - lo > 1) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (koff[mid] <= j)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const unsigned c = lo;
+        const unsigned pos = base_r[c] + (j - koff[c]);
+        const unsigned flag = a.rflag[pos];
+        const float az = a.raz[pos];
+        const unsigned src = a.rsrc[pos];
+        uint8_t lab = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0);
         if (flag) {
             lab |= URF_LABEL_CURB;
             my_curb++;
         } else if (az == az) {
             bool road = false;
+            const unsigned long long* af = actf + c * 6;
+            const unsigned long long* ab = actb + c * 6;
             int cf = (int)__builtin_floorf(az);
             cf = cf < 0 ? 0 : (cf > 360 ? 360 : cf);
             {
                 int w = cf >> 6;
                 const int b = cf & 63;
-                unsigned long long mm = actf[w] & (b == 63 ? ~0ull : ((2ull << b) - 1ull));
+                unsigned long long mm = af[w] & (b == 63 ? ~0ull : ((2ull << b) - 1ull));
                 while (mm == 0 && w > 0)
-                    mm = actf[--w];
+                    mm = af[--w];
                 if (mm) {
                     const int i = w * 64 + 63 - __clzll((long long)mm);
-                    road = az <= urf_fwd_hi(dp, i, c, qk);
+                    road = az <= urf_fwd_hi(dp, i, c, qk[c]);
                 }
             }
             if (!road) {
@@ -1364,12 +1542,12 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_label(urf_kargs a, urf_de
                 cb = cb < 0 ? 0 : (cb > 360 ? 360 : cb);
                 int w = cb >> 6;
                 const int b = cb & 63;
-                unsigned long long mm = actb[w] & (~0ull << b);
+                unsigned long long mm = ab[w] & (~0ull << b);
                 while (mm == 0 && w < 5)
-                    mm = actb[++w];
+                    mm = ab[++w];
                 if (mm) {
                     const int i = w * 64 + __ffsll((long long)mm) - 1;
-                    road = az >= urf_bwd_lo(dp, i, c, qk);
+                    road = az >= urf_bwd_lo(dp, i, c, qk[c]);
                 }
             }
             if (road) {
@@ -1377,22 +1555,24 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_label(urf_kargs a, urf_de
                 my_road++;
             }
         }
-        a.labels[off + src] = lab;
+        img[URF_IMG(src - tbase)] = lab;
     }
     if (my_road)
         atomicAdd(&cnt_road, my_road);
     if (my_curb)
         atomicAdd(&cnt_curb, my_curb);
     __syncthreads();
+    for (unsigned i = tid; i < URF_TILE; i += URF_TILE_THREADS) {
+        const uint8_t l = img[URF_IMG(i)];
+        if (l != 0xff && tbase + i < len)
+            a.labels[off + tbase + i] = l;   /* points on no ring keep the label k_ring_assign wrote */
+    }
     if (tid == 0) {
         urf_scan_info* o = &a.info[s];
         if (cnt_road)
             atomicAdd(&o->n_road, cnt_road);
         if (cnt_curb)
             atomicAdd(&o->n_curb, cnt_curb);
-        atomicAdd(&o->n_ring_pts, n);
-        if (c == 10)
-            atomicAdd(&o->n_ring10, n);
     }
 }
 
