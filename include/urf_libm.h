@@ -83,8 +83,11 @@ static inline URF_HD double urf__atan_poly(double t)
 static inline URF_HD double urf__asin01(double a)
 {
     const int small = a <= 0.5;
-    const double w = small ? a * a : (1.0 - a) * 0.5;   /* (1-a)/2 is exact */
-    const double s = small ? a : __builtin_sqrt(w);
+    double w = a * a, s = a;
+    if (!small) {                       /* a real branch: a wave of small arguments skips the sqrt */
+        w = (1.0 - a) * 0.5;            /* exact */
+        s = __builtin_sqrt(w);
+    }
     const double r = urf__asin_poly(s, w);
     return small ? r : __builtin_fma(-2.0, r, URF_PIO2_D);
 }
@@ -106,8 +109,11 @@ static inline URF_HD float urf_acosf(float x)
     if (!(a <= 1.0))
         return __builtin_nanf("");
     const int small = a <= 0.5;
-    const double w = small ? a * a : (1.0 - a) * 0.5;   /* exact */
-    const double s = small ? a : __builtin_sqrt(w);
+    double w = a * a, s = a;
+    if (!small) {
+        w = (1.0 - a) * 0.5;            /* exact */
+        s = __builtin_sqrt(w);
+    }
     const double p = urf__asin_poly(s, w);
     double r;
     if (small)

@@ -369,11 +369,11 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         stage++;
     };
     mark();
-    hipLaunchKernelGGL(k_ingest, g_tiles, dim3(URF_TILE_THREADS), (K + 1) * sizeof(unsigned), st, a, dp);
+    hipLaunchKernelGGL(k_ingest, g_tiles, dim3(URF_INGEST_THREADS), (K + 1) * sizeof(unsigned), st, a, dp);
     mark();
     hipLaunchKernelGGL(k_ring_table, g_scan, dim3(64), 0, st, a, dp);
     mark();
-    hipLaunchKernelGGL(k_ring_assign, g_tiles, dim3(URF_TILE_THREADS), 0, st, a, dp);
+    hipLaunchKernelGGL(k_ring_assign, g_tiles, dim3(URF_ASSIGN_THREADS), 0, st, a, dp);
     mark();
     if (star)
         URF_HIP(c, hipMemsetAsync(a.star_count, 0, 2 * sizeof(uint32_t), st));
@@ -398,7 +398,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     mark();
     hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_LABEL_THREADS), 0, st, a, dp);
     mark();
-    hipLaunchKernelGGL(k_label, g_tiles, dim3(URF_TILE_THREADS), 0, st, a, dp);
+    hipLaunchKernelGGL(k_label, g_tiles, dim3(URF_LABEL_TILE_THREADS), 0, st, a, dp);
     mark();
     URF_HIP(c, hipGetLastError());
     if (d_info)

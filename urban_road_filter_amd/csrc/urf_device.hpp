@@ -29,6 +29,19 @@ __device__ __forceinline__ unsigned long long urf_match_any(unsigned key, unsign
     return m;
 }
 
+/* Same, with two one-ballot shortcuts for the patterns an organised sweep produces in
+ * firing order: every lane holds the same key (one firing = one star sector), or lane l
+ * holds key0 + l (one firing = every ring once). */
+__device__ __forceinline__ unsigned long long urf_match_any_fast(unsigned key, unsigned nbits)
+{
+    const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)key);
+    if (__ballot(key != first) == 0)
+        return ~0ull;
+    if (__ballot(key != first + urf_lane()) == 0)
+        return 1ull << urf_lane();
+    return urf_match_any(key, nbits);
+}
+
 __device__ __forceinline__ unsigned urf_popc_below(unsigned long long m)
 {
     return __popcll(m & ((1ull << urf_lane()) - 1ull));

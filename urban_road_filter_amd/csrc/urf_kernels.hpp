@@ -39,6 +39,9 @@ __device__ __forceinline__ unsigned urf_hash_slot(unsigned v) { return (v * 2654
 #define URF_RING_THREADS 256
 #define URF_LABEL_THREADS 384
 #define URF_STAR_THREADS 64
+#define URF_INGEST_THREADS 256       /* tile kernels that need no big LDS tile run 8 workgroups per CU */
+#define URF_ASSIGN_THREADS 256
+#define URF_LABEL_TILE_THREADS 256   /* k_label: one tile per workgroup, 16 slots per thread, 8 workgroups per CU */
 #define URF_STAR_MID_CAP_ 2048
 
 /* ------------------------------------------------------------------------- */
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void k_pc2_to_soa(const uint8_t* __restrict__ 
 /* ------------------------------------------------------------------------- */
 /* k_ingest                                                                    */
 /* ------------------------------------------------------------------------- */
-__global__ __launch_bounds__(URF_TILE_THREADS) void k_ingest(urf_kargs a, urf_dev_params dp)
+__global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_dev_params dp)
 {
     extern __shared__ unsigned sh_hist[];   /* [sectors] sector histogram, [sectors] = ROI count */
     const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
@@ -87,19 +90,25 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_ingest(urf_kargs a, urf_de
         return;
     const unsigned K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
-    for (unsigned k = tid; k <= K; k += URF_TILE_THREADS)
+    for (unsigned k = tid; k <= K; k += URF_INGEST_THREADS)
         sh_hist[k] = 0;
     __syncthreads();
 
-    for (unsigned q = 0; q < URF_TILE / URF_TILE_THREADS; q++) {
-        const unsigned i = tbase + q * URF_TILE_THREADS + tid;
+    constexpr unsigned Q = URF_TILE / URF_INGEST_THREADS;
+    float px[Q], py[Q], pz[Q];
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {   /* all loads of the tile in flight before any arithmetic */
+        const unsigned i = tbase + q * URF_INGEST_THREADS + tid;
         const bool valid = i < len;
-        float x = 0.f, y = 0.f, z = 0.f;
-        if (valid) {
-            x = a.x[off + i];
-            y = a.y[off + i];
-            z = a.z[off + i];
-        }
+        px[q] = valid ? a.x[off + i] : 0.f;
+        py[q] = valid ? a.y[off + i] : 0.f;
+        pz[q] = valid ? a.z[off + i] : 0.f;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned i = tbase + q * URF_INGEST_THREADS + tid;
+        const bool valid = i < len;
+        const float x = px[q], y = py[q], z = pz[q];
         const bool roi = valid && urf_in_roi(dp.p, x, y, z);
         float va = -1.0f;
         unsigned key = URF_SEC_NONE;
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_ingest(urf_kargs a, urf_de
             a.seckey[off + i] = (uint16_t)key;
         }
         if (star) {
-            const unsigned long long m = urf_match_any(key == URF_SEC_NONE ? K : key, dp.sec_keybits);
+            const unsigned long long m = urf_match_any_fast(key == URF_SEC_NONE ? K : key, dp.sec_keybits);
             if (key != URF_SEC_NONE && urf_is_leader(m))
                 atomicAdd(&sh_hist[key], (unsigned)__popcll(m));
         }
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_ingest(urf_kargs a, urf_de
     __syncthreads();
     const size_t row = (size_t)s * a.tiles + t;
     if (star)
-        for (unsigned k = tid; k < K; k += URF_TILE_THREADS)
+        for (unsigned k = tid; k < K; k += URF_INGEST_THREADS)
             a.tile_sec[row * K + k] = sh_hist[k];
     if (tid == 0)
         a.tile_roi[row] = sh_hist[K];
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(64) void k_ring_table(urf_kargs a, urf_dev_params d
  * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are
  * contiguous and the first one is found by bisection with the very same float
  * predicate. */
-__global__ __launch_bounds__(URF_TILE_THREADS) void k_ring_assign(urf_kargs a, urf_dev_params dp)
+__global__ __launch_bounds__(URF_ASSIGN_THREADS) void k_ring_assign(urf_kargs a, urf_dev_params dp)
 {
     __shared__ float tab[URF_MAX_CHANNELS];
     __shared__ unsigned hist[URF_MAX_CHANNELS];
@@ -256,8 +265,8 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_ring_assign(urf_kargs a, u
     const urf_scan_info in = a.info[s];
     if (in.status != URF_OK) {
         /* nothing is published for this scan: all labels 0 */
-        for (unsigned q = 0; q < URF_TILE / URF_TILE_THREADS; q++) {
-            const unsigned i = tbase + q * URF_TILE_THREADS + tid;
+        for (unsigned q = 0; q < URF_TILE / URF_ASSIGN_THREADS; q++) {
+            const unsigned i = tbase + q * URF_ASSIGN_THREADS + tid;
             if (i < len)
                 a.labels[off + i] = 0;
         }
@@ -270,13 +279,21 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_ring_assign(urf_kargs a, u
     }
     __syncthreads();
     const float interval = dp.p.interval;
-    for (unsigned q = 0; q < URF_TILE / URF_TILE_THREADS; q++) {
-        const unsigned i = tbase + q * URF_TILE_THREADS + tid;
+    constexpr unsigned Q = URF_TILE / URF_ASSIGN_THREADS;
+    float va[Q];
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned i = tbase + q * URF_ASSIGN_THREADS + tid;
+        va[q] = i < len ? a.valpha[off + i] : -1.0f;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned i = tbase + q * URF_ASSIGN_THREADS + tid;
         const bool valid = i < len;
         unsigned key = URF_RING_NONE;
         uint8_t lab = 0;
         if (valid) {
-            const float v = a.valpha[off + i];
+            const float v = va[q];
             if (v >= 0.0f) {
                 lab = URF_FLAG_ROI;
                 unsigned lo = 0, hi = nR;
@@ -293,7 +310,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_ring_assign(urf_kargs a, u
             a.ringkey[off + i] = (uint8_t)key;
             a.labels[off + i] = lab;
         }
-        const unsigned long long m = urf_match_any(key == URF_RING_NONE ? C : key, dp.ring_keybits);
+        const unsigned long long m = urf_match_any_fast(key == URF_RING_NONE ? C : key, dp.ring_keybits);
         if (key != URF_RING_NONE && urf_is_leader(m))
             atomicAdd(&hist[key], (unsigned)__popcll(m));
     }
@@ -480,7 +497,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
         rkey[q] = valid ? (unsigned)a.ringkey[off + i] : URF_RING_NONE;
         {
             const unsigned mk = rkey[q] == URF_RING_NONE ? C : rkey[q];
-            const unsigned long long m = urf_match_any(mk, dp.ring_keybits);
+            const unsigned long long m = urf_match_any_fast(mk, dp.ring_keybits);
             const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
             unsigned old = 0;
             if (rkey[q] != URF_RING_NONE && leader == lane) {
@@ -494,7 +511,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
         if (star) {
             skey[q] = valid ? (unsigned)a.seckey[off + i] : URF_SEC_NONE;
             const unsigned mk = skey[q] == URF_SEC_NONE ? K : skey[q];
-            const unsigned long long m = urf_match_any(mk, dp.sec_keybits);
+            const unsigned long long m = urf_match_any_fast(mk, dp.sec_keybits);
             const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
             unsigned old = 0;
             if (skey[q] != URF_SEC_NONE && leader == lane) {
@@ -651,35 +668,53 @@ __device__ __forceinline__ unsigned urf_count_less64(const unsigned long long* b
     return pos;
 }
 
-/* Common tail: `fin[0..n)` holds the sorted keys, zs[pos] the heights.  Writes
- * slopes / distance terms / sorted input indices to global memory and returns
- * (all threads) the index of the first "static" hit, or n. */
-template <int NT>
+/* Common tail: `fin[0..n)` holds the sorted keys.  Writes slopes / distance terms / sorted
+ * input indices to global memory and returns (all threads) the index of the first "static"
+ * hit, or n.  The heights are gathered from the (still unsorted) sector-major array, which the
+ * results then overwrite: every read of the workgroup completes before its first write.
+ * EPT = elements per thread (compile-time bound), zs = optional LDS copy of the heights. */
+template <int NT, int EPT>
 __device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_dev_params& dp, unsigned base, unsigned n,
                                                   const unsigned long long* fin, const float* zs, unsigned* sh_first)
 {
     const unsigned tid = threadIdx.x;
     const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
     unsigned first = n;
-    for (unsigned i = tid; i < n; i += NT) {
-        const unsigned long long kb = fin[i];
-        const unsigned pb = (unsigned)kb;
-        float slp = 0.f, g = 0.f;
-        if (i >= 1) {
-            const unsigned long long ka = fin[i - 1];
-            const float ax = __uint_as_float((unsigned)(ka >> 32)), bx = __uint_as_float((unsigned)(kb >> 32));
-            const float ay = zs[(unsigned)ka], by = zs[pb];
-            slp = (by - ay) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
-            g = (bx - ax) * kdist;
-            if (slp > slope_param && i < first)
-                first = i;
+    float slp[EPT], g[EPT];
+    unsigned src[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const unsigned i = tid + (unsigned)e * NT;
+        slp[e] = 0.f;
+        g[e] = 0.f;
+        src[e] = 0;
+        if (i < n) {
+            const unsigned long long kb = fin[i];
+            const unsigned pb = (unsigned)kb;
+            src[e] = a.ssrc[base + pb];
+            if (i >= 1) {
+                const unsigned long long ka = fin[i - 1];
+                const float ax = __uint_as_float((unsigned)(ka >> 32)), bx = __uint_as_float((unsigned)(kb >> 32));
+                const float ay = zs ? zs[(unsigned)ka] : a.sz[base + (unsigned)ka];
+                const float by = zs ? zs[pb] : a.sz[base + pb];
+                slp[e] = (by - ay) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
+                g[e] = (bx - ax) * kdist;
+                if (slp[e] > slope_param && i < first)
+                    first = i;
+            }
         }
-        a.ssrt[base + i] = a.ssrc[base + pb];
-        a.sr[base + i] = slp;              /* the ranges are dead: reuse their storage */
-        a.sz[base + i] = g;
     }
     atomicMin(sh_first, first);
-    __syncthreads();
+    __syncthreads();   /* waits for every outstanding load of the workgroup */
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const unsigned i = tid + (unsigned)e * NT;
+        if (i < n) {
+            a.ssrt[base + i] = src[e];
+            a.sr[base + i] = slp[e];           /* the ranges are dead: reuse their storage */
+            a.sz[base + i] = g[e];
+        }
+    }
     return *sh_first;
 }
 
@@ -700,7 +735,6 @@ __global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs 
     constexpr unsigned NB = 512;                    /* buckets */
     __shared__ unsigned long long A[MAXB * 64];     /* keys by bucket, then the fully sorted sector */
     __shared__ unsigned cnt[NB + 1];                /* bucket counts, then exclusive offsets */
-    __shared__ float zs[MAXB * 64];
     __shared__ unsigned sh_first;
     const unsigned k = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
     if (a.info[s].status != URF_OK)
@@ -730,7 +764,6 @@ __global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs 
         if (q < B && i < n) {
             const unsigned rb = urf_fbits(a.sr[base + i]);
             key[q] = ((unsigned long long)rb << 32) | i;
-            zs[i] = a.sz[base + i];
             rmin = rb < rmin ? rb : rmin;
             rmax = rb > rmax ? rb : rmax;
         }
@@ -831,7 +864,7 @@ __global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs 
             A[rank[q]] = key[q];
     __syncthreads();
     const unsigned long long* fin = A;
-    const unsigned first = urf_star_emit<URF_STAR_THREADS>(a, dp, base, n, fin, zs, &sh_first);
+    const unsigned first = urf_star_emit<URF_STAR_THREADS, MAXB>(a, dp, base, n, fin, nullptr, &sh_first);
     if (lane == 0)
         a.star_first[(size_t)s * K + k] = first < n - 1 ? first : n - 1;   /* last index the walk may visit */
 }
@@ -888,7 +921,7 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_karg
             sh_first = n;
         __syncthreads();
         urf_bitonic_keys<URF_STAR_MID_THREADS>(keys, n);
-        const unsigned first = urf_star_emit<URF_STAR_MID_THREADS>(a, dp, base, n, keys, zs, &sh_first);
+        const unsigned first = urf_star_emit<URF_STAR_MID_THREADS, URF_STAR_MID_CAP / URF_STAR_MID_THREADS>(a, dp, base, n, keys, zs, &sh_first);
         if (threadIdx.x == 0)
             a.star_first[sk] = first < n - 1 ? first : n - 1;
         __syncthreads();
@@ -1119,16 +1152,42 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
     int maxd_bits = 0;
     __syncthreads();
 
-    for (int cs = 0; cs < n; cs += URF_RING_THREADS) {
-        /* stage [cs - cp, cs + 256 + cp) */
+    /* The ring streams through LDS in chunks of 256 points + halo.  The global loads of
+     * chunk i+1 are issued before chunk i is processed, so that their latency hides behind
+     * the arithmetic (two elements per thread cover 256 + 2*30 slots). */
+    float nx[2], ny[2], nz[2];
+    auto fetch = [&](int cs) {
         const int lo = cs - cp < 0 ? 0 : cs - cp;
         const int hi = cs + URF_RING_THREADS + cp > n ? n : cs + URF_RING_THREADS + cp;
-        for (int j = lo + (int)tid; j < hi; j += URF_RING_THREADS) {
-            const int li = j - cs + cp;
-            xs[li] = a.rx[base + j];
-            ys[li] = a.ry[base + j];
-            zs[li] = a.rz[base + j];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int j = lo + (int)tid + e * URF_RING_THREADS;
+            const bool on = j < hi;
+            nx[e] = on ? a.rx[base + j] : 0.f;
+            ny[e] = on ? a.ry[base + j] : 0.f;
+            nz[e] = on ? a.rz[base + j] : 0.f;
         }
+    };
+    if (n > 0)
+        fetch(0);
+    for (int cs = 0; cs < n; cs += URF_RING_THREADS) {
+        /* stage [cs - cp, cs + 256 + cp) */
+        {
+            const int lo = cs - cp < 0 ? 0 : cs - cp;
+            const int hi = cs + URF_RING_THREADS + cp > n ? n : cs + URF_RING_THREADS + cp;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int j = lo + (int)tid + e * URF_RING_THREADS;
+                if (j < hi) {
+                    const int li = j - cs + cp;
+                    xs[li] = nx[e];
+                    ys[li] = ny[e];
+                    zs[li] = nz[e];
+                }
+            }
+        }
+        if (cs + URF_RING_THREADS < n)
+            fetch(cs + URF_RING_THREADS);
         __syncthreads();
         const int p = cs + (int)tid;
         if (p < n) {
@@ -1439,7 +1498,7 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
  * bytes apart in input order, so the row (i >> 6) rotates the column (i & 63) to spread the
  * byte stores over the LDS banks */
 #define URF_IMG(i) (((i) & ~63u) | ((((i) & 63u) + ((i) >> 6)) & 63u))
-__global__ __launch_bounds__(URF_TILE_THREADS) void k_label(urf_kargs a, urf_dev_params dp)
+__global__ __launch_bounds__(URF_LABEL_TILE_THREADS) void k_label(urf_kargs a, urf_dev_params dp)
 {
     __shared__ unsigned long long actf[URF_MAX_CHANNELS * 6], actb[URF_MAX_CHANNELS * 6];
     __shared__ double qk[URF_MAX_CHANNELS];
@@ -1468,11 +1527,11 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_label(urf_kargs a, urf_dev
         koff[tid] = next - first;   /* count, scanned below */
         qk[tid] = tid < nR ? urf_arc_ratio(dp, maxd[0], maxd[tid]) : 0.0;
     }
-    for (unsigned w = tid; w < nR * 6; w += URF_TILE_THREADS) {
+    for (unsigned w = tid; w < nR * 6; w += URF_LABEL_TILE_THREADS) {
         actf[w] = a.act_f[(size_t)s * C * 6 + w];
         actb[w] = a.act_b[(size_t)s * C * 6 + w];
     }
-    for (unsigned i = tid; i < URF_TILE / 4; i += URF_TILE_THREADS)
+    for (unsigned i = tid; i < URF_TILE / 4; i += URF_LABEL_TILE_THREADS)
         ((unsigned*)img)[i] = 0xffffffffu;
     if (tid == 0) {
         cnt_road = 0;
@@ -1501,21 +1560,37 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_label(urf_kargs a, urf_dev
     const unsigned npts = koff[C];
 
     unsigned my_road = 0, my_curb = 0;
-    for (unsigned j = tid; j < npts; j += URF_TILE_THREADS) {
-        /* ring of slot j: last k with koff[k] <= j */
-        unsigned lo = 0, hi = C;
-        while (hi - lo > 1) {
-            const unsigned mid = (lo + hi) >> 1;
-            if (koff[mid] <= j)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const unsigned c = lo;
-        const unsigned pos = base_r[c] + (j - koff[c]);
-        const unsigned flag = a.rflag[pos];
-        const float az = a.raz[pos];
-        const unsigned src = a.rsrc[pos];
+    constexpr unsigned Q = URF_TILE / URF_LABEL_TILE_THREADS;
+    unsigned rc[Q], rpos[Q];
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        /* ring of slot j: last k with koff[k] <= j (branch-free bisection, C <= 128) */
+        const unsigned j = tid + q * URF_LABEL_TILE_THREADS;
+        unsigned lo = 0;
+#pragma unroll
+        for (unsigned step = URF_MAX_CHANNELS / 2; step > 0; step >>= 1)
+            if (lo + step < C && koff[lo + step] <= j)
+                lo += step;
+        rc[q] = lo;
+        rpos[q] = j < npts ? base_r[lo] + (j - koff[lo]) : 0xffffffffu;
+    }
+    unsigned rfl[Q], rsr[Q];
+    float raz[Q];
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {   /* all loads in flight before the tests */
+        const bool on = rpos[q] != 0xffffffffu;
+        rfl[q] = on ? (unsigned)a.rflag[rpos[q]] : 0u;
+        raz[q] = on ? a.raz[rpos[q]] : 0.f;
+        rsr[q] = on ? a.rsrc[rpos[q]] : 0u;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        if (rpos[q] == 0xffffffffu)
+            continue;
+        const unsigned c = rc[q];
+        const unsigned flag = rfl[q];
+        const float az = raz[q];
+        const unsigned src = rsr[q];
         uint8_t lab = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0);
         if (flag) {
             lab |= URF_LABEL_CURB;
@@ -1562,7 +1637,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_label(urf_kargs a, urf_dev
     if (my_curb)
         atomicAdd(&cnt_curb, my_curb);
     __syncthreads();
-    for (unsigned i = tid; i < URF_TILE; i += URF_TILE_THREADS) {
+    for (unsigned i = tid; i < URF_TILE; i += URF_LABEL_TILE_THREADS) {
         const uint8_t l = img[URF_IMG(i)];
         if (l != 0xff && tbase + i < len)
             a.labels[off + tbase + i] = l;   /* points on no ring keep the label k_ring_assign wrote */
