@@ -205,8 +205,8 @@ typedef enum urf_stage {
                                  (n_rings = not blocked, -1 = beam not cast) */
 } urf_stage;
 int urf_read_stage(urf_ctx* ctx, urf_stage what, uint32_t scan, void* host_dst, size_t bytes);
-/* URF_STAGE_RANGE2D needs one extra store per point; it is only kept when
- * capture is on (default off). */
+/* URF_STAGE_VALPHA and URF_STAGE_RANGE2D need one extra store per point each;
+ * they are only kept when capture is on (default off). */
 int urf_enable_stage_capture(urf_ctx* ctx, int on);
 
 /* ---- per-kernel timing (benchmark) ------------------------------------------
@@ -214,7 +214,7 @@ int urf_enable_stage_capture(urf_ctx* ctx, int on);
  * with hipEvents on the context's stream.  urf_kernel_timing() synchronises,
  * adds the elapsed milliseconds of all calls since the last query to
  * ms_sum[0..URF_NUM_KERNELS) and the number of calls to *n_calls, then resets. */
-#define URF_NUM_KERNELS 9
+#define URF_NUM_KERNELS 8
 int urf_enable_kernel_timing(urf_ctx* ctx, int on);
 int urf_kernel_timing(urf_ctx* ctx, double* ms_sum, uint32_t* n_calls);
 const char* urf_kernel_name(int index);

@@ -683,11 +683,6 @@ int urf_oracle_classify(const float* x, const float* y, const float* z, uint32_t
         for (j = 0; j < index; j++)
             for (int k = 0; k < indexArray[j]; k++)
                 dbg->detect[array3D[j][k].src] = array3D[j][k].detect;
-        /* star hits on ROI points that match no ring never reach array3D */
-        if (prm->star_shaped_method)
-            for (i = 0; i < piece; i++)
-                if (array2D[i].detect & 1)
-                    dbg->detect[array2D[i].src] |= 1;
     }
 
     for (j = 0; j < index; j++)   /* :289-291 */

@@ -29,7 +29,7 @@ typedef struct urf_oracle_debug {
     int16_t* ring;        /* per point; -1 if not bucketed */
     float*   azimuth;     /* per point (bucketed points only, else 0) */
     float*   range2d;     /* per point (bucketed points only, else 0) */
-    uint8_t* detect;      /* per point: bit0 star, bit1 x_zero, bit2 z_zero */
+    uint8_t* detect;      /* per point on a ring: bit0 star, bit1 x_zero, bit2 z_zero (as carried into array3D) */
     int16_t* sector;      /* per point; -1 outside the ROI, star disabled, or removed by the beam filter */
     float*   angle_table; /* [channels] sorted table, zero padded */
     float*   max_dist;    /* [channels] */

@@ -211,7 +211,7 @@ class Context:
     def enable_stage_capture(self, on=True):
         self._check(self._lib.urf_enable_stage_capture(self._h, int(on)), "urf_enable_stage_capture")
 
-    NUM_KERNELS = 9
+    NUM_KERNELS = 8
 
     def selftest(self):
         n = C.c_uint64(0)

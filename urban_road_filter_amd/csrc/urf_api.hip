@@ -296,7 +296,7 @@ extern "C" int urf_enable_kernel_timing(urf_ctx* c, int on)
 
 extern "C" const char* urf_kernel_name(int i)
 {
-    static const char* names[URF_NUM_KERNELS] = { "k_ingest", "k_ring_table", "k_ring_assign", "k_offsets", "k_scatter",
+    static const char* names[URF_NUM_KERNELS] = { "k_ring_table", "k_ingest", "k_offsets", "k_scatter",
                                                   "k_star", "k_ring", "k_beams", "k_label" };
     return (i >= 0 && i < URF_NUM_KERNELS) ? names[i] : "";
 }
@@ -347,8 +347,10 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     if (a.tiles == 0)
         a.tiles = 1;
     a.labels = d_labels;
-    if (!c->debug_rd2)
+    if (!c->debug_rd2) {
         a.rd2 = nullptr;
+        a.valpha = nullptr;
+    }
     const urf_dev_params dp = c->dp;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
@@ -369,11 +371,9 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         stage++;
     };
     mark();
-    hipLaunchKernelGGL(k_ingest, g_tiles, dim3(URF_INGEST_THREADS), (K + 1) * sizeof(unsigned), st, a, dp);
-    mark();
     hipLaunchKernelGGL(k_ring_table, g_scan, dim3(64), 0, st, a, dp);
     mark();
-    hipLaunchKernelGGL(k_ring_assign, g_tiles, dim3(URF_ASSIGN_THREADS), 0, st, a, dp);
+    hipLaunchKernelGGL(k_ingest, g_tiles, dim3(URF_INGEST_THREADS), (K + 1) * sizeof(unsigned), st, a, dp);
     mark();
     if (star)
         URF_HIP(c, hipMemsetAsync(a.star_count, 0, 2 * sizeof(uint32_t), st));
@@ -540,13 +540,14 @@ extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* h
         off = scan * c->last_n;
         len = c->last_n;
     }
-    const unsigned C = (unsigned)c->params.channels, K = (unsigned)c->params.sectors;
+    const unsigned C = (unsigned)c->params.channels;
     const urf_kargs& k = c->k;
     urf_scan_info in;
     URF_HIP(c, hipMemcpy(&in, k.info + scan, sizeof(in), hipMemcpyDeviceToHost));
     int rc;
     switch (what) {
     case URF_STAGE_VALPHA:
+        if (!c->debug_rd2) return URF_ERR_INVALID_ARG;
         if (bytes < len * sizeof(float)) return URF_ERR_INVALID_ARG;
         URF_HIP(c, hipMemcpy(host_dst, k.valpha + off, len * sizeof(float), hipMemcpyDeviceToHost));
         return URF_OK;
@@ -586,13 +587,6 @@ extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* h
             uint8_t* o = (uint8_t*)host_dst;
             for (uint32_t p = 0; p < nb; p++)
                 o[src[p]] = fl[p];
-            if (c->params.star_shaped_method) {   /* star hits on points that match no ring */
-                std::vector<int32_t> hit;
-                if ((rc = fetch(c, hit, k.star_hit + (size_t)scan * K, K)) != URF_OK) return rc;
-                for (uint32_t s = 0; s < K; s++)
-                    if (hit[s] >= 0 && (uint32_t)hit[s] < len)
-                        o[hit[s]] |= 1;
-            }
         } else {
             std::vector<float> v;
             if ((rc = fetch(c, v, (what == URF_STAGE_AZIMUTH ? k.raz : k.rd2) + off, nb)) != URF_OK) return rc;

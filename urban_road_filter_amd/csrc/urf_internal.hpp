@@ -79,7 +79,7 @@ struct urf_kargs {
     float*    sr;
     float*    sz;
     uint32_t* ssrc;
-    uint32_t* ssrt;             /* input index of the i-th point of the sector in sorted order */
+    uint32_t* ssrt;             /* ring-major position of the i-th point of the sector in sorted order */
     /* per scan x tile */
     uint32_t* tile_roi;         /* [S][tiles] ROI points of the tile */
     uint32_t* tile_ring;        /* [S][tiles][channels] per-tile ring counts; k_offsets turns them into the
@@ -91,7 +91,7 @@ struct urf_kargs {
     uint32_t* ring_off;         /* [S][channels+1] */
     uint32_t* sec_cnt;          /* [S][sectors] */
     uint32_t* sec_off;          /* [S][sectors+1] */
-    int32_t*  star_hit;         /* [S][sectors] input index (scan-relative) of the sector's curb point, -1 none */
+    int32_t*  star_hit;         /* [S][sectors] ring-major position of the sector's curb point; -1 = none or on no ring */
     uint32_t* star_first;       /* [S][sectors] last sorted index the walk may visit */
     uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 513..2048 points */
     uint32_t* star_list_big;    /* [S*sectors] ... with more than 2048 points */

@@ -5,13 +5,13 @@
  * the scan, the other grid dimension the tile / ring / sector inside it.
  * Pipeline (reference lines each kernel replaces; DESIGN.md has the full map):
  *
- *   k_ingest       ROI test, vertical angle, star sector + per-tile sector
- *                  histogram            lidar_segmentation.cpp:106-166, star_shaped_search.cpp:162-174
- *   k_ring_table   first-fit ring-angle table + sort            lidar_segmentation.cpp:124-126,168-196,205
- *   k_ring_assign  ring of every point + per-tile ring histogram lidar_segmentation.cpp:226-233
- *   k_offsets      exclusive scans of both histograms
+ *   k_ring_table   first-fit ring-angle table + sort, straight from x/y/z   lidar_segmentation.cpp:145-196,205
+ *   k_ingest       ROI test, vertical angle, ring of every point, star sector, per-tile ring and
+ *                  sector histograms    lidar_segmentation.cpp:106-166,226-233, star_shaped_search.cpp:162-174
+ *   k_offsets      piece < 30 test, exclusive scans of both histograms      lidar_segmentation.cpp:120-126
  *   k_scatter      stable split into ring-major and sector-major order   lidar_segmentation.cpp:238-242,276
- *   k_star         per-sector sort by range + slope scan        star_shaped_search.cpp:109-150
+ *   k_star_sort_*  per-sector sort by range, slopes             star_shaped_search.cpp:109-129
+ *   k_star_walk    per-sector running-mean slope test           star_shaped_search.cpp:123-149
  *   k_ring         x_zero, z_zero, azimuth, maxDistance, per-degree curb tables,
  *                  blind-spot quadrants   x_zero_method.cpp, z_zero_method.cpp,
  *                  lidar_segmentation.cpp:245-274, blind_spots.cpp:17-57
@@ -30,8 +30,6 @@
 #include "urf_device.hpp"
 
 #define URF_INT_NONE_MIN 0x7fffffff
-#define URF_HTAB 2048   /* >= 2 x URF_MAX_SECTORS */
-__device__ __forceinline__ unsigned urf_hash_slot(unsigned v) { return (v * 2654435761u) >> 21; }
 /* (float)sqrt(s) < 5.0 (x_zero_method.cpp:35-40, z_zero_method.cpp:23-28) holds exactly for the
  * doubles s below this one: sqrt and the rounding to float are monotone, the threshold is the
  * smallest double whose rounded root reaches 5.0f (found by bisection, tools/check_dist5.c). */
@@ -40,7 +38,6 @@ __device__ __forceinline__ unsigned urf_hash_slot(unsigned v) { return (v * 2654
 #define URF_LABEL_THREADS 384
 #define URF_STAR_THREADS 64
 #define URF_INGEST_THREADS 256       /* tile kernels that need no big LDS tile run 8 workgroups per CU */
-#define URF_ASSIGN_THREADS 256
 #define URF_LABEL_TILE_THREADS 256   /* k_label: one tile per workgroup, 16 slots per thread, 8 workgroups per CU */
 #define URF_STAR_MID_CAP_ 2048
 
@@ -82,18 +79,26 @@ __global__ __launch_bounds__(256) void k_pc2_to_soa(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_dev_params dp)
 {
     extern __shared__ unsigned sh_hist[];   /* [sectors] sector histogram, [sectors] = ROI count */
+    __shared__ float tab[URF_MAX_CHANNELS];
+    __shared__ unsigned rhist[URF_MAX_CHANNELS];
     const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned tbase = t * URF_TILE;
     if (tbase >= len)
         return;
-    const unsigned K = (unsigned)dp.p.sectors;
+    const unsigned K = (unsigned)dp.p.sectors, C = (unsigned)dp.p.channels;
     const bool star = dp.p.star_shaped_method != 0;
+    const unsigned nR = a.info[s].n_rings;
     for (unsigned k = tid; k <= K; k += URF_INGEST_THREADS)
         sh_hist[k] = 0;
+    if (tid < C) {
+        tab[tid] = tid < nR ? a.angle[(size_t)s * C + tid] : 0.f;
+        rhist[tid] = 0;
+    }
     __syncthreads();
 
+    const float interval = dp.p.interval;
     constexpr unsigned Q = URF_TILE / URF_INGEST_THREADS;
     float px[Q], py[Q], pz[Q];
 #pragma unroll
@@ -111,18 +116,39 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
         const float x = px[q], y = py[q], z = pz[q];
         const bool roi = valid && urf_in_roi(dp.p, x, y, z);
         float va = -1.0f;
-        unsigned key = URF_SEC_NONE;
+        unsigned key = URF_SEC_NONE, rkey = URF_RING_NONE;
         if (roi) {
-            va = urf_vertical_angle(x, y, z);
+            va = (dp.exp_flags & 8u) ? __builtin_fabsf(z) * 10.0f : urf_vertical_angle(x, y, z);
+            /* lidar_segmentation.cpp:226-233: first sorted table entry within `interval`.
+             * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are contiguous
+             * and the first one is found by bisection with the very same float predicate. */
+            unsigned lo = 0, hi = nR;
+            while (lo < hi) {
+                const unsigned mid = (lo + hi) >> 1;
+                if (tab[mid] - va >= -interval)
+                    hi = mid;
+                else
+                    lo = mid + 1;
+            }
+            if (lo < nR && __builtin_fabsf(tab[lo] - va) <= interval)
+                rkey = lo;
             if (star) {
-                key = urf_sector(x, y, dp.Kfi, K);
+                key = (dp.exp_flags & 8u) ? ((unsigned)(int)(x * 3.0f + 200.0f)) % K : urf_sector(x, y, dp.Kfi, K);
                 if (dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
                     key = URF_SEC_NONE;
             }
         }
         if (valid) {
-            a.valpha[off + i] = va;
+            if (a.valpha)
+                a.valpha[off + i] = va;   /* stage capture only */
             a.seckey[off + i] = (uint16_t)key;
+            a.ringkey[off + i] = (uint8_t)rkey;
+            a.labels[off + i] = roi ? URF_FLAG_ROI : 0;
+        }
+        {
+            const unsigned long long m = urf_match_any_fast(rkey == URF_RING_NONE ? C : rkey, dp.ring_keybits);
+            if (rkey != URF_RING_NONE && urf_is_leader(m))
+                atomicAdd(&rhist[rkey], (unsigned)__popcll(m));
         }
         if (star) {
             const unsigned long long m = urf_match_any_fast(key == URF_SEC_NONE ? K : key, dp.sec_keybits);
@@ -138,6 +164,8 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
     if (star)
         for (unsigned k = tid; k < K; k += URF_INGEST_THREADS)
             a.tile_sec[row * K + k] = sh_hist[k];
+    if (tid < C)
+        a.tile_ring[row * C + tid] = rhist[tid];
     if (tid == 0)
         a.tile_roi[row] = sh_hist[K];
 }
@@ -149,6 +177,8 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
  * angle to the table when no earlier entry lies within `interval`
  * (lidar_segmentation.cpp:168-196).  Equivalent formulation used here: leader
  * k+1 is the first point after leader k that matches none of the leaders 0..k.
+ * It runs first, straight from x/y/z, so that the one pass over the points that
+ * follows (k_ingest) can already assign rings.
  * One wave per scan walks the points 64 at a time; the leaders live in
  * registers (leader j in lane j & 63) and are broadcast with readlane, so a
  * chunk without new leaders costs one compare per leader, and a new leader is
@@ -162,19 +192,10 @@ __global__ __launch_bounds__(64) void k_ring_table(urf_kargs a, urf_dev_params d
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned C = (unsigned)dp.p.channels;
-    const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
-
-    /* piece = number of ROI points (lidar_segmentation.cpp:120) */
-    unsigned piece = 0;
-    for (unsigned t = lane; t < ntiles; t += 64)
-        piece += a.tile_roi[(size_t)s * a.tiles + t];
-    for (int o = 32; o > 0; o >>= 1)
-        piece += __shfl_xor(piece, o);
-    const bool too_few = piece < 30;   /* lidar_segmentation.cpp:124 */
     if (lane == 0) {
         urf_scan_info in;
-        in.status = too_few ? URF_TOO_FEW_POINTS : URF_OK;
-        in.n_roi = piece;
+        in.status = URF_OK;      /* k_offsets turns it into URF_TOO_FEW_POINTS when piece < 30 */
+        in.n_roi = 0;
         in.n_rings = 0;
         in.n_ring_pts = 0;
         in.n_road = 0;
@@ -183,8 +204,6 @@ __global__ __launch_bounds__(64) void k_ring_table(urf_kargs a, urf_dev_params d
         in.reserved = 0;
         a.info[s] = in;
     }
-    if (too_few)
-        return;
 
     const float interval = dp.p.interval;
     float L0 = 0.f, L1 = 0.f;      /* leader j lives in lane j & 63 of L0 (j < 64) or L1 */
@@ -192,7 +211,12 @@ __global__ __launch_bounds__(64) void k_ring_table(urf_kargs a, urf_dev_params d
     bool zero_seen = false;
     for (unsigned base = 0; base < len && nL < C; base += 64) {
         const unsigned i = base + lane;
-        const float v = i < len ? a.valpha[off + i] : -1.0f;
+        float v = -1.0f;
+        if (i < len) {             /* vertical angle of the ROI points of this chunk, computed on the fly */
+            const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
+            if (urf_in_roi(dp.p, x, y, z))
+                v = urf_vertical_angle(x, y, z);
+        }
         bool un = v >= 0.0f;       /* ROI point, not yet matched */
         for (unsigned j = 0; j < nmatch; j++) {
             const float lj = __shfl(j < 64 ? L0 : L1, (int)(j & 63));
@@ -245,81 +269,6 @@ __global__ __launch_bounds__(64) void k_ring_table(urf_kargs a, urf_dev_params d
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_ring_assign                                                               */
-/* ------------------------------------------------------------------------- */
-/* lidar_segmentation.cpp:226-233: first sorted table entry within `interval`.
- * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are
- * contiguous and the first one is found by bisection with the very same float
- * predicate. */
-__global__ __launch_bounds__(URF_ASSIGN_THREADS) void k_ring_assign(urf_kargs a, urf_dev_params dp)
-{
-    __shared__ float tab[URF_MAX_CHANNELS];
-    __shared__ unsigned hist[URF_MAX_CHANNELS];
-    const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-    unsigned off, len;
-    urf_scan_range(a, s, off, len);
-    const unsigned tbase = t * URF_TILE;
-    if (tbase >= len)
-        return;
-    const unsigned C = (unsigned)dp.p.channels;
-    const urf_scan_info in = a.info[s];
-    if (in.status != URF_OK) {
-        /* nothing is published for this scan: all labels 0 */
-        for (unsigned q = 0; q < URF_TILE / URF_ASSIGN_THREADS; q++) {
-            const unsigned i = tbase + q * URF_ASSIGN_THREADS + tid;
-            if (i < len)
-                a.labels[off + i] = 0;
-        }
-        return;
-    }
-    const unsigned nR = in.n_rings;
-    if (tid < C) {
-        tab[tid] = tid < nR ? a.angle[(size_t)s * C + tid] : 0.f;
-        hist[tid] = 0;
-    }
-    __syncthreads();
-    const float interval = dp.p.interval;
-    constexpr unsigned Q = URF_TILE / URF_ASSIGN_THREADS;
-    float va[Q];
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const unsigned i = tbase + q * URF_ASSIGN_THREADS + tid;
-        va[q] = i < len ? a.valpha[off + i] : -1.0f;
-    }
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const unsigned i = tbase + q * URF_ASSIGN_THREADS + tid;
-        const bool valid = i < len;
-        unsigned key = URF_RING_NONE;
-        uint8_t lab = 0;
-        if (valid) {
-            const float v = va[q];
-            if (v >= 0.0f) {
-                lab = URF_FLAG_ROI;
-                unsigned lo = 0, hi = nR;
-                while (lo < hi) {
-                    const unsigned mid = (lo + hi) >> 1;
-                    if (tab[mid] - v >= -interval)
-                        hi = mid;
-                    else
-                        lo = mid + 1;
-                }
-                if (lo < nR && __builtin_fabsf(tab[lo] - v) <= interval)
-                    key = lo;
-            }
-            a.ringkey[off + i] = (uint8_t)key;
-            a.labels[off + i] = lab;
-        }
-        const unsigned long long m = urf_match_any_fast(key == URF_RING_NONE ? C : key, dp.ring_keybits);
-        if (key != URF_RING_NONE && urf_is_leader(m))
-            atomicAdd(&hist[key], (unsigned)__popcll(m));
-    }
-    __syncthreads();
-    if (tid < C)
-        a.tile_ring[((size_t)s * a.tiles + t) * C + tid] = hist[tid];
-}
-
-/* ------------------------------------------------------------------------- */
 /* k_offsets                                                                   */
 /* ------------------------------------------------------------------------- */
 /* exclusive scan of cnt[0..K) (K <= 1024) by 256 threads -> off[0..K] */
@@ -362,12 +311,31 @@ __global__ __launch_bounds__(256) void k_offsets(urf_kargs a, urf_dev_params dp)
 {
     __shared__ unsigned sh[8];
     const unsigned s = blockIdx.x, tid = threadIdx.x;
-    if (a.info[s].status != URF_OK)
-        return;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
+    {   /* piece = number of ROI points (lidar_segmentation.cpp:120); < 30 => nothing is published (:124) */
+        unsigned piece = 0;
+        for (unsigned t = tid; t < ntiles; t += 256)
+            piece += a.tile_roi[(size_t)s * a.tiles + t];
+        for (int o = 32; o > 0; o >>= 1)
+            piece += __shfl_xor(piece, o);
+        if (urf_lane() == 0)
+            sh[tid >> 6] = piece;
+        __syncthreads();
+        piece = sh[0] + sh[1] + sh[2] + sh[3];
+        __syncthreads();
+        if (tid == 0) {
+            a.info[s].n_roi = piece;
+            if (piece < 30) {
+                a.info[s].status = URF_TOO_FEW_POINTS;
+                a.info[s].n_rings = 0;
+            }
+        }
+        if (piece < 30)
+            return;
+    }
     /* rings */
     for (unsigned k = tid; k < C; k += 256) {
         unsigned run = 0;
@@ -458,8 +426,12 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
     const unsigned tbase = t * URF_TILE;
     if (tbase >= len)
         return;
-    if (a.info[s].status != URF_OK)
+    if (a.info[s].status != URF_OK) {
+        /* nothing is published for this scan (lidar_segmentation.cpp:124-126): all labels 0 */
+        for (unsigned i = tbase + tid; i < len && i < tbase + URF_TILE; i += URF_TILE_THREADS)
+            a.labels[off + i] = 0;
         return;
+    }
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
     constexpr unsigned Q = 256 / 64;
@@ -563,10 +535,11 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
     const unsigned tile_ring_pts = koff[C - 1] + tot_r[C - 1];
 
     /* step 4: ring slot inside the tile (lp), sector-major destination (sdst) */
-    unsigned lp[Q], sdst[Q];
+    unsigned lp[Q], sdst[Q], rdst[Q];
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
         lp[q] = rkey[q] != URF_RING_NONE ? koff[rkey[q]] + my_r[rkey[q]] + rrank[q] : 0xffffffffu;
+        rdst[q] = rkey[q] != URF_RING_NONE ? base_r[rkey[q]] + my_r[rkey[q]] + rrank[q] : 0xffffffffu;
         sdst[q] = skey[q] != URF_SEC_NONE ? base_s[skey[q]] + my_s[skey[q]] + srank[q] : 0xffffffffu;
     }
     __syncthreads();   /* wcnt is dead: its memory becomes the staging buffers */
@@ -591,7 +564,10 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
         if (sdst[q] != 0xffffffffu) {
             a.sr[sdst[q]] = __builtin_sqrtf(x * x + y * y);   /* star_shaped_search.cpp:164 */
             a.sz[sdst[q]] = z;
-            a.ssrc[sdst[q]] = i;
+            /* where a star-shaped hit on this point has to be reported: its ring-major position
+             * (none if the point lies on no ring: such a hit ends the walk but marks nothing
+             * that reaches the output, lidar_segmentation.cpp:235-242) */
+            a.ssrc[sdst[q]] = rdst[q];
         }
     }
     __syncthreads();
@@ -1096,20 +1072,27 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
 /* k_ring                                                                      */
 /* ------------------------------------------------------------------------- */
 /* One workgroup per (ring, scan).  The ring's points (input order) stream
- * through LDS in chunks of 256 with a halo of curbPoints on both sides; every
- * thread owns one point and evaluates
+ * through LDS in chunks of 1024 with a halo of curbPoints on both sides; every
+ * thread owns four points per chunk and evaluates for each
  *   - x_zero for the triple (p - cp/2, p, p - cp/2 + cp) that marks p,
  *   - z_zero for the centre p,
  *   - azimuth and planar range of p,
- * then feeds the per-degree curb tables used by the beam march. */
+ * then feeds the per-degree curb tables used by the beam march.
+ * The star-shaped hits arrive as ring-major positions (k_scatter stores them in
+ * the sector-major records), so the ring only has to collect the handful that
+ * fall into its own range. */
+#define URF_RING_PPT 4
+#define URF_RING_CHUNK (URF_RING_THREADS * URF_RING_PPT)
 __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_params dp)
 {
     constexpr int HALO = URF_MAX_CURB_POINTS;
-    __shared__ float xs[URF_RING_THREADS + 2 * HALO], ys[URF_RING_THREADS + 2 * HALO], zs[URF_RING_THREADS + 2 * HALO];
+    constexpr int CH = URF_RING_CHUNK;
+    __shared__ float xs[CH + 2 * HALO], ys[CH + 2 * HALO], zs[CH + 2 * HALO];
     __shared__ int cmin[URF_DEG_CELLS], cmax[URF_DEG_CELLS];
     __shared__ int sh_q[4];
     __shared__ int sh_maxd;
-    __shared__ unsigned htab[URF_HTAB];
+    __shared__ unsigned hits[URF_MAX_SECTORS + 2];
+    __shared__ unsigned n_hits;
     const unsigned c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
     const urf_scan_info in = a.info[s];
     if (in.status != URF_OK || c >= in.n_rings)
@@ -1120,27 +1103,12 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
     const int n = (int)a.ring_cnt[(size_t)s * C + c];
     const unsigned base = off + a.ring_off[(size_t)s * (C + 1) + c];
     const int cp = dp.p.curbPoints;
-    const bool star = dp.p.star_shaped_method != 0;
+    const bool star = dp.p.star_shaped_method != 0 && !(dp.exp_flags & 128u);
     const bool want_quad = (c == 1) && dp.p.blind_spots;
 
     for (unsigned i = tid; i < URF_DEG_CELLS; i += URF_RING_THREADS) {
         cmin[i] = URF_INT_NONE_MIN;
         cmax[i] = -1;
-    }
-    if (star) {
-        /* the scan's <= `sectors` star-shaped hits (input indices) as an open-addressing
-         * hash set: one LDS probe per point instead of a sector-key gather from HBM */
-        for (unsigned i = tid; i < URF_HTAB; i += URF_RING_THREADS)
-            htab[i] = 0xffffffffu;
-        __syncthreads();
-        for (unsigned k = tid; k < K; k += URF_RING_THREADS) {
-            const int h = a.star_hit[(size_t)s * K + k];
-            if (h >= 0) {
-                unsigned slot = urf_hash_slot((unsigned)h);
-                while (atomicCAS(&htab[slot], 0xffffffffu, (unsigned)h) != 0xffffffffu)
-                    slot = (slot + 1) & (URF_HTAB - 1);
-            }
-        }
     }
     if (tid == 0) {
         sh_q[0] = (int)urf_fbits(0.f);
@@ -1148,68 +1116,50 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
         sh_q[2] = (int)urf_fbits(180.f);
         sh_q[3] = (int)urf_fbits(360.f);
         sh_maxd = 0;
+        n_hits = 0;
+    }
+    __syncthreads();
+    if (star) {   /* lidar_segmentation.cpp:241-242: the star-shaped hits that lie on this ring */
+        for (unsigned k = tid; k < K; k += URF_RING_THREADS) {
+            const unsigned h = (unsigned)a.star_hit[(size_t)s * K + k];   /* ring-major position or 0xffffffff */
+            if (h >= base && h < base + (unsigned)n)
+                hits[atomicAdd(&n_hits, 1u)] = h - base;
+        }
     }
     int maxd_bits = 0;
-    __syncthreads();
 
-    /* The ring streams through LDS in chunks of 256 points + halo.  The global loads of
-     * chunk i+1 are issued before chunk i is processed, so that their latency hides behind
-     * the arithmetic (two elements per thread cover 256 + 2*30 slots). */
-    float nx[2], ny[2], nz[2];
-    auto fetch = [&](int cs) {
-        const int lo = cs - cp < 0 ? 0 : cs - cp;
-        const int hi = cs + URF_RING_THREADS + cp > n ? n : cs + URF_RING_THREADS + cp;
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int j = lo + (int)tid + e * URF_RING_THREADS;
-            const bool on = j < hi;
-            nx[e] = on ? a.rx[base + j] : 0.f;
-            ny[e] = on ? a.ry[base + j] : 0.f;
-            nz[e] = on ? a.rz[base + j] : 0.f;
-        }
-    };
-    if (n > 0)
-        fetch(0);
-    for (int cs = 0; cs < n; cs += URF_RING_THREADS) {
-        /* stage [cs - cp, cs + 256 + cp) */
+    for (int cs = 0; cs < n; cs += CH) {
+        /* stage [cs - cp, cs + CH + cp) */
         {
             const int lo = cs - cp < 0 ? 0 : cs - cp;
-            const int hi = cs + URF_RING_THREADS + cp > n ? n : cs + URF_RING_THREADS + cp;
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const int j = lo + (int)tid + e * URF_RING_THREADS;
-                if (j < hi) {
-                    const int li = j - cs + cp;
-                    xs[li] = nx[e];
-                    ys[li] = ny[e];
-                    zs[li] = nz[e];
-                }
+            const int hi = cs + CH + cp > n ? n : cs + CH + cp;
+            for (int j = lo + (int)tid; j < hi; j += URF_RING_THREADS) {
+                const int li = j - cs + cp;
+                xs[li] = a.rx[base + j];
+                ys[li] = a.ry[base + j];
+                zs[li] = a.rz[base + j];
             }
         }
-        if (cs + URF_RING_THREADS < n)
-            fetch(cs + URF_RING_THREADS);
         __syncthreads();
-        const int p = cs + (int)tid;
-        if (p < n) {
-            const int lp = (int)tid + cp;   /* LDS slot of p */
+        const unsigned nh = n_hits;
+#pragma unroll
+        for (int e = 0; e < URF_RING_PPT; e++) {
+            const int p = cs + e * URF_RING_THREADS + (int)tid;
+            if (p >= n)
+                continue;
+            const int lp = p - cs + cp;   /* LDS slot of p */
             const float px = xs[lp], py = ys[lp], pz = zs[lp];
             unsigned flag = 0;
 
-            if (star) {   /* lidar_segmentation.cpp:241-242: carry the star-shaped hit over */
-                const unsigned src = a.rsrc[base + p];
-                unsigned slot = urf_hash_slot(src);
-                for (unsigned v; (v = htab[slot]) != 0xffffffffu; slot = (slot + 1) & (URF_HTAB - 1))
-                    if (v == src) {
-                        flag |= 1u;
-                        break;
-                    }
-            }
+            for (unsigned i = 0; i < nh; i++)
+                if (hits[i] == (unsigned)p)
+                    flag |= 1u;
 
             /* Both detectors are an && of an angle test (f64 sqrt/div, acos) and cheap float
              * height tests.  The height tests run first: on road surface they fail for
              * whole waves, which then skip the expensive part.  (Reordering an && chain of
              * side-effect-free tests does not change its value.) */
-            if (dp.p.x_zero_method) {   /* x_zero_method.cpp:30-68, evaluated for the point it marks */
+            if (dp.p.x_zero_method && !(dp.exp_flags & 64u)) {   /* x_zero_method.cpp:30-68, evaluated for the point it marks */
                 const int j = p - cp / 2;
                 if (j >= cp && j <= (n - 1) - cp) {
                     const int lj = lp - cp / 2, l3 = lj + cp;
@@ -1243,7 +1193,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
                 }
             }
 
-            if (dp.p.z_zero_method) {   /* z_zero_method.cpp:21-72 */
+            if (dp.p.z_zero_method && !(dp.exp_flags & 32u)) {   /* z_zero_method.cpp:21-72 */
                 if (p >= cp && p <= (n - 1) - cp) {
                     const float az = __builtin_fabsf(pz);
                     float max1 = az, max2 = az;
@@ -1289,7 +1239,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
             }
 
             float d2;
-            const float az = urf_azimuth(px, py, &d2);   /* lidar_segmentation.cpp:245-269 */
+            const float az = (dp.exp_flags & 16u) ? (d2 = px * px + py * py, px + 180.0f) : urf_azimuth(px, py, &d2);   /* lidar_segmentation.cpp:245-269 */
             a.raz[base + p] = az;
             a.rflag[base + p] = (uint8_t)flag;
             if (a.rd2)
@@ -1334,7 +1284,6 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
      * Six 64-cell segments: suffix-min / prefix-max inside a segment by wave
      * shuffles, then combined with the totals of the segments behind / in front. */
     __shared__ int segmin[6], segmax[6];
-    __syncthreads();
     const unsigned wave = tid >> 6, lane = tid & 63;
     for (unsigned seg = wave; seg < 6; seg += URF_RING_THREADS / 64) {
         const unsigned cidx = seg * 64 + lane;
