@@ -705,32 +705,14 @@ __device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_
  * bucket collects more than 64 keys (heavily clustered ranges) the wave falls back to the
  * general path: every 64-key block is sorted in registers by an in-wave
  * bitonic network and the blocks are merged by ranking. */
-__global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs a, urf_dev_params dp)
+template <unsigned MAXB>
+__device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const urf_dev_params& dp, unsigned base, unsigned n,
+                                                     unsigned long long* A, unsigned* cnt, unsigned* sh_first,
+                                                     uint32_t* star_first_out)
 {
-    constexpr unsigned MAXB = 8;
-    constexpr unsigned NB = 512;                    /* buckets */
-    __shared__ unsigned long long A[MAXB * 64];     /* keys by bucket, then the fully sorted sector */
-    __shared__ unsigned cnt[NB + 1];                /* bucket counts, then exclusive offsets */
-    __shared__ unsigned sh_first;
-    const unsigned k = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
-    if (a.info[s].status != URF_OK)
-        return;
-    const unsigned K = (unsigned)dp.p.sectors;
-    const unsigned n = a.sec_cnt[(size_t)s * K + k];
-    if (n > 512)
-        return;   /* on a work list (k_offsets) */
-    if (n < 2) {
-        if (lane == 0)
-            a.star_first[(size_t)s * K + k] = 0;   /* nothing to walk */
-        return;
-    }
-    unsigned off, len;
-    urf_scan_range(a, s, off, len);
-    const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
+    constexpr unsigned NB = 512;
+    const unsigned lane = threadIdx.x;
     const unsigned B = (n + 63) >> 6;
-    if (lane == 0)
-        sh_first = n;
-
     unsigned long long key[MAXB];
     unsigned rmin = 0xffffffffu, rmax = 0;
 #pragma unroll
@@ -840,9 +822,40 @@ __global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs 
             A[rank[q]] = key[q];
     __syncthreads();
     const unsigned long long* fin = A;
-    const unsigned first = urf_star_emit<URF_STAR_THREADS, MAXB>(a, dp, base, n, fin, nullptr, &sh_first);
+    const unsigned first = urf_star_emit<URF_STAR_THREADS, MAXB>(a, dp, base, n, fin, nullptr, sh_first);
     if (lane == 0)
-        a.star_first[(size_t)s * K + k] = first < n - 1 ? first : n - 1;   /* last index the walk may visit */
+        *star_first_out = first < n - 1 ? first : n - 1;   /* last index the walk may visit */
+}
+
+
+__global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs a, urf_dev_params dp)
+{
+    constexpr unsigned NB = 512;                    /* buckets */
+    __shared__ unsigned long long A[8 * 64];        /* keys by bucket, then the fully sorted sector */
+    __shared__ unsigned cnt[NB + 1];                /* bucket counts, then exclusive offsets */
+    __shared__ unsigned sh_first;
+    const unsigned k = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+    if (a.info[s].status != URF_OK)
+        return;
+    const unsigned K = (unsigned)dp.p.sectors;
+    const unsigned n = a.sec_cnt[(size_t)s * K + k];
+    if (n > 512)
+        return;   /* on a work list (k_offsets) */
+    if (n < 2) {
+        if (lane == 0)
+            a.star_first[(size_t)s * K + k] = 0;   /* nothing to walk */
+        return;
+    }
+    unsigned off, len;
+    urf_scan_range(a, s, off, len);
+    const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
+    if (lane == 0)
+        sh_first = n;
+    /* per-lane element count fixed at compile time: 6 covers a sector of a 64 x 2048 sweep */
+    if (n <= 384)
+        urf_star_sort_sector<6>(a, dp, base, n, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
+    else
+        urf_star_sort_sector<8>(a, dp, base, n, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
 }
 
 template <int NT>
@@ -1013,7 +1026,7 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
     const float kdev = dp.p.kdev_param, slope_param = dp.slope_param;
     const int dmin = dp.p.dmin_param;
     float avg = 0.f, dev = 0.f, nan = 0.f;
-    int hit = -1;
+    unsigned hit_i = 0;              /* sorted index of the sector's curb point, 0 = none */
     bool running = last >= 1;
     for (unsigned c0 = 0; c0 <= maxlast; c0 += URF_WALK_CHUNK) {
         if (!__any(running))
@@ -1026,44 +1039,54 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
             }
         }
         __syncthreads();
-        if (running) {
-            for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
-                const unsigned i = c0 + j;
-                if (i < 1)
-                    continue;
-                if (i > last) {
-                    running = false;
-                    break;
-                }
-                const float slp = tS[lane][j];
-                if (slp != slp) {
-                    nan += 1.0f;                                   /* :131-132 */
-                } else {
-                    float w, u;
-                    if (nan == 0.0f) {
-                        w = (float)(int)(i - 1);                   /* == (float)i - 0 - 1, exact */
-                        u = a.inv_i[i];                            /* 1.0f / (float)i */
+        /* all lanes step through the chunk in lockstep (i is wave-uniform); a lane that is past
+         * its sector's end or has found its curb point just stops updating its state */
+#pragma unroll
+        for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
+            const unsigned i = c0 + j;
+            const bool active = running && i >= 1 && i <= last;
+            const float slp = tS[lane][j];
+            const bool isnan = slp != slp;
+            if (__any(active && (isnan || nan != 0.0f))) {
+                /* rare: a NaN slope has been seen (star_shaped_search.cpp:131-132, 135-140 with nan > 0) */
+                if (active) {
+                    if (isnan) {
+                        nan += 1.0f;
                     } else {
-                        w = (float)(int)i - nan - 1.0f;
-                        u = 1.0f / ((float)(int)i - nan);
+                        const float w = (float)(int)i - nan - 1.0f;
+                        const float u = 1.0f / ((float)(int)i - nan);
+                        avg *= w;
+                        avg += slp;
+                        avg *= u;
+                        dev *= w;
+                        dev += __builtin_fabsf(slp - avg);
+                        dev *= u;
                     }
-                    avg *= w;                                      /* :135-140 */
-                    avg += slp;
-                    avg *= u;
-                    dev *= w;
-                    dev += __builtin_fabsf(slp - avg);
-                    dev *= u;
                 }
-                if (slp > slope_param ||                           /* :142-143 */
-                    ((int)i > dmin && (slp * slp - avg * avg) * kdev * tG[lane][j] > dev)) {
-                    hit = (int)a.ssrt[base + i];                   /* :146 */
-                    running = false;
-                    break;
-                }
+            } else {
+                const float w = (float)(int)(i - 1);           /* == (float)i - 0 - 1, exact */
+                const float u = a.inv_i[i];                    /* 1.0f / (float)i */
+                float na = avg * w;                            /* :135-140 */
+                na = na + slp;
+                na = na * u;
+                float nd = dev * w;
+                nd = nd + __builtin_fabsf(slp - na);
+                nd = nd * u;
+                avg = active ? na : avg;
+                dev = active ? nd : dev;
+            }
+            const bool h = slp > slope_param ||                /* :142-143 */
+                           ((int)i > dmin && (slp * slp - avg * avg) * kdev * tG[lane][j] > dev);
+            if (active && h) {
+                hit_i = i;                                     /* :146 */
+                running = false;
             }
         }
+        if (c0 + URF_WALK_CHUNK > last)
+            running = false;
         __syncthreads();
     }
+    const int hit = hit_i ? (int)a.ssrt[base + hit_i] : -1;
     if (have)
         a.star_hit[(size_t)s * K + k] = hit;
 }
