@@ -1,0 +1,79 @@
+"""Random unorganised clouds and random parameter sets for differential testing
+(oracle B vs the reference binary on CPU, HIP path vs oracle B on the GPU).
+
+The clouds deliberately violate everything an organised sweep guarantees: arbitrary point
+order, uneven rings, empty / crowded sectors, points outside the ROI, NaNs, few points.
+What they avoid is only what the REFERENCE ITSELF leaves undefined:
+exact planar-range ties inside a star sector (unstable std::sort), x == y == 0 (NaN azimuth
+inside the Lomuto quicksort), the sector-360 band (null dereference)."""
+import numpy as np
+
+import urban_road_filter_amd as u
+
+
+def random_params(rng, for_reference=False):
+    p = u.default_params()
+    p.x_zero_method = int(rng.random() < 0.8)
+    p.z_zero_method = int(rng.random() < 0.8)
+    p.star_shaped_method = int(rng.random() < 0.8)
+    p.blind_spots = int(rng.random() < 0.7)
+    p.xDirection = int(rng.integers(0, 3))
+    p.interval = float(rng.choice([0.05, 0.18, 0.5, 1.5]))
+    p.curbHeight = float(rng.choice([0.01, 0.05, 0.2]))
+    p.curbPoints = int(rng.choice([1, 2, 5, 9, 30]))
+    p.beamZone = float(rng.choice([10.0, 30.0, 45.5, 100.0]))
+    half = float(rng.choice([15.0, 60.0, 200.0]))
+    p.min_X, p.max_X, p.min_Y, p.max_Y = -half, half, -half * 0.8, half
+    p.min_Z, p.max_Z = -3.0, float(rng.choice([-1.0, 0.5]))
+    p.angleFilter1 = float(rng.choice([120.0, 150.0, 175.0]))
+    p.angleFilter2 = float(rng.choice([100.0, 140.0, 170.0]))
+    p.angleFilter3 = float(rng.choice([5.0, 50.0, 80.0]))
+    p.kdev_param = float(rng.choice([0.5, 1.225, 5.0]))
+    p.kdist_param = float(rng.choice([0.4, 2.0, 10.0]))
+    p.starbeam_filter = int(rng.random() < 0.3)
+    p.dmin_param = int(rng.choice([3, 10, 30]))
+    # the reference reads array3D[1] / array3D[10] unconditionally: keep channels > 10 when it is the judge
+    p.channels = int(rng.choice([16, 64, 128] if for_reference else [1, 2, 7, 11, 16, 64, 128]))
+    return p
+
+
+def random_cloud(rng, n):
+    kind = rng.integers(0, 3)
+    if kind == 0:      # scattered returns from a ground-like sheet with steps
+        x = rng.uniform(-40, 40, n)
+        y = rng.uniform(-40, 40, n)
+        z = -1.8 + 0.15 * (np.abs(y) > 4) + 0.02 * rng.standard_normal(n)
+    elif kind == 1:    # a handful of elevation rings in random azimuth order
+        rings = rng.integers(2, 40)
+        elev = np.deg2rad(-25 + 23 * rng.random(rings))[rng.integers(0, rings, n)]
+        az = rng.uniform(0, 2 * np.pi, n)
+        h = 1.8 - 0.15 * (rng.random(n) < 0.2)
+        t = h / -np.sin(elev)
+        x, y, z = t * np.cos(elev) * np.cos(az), t * np.cos(elev) * np.sin(az), t * np.sin(elev)
+    else:              # everything in a narrow wedge: few crowded sectors, long rings
+        az = np.deg2rad(rng.uniform(20, 24, n))
+        elev = np.deg2rad(rng.choice([-20.0, -12.0, -6.0], n))
+        t = 1.8 / -np.sin(elev) * (1 + 0.05 * rng.random(n))
+        x, y, z = t * np.cos(elev) * np.cos(az), t * np.cos(elev) * np.sin(az), t * np.sin(elev) + 0.1 * (rng.random(n) < 0.1)
+    x, y, z = x.astype(np.float32), y.astype(np.float32), z.astype(np.float32)
+    # a few hostile values (dropped by the ROI stage)
+    bad = rng.integers(0, n, max(1, n // 200))
+    x[bad[: len(bad) // 2]] = np.nan
+    z[bad[len(bad) // 2:]] = 50.0
+    # what the reference leaves undefined: planar-range ties inside a sector, x == y == 0
+    keep = ~((x == 0) & (y == 0))
+    r = np.sqrt(x * x + y * y)
+    _, first = np.unique(np.where(np.isnan(r), -1.0, r), return_index=True)
+    m = np.zeros(n, bool)
+    m[first] = True
+    m |= np.isnan(r)
+    keep &= m
+    fi = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+    keep &= ~((fi < 0) & (fi > -1e-5))   # stay clear of the sector-360 band
+    return x[keep], y[keep], z[keep]
+
+
+def case(seed, for_reference=False):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([40, 300, 3000, 20000]))
+    return random_cloud(rng, n), random_params(rng, for_reference)
