@@ -35,6 +35,20 @@ N_PTS = RINGS * COLS
 ALG_BYTES_PER_SCAN = 13 * N_PTS          # 12 B x,y,z read + 1 B label written per point
 HBM_PEAK_GBS = 8000.0                    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+# The default workload is cfg3 (the one the metric is quoted on).  The others are the remaining
+# BASELINE.json configurations, for the per-configuration table in profiles/ (not bench lines).
+WORKLOADS = {
+    "cfg3": dict(rings=64, cols=2048, scans=1024, params="cfg2",
+                 text="cfg3: batch of %d independent 64x2048 street sweeps per GPU, all three detectors + blind_spots, "
+                      "reference default parameters with ROI x,y widened to +-200 m, inputs resident in HBM (SoA x/y/z)"),
+    "cfg2": dict(rings=64, cols=2048, scans=1, params="cfg2",
+                 text="cfg2: %d single 64x2048 street sweep, all three detectors + blind_spots, ROI +-200 m, resident in HBM (latency)"),
+    "cfg5": dict(rings=128, cols=4096, scans=256, params="cfg5",
+                 text="cfg5: batch of %d 128x4096 street sweeps, channels=128, interval=0.05, star at 360 sectors, ROI +-200 m"),
+    "default_roi": dict(rings=64, cols=2048, scans=1024, params="default_roi",
+                        text="batch of %d 64x2048 street sweeps with the reference's DEFAULT ROI (x 0..30, y -10..10: ~40 %% of the points survive)"),
+}
+
 
 def gen_batch(n_scans, seed0):
     """n_scans distinct street sweeps (seeds seed0..), generated on a thread pool
@@ -106,7 +120,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scans", type=int, default=1024, help="sweeps per GPU per step (BASELINE cfg3: 1024)")
+    ap.add_argument("--scans", type=int, default=0, help="sweeps per GPU per step (default: the workload's, cfg3: 1024)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-scans", type=int, default=4)
     args = ap.parse_args()
@@ -135,8 +150,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
-    S = args.scans
-    params = O.cfg_params("cfg2")   # reference defaults, ROI widened to +-200 m
+    global RINGS, COLS, N_PTS, ALG_BYTES_PER_SCAN
+    wl = WORKLOADS[args.workload]
+    RINGS, COLS = wl["rings"], wl["cols"]
+    N_PTS = RINGS * COLS
+    ALG_BYTES_PER_SCAN = 13 * N_PTS
+    S = args.scans or wl["scans"]
+    params = O.cfg_params(wl["params"])   # cfg3: reference defaults, ROI widened to +-200 m
     t_gen = time.perf_counter()
     X, Y, Z = gen_batch(S, sharding.shard_seeds(S, rank)[0])   # seeds 1..S on rank 0, S+1..2S on rank 1, ...
     t_gen = time.perf_counter() - t_gen
@@ -201,7 +221,7 @@ def main():
         achieved = alg_bytes_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         whole = ALG_BYTES_PER_SCAN * S / (ms_step * 1e-3) / 1e9
         out = {
-            "metric": "scans/sec (64-ring x 2048-column cloud)",
+            "metric": "scans/sec (%d-ring x %d-column cloud)" % (RINGS, COLS),
             "value": round(value, 2),
             "unit": "scans/s",
             "n_gpus": world,
@@ -213,9 +233,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32+f64",
             "data": "synthetic",
-            "config": {"workload": "cfg3: batch of %d independent 64x2048 street sweeps per GPU, all three detectors "
-                                   "+ blind_spots, reference default parameters with ROI x,y widened to +-200 m, "
-                                   "inputs resident in HBM (SoA x/y/z)" % S,
+            "config": {"workload": wl["text"] % S,
                        "scans_per_gpu": S, "points_per_scan": N_PTS, "sharding": "one batch per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
@@ -238,7 +256,7 @@ def main():
                     out["roofline"]["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc, corrected per MI355X_MICROARCH.md)"
             except Exception:
                 pass
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cfg3":
             out["cpu_baseline"] = cpu_baseline(params)
         else:
             out["cpu_baseline"] = None

@@ -371,7 +371,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         stage++;
     };
     mark();
-    hipLaunchKernelGGL(k_ring_table, g_scan, dim3(64), 0, st, a, dp);
+    hipLaunchKernelGGL(k_ring_table, g_scan, dim3(256), 0, st, a, dp);
     mark();
     hipLaunchKernelGGL(k_ingest, g_tiles, dim3(URF_INGEST_THREADS), (K + 1) * sizeof(unsigned), st, a, dp);
     mark();

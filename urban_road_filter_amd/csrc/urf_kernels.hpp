@@ -179,20 +179,43 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
  * k+1 is the first point after leader k that matches none of the leaders 0..k.
  * It runs first, straight from x/y/z, so that the one pass over the points that
  * follows (k_ingest) can already assign rings.
- * One wave per scan walks the points 64 at a time; the leaders live in
- * registers (leader j in lane j & 63) and are broadcast with readlane, so a
- * chunk without new leaders costs one compare per leader, and a new leader is
- * found with one ballot.  The walk ends as soon as the table is full (after
- * the first firing of an organised sweep).  The `angle[j] == 0` end-of-table
- * sentinel (:176) is honoured: once a leader equal to 0 has been stored, only
- * the leaders in front of it take part in matching. */
-__global__ __launch_bounds__(64) void k_ring_table(urf_kargs a, urf_dev_params dp)
+ *
+ * One workgroup per scan, two alternating modes:
+ *   serial   one wave takes the next 64 points; a new leader costs one ballot
+ *            (an organised sweep fills the table within its first firing);
+ *   scan     when a 64-point step brought no new leader, all four waves look
+ *            ahead 1024 points at a time for the first point that no leader
+ *            matches (usually there is none: sweeps whose region of interest
+ *            cuts off the outer rings never fill the table).
+ * Matching "is there a leader within interval" is a bisection in a sorted copy
+ * of the leaders: fl(leader - alpha) is monotone in the leader.  The walk ends as
+ * soon as the table is full.  The `angle[j] == 0` end-of-table sentinel (:176)
+ * is honoured: once a leader equal to 0 has been stored, only the leaders in
+ * front of it take part in matching. */
+__device__ __forceinline__ bool urf_leader_match(const float* SL, unsigned nmatch, float v, float interval)
 {
-    const unsigned s = blockIdx.x, lane = threadIdx.x;
+    unsigned lo = 0, hi = nmatch;
+    while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (SL[mid] - v >= -interval)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo < nmatch && __builtin_fabsf(SL[lo] - v) <= interval;
+}
+
+__global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params dp)
+{
+    __shared__ float L[URF_MAX_CHANNELS];    /* leaders in insertion order (the reference's angle[]) */
+    __shared__ float SL[URF_MAX_CHANNELS];   /* the matchable ones, ascending */
+    __shared__ unsigned sh_nL, sh_nmatch, sh_zero, sh_new;
+    __shared__ unsigned sh_min[4];
+    const unsigned s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned C = (unsigned)dp.p.channels;
-    if (lane == 0) {
+    if (tid == 0) {
         urf_scan_info in;
         in.status = URF_OK;      /* k_offsets turns it into URF_TOO_FEW_POINTS when piece < 30 */
         in.n_roi = 0;
@@ -203,69 +226,115 @@ __global__ __launch_bounds__(64) void k_ring_table(urf_kargs a, urf_dev_params d
         in.n_ring10 = 0;
         in.reserved = 0;
         a.info[s] = in;
+        sh_nL = 0;
+        sh_nmatch = 0;
+        sh_zero = 0;
     }
+    __syncthreads();
 
     const float interval = dp.p.interval;
-    float L0 = 0.f, L1 = 0.f;      /* leader j lives in lane j & 63 of L0 (j < 64) or L1 */
-    unsigned nL = 0, nmatch = 0;
-    bool zero_seen = false;
-    for (unsigned base = 0; base < len && nL < C; base += 64) {
-        const unsigned i = base + lane;
-        float v = -1.0f;
-        if (i < len) {             /* vertical angle of the ROI points of this chunk, computed on the fly */
-            const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
-            if (urf_in_roi(dp.p, x, y, z))
-                v = urf_vertical_angle(x, y, z);
-        }
-        bool un = v >= 0.0f;       /* ROI point, not yet matched */
-        for (unsigned j = 0; j < nmatch; j++) {
-            const float lj = __shfl(j < 64 ? L0 : L1, (int)(j & 63));
-            if (__builtin_fabsf(lj - v) <= interval)
-                un = false;
-        }
-        unsigned long long m;
-        while ((m = __ballot(un)) != 0 && nL < C) {
-            const unsigned f = (unsigned)__ffsll((long long)m) - 1u;
-            const float lv = __shfl(v, (int)f);
-            if (lane == (nL & 63)) {
-                if (nL < 64)
-                    L0 = lv;
-                else
-                    L1 = lv;
+    unsigned pos = 0;
+    while (pos < len && sh_nL < C) {
+        /* ---- serial step: wave 0, points [pos, pos + 64) ---- */
+        if (wave == 0) {
+            const unsigned i = pos + lane;
+            float v = -1.0f;
+            if (i < len) {
+                const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
+                if (urf_in_roi(dp.p, x, y, z))
+                    v = urf_vertical_angle(x, y, z);
             }
-            bool matchable = false;
-            if (!zero_seen) {
-                if (lv == 0.0f)
-                    zero_seen = true;
-                else {
-                    nmatch = nL + 1;
-                    matchable = true;
+            unsigned nL = sh_nL, nmatch = sh_nmatch;
+            bool zero_seen = sh_zero != 0;
+            const unsigned nL0 = nL;
+            bool un = v >= 0.0f && !urf_leader_match(SL, nmatch, v, interval);
+            unsigned long long m;
+            while ((m = __ballot(un)) != 0 && nL < C) {
+                const unsigned f = (unsigned)__ffsll((long long)m) - 1u;
+                const float lv = __shfl(v, (int)f);
+                bool matchable = false;
+                if (lane == 0) {
+                    L[nL] = lv;
+                    if (!zero_seen && lv != 0.0f) {   /* insert into the sorted copy */
+                        unsigned k = nmatch;
+                        while (k > 0 && SL[k - 1] > lv) {
+                            SL[k] = SL[k - 1];
+                            k--;
+                        }
+                        SL[k] = lv;
+                    }
+                }
+                if (!zero_seen) {
+                    if (lv == 0.0f)
+                        zero_seen = true;
+                    else {
+                        nmatch++;
+                        matchable = true;
+                    }
+                }
+                nL++;
+                if (lane <= f)
+                    un = false;
+                else if (matchable && __builtin_fabsf(lv - v) <= interval)
+                    un = false;
+            }
+            if (lane == 0) {
+                sh_nL = nL;
+                sh_nmatch = nmatch;
+                sh_zero = zero_seen ? 1u : 0u;
+                sh_new = nL != nL0;
+            }
+        }
+        __syncthreads();
+        pos += 64;
+        if (sh_new || sh_nL >= C)
+            continue;
+        /* ---- scan mode: first point in [pos, len) that no leader matches ---- */
+        const unsigned nmatch = sh_nmatch;
+        while (pos < len) {
+            unsigned first = 0xffffffffu;
+#pragma unroll
+            for (unsigned q = 0; q < 4; q++) {
+                const unsigned i = pos + q * 256 + tid;
+                if (i < len && first == 0xffffffffu) {
+                    const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
+                    if (urf_in_roi(dp.p, x, y, z) && !urf_leader_match(SL, nmatch, urf_vertical_angle(x, y, z), interval))
+                        first = i;
                 }
             }
-            nL++;
-            if (lane <= f)
-                un = false;
-            else if (matchable && __builtin_fabsf(lv - v) <= interval)
-                un = false;
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned w = __shfl_xor(first, o);
+                first = w < first ? w : first;
+            }
+            if (lane == 0)
+                sh_min[wave] = first;
+            __syncthreads();
+            unsigned m = sh_min[0];
+            for (int w = 1; w < 4; w++)
+                m = sh_min[w] < m ? sh_min[w] : m;
+            __syncthreads();
+            if (m != 0xffffffffu) {
+                pos = m;   /* the serial step resumes exactly there */
+                break;
+            }
+            pos += 1024;
         }
     }
+    __syncthreads();
 
     /* std::sort(angle, angle + index), lidar_segmentation.cpp:205 (rank sort) */
-    for (unsigned h = 0; h < 2; h++) {
-        const unsigned me = h * 64 + lane;
-        if (h * 64 >= nL)
-            break;
-        const float v = h == 0 ? L0 : L1;
+    const unsigned n = sh_nL;
+    if (tid < n) {
+        const float v = L[tid];
         unsigned rank = 0;
-        for (unsigned j = 0; j < nL; j++) {
-            const float w = __shfl(j < 64 ? L0 : L1, (int)(j & 63));
-            rank += (w < v) || (w == v && j < me);
+        for (unsigned j = 0; j < n; j++) {
+            const float w = L[j];
+            rank += (w < v) || (w == v && j < tid);
         }
-        if (me < nL)
-            a.angle[(size_t)s * C + rank] = v;
+        a.angle[(size_t)s * C + rank] = v;
     }
-    if (lane == 0)
-        a.info[s].n_rings = nL;
+    if (tid == 0)
+        a.info[s].n_rings = n;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -885,16 +954,21 @@ __device__ __forceinline__ void urf_bitonic_keys(unsigned long long* keys, unsig
 }
 
 /* sectors with 513..2048 points (e.g. 128 rings x 4096 columns): persistent
- * workgroups of 256 threads walk the work list built by k_offsets */
+ * workgroups of 256 threads walk the work list built by k_offsets.  Same
+ * distribution sort as above with 2048 buckets and workgroup-wide reductions;
+ * clustered sectors fall back to the bitonic network in LDS. */
 #define URF_STAR_MID_THREADS 256
 #define URF_STAR_MID_CAP 2048
 __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_kargs a, urf_dev_params dp)
 {
-    __shared__ unsigned long long keys[URF_STAR_MID_CAP];
-    __shared__ float zs[URF_STAR_MID_CAP];
-    __shared__ unsigned sh_first;
+    constexpr unsigned NT = URF_STAR_MID_THREADS, NB = 2048, EPT = URF_STAR_MID_CAP / NT;
+    __shared__ unsigned long long A[URF_STAR_MID_CAP];
+    __shared__ unsigned cnt[NB + 1];
+    __shared__ unsigned sh_first, sh_rmin, sh_rmax, sh_maxc;
+    __shared__ unsigned sh_w[NT / 64];
     const unsigned K = (unsigned)dp.p.sectors;
     const unsigned count = a.star_count[0];
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
         const unsigned sk = a.star_list_mid[w];
         const unsigned s = sk / K, k = sk % K;
@@ -902,16 +976,123 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_karg
         urf_scan_range(a, s, off, len);
         const unsigned n = a.sec_cnt[(size_t)s * K + k];
         const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
-        for (unsigned i = threadIdx.x; i < n; i += URF_STAR_MID_THREADS) {
-            keys[i] = ((unsigned long long)urf_fbits(a.sr[base + i]) << 32) | i;
-            zs[i] = a.sz[base + i];
-        }
-        if (threadIdx.x == 0)
+        if (tid == 0) {
             sh_first = n;
+            sh_rmin = 0xffffffffu;
+            sh_rmax = 0;
+            sh_maxc = 0;
+        }
+        for (unsigned c = tid; c <= NB; c += NT)
+            cnt[c] = 0;
         __syncthreads();
-        urf_bitonic_keys<URF_STAR_MID_THREADS>(keys, n);
-        const unsigned first = urf_star_emit<URF_STAR_MID_THREADS, URF_STAR_MID_CAP / URF_STAR_MID_THREADS>(a, dp, base, n, keys, zs, &sh_first);
-        if (threadIdx.x == 0)
+        unsigned long long key[EPT];
+        unsigned rmin = 0xffffffffu, rmax = 0;
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++) {
+            const unsigned i = tid + e * NT;
+            key[e] = ~0ull;
+            if (i < n) {
+                const unsigned rb = urf_fbits(a.sr[base + i]);
+                key[e] = ((unsigned long long)rb << 32) | i;
+                rmin = rb < rmin ? rb : rmin;
+                rmax = rb > rmax ? rb : rmax;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = __shfl_xor(rmin, o), hi = __shfl_xor(rmax, o);
+            rmin = lo < rmin ? lo : rmin;
+            rmax = hi > rmax ? hi : rmax;
+        }
+        if (lane == 0) {
+            atomicMin(&sh_rmin, rmin);
+            atomicMax(&sh_rmax, rmax);
+        }
+        __syncthreads();
+        rmin = sh_rmin;
+        const unsigned range = sh_rmax - rmin;
+        const unsigned sh = range < NB ? 0u : (unsigned)(32 - __clz((int)range)) - 11u;   /* (range >> sh) < 2048 */
+        unsigned bkt[EPT], wq[EPT];
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++) {
+            bkt[e] = 0;
+            wq[e] = 0;
+            if (key[e] != ~0ull) {
+                bkt[e] = ((unsigned)(key[e] >> 32) - rmin) >> sh;
+                wq[e] = atomicAdd(&cnt[bkt[e]], 1u);
+            }
+        }
+        __syncthreads();
+        {   /* exclusive scan of the 2048 counts: 8 consecutive counters per thread */
+            unsigned c8[NB / NT], sum = 0, maxc = 0;
+#pragma unroll
+            for (unsigned e = 0; e < NB / NT; e++) {
+                c8[e] = cnt[tid * (NB / NT) + e];
+                sum += c8[e];
+                maxc = c8[e] > maxc ? c8[e] : maxc;
+            }
+            unsigned inc = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = __shfl_up(inc, o);
+                if ((int)lane >= o)
+                    inc += v;
+            }
+            if (lane == 63)
+                sh_w[wave] = inc;
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned v = __shfl_xor(maxc, o);
+                maxc = v > maxc ? v : maxc;
+            }
+            if (lane == 0)
+                atomicMax(&sh_maxc, maxc);
+            __syncthreads();
+            unsigned run = inc - sum;
+            for (unsigned v = 0; v < wave; v++)
+                run += sh_w[v];
+#pragma unroll
+            for (unsigned e = 0; e < NB / NT; e++) {
+                cnt[tid * (NB / NT) + e] = run;
+                run += c8[e];
+            }
+            if (tid == NT - 1)
+                cnt[NB] = run;
+        }
+        __syncthreads();
+        if (sh_maxc <= 64 && !(dp.exp_flags & 4u)) {
+            unsigned rank[EPT];
+#pragma unroll
+            for (unsigned e = 0; e < EPT; e++)
+                if (key[e] != ~0ull)
+                    A[cnt[bkt[e]] + wq[e]] = key[e];
+            __syncthreads();
+#pragma unroll
+            for (unsigned e = 0; e < EPT; e++) {
+                rank[e] = 0;
+                if (key[e] != ~0ull) {
+                    const unsigned b0 = cnt[bkt[e]], b1 = cnt[bkt[e] + 1];
+                    unsigned r = b0;
+                    for (unsigned t = b0; t < b1; t++)
+                        r += A[t] < key[e];
+                    rank[e] = r;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (unsigned e = 0; e < EPT; e++)
+                if (key[e] != ~0ull)
+                    A[rank[e]] = key[e];
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (unsigned e = 0; e < EPT; e++) {
+                const unsigned i = tid + e * NT;
+                if (i < n)
+                    A[i] = key[e];
+            }
+            __syncthreads();
+            urf_bitonic_keys<NT>(A, n);
+        }
+        const unsigned first = urf_star_emit<NT, EPT>(a, dp, base, n, A, nullptr, &sh_first);
+        if (tid == 0)
             a.star_first[sk] = first < n - 1 ? first : n - 1;
         __syncthreads();
     }
