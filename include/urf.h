@@ -196,7 +196,7 @@ typedef enum urf_stage {
     URF_STAGE_RING = 2,       /* int16  per point: sorted ring index or -1, lidar_segmentation.cpp:226-233 */
     URF_STAGE_AZIMUTH = 3,    /* float  per point: azimuth alpha [deg], lidar_segmentation.cpp:248-269 */
     URF_STAGE_RANGE2D = 4,    /* float  per point: planar d, lidar_segmentation.cpp:245 */
-    URF_STAGE_DETECT = 5,     /* uint8  per point: bit0 star, bit1 x_zero, bit2 z_zero hit */
+    URF_STAGE_DETECT = 5,     /* uint8  per point on a ring: bit0 star, bit1 x_zero, bit2 z_zero hit (0 elsewhere) */
     URF_STAGE_SECTOR = 6,     /* int16  per point: star sector or -1, star_shaped_search.cpp:171 */
     URF_STAGE_ANGLE_TABLE = 7,/* float[channels]: sorted ring-angle table, lidar_segmentation.cpp:205 */
     URF_STAGE_MAXDIST = 8,    /* float[channels]: maxDistance, lidar_segmentation.cpp:271-274 */

@@ -242,6 +242,28 @@ def test_crowded_sectors(ctx_big, n_pts):
     assert np.array_equal(lg, lb) and info_equal(ig, ib)
 
 
+@pytest.mark.parametrize("n_pts", [300, 1500, 6000])
+def test_equal_ranges_are_ordered_by_input_index(ctx_big, n_pts):
+    """Exact planar-range ties inside a sector: the reference's std::sort leaves their order open
+    (star_shaped_search.cpp:109); this implementation and oracle B order them by input index
+    (DESIGN.md deviation D2).  Duplicated points exercise that rule on all three sort paths."""
+    p = O.cfg_params("cfg2")
+    p.interval = 1.0
+    x, y, z = crowded_cloud(n_pts, seed=9)
+    rng = np.random.default_rng(4)
+    dup = rng.integers(0, len(x), len(x) // 3)
+    x = np.concatenate([x, x[dup]])
+    y = np.concatenate([y, y[dup]])
+    z = np.concatenate([z, (z[dup] + 0.2 * rng.random(len(dup))).astype(np.float32)])   # same range, other height
+    perm = rng.permutation(len(x))
+    x, y, z = x[perm], y[perm], z[perm]
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, len(x)), st["detect"])
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+
+
 def test_star_sort_paths(ctx_big, monkeypatch):
     """k_star_sort_small has a distribution-sort fast path and a general path (in-register block
     sorts merged by ranking).  (a) force the general path on a normal sweep; (b) a cloud whose

@@ -45,7 +45,7 @@ struct urf_dev_params {
     float    inv_cp;        /* 1 / (float)curbPoints (z_zero_method.cpp:52) */
     uint32_t sec_keybits;   /* bits needed for sector keys incl. "none" */
     uint32_t ring_keybits;
-    uint32_t exp_flags;     /* experiments (env URF_EXP), 0 in production */
+    uint32_t exp_flags;     /* test hook (env URF_EXP): bit 2 forces the general star sort path; 0 in production */
 };
 
 /* Everything a kernel needs to find a scan's data.  All pointers are device
@@ -80,6 +80,8 @@ struct urf_kargs {
     float*    sz;
     uint32_t* ssrc;
     uint32_t* ssrt;             /* ring-major position of the i-th point of the sector in sorted order */
+    float*    wslp;             /* slope between the (i-1)-th and i-th point of the sector in sorted order */
+    float*    wg;               /* (r_i - r_{i-1}) * kdist */
     /* per scan x tile */
     uint32_t* tile_roi;         /* [S][tiles] ROI points of the tile */
     uint32_t* tile_ring;        /* [S][tiles][channels] per-tile ring counts; k_offsets turns them into the

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
         float va = -1.0f;
         unsigned key = URF_SEC_NONE, rkey = URF_RING_NONE;
         if (roi) {
-            va = (dp.exp_flags & 8u) ? __builtin_fabsf(z) * 10.0f : urf_vertical_angle(x, y, z);
+            va = urf_vertical_angle(x, y, z);
             /* lidar_segmentation.cpp:226-233: first sorted table entry within `interval`.
              * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are contiguous
              * and the first one is found by bisection with the very same float predicate. */
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
             if (lo < nR && __builtin_fabsf(tab[lo] - va) <= interval)
                 rkey = lo;
             if (star) {
-                key = (dp.exp_flags & 8u) ? ((unsigned)(int)(x * 3.0f + 200.0f)) % K : urf_sector(x, y, dp.Kfi, K);
+                key = urf_sector(x, y, dp.Kfi, K);
                 if (dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
                     key = URF_SEC_NONE;
             }
@@ -713,52 +713,44 @@ __device__ __forceinline__ unsigned urf_count_less64(const unsigned long long* b
     return pos;
 }
 
-/* Common tail: `fin[0..n)` holds the sorted keys.  Writes slopes / distance terms / sorted
- * input indices to global memory and returns (all threads) the index of the first "static"
- * hit, or n.  The heights are gathered from the (still unsorted) sector-major array, which the
- * results then overwrite: every read of the workgroup completes before its first write.
- * EPT = elements per thread (compile-time bound), zs = optional LDS copy of the heights. */
+/* Common tail: `fin[0..n)` holds the sorted keys.  Writes slopes / distance terms / ring
+ * positions in sorted order (wslp, wg, ssrt) and returns (all threads) the index of the
+ * first "static" hit (slope > slope_param), or n.  The walk can never pass that index, so
+ * the tail stops after the chunk of NT elements that contains it: on a street most sectors
+ * meet the curb within their first third.  The heights are gathered from the unsorted
+ * sector-major array (or from an LDS copy `zs`). */
 template <int NT, int EPT>
 __device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_dev_params& dp, unsigned base, unsigned n,
                                                   const unsigned long long* fin, const float* zs, unsigned* sh_first)
 {
     const unsigned tid = threadIdx.x;
     const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
-    unsigned first = n;
-    float slp[EPT], g[EPT];
-    unsigned src[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
         const unsigned i = tid + (unsigned)e * NT;
-        slp[e] = 0.f;
-        g[e] = 0.f;
-        src[e] = 0;
+        if ((unsigned)e * NT >= n)
+            break;
         if (i < n) {
             const unsigned long long kb = fin[i];
             const unsigned pb = (unsigned)kb;
-            src[e] = a.ssrc[base + pb];
+            float slp = 0.f, g = 0.f;
             if (i >= 1) {
                 const unsigned long long ka = fin[i - 1];
                 const float ax = __uint_as_float((unsigned)(ka >> 32)), bx = __uint_as_float((unsigned)(kb >> 32));
                 const float ay = zs ? zs[(unsigned)ka] : a.sz[base + (unsigned)ka];
                 const float by = zs ? zs[pb] : a.sz[base + pb];
-                slp[e] = (by - ay) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
-                g[e] = (bx - ax) * kdist;
-                if (slp[e] > slope_param && i < first)
-                    first = i;
+                slp = (by - ay) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
+                g = (bx - ax) * kdist;
+                if (slp > slope_param)
+                    atomicMin(sh_first, i);
             }
+            a.ssrt[base + i] = a.ssrc[base + pb];
+            a.wslp[base + i] = slp;
+            a.wg[base + i] = g;
         }
-    }
-    atomicMin(sh_first, first);
-    __syncthreads();   /* waits for every outstanding load of the workgroup */
-#pragma unroll
-    for (int e = 0; e < EPT; e++) {
-        const unsigned i = tid + (unsigned)e * NT;
-        if (i < n) {
-            a.ssrt[base + i] = src[e];
-            a.sr[base + i] = slp[e];           /* the ranges are dead: reuse their storage */
-            a.sz[base + i] = g[e];
-        }
+        __syncthreads();
+        if (*sh_first < ((unsigned)e + 1) * NT)
+            break;
     }
     return *sh_first;
 }
@@ -1099,8 +1091,8 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_karg
 }
 
 /* sectors with more than 2048 points (adversarial clouds): sorted in place in
- * global memory by one workgroup each, same network, keys (range, input index);
- * then slopes in a second sweep (reads complete before the in-place writes). */
+ * global memory by one workgroup each, same network, keys (range, position in the
+ * sector = input order); then slopes in a second sweep. */
 __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_params dp)
 {
     __shared__ unsigned sh_first;
@@ -1117,8 +1109,13 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
         float* R = a.sr + base;
         float* Z = a.sz + base;
         unsigned* I = a.ssrc + base;
+        unsigned* Pq = a.ssrt + base;   /* original position in the sector = input order: the tie-break */
         if (threadIdx.x == 0)
             sh_first = n;
+        for (unsigned i = threadIdx.x; i < n; i += 256)
+            Pq[i] = i;
+        __threadfence_block();
+        __syncthreads();
         unsigned P = 1;
         while (P < n)
             P <<= 1;
@@ -1129,13 +1126,13 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
                     const unsigned lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
                     const unsigned hi = flip ? ((lo & ~(kk - 1)) + (kk - 1) - (lo & (kk - 1))) : lo + j;
                     if (hi < n) {
-                        const unsigned long long ka = ((unsigned long long)urf_fbits(R[lo]) << 32) | I[lo];
-                        const unsigned long long kb = ((unsigned long long)urf_fbits(R[hi]) << 32) | I[hi];
+                        const unsigned long long ka = ((unsigned long long)urf_fbits(R[lo]) << 32) | Pq[lo];
+                        const unsigned long long kb = ((unsigned long long)urf_fbits(R[hi]) << 32) | Pq[hi];
                         if (ka > kb) {
                             const float r0 = R[lo], z0 = Z[lo];
-                            const unsigned i0 = I[lo];
-                            R[lo] = R[hi]; Z[lo] = Z[hi]; I[lo] = I[hi];
-                            R[hi] = r0; Z[hi] = z0; I[hi] = i0;
+                            const unsigned i0 = I[lo], p0 = Pq[lo];
+                            R[lo] = R[hi]; Z[lo] = Z[hi]; I[lo] = I[hi]; Pq[lo] = Pq[hi];
+                            R[hi] = r0; Z[hi] = z0; I[hi] = i0; Pq[hi] = p0;
                         }
                     }
                 }
@@ -1143,27 +1140,18 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
                 __syncthreads();
             }
         }
-        /* slopes: chunks from the back, so that element i-1 is still a range when i is computed */
         unsigned first = n;
-        for (unsigned hi = n; hi > 0;) {
-            const unsigned lo = hi > 256 ? hi - 256 : 0;
-            const unsigned i = lo + threadIdx.x;
+        for (unsigned i = threadIdx.x; i < n; i += 256) {
             float slp = 0.f, g = 0.f;
-            if (i >= 1 && i < hi) {
+            if (i >= 1) {
                 slp = (Z[i] - Z[i - 1]) / (R[i] - R[i - 1]);
                 g = (R[i] - R[i - 1]) * kdist;
                 if (slp > slope_param && i < first)
                     first = i;
             }
-            __syncthreads();
-            if (i < hi) {
-                R[i] = slp;
-                Z[i] = g;
-                a.ssrt[base + i] = I[i];
-            }
-            __threadfence_block();
-            __syncthreads();
-            hi = lo;
+            a.wslp[base + i] = slp;
+            a.wg[base + i] = g;
+            a.ssrt[base + i] = I[i];
         }
         atomicMin(&sh_first, first);
         __syncthreads();
@@ -1174,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
 }
 
 /* star_shaped_search.cpp:123-149, one LANE per (sector, scan), one wave per 64
- * sectors.  sr = slopes, sz = distance terms, both in sorted order; the walk of
+ * sectors.  wslp = slopes, wg = distance terms, both in sorted order; the walk of
  * a sector visits i = 1..star_first.  A lane reading its own sector directly
  * would touch 64 different cache lines per load, so the wave fetches the next
  * 16 steps of all its sectors cooperatively (16 consecutive floats = one line
@@ -1194,7 +1182,7 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
     const bool have = k < K;
     const unsigned n = have ? a.sec_cnt[(size_t)s * K + k] : 0;
     const unsigned base = have ? off + a.sec_off[(size_t)s * (K + 1) + k] : 0;
-    unsigned last = (n >= 2 && !(dp.exp_flags & 2u)) ? a.star_first[(size_t)s * K + k] : 0;
+    unsigned last = n >= 2 ? a.star_first[(size_t)s * K + k] : 0;
     sbase[lane] = base;
     slast[lane] = last;
     unsigned maxlast = last;
@@ -1215,8 +1203,8 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
         for (unsigned r = 0; r < 64; r += 4) {
             const unsigned sec = r + (lane >> 4), e = c0 + (lane & 15);
             if (e >= 1 && e <= slast[sec]) {
-                tS[sec][lane & 15] = a.sr[sbase[sec] + e];
-                tG[sec][lane & 15] = a.sz[sbase[sec] + e];
+                tS[sec][lane & 15] = a.wslp[sbase[sec] + e];
+                tG[sec][lane & 15] = a.wg[sbase[sec] + e];
             }
         }
         __syncthreads();
@@ -1307,7 +1295,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
     const int n = (int)a.ring_cnt[(size_t)s * C + c];
     const unsigned base = off + a.ring_off[(size_t)s * (C + 1) + c];
     const int cp = dp.p.curbPoints;
-    const bool star = dp.p.star_shaped_method != 0 && !(dp.exp_flags & 128u);
+    const bool star = dp.p.star_shaped_method != 0;
     const bool want_quad = (c == 1) && dp.p.blind_spots;
 
     for (unsigned i = tid; i < URF_DEG_CELLS; i += URF_RING_THREADS) {
@@ -1363,7 +1351,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
              * height tests.  The height tests run first: on road surface they fail for
              * whole waves, which then skip the expensive part.  (Reordering an && chain of
              * side-effect-free tests does not change its value.) */
-            if (dp.p.x_zero_method && !(dp.exp_flags & 64u)) {   /* x_zero_method.cpp:30-68, evaluated for the point it marks */
+            if (dp.p.x_zero_method) {   /* x_zero_method.cpp:30-68, evaluated for the point it marks */
                 const int j = p - cp / 2;
                 if (j >= cp && j <= (n - 1) - cp) {
                     const int lj = lp - cp / 2, l3 = lj + cp;
@@ -1397,7 +1385,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
                 }
             }
 
-            if (dp.p.z_zero_method && !(dp.exp_flags & 32u)) {   /* z_zero_method.cpp:21-72 */
+            if (dp.p.z_zero_method) {   /* z_zero_method.cpp:21-72 */
                 if (p >= cp && p <= (n - 1) - cp) {
                     const float az = __builtin_fabsf(pz);
                     float max1 = az, max2 = az;
@@ -1443,7 +1431,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
             }
 
             float d2;
-            const float az = (dp.exp_flags & 16u) ? (d2 = px * px + py * py, px + 180.0f) : urf_azimuth(px, py, &d2);   /* lidar_segmentation.cpp:245-269 */
+            const float az = urf_azimuth(px, py, &d2);   /* lidar_segmentation.cpp:245-269 */
             a.raz[base + p] = az;
             a.rflag[base + p] = (uint8_t)flag;
             if (a.rd2)
