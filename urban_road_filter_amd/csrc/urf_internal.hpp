@@ -17,8 +17,8 @@
 #define URF_DEG_CELLS       361    /* integer degrees 0..360 (blind_spots.cpp:68,177) */
 
 /* one tile = the unit of the stable multi-split by ring / by sector */
-#define URF_TILE            4096
-#define URF_TILE_THREADS    1024
+#define URF_TILE            2048
+#define URF_TILE_THREADS    512     /* k_scatter: one wave per 256 points of the tile */
 #define URF_TILE_GROUPS     (URF_TILE / 64)   /* wave-sized groups per tile */
 
 #define URF_RING_NONE       0xFFu
