@@ -186,6 +186,18 @@ int urf_compact_indices(urf_ctx* ctx, const uint8_t* d_labels, uint32_t n_points
                         uint32_t* d_road, uint32_t* d_curb, uint32_t* d_roi, uint32_t* d_ring10,
                         uint32_t* d_counts);
 
+/* ---- the published clouds, in the reference's order ------------------------
+ * The reference fills "road", "curb" and "road_probably" ring by ring (sorted
+ * ring index ascending), each ring in ascending azimuth (its per-ring quicksort,
+ * lidar_segmentation.cpp:70-93, 289-291, 354-367, 605-608); "roi" is in input
+ * order.  After a classify call this returns the input indices of scan `scan`
+ * in exactly that order (points of equal azimuth stay in input order; the
+ * reference's unstable sort leaves their order open).  Host buffers with room
+ * for n_points entries each (any may be NULL); counts[3] = {road, curb,
+ * road_probably}.  Synchronous; costs one extra per-ring sort. */
+int urf_ordered_indices(urf_ctx* ctx, uint32_t scan, uint32_t* road, uint32_t* curb, uint32_t* ring10,
+                        uint32_t* counts);
+
 /* ---- stage-wise inspection (parity tests) ----------------------------------
  * After a classify call, copies one intermediate array of scan `scan` to host
  * memory.  Arrays indexed by input point have n_points entries; values of

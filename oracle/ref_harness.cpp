@@ -21,7 +21,8 @@
  *   in : "URFREFIN" u32 n_scans u32 n_points u32 repeat u32 reserved
  *        urf_params (sizeof) then n_scans x { x[n] y[n] z[n] } float32
  *   out: "URFREFOU" u32 n_scans u32 n_points f64 ms_per_scan_steady f64 ms_first
- *        then n_scans x { urf_scan_info, labels[n] }
+ *        then n_scans x { urf_scan_info, labels[n], road[n_road], curb[n_curb], road_probably[n_ring10] }
+ *        (u32 input indices in the order the reference published them)
  * Points are identified by writing the input index into `intensity`
  * (exact in float up to 2^24 points).  `repeat` > 1 re-runs the whole set for
  * timing; the first call of the process is excluded from the steady figure.
@@ -99,7 +100,8 @@ struct Job {
     int rc;
 };
 
-static void label_from(const char* topic, uint8_t bits, uint8_t* labels, uint32_t n, uint32_t* count)
+static void label_from(const char* topic, uint8_t bits, uint8_t* labels, uint32_t n, uint32_t* count,
+                       std::vector<uint32_t>* order = nullptr)
 {
     auto it = pcl::shim_store().find(topic);
     if (it == pcl::shim_store().end())
@@ -108,6 +110,8 @@ static void label_from(const char* topic, uint8_t bits, uint8_t* labels, uint32_
         uint32_t id = (uint32_t)p.intensity;
         if (id < n)
             labels[id] |= bits;
+        if (order)
+            order->push_back(id);
     }
     if (count)
         *count = (uint32_t)it->second.size();
@@ -143,6 +147,7 @@ static void* run(void* arg)
 
     std::vector<std::vector<uint8_t>> labels(n_scans, std::vector<uint8_t>(n, 0));
     std::vector<urf_scan_info> infos(n_scans);
+    std::vector<std::vector<uint32_t>> o_road(n_scans), o_curb(n_scans), o_r10(n_scans);
     pcl::PointCloud<pcl::PointXYZI> cloud;
     cloud.points.resize(n);
     double ms_first = 0, ms_sum = 0;
@@ -174,9 +179,9 @@ static void* run(void* arg)
                     in.status = URF_TOO_FEW_POINTS;   /* nothing published, lidar_segmentation.cpp:124-126 */
                 } else {
                     label_from("roi", URF_FLAG_ROI, L, n, &in.n_roi);
-                    label_from("road", URF_LABEL_ROAD, L, n, &in.n_road);
-                    label_from("curb", URF_LABEL_CURB, L, n, &in.n_curb);
-                    label_from("road_probably", URF_FLAG_RING10, L, n, &in.n_ring10);
+                    label_from("road", URF_LABEL_ROAD, L, n, &in.n_road, &o_road[s]);
+                    label_from("curb", URF_LABEL_CURB, L, n, &in.n_curb, &o_curb[s]);
+                    label_from("road_probably", URF_FLAG_RING10, L, n, &in.n_ring10, &o_r10[s]);
                 }
             }
         }
@@ -193,6 +198,9 @@ static void* run(void* arg)
     for (uint32_t s = 0; s < n_scans; s++) {
         fwrite(&infos[s], sizeof(urf_scan_info), 1, o);
         fwrite(labels[s].data(), 1, n, o);
+        fwrite(o_road[s].data(), 4, o_road[s].size(), o);
+        fwrite(o_curb[s].data(), 4, o_curb[s].size(), o);
+        fwrite(o_r10[s].data(), 4, o_r10[s].size(), o);
     }
     fclose(o);
     job->rc = 0;

@@ -701,7 +701,13 @@ int urf_oracle_classify(const float* x, const float* y, const float* z, uint32_t
             uint8_t l = URF_FLAG_ROI | URF_FLAG_RING;
             if (q->isCurbPoint == 1) { l |= URF_LABEL_ROAD; n_road++; }
             else if (q->isCurbPoint == 2) { l |= URF_LABEL_CURB; n_curb++; }
-            if (j == 10 && channels > 10) { l |= URF_FLAG_RING10; n_ring10++; }   /* deviation D4 */
+            if (q->isCurbPoint == 1 && dbg && dbg->road_order) dbg->road_order[n_road - 1] = q->src;
+            if (q->isCurbPoint == 2 && dbg && dbg->curb_order) dbg->curb_order[n_curb - 1] = q->src;
+            if (j == 10 && channels > 10) {   /* deviation D4 */
+                if (dbg && dbg->ring10_order) dbg->ring10_order[n_ring10] = q->src;
+                l |= URF_FLAG_RING10;
+                n_ring10++;
+            }
             labels[q->src] = l;
             n_ring++;
         }

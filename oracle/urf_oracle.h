@@ -35,6 +35,12 @@ typedef struct urf_oracle_debug {
     float*   max_dist;    /* [channels] */
     float*   quadrants;   /* [4] q1..q4 */
     int16_t* beam_stop;   /* [2*361] first blocked ring per fwd/bwd beam; n_rings = free; -1 = not cast */
+    /* the published clouds as input-index sequences in the reference's order (ring-major,
+     * azimuth ascending, lidar_segmentation.cpp:354-367, 605-608); n entries of room each;
+     * the lengths are info.n_road / n_curb / n_ring10 */
+    uint32_t* road_order;
+    uint32_t* curb_order;
+    uint32_t* ring10_order;
 } urf_oracle_debug;
 
 /* Classifies one scan given as SoA.  labels: n bytes (urf.h label byte).

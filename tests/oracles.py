@@ -25,7 +25,8 @@ class OracleDebug(C.Structure):
     _fields_ = [("valpha", C.c_void_p), ("ring", C.c_void_p), ("azimuth", C.c_void_p),
                 ("range2d", C.c_void_p), ("detect", C.c_void_p), ("sector", C.c_void_p),
                 ("angle_table", C.c_void_p), ("max_dist", C.c_void_p), ("quadrants", C.c_void_p),
-                ("beam_stop", C.c_void_p)]
+                ("beam_stop", C.c_void_p), ("road_order", C.c_void_p), ("curb_order", C.c_void_p),
+                ("ring10_order", C.c_void_p)]
 
 
 _B = None
@@ -77,12 +78,18 @@ def run_b(x, y, z, params, debug=False):
               "azimuth": np.zeros(n, np.float32), "range2d": np.zeros(n, np.float32),
               "detect": np.zeros(n, np.uint8), "sector": np.zeros(n, np.int16),
               "angle_table": np.zeros(ch, np.float32), "max_dist": np.zeros(ch, np.float32),
-              "quadrants": np.zeros(4, np.float32), "beam_stop": np.zeros(2 * 361, np.int16)}
+              "quadrants": np.zeros(4, np.float32), "beam_stop": np.zeros(2 * 361, np.int16),
+              "road_order": np.zeros(n, np.uint32), "curb_order": np.zeros(n, np.uint32),
+              "ring10_order": np.zeros(n, np.uint32)}
         dbg = OracleDebug(*[st[k].ctypes.data for k, _ in OracleDebug._fields_])
     rc = oracle_b().urf_oracle_classify(x.ctypes.data, y.ctypes.data, z.ctypes.data, n, C.byref(params),
                                         labels.ctypes.data, C.byref(info), C.byref(dbg) if dbg else None)
     if rc < 0:
         raise RuntimeError("oracle B failed: %d" % rc)
+    if st is not None:
+        st["road_order"] = st["road_order"][:info.n_road]
+        st["curb_order"] = st["curb_order"][:info.n_curb]
+        st["ring10_order"] = st["ring10_order"][:info.n_ring10]
     return labels, info.as_dict(), st
 
 
@@ -115,7 +122,11 @@ def run_a(scans, params, repeat=1, timeout=1200):
         pos += C.sizeof(ScanInfo)
         labels.append(np.frombuffer(blob, np.uint8, nn, pos).copy())
         pos += nn
-        infos.append(info.as_dict())
+        d = info.as_dict()
+        for key, cnt in (("road_order", info.n_road), ("curb_order", info.n_curb), ("ring10_order", info.n_ring10)):
+            d[key] = np.frombuffer(blob, np.uint32, cnt, pos).copy()   # the published order of the reference
+            pos += 4 * cnt
+        infos.append(d)
     return labels, infos, ms_steady, ms_first
 
 

@@ -36,8 +36,12 @@ def test_adapter_clouds_equal_oracle(tmp_path, scene, seed):
     assert r.returncode == 0, r.stderr
     x, y, z = u.synth_cloud(64, 2048, scene, seed)
     p = O.cfg_params("cfg2")
-    lb, ib, _ = O.run_b(x, y, z, p)
-    got = np.fromfile(out, np.uint8)
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    blob = open(out, "rb").read()
+    got = np.frombuffer(blob, np.uint8, len(x))
     assert np.array_equal(got, lb & O.MASK_NO_RING)
+    road_seq = np.frombuffer(blob, np.uint32, ib["n_road"], len(x))
+    assert np.array_equal(road_seq, st["road_order"])   # setReferenceOrder(true): the reference's own order
     assert "road %d curb %d roi %d road_probably %d" % (ib["n_road"], ib["n_curb"], ib["n_roi"], ib["n_ring10"]) in r.stdout
     assert "frame left_os1/os1_lidar" in r.stdout
+    assert "pc2 published 1 same_labels 1" in r.stdout   # sensor_msgs/PointCloud2 with a permuted field table

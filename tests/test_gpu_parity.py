@@ -328,6 +328,24 @@ def test_storage_order_invariance(ctx_big):
     assert np.array_equal(l1[perm], l2)
 
 
+@pytest.mark.parametrize("cfg,seed", [("cfg2", 5), ("narrow", 6), ("default_roi", 7), ("cfg5", 3), ("cfg1", 2)])
+def test_published_order(ctx_big, cfg, seed):
+    """urf_ordered_indices: the road / curb / road_probably clouds as the reference publishes them
+    (ring by ring, ascending azimuth -- its per-ring quicksort).  cfg5 has 4096-point rings, which
+    take the global-memory sort path."""
+    p = O.cfg_params(cfg)
+    x, y, z = O.cfg_cloud(cfg, seed)
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    road, curb, r10 = ctx_big.ordered_indices(len(x))
+    assert np.array_equal(road, st["road_order"])
+    assert np.array_equal(curb, st["curb_order"])
+    assert np.array_equal(r10, st["ring10_order"])
+    # and they are the same sets the label bytes describe
+    assert np.array_equal(np.sort(road), np.nonzero((lg & 3) == 1)[0]) and np.array_equal(np.sort(curb), np.nonzero((lg & 3) == 2)[0])
+
+
 def test_index_lists(ctx_big):
     p = O.cfg_params("cfg2")
     x, y, z = O.cfg_cloud("cfg2", 81)

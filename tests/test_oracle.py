@@ -52,9 +52,12 @@ def test_oracle_b_equals_oracle_a_live(cfg, seeds, tweak):
     scans = [O.cfg_cloud(cfg, s) for s in seeds]
     la, ia, _, _ = O.run_a(scans, p)
     for k in range(len(seeds)):
-        lb, ib, _ = O.run_b(*scans[k], p)
+        lb, ib, st = O.run_b(*scans[k], p, debug=True)
         assert np.array_equal(la[k], lb & O.MASK_NO_RING), (cfg, seeds[k])
         assert ia[k]["n_road"] == ib["n_road"] and ia[k]["n_curb"] == ib["n_curb"] and ia[k]["n_roi"] == ib["n_roi"]
+        # the clouds in the order the reference published them (ring-major, azimuth ascending)
+        for key in ("road_order", "curb_order", "ring10_order"):
+            assert np.array_equal(ia[k][key], st[key]), key
 
 
 @pytest.mark.skipif(not O.has_oracle_a(), reason="oracle A binary (reference build) not available")

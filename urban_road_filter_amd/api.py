@@ -96,6 +96,7 @@ def lib():
         "urf_classify_batch_pc2": [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p, vp],
         "urf_compact_indices": [vp, u8p, C.c_uint32, u32p, u32p, u32p, u32p, u32p],
         "urf_read_stage": [vp, C.c_int, C.c_uint32, vp, C.c_size_t],
+        "urf_ordered_indices": [vp, C.c_uint32, vp, vp, vp, vp],
         "urf_enable_stage_capture": [vp, C.c_int],
         "urf_enable_kernel_timing": [vp, C.c_int],
         "urf_selftest": [vp, C.c_void_p],
@@ -267,6 +268,15 @@ class Context:
     def compact_indices(self, d_labels, n_points, d_road, d_curb, d_roi, d_ring10, d_counts):
         self._check(self._lib.urf_compact_indices(self._h, _ptr(d_labels), n_points, _ptr(d_road), _ptr(d_curb),
                                                   _ptr(d_roi), _ptr(d_ring10), _ptr(d_counts)), "urf_compact_indices")
+
+    def ordered_indices(self, n_points, scan=0):
+        """Input indices of the road / curb / road_probably clouds of scan `scan` in the order the
+        reference publishes them (ring-major, azimuth ascending).  Returns three uint32 arrays."""
+        bufs = [np.zeros(n_points, np.uint32) for _ in range(3)]
+        cnt = np.zeros(3, np.uint32)
+        self._check(self._lib.urf_ordered_indices(self._h, scan, bufs[0].ctypes.data, bufs[1].ctypes.data,
+                                                  bufs[2].ctypes.data, cnt.ctypes.data), "urf_ordered_indices")
+        return tuple(b[:int(c)] for b, c in zip(bufs, cnt))
 
     # -- stage-wise inspection ----------------------------------------------------
     _STAGE_DTYPE = {STAGE_VALPHA: np.float32, STAGE_RING: np.int16, STAGE_AZIMUTH: np.float32,

@@ -58,6 +58,20 @@ void Detector::split(const PointXYZI* pts, uint32_t n, const Header& h)
         if (l & URF_FLAG_RING10)
             road_probably_.points.push_back(pts[i]);
     }
+    if (reference_order_) {
+        std::vector<uint32_t> ro(n), co(n), po(n);
+        uint32_t cnt[3] = { 0, 0, 0 };
+        check(urf_ordered_indices(ctx_, 0, ro.data(), co.data(), po.data(), cnt), "urf_ordered_indices");
+        road_.points.clear();
+        curb_.points.clear();
+        road_probably_.points.clear();
+        for (uint32_t i = 0; i < cnt[0]; i++)
+            road_.points.push_back(pts[ro[i]]);
+        for (uint32_t i = 0; i < cnt[1]; i++)
+            curb_.points.push_back(pts[co[i]]);
+        for (uint32_t i = 0; i < cnt[2]; i++)
+            road_probably_.points.push_back(pts[po[i]]);
+    }
 }
 
 bool Detector::filtered(const PointCloud& cloud)
@@ -87,6 +101,28 @@ bool Detector::filtered(const uint8_t* data, uint32_t n_points, uint32_t point_s
     }
     split(pts.data(), n_points, header);
     return info_.status == URF_OK;
+}
+
+bool Detector::filtered(const PointCloud2& msg)
+{
+    if (msg.is_bigendian)
+        throw Error(URF_ERR_INVALID_ARG, "big-endian PointCloud2 is not supported");
+    uint32_t off[3] = { 0, 0, 0 };
+    bool have[3] = { false, false, false };
+    for (const PointField& f : msg.fields)
+        for (int k = 0; k < 3; k++)
+            if (f.name == (k == 0 ? "x" : k == 1 ? "y" : "z")) {
+                if (f.datatype != PointField::FLOAT32)
+                    throw Error(URF_ERR_INVALID_ARG, "field " + f.name + " is not FLOAT32");
+                off[k] = f.offset;
+                have[k] = true;
+            }
+    if (!have[0] || !have[1] || !have[2])
+        throw Error(URF_ERR_INVALID_ARG, "PointCloud2 without x/y/z fields");
+    const uint64_t n = (uint64_t)msg.width * msg.height;
+    if (msg.point_step < 4 || n * msg.point_step > msg.data.size())
+        throw Error(URF_ERR_INVALID_ARG, "PointCloud2 data shorter than width*height*point_step");
+    return filtered(msg.data.data(), (uint32_t)n, msg.point_step, off[0], off[1], off[2], msg.header);
 }
 
 }   // namespace urf

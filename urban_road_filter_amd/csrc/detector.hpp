@@ -16,8 +16,8 @@
  *
  * A ROS node keeps its subscriber/publishers and calls this class from its
  * callback; see INTEGRATION.md.  Points keep their intensity; the order inside
- * the output clouds is input order (the reference emits ring-major,
- * azimuth-ascending; consumers of these topics treat them as unordered sets).
+ * the output clouds is input order, or, after setReferenceOrder(true), exactly
+ * the reference's (ring-major, azimuth ascending).
  */
 #ifndef URF_DETECTOR_HPP
 #define URF_DETECTOR_HPP
@@ -49,6 +49,24 @@ struct PointCloud {
     std::vector<PointXYZI> points;
 };
 
+/* sensor_msgs/PointField and sensor_msgs/PointCloud2, field for field */
+struct PointField {
+    enum { INT8 = 1, UINT8 = 2, INT16 = 3, UINT16 = 4, INT32 = 5, UINT32 = 6, FLOAT32 = 7, FLOAT64 = 8 };
+    std::string name;
+    uint32_t offset = 0;
+    uint8_t datatype = 0;
+    uint32_t count = 1;
+};
+struct PointCloud2 {
+    Header header;
+    uint32_t height = 1, width = 0;
+    std::vector<PointField> fields;
+    bool is_bigendian = false;
+    uint32_t point_step = 0, row_step = 0;
+    std::vector<uint8_t> data;
+    bool is_dense = false;
+};
+
 struct Error : std::runtime_error {
     int code;
     Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
@@ -61,6 +79,11 @@ public:
     Detector(const Detector&) = delete;
     Detector& operator=(const Detector&) = delete;
 
+    /* Emit road / curb / road_probably in the reference's own order (ring by ring, ascending
+     * azimuth inside a ring -- lidar_segmentation.cpp:289-291, 354-367) instead of input order.
+     * Costs one extra per-ring sort on the GPU; roi is in input order either way. */
+    void setReferenceOrder(bool on) { reference_order_ = on; }
+
     /* main.cpp:4-34 paramsCallback: callable between scans */
     void setParams(const urf_params& p);
     urf_params params() const;
@@ -71,6 +94,10 @@ public:
      * the x/y/z FLOAT32 fields); the output clouds then carry x,y,z and intensity = input index. */
     bool filtered(const uint8_t* data, uint32_t n_points, uint32_t point_step,
                   uint32_t off_x, uint32_t off_y, uint32_t off_z, const Header& header = Header());
+
+    /* The wire message itself: resolves the x / y / z FLOAT32 fields by name, as pcl::fromROSMsg does
+     * for pcl::PointXYZI (every other field is ignored), and classifies width*height points. */
+    bool filtered(const PointCloud2& msg);
 
     const PointCloud& road() const { return road_; }                    /* topic "road" */
     const PointCloud& curb() const { return curb_; }                    /* topic "curb" */
@@ -83,6 +110,7 @@ private:
     void check(int rc, const char* what) const;
     void split(const PointXYZI* pts, uint32_t n, const Header& h);
     urf_ctx* ctx_ = nullptr;
+    bool reference_order_ = false;
     std::vector<uint8_t> labels_;
     urf_scan_info info_{};
     PointCloud road_, curb_, roi_, road_probably_;

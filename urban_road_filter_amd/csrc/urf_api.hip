@@ -33,6 +33,9 @@ struct urf_ctx {
     uint8_t* raw = nullptr;         /* PointCloud2 staging (single scan) */
     size_t raw_bytes = 0;
     uint8_t* labels1 = nullptr;     /* labels of the single-scan entry point */
+    unsigned long long* ord_keys = nullptr;   /* lazily: scratch of urf_ordered_indices, max_points each */
+    uint32_t* ord_pos = nullptr;
+    uint32_t* ord_lists = nullptr;  /* 3 x max_points + 4 */
     float* d_newY = nullptr;
     float* d_inv_i = nullptr;
     urf_beam* d_beams = nullptr;
@@ -211,6 +214,11 @@ extern "C" int urf_destroy(urf_ctx* c)
         (void)hipFree(p);
     if (c->raw)
         (void)hipFree(c->raw);
+    if (c->ord_keys) {
+        (void)hipFree(c->ord_keys);
+        (void)hipFree(c->ord_pos);
+        (void)hipFree(c->ord_lists);
+    }
     if (c->sx) {
         (void)hipFree(c->sx);
         (void)hipFree(c->sy);
@@ -512,6 +520,50 @@ extern "C" int urf_compact_indices(urf_ctx* c, const uint8_t* d_labels, uint32_t
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, c->stream, d_labels, n_points, d_road, d_curb, d_roi, d_ring10,
                        d_counts);
     URF_HIP(c, hipGetLastError());
+    return URF_OK;
+}
+
+extern "C" int urf_ordered_indices(urf_ctx* c, uint32_t scan, uint32_t* road, uint32_t* curb, uint32_t* ring10,
+                                   uint32_t* counts)
+{
+    if (!c || !counts || scan >= c->last_scans || !c->last_labels)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    if (!c->ord_keys) {
+        void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+        URF_HIP(c, hipMalloc(&p0, (size_t)c->max_points * sizeof(unsigned long long)));
+        URF_HIP(c, hipMalloc(&p1, (size_t)c->max_points * sizeof(uint32_t)));
+        URF_HIP(c, hipMalloc(&p2, ((size_t)c->max_points * 3 + 4) * sizeof(uint32_t)));
+        c->ord_keys = (unsigned long long*)p0;
+        c->ord_pos = (uint32_t*)p1;
+        c->ord_lists = (uint32_t*)p2;
+    }
+    urf_kargs a = c->k;
+    a.offsets = c->last_offsets;
+    a.n_per_scan = c->last_n;
+    a.n_scans = c->last_scans;
+    a.labels = const_cast<uint8_t*>(c->last_labels);
+    const size_t mp = c->max_points;
+    uint32_t* d_road = c->ord_lists;
+    uint32_t* d_curb = d_road + mp;
+    uint32_t* d_r10 = d_curb + mp;
+    uint32_t* d_cnt = d_r10 + mp;
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(k_ring_order, dim3((unsigned)c->dp.p.channels), dim3(256), 0, st, a, c->dp, scan, c->ord_keys, c->ord_pos);
+    hipLaunchKernelGGL(k_ordered_lists, dim3(1), dim3(1024), 0, st, a, c->dp, scan, c->ord_pos, d_road, d_curb, d_r10, d_cnt);
+    URF_HIP(c, hipGetLastError());
+    uint32_t h[3] = { 0, 0, 0 };
+    URF_HIP(c, hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+    URF_HIP(c, hipStreamSynchronize(st));
+    if (road && h[0])
+        URF_HIP(c, hipMemcpy(road, d_road, h[0] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (curb && h[1])
+        URF_HIP(c, hipMemcpy(curb, d_curb, h[1] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (ring10 && h[2])
+        URF_HIP(c, hipMemcpy(ring10, d_r10, h[2] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    counts[0] = h[0];
+    counts[1] = h[1];
+    counts[2] = h[2];
     return URF_OK;
 }
 

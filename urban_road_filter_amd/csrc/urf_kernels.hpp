@@ -945,10 +945,135 @@ __device__ __forceinline__ void urf_bitonic_keys(unsigned long long* keys, unsig
     }
 }
 
+/* Workgroup-wide sort of up to NT*EPT 64-bit keys (element tid + e*NT in key[e], ~0 = none):
+ * the distribution sort of k_star_sort_small with NB buckets and workgroup-wide reductions,
+ * the normalised bitonic network in LDS as the fallback for clustered keys.  The sorted keys
+ * end up in A[0..n). */
+struct urf_sort_shared {
+    unsigned rmin, rmax, maxc;
+    unsigned w[8];
+};
+template <int NT, int EPT, int NB>
+__device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EPT], unsigned n, unsigned long long* A,
+                                                    unsigned* cnt, urf_sort_shared* sh, bool force_general)
+{
+    static_assert(NB % NT == 0 && NT / 64 <= 8, "bucket scan layout");
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        sh->rmin = 0xffffffffu;
+        sh->rmax = 0;
+        sh->maxc = 0;
+    }
+    for (unsigned c = tid; c <= NB; c += NT)
+        cnt[c] = 0;
+    __syncthreads();
+    unsigned rmin = 0xffffffffu, rmax = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; e++)
+        if (key[e] != ~0ull) {
+            const unsigned rb = (unsigned)(key[e] >> 32);
+            rmin = rb < rmin ? rb : rmin;
+            rmax = rb > rmax ? rb : rmax;
+        }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor(rmin, o), hi = __shfl_xor(rmax, o);
+        rmin = lo < rmin ? lo : rmin;
+        rmax = hi > rmax ? hi : rmax;
+    }
+    if (lane == 0) {
+        atomicMin(&sh->rmin, rmin);
+        atomicMax(&sh->rmax, rmax);
+    }
+    __syncthreads();
+    rmin = sh->rmin;
+    const unsigned range = sh->rmax - rmin;
+    unsigned shf = 0;
+    while ((range >> shf) >= (unsigned)NB)   /* (range >> shf) < NB */
+        shf++;
+    unsigned bkt[EPT], wq[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        bkt[e] = 0;
+        wq[e] = 0;
+        if (key[e] != ~0ull) {
+            bkt[e] = ((unsigned)(key[e] >> 32) - rmin) >> shf;
+            wq[e] = atomicAdd(&cnt[bkt[e]], 1u);
+        }
+    }
+    __syncthreads();
+    {   /* exclusive scan of the NB counts: NB/NT consecutive counters per thread */
+        unsigned c8[NB / NT], sum = 0, maxc = 0;
+#pragma unroll
+        for (int e = 0; e < NB / NT; e++) {
+            c8[e] = cnt[tid * (NB / NT) + e];
+            sum += c8[e];
+            maxc = c8[e] > maxc ? c8[e] : maxc;
+        }
+        unsigned inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(inc, o);
+            if ((int)lane >= o)
+                inc += v;
+        }
+        if (lane == 63)
+            sh->w[wave] = inc;
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned v = __shfl_xor(maxc, o);
+            maxc = v > maxc ? v : maxc;
+        }
+        if (lane == 0)
+            atomicMax(&sh->maxc, maxc);
+        __syncthreads();
+        unsigned run = inc - sum;
+        for (unsigned v = 0; v < wave; v++)
+            run += sh->w[v];
+#pragma unroll
+        for (int e = 0; e < NB / NT; e++) {
+            cnt[tid * (NB / NT) + e] = run;
+            run += c8[e];
+        }
+        if (tid == NT - 1)
+            cnt[NB] = run;
+    }
+    __syncthreads();
+    if (sh->maxc <= 64 && !force_general) {
+        unsigned rank[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++)
+            if (key[e] != ~0ull)
+                A[cnt[bkt[e]] + wq[e]] = key[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            rank[e] = 0;
+            if (key[e] != ~0ull) {
+                const unsigned b0 = cnt[bkt[e]], b1 = cnt[bkt[e] + 1];
+                unsigned r = b0;
+                for (unsigned t = b0; t < b1; t++)
+                    r += A[t] < key[e];
+                rank[e] = r;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; e++)
+            if (key[e] != ~0ull)
+                A[rank[e]] = key[e];
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const unsigned i = tid + (unsigned)e * NT;
+            if (i < n)
+                A[i] = key[e];
+        }
+        __syncthreads();
+        urf_bitonic_keys<NT>(A, n);
+    }
+}
+
 /* sectors with 513..2048 points (e.g. 128 rings x 4096 columns): persistent
- * workgroups of 256 threads walk the work list built by k_offsets.  Same
- * distribution sort as above with 2048 buckets and workgroup-wide reductions;
- * clustered sectors fall back to the bitonic network in LDS. */
+ * workgroups of 256 threads walk the work list built by k_offsets. */
 #define URF_STAR_MID_THREADS 256
 #define URF_STAR_MID_CAP 2048
 __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_kargs a, urf_dev_params dp)
@@ -956,11 +1081,11 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_karg
     constexpr unsigned NT = URF_STAR_MID_THREADS, NB = 2048, EPT = URF_STAR_MID_CAP / NT;
     __shared__ unsigned long long A[URF_STAR_MID_CAP];
     __shared__ unsigned cnt[NB + 1];
-    __shared__ unsigned sh_first, sh_rmin, sh_rmax, sh_maxc;
-    __shared__ unsigned sh_w[NT / 64];
+    __shared__ urf_sort_shared ssh;
+    __shared__ unsigned sh_first;
     const unsigned K = (unsigned)dp.p.sectors;
     const unsigned count = a.star_count[0];
-    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned tid = threadIdx.x;
     for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
         const unsigned sk = a.star_list_mid[w];
         const unsigned s = sk / K, k = sk % K;
@@ -968,121 +1093,15 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_karg
         urf_scan_range(a, s, off, len);
         const unsigned n = a.sec_cnt[(size_t)s * K + k];
         const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
-        if (tid == 0) {
+        if (tid == 0)
             sh_first = n;
-            sh_rmin = 0xffffffffu;
-            sh_rmax = 0;
-            sh_maxc = 0;
-        }
-        for (unsigned c = tid; c <= NB; c += NT)
-            cnt[c] = 0;
-        __syncthreads();
         unsigned long long key[EPT];
-        unsigned rmin = 0xffffffffu, rmax = 0;
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++) {
             const unsigned i = tid + e * NT;
-            key[e] = ~0ull;
-            if (i < n) {
-                const unsigned rb = urf_fbits(a.sr[base + i]);
-                key[e] = ((unsigned long long)rb << 32) | i;
-                rmin = rb < rmin ? rb : rmin;
-                rmax = rb > rmax ? rb : rmax;
-            }
+            key[e] = i < n ? ((unsigned long long)urf_fbits(a.sr[base + i]) << 32) | i : ~0ull;
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned lo = __shfl_xor(rmin, o), hi = __shfl_xor(rmax, o);
-            rmin = lo < rmin ? lo : rmin;
-            rmax = hi > rmax ? hi : rmax;
-        }
-        if (lane == 0) {
-            atomicMin(&sh_rmin, rmin);
-            atomicMax(&sh_rmax, rmax);
-        }
-        __syncthreads();
-        rmin = sh_rmin;
-        const unsigned range = sh_rmax - rmin;
-        const unsigned sh = range < NB ? 0u : (unsigned)(32 - __clz((int)range)) - 11u;   /* (range >> sh) < 2048 */
-        unsigned bkt[EPT], wq[EPT];
-#pragma unroll
-        for (unsigned e = 0; e < EPT; e++) {
-            bkt[e] = 0;
-            wq[e] = 0;
-            if (key[e] != ~0ull) {
-                bkt[e] = ((unsigned)(key[e] >> 32) - rmin) >> sh;
-                wq[e] = atomicAdd(&cnt[bkt[e]], 1u);
-            }
-        }
-        __syncthreads();
-        {   /* exclusive scan of the 2048 counts: 8 consecutive counters per thread */
-            unsigned c8[NB / NT], sum = 0, maxc = 0;
-#pragma unroll
-            for (unsigned e = 0; e < NB / NT; e++) {
-                c8[e] = cnt[tid * (NB / NT) + e];
-                sum += c8[e];
-                maxc = c8[e] > maxc ? c8[e] : maxc;
-            }
-            unsigned inc = sum;
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned v = __shfl_up(inc, o);
-                if ((int)lane >= o)
-                    inc += v;
-            }
-            if (lane == 63)
-                sh_w[wave] = inc;
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned v = __shfl_xor(maxc, o);
-                maxc = v > maxc ? v : maxc;
-            }
-            if (lane == 0)
-                atomicMax(&sh_maxc, maxc);
-            __syncthreads();
-            unsigned run = inc - sum;
-            for (unsigned v = 0; v < wave; v++)
-                run += sh_w[v];
-#pragma unroll
-            for (unsigned e = 0; e < NB / NT; e++) {
-                cnt[tid * (NB / NT) + e] = run;
-                run += c8[e];
-            }
-            if (tid == NT - 1)
-                cnt[NB] = run;
-        }
-        __syncthreads();
-        if (sh_maxc <= 64 && !(dp.exp_flags & 4u)) {
-            unsigned rank[EPT];
-#pragma unroll
-            for (unsigned e = 0; e < EPT; e++)
-                if (key[e] != ~0ull)
-                    A[cnt[bkt[e]] + wq[e]] = key[e];
-            __syncthreads();
-#pragma unroll
-            for (unsigned e = 0; e < EPT; e++) {
-                rank[e] = 0;
-                if (key[e] != ~0ull) {
-                    const unsigned b0 = cnt[bkt[e]], b1 = cnt[bkt[e] + 1];
-                    unsigned r = b0;
-                    for (unsigned t = b0; t < b1; t++)
-                        r += A[t] < key[e];
-                    rank[e] = r;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (unsigned e = 0; e < EPT; e++)
-                if (key[e] != ~0ull)
-                    A[rank[e]] = key[e];
-            __syncthreads();
-        } else {
-#pragma unroll
-            for (unsigned e = 0; e < EPT; e++) {
-                const unsigned i = tid + e * NT;
-                if (i < n)
-                    A[i] = key[e];
-            }
-            __syncthreads();
-            urf_bitonic_keys<NT>(A, n);
-        }
+        urf_block_sort_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, (dp.exp_flags & 4u) != 0);
         const unsigned first = urf_star_emit<NT, EPT>(a, dp, base, n, A, nullptr, &sh_first);
         if (tid == 0)
             a.star_first[sk] = first < n - 1 ? first : n - 1;
@@ -1837,6 +1856,133 @@ __global__ __launch_bounds__(1024) void k_compact(const uint8_t* __restrict__ la
         __syncthreads();
     }
     if (tid < 4 && counts)
+        counts[tid] = run[tid];
+}
+
+/* ------------------------------------------------------------------------- */
+/* published order                                                             */
+/* ------------------------------------------------------------------------- */
+/* The reference sorts every ring by azimuth (lidar_segmentation.cpp:70-93, 289-291) and fills
+ * its road / curb / road_probably clouds ring by ring in that order (:354-367, 605-608).  The
+ * labels do not need that sort; callers that want the clouds in the reference's order do.
+ * k_ring_order: one workgroup per ring of ONE scan sorts (azimuth bits, position in the ring)
+ * -- equal azimuths stay in input order, where the reference's unstable quicksort leaves their
+ * order open -- and writes the ring-major position of the i-th point of the ring in azimuth
+ * order.  Rings of up to 2048 points sort in LDS, longer ones in global memory. */
+__global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params dp, unsigned s,
+                                                    unsigned long long* gkeys, unsigned* rord)
+{
+    constexpr unsigned NT = 256, NB = 2048, EPT = 8, CAP = NT * EPT;
+    __shared__ unsigned long long A[CAP];
+    __shared__ unsigned cnt[NB + 1];
+    __shared__ urf_sort_shared ssh;
+    const unsigned c = blockIdx.x, tid = threadIdx.x;
+    const urf_scan_info in = a.info[s];
+    if (in.status != URF_OK || c >= in.n_rings)
+        return;
+    unsigned off, len;
+    urf_scan_range(a, s, off, len);
+    const unsigned C = (unsigned)dp.p.channels;
+    const unsigned n = a.ring_cnt[(size_t)s * C + c];
+    const unsigned rel = a.ring_off[(size_t)s * (C + 1) + c];   /* scan-relative start of the ring */
+    const unsigned base = off + rel;
+    if (n <= CAP) {
+        unsigned long long key[EPT];
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++) {
+            const unsigned i = tid + e * NT;
+            key[e] = i < n ? ((unsigned long long)urf_fbits(a.raz[base + i]) << 32) | i : ~0ull;
+        }
+        urf_block_sort_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, false);
+        for (unsigned i = tid; i < n; i += NT)
+            rord[rel + i] = rel + (unsigned)A[i];
+    } else {
+        unsigned long long* G = gkeys + rel;
+        for (unsigned i = tid; i < n; i += NT)
+            G[i] = ((unsigned long long)urf_fbits(a.raz[base + i]) << 32) | i;
+        __threadfence_block();
+        __syncthreads();
+        unsigned P = 1;
+        while (P < n)
+            P <<= 1;
+        for (unsigned kk = 2; kk <= P; kk <<= 1)
+            for (unsigned j = kk >> 1; j > 0; j >>= 1) {
+                const bool flip = (j == (kk >> 1));
+                for (unsigned tt = tid; tt < (P >> 1); tt += NT) {
+                    const unsigned lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
+                    const unsigned hi = flip ? ((lo & ~(kk - 1)) + (kk - 1) - (lo & (kk - 1))) : lo + j;
+                    if (hi < n) {
+                        const unsigned long long ka = G[lo], kb = G[hi];
+                        if (ka > kb) {
+                            G[lo] = kb;
+                            G[hi] = ka;
+                        }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+        for (unsigned i = tid; i < n; i += NT)
+            rord[rel + i] = rel + (unsigned)G[i];
+    }
+}
+
+/* Walks the rings of one scan in order, every ring in azimuth order (rord), and appends the
+ * input index of each point to the list(s) its label puts it in.  Single workgroup; order is
+ * kept by ballot + prefix per 1024 points. */
+__global__ __launch_bounds__(1024) void k_ordered_lists(urf_kargs a, urf_dev_params dp, unsigned s, const unsigned* rord,
+                                                        unsigned* road, unsigned* curb, unsigned* ring10, unsigned* counts)
+{
+    __shared__ unsigned wsum[3][16];
+    __shared__ unsigned run[3];
+    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const urf_scan_info in = a.info[s];
+    if (tid < 3)
+        run[tid] = 0;
+    __syncthreads();
+    if (in.status == URF_OK) {
+        unsigned off, len;
+        urf_scan_range(a, s, off, len);
+        const unsigned C = (unsigned)dp.p.channels;
+        const unsigned* roff = a.ring_off + (size_t)s * (C + 1);
+        const unsigned total = roff[in.n_rings];
+        const unsigned r10lo = in.n_rings > 10 ? roff[10] : 0, r10hi = in.n_rings > 10 ? roff[11] : 0;
+        for (unsigned b0 = 0; b0 < total; b0 += 1024) {
+            const unsigned p = b0 + tid;
+            unsigned src = 0, l = 0;
+            if (p < total) {
+                src = a.rsrc[off + rord[p]];
+                l = a.labels[off + src];
+            }
+            const bool f[3] = { p < total && (l & URF_LABEL_MASK) == URF_LABEL_ROAD,
+                                p < total && (l & URF_LABEL_MASK) == URF_LABEL_CURB, p >= r10lo && p < r10hi };
+            unsigned below[3];
+            for (int k = 0; k < 3; k++) {
+                const unsigned long long m = __ballot(f[k]);
+                below[k] = __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == 0)
+                    wsum[k][wave] = __popcll(m);
+            }
+            __syncthreads();
+            unsigned* outs[3] = { road, curb, ring10 };
+            for (int k = 0; k < 3; k++) {
+                unsigned pre = run[k];
+                for (unsigned w = 0; w < wave; w++)
+                    pre += wsum[k][w];
+                if (f[k] && outs[k])
+                    outs[k][pre + below[k]] = src;
+            }
+            __syncthreads();
+            if (tid < 3) {
+                unsigned t = 0;
+                for (int w = 0; w < 16; w++)
+                    t += wsum[tid][w];
+                run[tid] += t;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < 3)
         counts[tid] = run[tid];
 }
 
