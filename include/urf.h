@@ -198,6 +198,27 @@ int urf_compact_indices(urf_ctx* ctx, const uint8_t* d_labels, uint32_t n_points
 int urf_ordered_indices(urf_ctx* ctx, uint32_t scan, uint32_t* road, uint32_t* curb, uint32_t* ring10,
                         uint32_t* counts);
 
+/* ---- road_marker: the marker points ------------------------------------------
+ * lidar_segmentation.cpp:295-351: for every integer degree i = 0..360 the farthest road point
+ * with azimuth in [i, i+1), scanning ring by ring (each ring in ascending azimuth) until the first
+ * point of that degree that is not road; `red` tells whether such a point was met.  After a
+ * classify call this returns the marker points of scan `scan`: pts[4*k + 0..3] = x, y, z, red
+ * (host buffer with room for 361 points), *count = their number (the reference's cM).
+ * The line strips the reference builds from them (colour grouping, Douglas-Peucker
+ * simplification, ghost deletion, :369-602) are host code: urf::Detector::road_marker().
+ * Synchronous; costs one extra per-ring sort. */
+int urf_marker_points(urf_ctx* ctx, uint32_t scan, float* pts, uint32_t* count);
+
+/* The polygon parameters of the reference (cfg/LidarFilters.cfg:75-84 -> main.cpp:29-32). */
+typedef struct urf_marker_params {
+    uint32_t size;              /* = sizeof(urf_marker_params) */
+    int32_t  simple_poly_allow; /* cfg:76  bool, default true */
+    float    poly_s_param;      /* cfg:79  Douglas-Peucker distance, default 0.7 */
+    float    poly_z_manual;     /* cfg:82  default -1.5 */
+    int32_t  poly_z_avg_allow;  /* cfg:85  bool, default true */
+} urf_marker_params;
+int urf_default_marker_params(urf_marker_params* p);
+
 /* ---- stage-wise inspection (parity tests) ----------------------------------
  * After a classify call, copies one intermediate array of scan `scan` to host
  * memory.  Arrays indexed by input point have n_points entries; values of

@@ -18,11 +18,15 @@
  *     callback runs on a thread with a large stack.
  *
  * Usage:  urf_ref <in.bin> <out.bin>
- *   in : "URFREFIN" u32 n_scans u32 n_points u32 repeat u32 reserved
- *        urf_params (sizeof) then n_scans x { x[n] y[n] z[n] } float32
+ *   in : "URFREFIN" u32 n_scans u32 n_points u32 repeat u32 flags
+ *        urf_params (sizeof) [urf_marker_params if flags & 1] then n_scans x { x[n] y[n] z[n] } float32
  *   out: "URFREFOU" u32 n_scans u32 n_points f64 ms_per_scan_steady f64 ms_first
  *        then n_scans x { urf_scan_info, labels[n], road[n_road], curb[n_curb], road_probably[n_ring10] }
  *        (u32 input indices in the order the reference published them)
+ *        and, if flags & 1, the road_marker MarkerArray of the scan: u32 published, u32 n_markers,
+ *        n_markers x { i32 id, action, type; f32 r, g, b, a; u32 n_points; f64 xyz[n_points][3] }
+ *        (the scans are run in sequence by ONE Detector, so ghostcount and the member linestring
+ *        carry over from scan to scan exactly as in the node)
  * Points are identified by writing the input index into `intensity`
  * (exact in float up to 2^24 points).  `repeat` > 1 re-runs the whole set for
  * timing; the first call of the process is excluded from the steady figure.
@@ -131,7 +135,15 @@ static void* run(void* arg)
         fprintf(stderr, "bad input header\n");
         return nullptr;
     }
-    const uint32_t n_scans = hdr[0], n = hdr[1], repeat = hdr[2] ? hdr[2] : 1;
+    const uint32_t n_scans = hdr[0], n = hdr[1], repeat = hdr[2] ? hdr[2] : 1, flags = hdr[3];
+    if (flags & 1u) {
+        urf_marker_params mp;
+        if (fread(&mp, sizeof(mp), 1, f) != 1 || mp.size != sizeof(mp)) { fprintf(stderr, "bad marker params\n"); return nullptr; }
+        params::polysimp_allow = mp.simple_poly_allow != 0;   /* main.cpp:29-32 */
+        params::polysimp = mp.poly_s_param;
+        params::polyz = mp.poly_z_manual;
+        params::zavg_allow = mp.poly_z_avg_allow != 0;
+    }
     if (prm.sectors != rep) {
         fprintf(stderr, "the reference is compiled for rep=%d sectors\n", rep);
         return nullptr;
@@ -148,6 +160,8 @@ static void* run(void* arg)
     std::vector<std::vector<uint8_t>> labels(n_scans, std::vector<uint8_t>(n, 0));
     std::vector<urf_scan_info> infos(n_scans);
     std::vector<std::vector<uint32_t>> o_road(n_scans), o_curb(n_scans), o_r10(n_scans);
+    std::vector<visualization_msgs::MarkerArray> o_ma(n_scans);
+    std::vector<uint32_t> o_pub(n_scans, 0);
     pcl::PointCloud<pcl::PointXYZI> cloud;
     cloud.points.resize(n);
     double ms_first = 0, ms_sum = 0;
@@ -165,6 +179,8 @@ static void* run(void* arg)
                 cloud.points[i].intensity = (float)i;
             }
             pcl::shim_store().clear();
+            delete visualization_msgs::shim_markers();
+            visualization_msgs::shim_markers() = nullptr;
             auto t0 = std::chrono::steady_clock::now();
             det.filtered(cloud);   /* the reference callback, lidar_segmentation.cpp:95 */
             auto t1 = std::chrono::steady_clock::now();
@@ -182,6 +198,10 @@ static void* run(void* arg)
                     label_from("road", URF_LABEL_ROAD, L, n, &in.n_road, &o_road[s]);
                     label_from("curb", URF_LABEL_CURB, L, n, &in.n_curb, &o_curb[s]);
                     label_from("road_probably", URF_FLAG_RING10, L, n, &in.n_ring10, &o_r10[s]);
+                }
+                if (visualization_msgs::shim_markers()) {
+                    o_pub[s] = 1;
+                    o_ma[s] = *visualization_msgs::shim_markers();
                 }
             }
         }
@@ -201,6 +221,23 @@ static void* run(void* arg)
         fwrite(o_road[s].data(), 4, o_road[s].size(), o);
         fwrite(o_curb[s].data(), 4, o_curb[s].size(), o);
         fwrite(o_r10[s].data(), 4, o_r10[s].size(), o);
+        if (flags & 1u) {
+            const uint32_t nm = (uint32_t)o_ma[s].markers.size();
+            fwrite(&o_pub[s], 4, 1, o);
+            fwrite(&nm, 4, 1, o);
+            for (const visualization_msgs::Marker& m : o_ma[s].markers) {
+                const int32_t ia[3] = { m.id, m.action, m.type };
+                const float col[4] = { m.color.r, m.color.g, m.color.b, m.color.a };
+                const uint32_t np = (uint32_t)m.points.size();
+                fwrite(ia, 4, 3, o);
+                fwrite(col, 4, 4, o);
+                fwrite(&np, 4, 1, o);
+                for (const geometry_msgs::Point& q : m.points) {
+                    const double xyz[3] = { q.x, q.y, q.z };
+                    fwrite(xyz, 8, 3, o);
+                }
+            }
+        }
     }
     fclose(o);
     job->rc = 0;

@@ -1,10 +1,12 @@
 /*
  * Stand-in for <boost/geometry.hpp> and <boost/assign.hpp>; see ros/ros.h.
- * Only the road_marker polygon (outside the hot path) uses these, so
- * simplify() is a plain copy.  TEST INFRASTRUCTURE ONLY.
+ * Only the road_marker polygon uses these.  simplify() is the Douglas-Peucker restatement of
+ * oracle/urf_rdp.c (see urf_rdp.h for what is and is not pinned).  TEST INFRASTRUCTURE ONLY.
  */
 #pragma once
 #include <vector>
+
+#include "urf_rdp.h"
 
 namespace boost {
 namespace geometry {
@@ -31,9 +33,19 @@ void clear(C& c)
     c.clear();
 }
 template <class C, class D>
-void simplify(const C& in, C& out, D)
+void simplify(const C& in, C& out, D max_distance)
 {
-    out = in;
+    const int n = (int)in.size();
+    std::vector<float> x(n), y(n);
+    std::vector<unsigned char> keep(n ? n : 1);
+    for (int i = 0; i < n; i++) {
+        x[i] = in[i].px;
+        y[i] = in[i].py;
+    }
+    urf_rdp_float(x.data(), y.data(), n, (float)max_distance, keep.data());
+    for (int i = 0; i < n; i++)
+        if (keep[i])
+            out.push_back(in[i]);   /* boost appends to the output range */
 }
 }   // namespace geometry
 

@@ -16,6 +16,15 @@ struct Marker {
 struct MarkerArray {
     std::vector<Marker> markers;
 };
-/* the road_marker polygon is outside the hot path: captured and dropped */
-inline void shim_capture(const std::string&, const MarkerArray&) {}
+/* the last MarkerArray published (topic "road_marker"); null when nothing was published */
+inline MarkerArray*& shim_markers()
+{
+    static MarkerArray* m = nullptr;
+    return m;
+}
+inline void shim_capture(const std::string&, const MarkerArray& ma)
+{
+    delete shim_markers();
+    shim_markers() = new MarkerArray(ma);
+}
 }   // namespace visualization_msgs

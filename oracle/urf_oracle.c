@@ -33,6 +33,7 @@
 
 #include "urf_oracle.h"
 #include "urf_libm.h"
+#include "urf_rdp.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -691,6 +692,43 @@ int urf_oracle_classify(const float* x, const float* y, const float* z, uint32_t
     blind_spots(array3D, index, indexArray, maxDistance, prm, channels,
                 dbg ? dbg->quadrants : NULL, dbg ? dbg->beam_stop : NULL);   /* :293 */
 
+    /* :295-351 marker points: per integer degree the farthest road point met before the first
+     * non-road point of that degree, rings in order, every ring in azimuth order */
+    if (dbg && dbg->marker_pts && dbg->n_marker_pts) {
+        uint32_t cM = 0;
+        for (int deg = 0; deg <= 360; deg++) {
+            int ID1 = -1, ID2 = -1, redPoints = 0;
+            float maxDistanceRoad = 0, d;
+            for (j = 0; j < index; j++) {
+                for (int k = 0; k < indexArray[j]; k++) {
+                    const pt3* q = &array3D[j][k];
+                    if (q->isCurbPoint != 1 && q->alpha >= (float)deg && q->alpha < (float)(deg + 1)) {   /* :318 */
+                        redPoints = 1;
+                        break;
+                    }
+                    if (q->isCurbPoint == 1 && q->alpha >= (float)deg && q->alpha < (float)(deg + 1)) {   /* :325 */
+                        d = (float)sqrt((double)(0 - q->x) * (double)(0 - q->x) + (double)(0 - q->y) * (double)(0 - q->y));
+                        if (d > maxDistanceRoad) {
+                            maxDistanceRoad = d;
+                            ID1 = j;
+                            ID2 = k;
+                        }
+                    }
+                }
+                if (redPoints == 1)
+                    break;
+            }
+            if (ID1 != -1 && ID2 != -1) {   /* :343-350 */
+                dbg->marker_pts[4 * cM + 0] = array3D[ID1][ID2].x;
+                dbg->marker_pts[4 * cM + 1] = array3D[ID1][ID2].y;
+                dbg->marker_pts[4 * cM + 2] = array3D[ID1][ID2].z;
+                dbg->marker_pts[4 * cM + 3] = (float)redPoints;
+                cM++;
+            }
+        }
+        *dbg->n_marker_pts = cM;
+    }
+
     /* :354-367 road / curb; :620 roi; :605-608 road_probably */
     uint32_t n_road = 0, n_curb = 0, n_ring = 0, n_ring10 = 0;
     for (i = 0; i < piece; i++)
@@ -730,4 +768,142 @@ int urf_oracle_classify(const float* x, const float* y, const float* z, uint32_t
     free(angle);
     free(array2D);
     return URF_OK;
+}
+
+/* ---- lidar_segmentation.cpp:369-602: line strips from the marker points ------------------ */
+typedef struct {
+    int32_t id, action;
+    float r, g, b, a;
+    double pts[3 * 1024];
+    int n;
+} strip;
+
+static void strip_push(strip* s, double x, double y, double z)
+{
+    if (s->n < 1024) {
+        s->pts[3 * s->n] = x; s->pts[3 * s->n + 1] = y; s->pts[3 * s->n + 2] = z;
+        s->n++;
+    }
+}
+static void line_push(urf_oracle_marker_state* st, float x, float y)
+{
+    if (st->line_n < 1024) {
+        st->line_x[st->line_n] = x; st->line_y[st->line_n] = y;
+        st->line_n++;
+    }
+}
+static int emit(urf_oracle_markers* out, const strip* s)
+{
+    if (out->n_markers >= out->cap_markers || out->n_points + (uint32_t)s->n > out->cap_points)
+        return -1;
+    urf_oracle_marker* m = &out->markers[out->n_markers++];
+    m->id = s->id; m->action = s->action; m->type = 4;
+    m->r = s->r; m->g = s->g; m->b = s->b; m->a = s->a;
+    m->first_point = out->n_points; m->n_points = (uint32_t)s->n;
+    memcpy(out->pts + 3 * out->n_points, s->pts, sizeof(double) * 3 * (size_t)s->n);
+    out->n_points += (uint32_t)s->n;
+    return 0;
+}
+/* :471-485 etc.: replace the strip's points by the simplified member line, z = polyz */
+static void simplify_into(strip* s, const urf_oracle_marker_state* st, const urf_marker_params* mp)
+{
+    unsigned char keep[1024];
+    s->n = 0;
+    urf_rdp_float(st->line_x, st->line_y, st->line_n, mp->poly_s_param, keep);
+    for (int i = 0; i < st->line_n; i++)
+        if (keep[i])
+            strip_push(s, (double)st->line_x[i], (double)st->line_y[i], (double)mp->poly_z_manual);
+}
+
+int urf_oracle_marker_strips(const float* mpts, uint32_t cM_in, const urf_marker_params* mp,
+                             urf_oracle_marker_state* st, urf_oracle_markers* out)
+{
+    if (!mpts || !mp || !st || !out || mp->size != sizeof(*mp) || cM_in > 361)
+        return URF_ERR_INVALID_ARG;
+    const int cM = (int)cM_in;
+    out->n_markers = 0;
+    out->n_points = 0;
+    out->published = 0;
+    if (cM <= 2)   /* :371 */
+        return URF_OK;
+    float flag[361];
+    int i;
+    for (i = 0; i < cM; i++)
+        flag[i] = mpts[4 * i + 3];
+    if (flag[0] == 0 && flag[1] == 1) flag[0] = 1;                     /* :381 */
+    if (flag[cM - 1] == 0 && flag[cM - 2] == 1) flag[cM - 1] = 1;      /* :386 */
+    if (flag[0] == 1 && flag[1] == 0) flag[0] = 0;                     /* :391 */
+    if (flag[cM - 1] == 1 && flag[cM - 2] == 0) flag[cM - 1] = 0;      /* :396 */
+    for (i = 2; i <= cM - 3; i++)                                      /* :402 */
+        if (flag[i] == 0 && flag[i - 1] == 1 && flag[i + 1] == 1) flag[i] = 1;
+    for (i = 2; i <= cM - 3; i++)                                      /* :411 */
+        if (flag[i] == 1 && flag[i - 1] == 0 && flag[i + 1] == 0) flag[i] = 0;
+
+    strip ls;
+    memset(&ls, 0, sizeof(ls));
+    ls.action = 0;   /* ADD, :427 */
+    float zavg = 0.0f;
+    int lineStripID = 0;
+    int rc = 0;
+    for (i = 0; i < cM; i++) {   /* :430 */
+        const double px = (double)mpts[4 * i], py = (double)mpts[4 * i + 1], pz = (double)mpts[4 * i + 2];
+        zavg *= (float)i;                         /* :436-438 */
+        zavg = (float)((double)zavg + pz);
+        zavg /= (float)(i + 1);
+        if (i == 0) {                             /* :442 */
+            strip_push(&ls, px, py, pz);
+            line_push(st, (float)px, (float)py);
+        } else if (flag[i] == flag[i - 1]) {      /* :450 */
+            strip_push(&ls, px, py, pz);
+            line_push(st, (float)px, (float)py);
+            if (i == cM - 1) {
+                ls.id = lineStripID;
+                if (flag[i] == 0) { ls.r = 0; ls.g = 1; ls.b = 0; ls.a = 1; }
+                else { ls.r = 1; ls.g = 0; ls.b = 0; ls.a = 1; }
+                if (mp->simple_poly_allow)
+                    simplify_into(&ls, st, mp);
+                rc |= emit(out, &ls);
+                ls.n = 0;
+                st->line_n = 0;
+            }
+        } else if (flag[i] == 0) {                /* :495 red -> green */
+            strip_push(&ls, px, py, pz);
+            line_push(st, (float)px, (float)py);
+            ls.id = lineStripID;
+            lineStripID++;
+            ls.r = 1; ls.g = 0; ls.b = 0; ls.a = 1;
+            if (mp->simple_poly_allow)
+                simplify_into(&ls, st, mp);
+            rc |= emit(out, &ls);
+            ls.n = 0;
+            st->line_n = 0;
+            strip_push(&ls, px, py, pz);
+            line_push(st, (float)px, (float)py);
+        } else {                                  /* :534 green -> red */
+            ls.id = lineStripID;
+            lineStripID++;
+            ls.r = 0; ls.g = 1; ls.b = 0; ls.a = 1;
+            if (mp->simple_poly_allow)
+                simplify_into(&ls, st, mp);
+            rc |= emit(out, &ls);
+            ls.n = 0;
+            st->line_n = 0;
+            const double qx = (double)mpts[4 * (i - 1)], qy = (double)mpts[4 * (i - 1) + 1], qz = (double)mpts[4 * (i - 1) + 2];
+            strip_push(&ls, qx, qy, qz);
+            line_push(st, (float)qx, (float)qy);
+            strip_push(&ls, px, py, pz);
+            line_push(st, (float)px, (float)py);
+        }
+    }
+    if (mp->poly_z_avg_allow)                     /* :580-589 */
+        for (uint32_t k = 0; k < out->n_points; k++)
+            out->pts[3 * k + 2] = (double)zavg;
+    ls.action = 2;                                /* DELETE, :592-597 */
+    for (int del = lineStripID; del < st->ghostcount; del++) {
+        ls.id++;
+        rc |= emit(out, &ls);
+    }
+    st->ghostcount = lineStripID;                 /* :598 */
+    out->published = 1;                           /* :601 */
+    return rc ? URF_ERR_CAPACITY : URF_OK;
 }

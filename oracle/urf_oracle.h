@@ -41,7 +41,34 @@ typedef struct urf_oracle_debug {
     uint32_t* road_order;
     uint32_t* curb_order;
     uint32_t* ring10_order;
+    /* lidar_segmentation.cpp:295-351: marker points x,y,z,red (room for 361*4 floats) and their number */
+    float*    marker_pts;
+    uint32_t* n_marker_pts;
 } urf_oracle_debug;
+
+/* ---- road_marker line strips (lidar_segmentation.cpp:369-602) ---------------- */
+typedef struct urf_oracle_marker {
+    int32_t  id, action, type;     /* action 0 = ADD, 2 = DELETE; type 4 = LINE_STRIP */
+    float    r, g, b, a;
+    uint32_t first_point, n_points;   /* into urf_oracle_markers.pts (x,y,z doubles) */
+} urf_oracle_marker;
+typedef struct urf_oracle_markers {
+    urf_oracle_marker* markers;    /* caller: room for cap_markers */
+    uint32_t n_markers, cap_markers;
+    double*  pts;                  /* caller: room for 3*cap_points doubles */
+    uint32_t n_points, cap_points;
+    int32_t  published;            /* 0: nothing published (cM <= 2) */
+} urf_oracle_markers;
+/* state the reference keeps between callbacks: ghostcount (lidar_segmentation.cpp:23) and the
+ * member linestring `line` (data_structures.hpp:139), which keeps the points of a strip that was
+ * started but not closed */
+typedef struct urf_oracle_marker_state {
+    int32_t ghostcount;
+    float   line_x[1024], line_y[1024];
+    int32_t line_n;
+} urf_oracle_marker_state;
+int urf_oracle_marker_strips(const float* marker_pts, uint32_t n_marker_pts, const urf_marker_params* mp,
+                             urf_oracle_marker_state* state, urf_oracle_markers* out);
 
 /* Classifies one scan given as SoA.  labels: n bytes (urf.h label byte).
  * Returns URF_OK, URF_TOO_FEW_POINTS, or a negative error. */

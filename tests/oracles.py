@@ -21,12 +21,75 @@ ORACLE_A = os.path.join(ORACLE_DIR, "_ref", "urf_ref")
 REFERENCE = "/root/reference"
 
 
+class MarkerParams(C.Structure):
+    """struct urf_marker_params (cfg/LidarFilters.cfg:75-84)."""
+    _fields_ = [("size", C.c_uint32), ("simple_poly_allow", C.c_int32), ("poly_s_param", C.c_float),
+                ("poly_z_manual", C.c_float), ("poly_z_avg_allow", C.c_int32)]
+
+    @classmethod
+    def default(cls):
+        return cls(C.sizeof(cls), 1, 0.7, -1.5, 1)
+
+
+class OracleMarker(C.Structure):
+    _fields_ = [("id", C.c_int32), ("action", C.c_int32), ("type", C.c_int32), ("r", C.c_float), ("g", C.c_float),
+                ("b", C.c_float), ("a", C.c_float), ("first_point", C.c_uint32), ("n_points", C.c_uint32)]
+
+
+class OracleMarkers(C.Structure):
+    _fields_ = [("markers", C.POINTER(OracleMarker)), ("n_markers", C.c_uint32), ("cap_markers", C.c_uint32),
+                ("pts", C.POINTER(C.c_double)), ("n_points", C.c_uint32), ("cap_points", C.c_uint32),
+                ("published", C.c_int32)]
+
+
+class OracleMarkerState(C.Structure):
+    _fields_ = [("ghostcount", C.c_int32), ("line_x", C.c_float * 1024), ("line_y", C.c_float * 1024),
+                ("line_n", C.c_int32)]
+
+
+def marker_strips_b(marker_pts, mparams, state):
+    """oracle B: marker points [k,4] -> list of markers (dicts) or None when nothing is published."""
+    L = oracle_b()
+    L.urf_oracle_marker_strips.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(MarkerParams), C.POINTER(OracleMarkerState),
+                                           C.POINTER(OracleMarkers)]
+    L.urf_oracle_marker_strips.restype = C.c_int
+    mk = (OracleMarker * 1200)()
+    pts = (C.c_double * (3 * 8000))()
+    out = OracleMarkers(mk, 0, 1200, pts, 0, 8000, 0)
+    mp = np.ascontiguousarray(marker_pts, np.float32).reshape(-1, 4)
+    rc = L.urf_oracle_marker_strips(mp.ctypes.data, len(mp), C.byref(mparams), C.byref(state), C.byref(out))
+    assert rc == 0, rc
+    if not out.published:
+        return None
+    res = []
+    for i in range(out.n_markers):
+        m = mk[i]
+        p = np.array(pts[3 * m.first_point:3 * (m.first_point + m.n_points)], np.float64).reshape(-1, 3)
+        res.append({"id": m.id, "action": m.action, "type": m.type, "color": (m.r, m.g, m.b, m.a), "points": p})
+    return res
+
+
+def markers_equal(ma, mb):
+    if ma is None or mb is None:
+        return ma is None and mb is None
+    if len(ma) != len(mb):
+        return False
+    for a, b in zip(ma, mb):
+        if (a["id"], a["action"], a["type"]) != (b["id"], b["action"], b["type"]):
+            return False
+        if tuple(np.float32(a["color"])) != tuple(np.float32(b["color"])):
+            return False
+        if a["points"].shape != b["points"].shape or not np.array_equal(a["points"], b["points"]):
+            return False
+    return True
+
+
 class OracleDebug(C.Structure):
     _fields_ = [("valpha", C.c_void_p), ("ring", C.c_void_p), ("azimuth", C.c_void_p),
                 ("range2d", C.c_void_p), ("detect", C.c_void_p), ("sector", C.c_void_p),
                 ("angle_table", C.c_void_p), ("max_dist", C.c_void_p), ("quadrants", C.c_void_p),
                 ("beam_stop", C.c_void_p), ("road_order", C.c_void_p), ("curb_order", C.c_void_p),
-                ("ring10_order", C.c_void_p)]
+                ("ring10_order", C.c_void_p), ("marker_pts", C.c_void_p), ("n_marker_pts", C.c_void_p)]
 
 
 _B = None
@@ -80,7 +143,8 @@ def run_b(x, y, z, params, debug=False):
               "angle_table": np.zeros(ch, np.float32), "max_dist": np.zeros(ch, np.float32),
               "quadrants": np.zeros(4, np.float32), "beam_stop": np.zeros(2 * 361, np.int16),
               "road_order": np.zeros(n, np.uint32), "curb_order": np.zeros(n, np.uint32),
-              "ring10_order": np.zeros(n, np.uint32)}
+              "ring10_order": np.zeros(n, np.uint32), "marker_pts": np.zeros(361 * 4, np.float32),
+              "n_marker_pts": np.zeros(1, np.uint32)}
         dbg = OracleDebug(*[st[k].ctypes.data for k, _ in OracleDebug._fields_])
     rc = oracle_b().urf_oracle_classify(x.ctypes.data, y.ctypes.data, z.ctypes.data, n, C.byref(params),
                                         labels.ctypes.data, C.byref(info), C.byref(dbg) if dbg else None)
@@ -90,20 +154,26 @@ def run_b(x, y, z, params, debug=False):
         st["road_order"] = st["road_order"][:info.n_road]
         st["curb_order"] = st["curb_order"][:info.n_curb]
         st["ring10_order"] = st["ring10_order"][:info.n_ring10]
+        st["marker_pts"] = st["marker_pts"][:4 * int(st["n_marker_pts"][0])].reshape(-1, 4)
     return labels, info.as_dict(), st
 
 
-def run_a(scans, params, repeat=1, timeout=1200):
+def run_a(scans, params, repeat=1, timeout=1200, marker_params=None):
     """scans: list of (x, y, z) with equal length.  Returns (list of labels, list of info dicts,
-    ms_per_scan_steady, ms_first).  The RING bit is not observable from the reference."""
+    ms_per_scan_steady, ms_first).  The RING bit is not observable from the reference.
+    With marker_params the info dicts also carry "markers": the road_marker MarkerArray of the scan
+    (list of dicts) or None when the reference published none; the scans run in sequence in one
+    Detector, as in the node."""
     assert has_oracle_a(), "oracle A (reference build) not available"
     n = len(scans[0][0])
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         with open(fin, "wb") as f:
             f.write(b"URFREFIN")
-            f.write(struct.pack("<4I", len(scans), n, repeat, 0))
+            f.write(struct.pack("<4I", len(scans), n, repeat, 1 if marker_params is not None else 0))
             f.write(bytes(params))
+            if marker_params is not None:
+                f.write(bytes(marker_params))
             for x, y, z in scans:
                 assert len(x) == n
                 f.write(np.ascontiguousarray(x, np.float32).tobytes())
@@ -126,6 +196,19 @@ def run_a(scans, params, repeat=1, timeout=1200):
         for key, cnt in (("road_order", info.n_road), ("curb_order", info.n_curb), ("ring10_order", info.n_ring10)):
             d[key] = np.frombuffer(blob, np.uint32, cnt, pos).copy()   # the published order of the reference
             pos += 4 * cnt
+        if marker_params is not None:
+            published, nm = struct.unpack_from("<2I", blob, pos)
+            pos += 8
+            ms = []
+            for _ in range(nm):
+                mid, act, typ = struct.unpack_from("<3i", blob, pos)
+                col = struct.unpack_from("<4f", blob, pos + 12)
+                (npt,) = struct.unpack_from("<I", blob, pos + 28)
+                pos += 32
+                p = np.frombuffer(blob, np.float64, 3 * npt, pos).reshape(-1, 3).copy()
+                pos += 24 * npt
+                ms.append({"id": mid, "action": act, "type": typ, "color": col, "points": p})
+            d["markers"] = ms if published else None
         infos.append(d)
     return labels, infos, ms_steady, ms_first
 

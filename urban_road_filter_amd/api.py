@@ -97,6 +97,7 @@ def lib():
         "urf_compact_indices": [vp, u8p, C.c_uint32, u32p, u32p, u32p, u32p, u32p],
         "urf_read_stage": [vp, C.c_int, C.c_uint32, vp, C.c_size_t],
         "urf_ordered_indices": [vp, C.c_uint32, vp, vp, vp, vp],
+        "urf_marker_points": [vp, C.c_uint32, vp, vp],
         "urf_enable_stage_capture": [vp, C.c_int],
         "urf_enable_kernel_timing": [vp, C.c_int],
         "urf_selftest": [vp, C.c_void_p],
@@ -277,6 +278,13 @@ class Context:
         self._check(self._lib.urf_ordered_indices(self._h, scan, bufs[0].ctypes.data, bufs[1].ctypes.data,
                                                   bufs[2].ctypes.data, cnt.ctypes.data), "urf_ordered_indices")
         return tuple(b[:int(c)] for b, c in zip(bufs, cnt))
+
+    def marker_points(self, scan=0):
+        """lidar_segmentation.cpp:295-351: the marker points of scan `scan`, float32 [k, 4] = x, y, z, red."""
+        buf = np.zeros(361 * 4, np.float32)
+        n = C.c_uint32(0)
+        self._check(self._lib.urf_marker_points(self._h, scan, buf.ctypes.data, C.byref(n)), "urf_marker_points")
+        return buf[:4 * n.value].reshape(-1, 4)
 
     # -- stage-wise inspection ----------------------------------------------------
     _STAGE_DTYPE = {STAGE_VALPHA: np.float32, STAGE_RING: np.int16, STAGE_AZIMUTH: np.float32,

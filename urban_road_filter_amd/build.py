@@ -15,8 +15,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liburf_hip.so")
 
-SOURCES = ["urf_api.hip", "params.cpp", "synth.cpp", "detector.cpp"]
-HEADERS = ["urf_internal.hpp", "urf_device.hpp", "urf_kernels.hpp", "detector.hpp",
+SOURCES = ["urf_api.hip", "params.cpp", "synth.cpp", "detector.cpp", "marker.cpp"]
+HEADERS = ["urf_internal.hpp", "urf_device.hpp", "urf_kernels.hpp", "detector.hpp", "marker.hpp",
            "../../include/urf.h", "../../include/urf_libm.h"]
 
 # -ffp-contract=off: the reference is built without FMA contraction and label

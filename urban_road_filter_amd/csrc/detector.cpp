@@ -40,6 +40,7 @@ void Detector::split(const PointXYZI* pts, uint32_t n, const Header& h)
     roi_.points.clear();
     road_probably_.points.clear();
     road_.header = curb_.header = roi_.header = road_probably_.header = h;   /* lidar_segmentation.cpp:612-615 */
+    marker_published_ = false;
     if (info_.status != URF_OK)
         return;
     road_.points.reserve(info_.n_road);
@@ -57,6 +58,12 @@ void Detector::split(const PointXYZI* pts, uint32_t n, const Header& h)
             curb_.points.push_back(pts[i]);
         if (l & URF_FLAG_RING10)
             road_probably_.points.push_back(pts[i]);
+    }
+    if (marker_on_) {
+        float mp[361 * 4];
+        uint32_t k = 0;
+        check(urf_marker_points(ctx_, 0, mp, &k), "urf_marker_points");
+        marker_published_ = marker_.build(mp, k, markers_);
     }
     if (reference_order_) {
         std::vector<uint32_t> ro(n), co(n), po(n);

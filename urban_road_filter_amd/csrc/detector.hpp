@@ -27,6 +27,7 @@
 #include <string>
 #include <vector>
 
+#include "marker.hpp"
 #include "urf.h"
 
 namespace urf {
@@ -84,6 +85,17 @@ public:
      * Costs one extra per-ring sort on the GPU; roi is in input order either way. */
     void setReferenceOrder(bool on) { reference_order_ = on; }
 
+    /* Also build the "road_marker" MarkerArray (lidar_segmentation.cpp:295-351, 369-602, topic :59,601);
+     * fixedFrame = params::fixedFrame (cfg:10).  Off by default: the polygon is a visualisation product. */
+    void enableRoadMarker(bool on, const std::string& fixed_frame = "left_os1/os1_lidar")
+    {
+        marker_on_ = on;
+        marker_.setFixedFrame(fixed_frame);
+    }
+    void setMarkerParams(const urf_marker_params& p) { marker_.setParams(p); }
+    /* nullptr when the reference would not publish a MarkerArray for the last sweep */
+    const MarkerArray* road_marker() const { return marker_published_ ? &markers_ : nullptr; }
+
     /* main.cpp:4-34 paramsCallback: callable between scans */
     void setParams(const urf_params& p);
     urf_params params() const;
@@ -111,6 +123,9 @@ private:
     void split(const PointXYZI* pts, uint32_t n, const Header& h);
     urf_ctx* ctx_ = nullptr;
     bool reference_order_ = false;
+    bool marker_on_ = false, marker_published_ = false;
+    MarkerBuilder marker_;
+    MarkerArray markers_;
     std::vector<uint8_t> labels_;
     urf_scan_info info_{};
     PointCloud road_, curb_, roi_, road_probably_;

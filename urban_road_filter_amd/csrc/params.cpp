@@ -44,6 +44,18 @@ extern "C" int urf_default_params(urf_params* p)
     return URF_OK;
 }
 
+extern "C" int urf_default_marker_params(urf_marker_params* p)
+{
+    if (!p)
+        return URF_ERR_INVALID_ARG;
+    p->size = sizeof(urf_marker_params);
+    p->simple_poly_allow = 1;    /* cfg:76 */
+    p->poly_s_param = 0.7f;      /* cfg:79 */
+    p->poly_z_manual = -1.5f;    /* cfg:82 */
+    p->poly_z_avg_allow = 1;     /* cfg:85 */
+    return URF_OK;
+}
+
 int urf_validate_params(const urf_params* p)
 {
     if (!p || p->size != sizeof(urf_params))

@@ -36,6 +36,10 @@ struct urf_ctx {
     unsigned long long* ord_keys = nullptr;   /* lazily: scratch of urf_ordered_indices, max_points each */
     uint32_t* ord_pos = nullptr;
     uint32_t* ord_lists = nullptr;  /* 3 x max_points + 4 */
+    float* mk_d = nullptr;          /* lazily: scratch of urf_marker_points */
+    uint32_t* mk_pos = nullptr;
+    uint8_t* mk_red = nullptr;
+    float* mk_out = nullptr;        /* 361 x 4 floats + 1 count */
     float* d_newY = nullptr;
     float* d_inv_i = nullptr;
     urf_beam* d_beams = nullptr;
@@ -214,6 +218,12 @@ extern "C" int urf_destroy(urf_ctx* c)
         (void)hipFree(p);
     if (c->raw)
         (void)hipFree(c->raw);
+    if (c->mk_d) {
+        (void)hipFree(c->mk_d);
+        (void)hipFree(c->mk_pos);
+        (void)hipFree(c->mk_red);
+        (void)hipFree(c->mk_out);
+    }
     if (c->ord_keys) {
         (void)hipFree(c->ord_keys);
         (void)hipFree(c->ord_pos);
@@ -564,6 +574,45 @@ extern "C" int urf_ordered_indices(urf_ctx* c, uint32_t scan, uint32_t* road, ui
     counts[0] = h[0];
     counts[1] = h[1];
     counts[2] = h[2];
+    return URF_OK;
+}
+
+extern "C" int urf_marker_points(urf_ctx* c, uint32_t scan, float* pts, uint32_t* count)
+{
+    if (!c || !pts || !count || scan >= c->last_scans || !c->last_labels)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    const size_t cells = (size_t)URF_MAX_CHANNELS * URF_DEG_CELLS;
+    if (!c->mk_d) {
+        void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
+        URF_HIP(c, hipMalloc(&p0, cells * sizeof(float)));
+        URF_HIP(c, hipMalloc(&p1, cells * sizeof(uint32_t)));
+        URF_HIP(c, hipMalloc(&p2, cells));
+        URF_HIP(c, hipMalloc(&p3, (URF_DEG_CELLS * 4 + 4) * sizeof(float)));
+        c->mk_d = (float*)p0;
+        c->mk_pos = (uint32_t*)p1;
+        c->mk_red = (uint8_t*)p2;
+        c->mk_out = (float*)p3;
+    }
+    urf_kargs a = c->k;
+    a.offsets = c->last_offsets;
+    a.n_per_scan = c->last_n;
+    a.n_scans = c->last_scans;
+    a.labels = const_cast<uint8_t*>(c->last_labels);
+    hipStream_t st = c->stream;
+    unsigned* d_cnt = (unsigned*)(c->mk_out + URF_DEG_CELLS * 4);
+    hipLaunchKernelGGL(k_marker_ring, dim3((unsigned)c->dp.p.channels), dim3(256), 0, st, a, c->dp, scan, c->mk_d, c->mk_pos, c->mk_red);
+    hipLaunchKernelGGL(k_marker_bins, dim3(1), dim3(384), 0, st, a, c->dp, scan, c->mk_d, c->mk_pos, c->mk_red, c->mk_out, d_cnt);
+    URF_HIP(c, hipGetLastError());
+    std::vector<float> h(URF_DEG_CELLS * 4 + 4);
+    URF_HIP(c, hipMemcpyAsync(h.data(), c->mk_out, h.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    URF_HIP(c, hipStreamSynchronize(st));
+    uint32_t n = 0;
+    std::memcpy(&n, &h[URF_DEG_CELLS * 4], sizeof(n));
+    if (n > URF_DEG_CELLS)
+        return URF_ERR_HIP;
+    std::memcpy(pts, h.data(), (size_t)n * 4 * sizeof(float));
+    *count = n;
     return URF_OK;
 }
 

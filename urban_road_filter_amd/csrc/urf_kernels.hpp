@@ -1987,6 +1987,119 @@ __global__ __launch_bounds__(1024) void k_ordered_lists(urf_kargs a, urf_dev_par
 }
 
 /* ------------------------------------------------------------------------- */
+/* road_marker: marker points                                                  */
+/* ------------------------------------------------------------------------- */
+/* lidar_segmentation.cpp:305-351 scans, for every integer degree, all rings in order and every ring
+ * in ascending azimuth, remembers the farthest road point of that degree and stops at the first point
+ * of that degree that is not road.  Per ring and degree that is: the smallest azimuth of a non-road
+ * point (where the scan of this ring stops, and with it the whole scan), and the farthest road point
+ * in front of it (ties: the first in azimuth order).  k_marker_ring builds these two tables per ring
+ * in LDS (no sort needed), k_marker_bins walks the rings per degree. */
+__global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params dp, unsigned s,
+                                                     float* m_d, unsigned* m_pos, uint8_t* m_red)
+{
+    __shared__ int nrmin[URF_DEG_CELLS];
+    __shared__ unsigned long long best[URF_DEG_CELLS];
+    __shared__ unsigned bestpos[URF_DEG_CELLS];
+    const unsigned c = blockIdx.x, tid = threadIdx.x;
+    const urf_scan_info in = a.info[s];
+    if (in.status != URF_OK || c >= in.n_rings)
+        return;
+    unsigned off, len;
+    urf_scan_range(a, s, off, len);
+    const unsigned C = (unsigned)dp.p.channels;
+    const unsigned n = a.ring_cnt[(size_t)s * C + c];
+    const unsigned base = off + a.ring_off[(size_t)s * (C + 1) + c];
+    for (unsigned i = tid; i < URF_DEG_CELLS; i += 256) {
+        nrmin[i] = URF_INT_NONE_MIN;
+        best[i] = 0;
+        bestpos[i] = 0xffffffffu;
+    }
+    __syncthreads();
+    /* pass 1: where does the scan of this ring stop in each degree (:318) */
+    for (unsigned p = tid; p < n; p += 256) {
+        const float az = a.raz[base + p];
+        const unsigned lab = a.labels[off + a.rsrc[base + p]] & URF_LABEL_MASK;
+        if (az == az && lab != URF_LABEL_ROAD) {
+            int bin = (int)__builtin_floorf(az);
+            bin = bin < 0 ? 0 : (bin > 360 ? 360 : bin);
+            atomicMin(&nrmin[bin], (int)urf_fbits(az));
+        }
+    }
+    __syncthreads();
+    /* pass 2: farthest road point in front of it (:325-335); key = (d, first in azimuth order) */
+    for (int pass = 0; pass < 2; pass++) {
+        for (unsigned p = tid; p < n; p += 256) {
+            const float az = a.raz[base + p];
+            const unsigned lab = a.labels[off + a.rsrc[base + p]] & URF_LABEL_MASK;
+            if (az == az && lab == URF_LABEL_ROAD) {
+                int bin = (int)__builtin_floorf(az);
+                bin = bin < 0 ? 0 : (bin > 360 ? 360 : bin);
+                if ((int)urf_fbits(az) < nrmin[bin]) {
+                    const float x = a.rx[base + p], y = a.ry[base + p];
+                    const float d = (float)__builtin_sqrt((double)(0.f - x) * (double)(0.f - x) + (double)(0.f - y) * (double)(0.f - y));
+                    if (d > 0.0f) {   /* "d > maxDistanceRoad" with maxDistanceRoad starting at 0 */
+                        const unsigned long long key = ((unsigned long long)urf_fbits(d) << 32) | (0xffffffffu - urf_fbits(az));
+                        if (pass == 0)
+                            atomicMax(&best[bin], key);
+                        else if (key == best[bin])
+                            atomicMin(&bestpos[bin], p);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (unsigned i = tid; i < URF_DEG_CELLS; i += 256) {
+        const size_t o = (size_t)c * URF_DEG_CELLS + i;
+        m_d[o] = __uint_as_float((unsigned)(best[i] >> 32));
+        m_pos[o] = bestpos[i] == 0xffffffffu ? 0xffffffffu : base + bestpos[i];
+        m_red[o] = nrmin[i] != URF_INT_NONE_MIN;
+    }
+}
+
+__global__ __launch_bounds__(384) void k_marker_bins(urf_kargs a, urf_dev_params dp, unsigned s, const float* m_d,
+                                                     const unsigned* m_pos, const uint8_t* m_red, float* out, unsigned* count)
+{
+    __shared__ unsigned wsum[6];
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const urf_scan_info in = a.info[s];
+    const unsigned nR = in.status == URF_OK ? in.n_rings : 0;
+    unsigned id = 0xffffffffu;
+    float red = 0.f;
+    if (tid <= 360) {
+        float maxd = 0.f;
+        for (unsigned j = 0; j < nR; j++) {
+            const size_t o = (size_t)j * URF_DEG_CELLS + tid;
+            if (m_pos[o] != 0xffffffffu && m_d[o] > maxd) {   /* :329 */
+                maxd = m_d[o];
+                id = m_pos[o];
+            }
+            if (m_red[o]) {                                  /* :318-321, 338-339 */
+                red = 1.f;
+                break;
+            }
+        }
+    }
+    const bool valid = id != 0xffffffffu;                    /* :343 */
+    const unsigned long long m = __ballot(valid);
+    if (lane == 0)
+        wsum[wave] = __popcll(m);
+    __syncthreads();
+    unsigned pre = __popcll(m & ((1ull << lane) - 1ull));
+    for (unsigned w = 0; w < wave; w++)
+        pre += wsum[w];
+    if (valid) {
+        out[4 * pre + 0] = a.rx[id];
+        out[4 * pre + 1] = a.ry[id];
+        out[4 * pre + 2] = a.rz[id];
+        out[4 * pre + 3] = red;
+    }
+    if (tid == 0)
+        *count = wsum[0] + wsum[1] + wsum[2] + wsum[3] + wsum[4] + wsum[5];
+}
+
+/* ------------------------------------------------------------------------- */
 /* self test                                                                   */
 /* ------------------------------------------------------------------------- */
 /* urf_div_pi(a) == a / M_PI for every float a in [0, 600] (bit patterns 0..0x44160000) */
