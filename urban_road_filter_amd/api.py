@@ -67,7 +67,8 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(_HERE, "liburf_hip.so")
+    # URF_LIB_PATH: tuning experiments load an alternative build of the same library
+    return os.environ.get("URF_LIB_PATH") or os.path.join(_HERE, "liburf_hip.so")
 
 
 def lib():

@@ -34,7 +34,7 @@
  * doubles s below this one: sqrt and the rounding to float are monotone, the threshold is the
  * smallest double whose rounded root reaches 5.0f (found by bisection, tools/check_dist5.c). */
 #define URF_DIST5_SQ 0x1.8ffffd800000fp+4
-#define URF_RING_THREADS 256
+#define URF_RING_THREADS 128
 #define URF_LABEL_THREADS 384
 #define URF_STAR_THREADS 64
 #define URF_INGEST_THREADS 256       /* tile kernels that need no big LDS tile run 8 workgroups per CU */
