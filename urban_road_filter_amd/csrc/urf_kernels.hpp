@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
 #define URF_WALK_CHUNK 16
 __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp)
 {
-    __shared__ float tS[64][URF_WALK_CHUNK + 1], tG[64][URF_WALK_CHUNK + 1];
+    __shared__ float tS[2][64][URF_WALK_CHUNK + 1], tG[2][64][URF_WALK_CHUNK + 1];
     __shared__ unsigned sbase[64], slast[64];
     const unsigned K = (unsigned)dp.p.sectors;
     const unsigned s = blockIdx.y, lane = threadIdx.x;
@@ -1211,29 +1211,49 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
     }
     __syncthreads();
 
+    /* the next 16 steps of all 64 sectors: 32 loads in flight, then parked in registers until the
+     * LDS buffer they belong to is free (double buffering: chunk c+1 loads while chunk c is walked) */
+    float vs[16], vg[16];
+    auto fetch = [&](unsigned c0) {
+#pragma unroll
+        for (unsigned r = 0; r < 16; r++) {
+            const unsigned sec = r * 4 + (lane >> 4), e = c0 + (lane & 15);
+            const bool on = e >= 1 && e <= slast[sec];
+            vs[r] = on ? a.wslp[sbase[sec] + e] : 0.f;
+            vg[r] = on ? a.wg[sbase[sec] + e] : 0.f;
+        }
+    };
+    auto park = [&](unsigned buf) {
+#pragma unroll
+        for (unsigned r = 0; r < 16; r++) {
+            const unsigned sec = r * 4 + (lane >> 4);
+            tS[buf][sec][lane & 15] = vs[r];
+            tG[buf][sec][lane & 15] = vg[r];
+        }
+    };
+
     const float kdev = dp.p.kdev_param, slope_param = dp.slope_param;
     const int dmin = dp.p.dmin_param;
     float avg = 0.f, dev = 0.f, nan = 0.f;
     unsigned hit_i = 0;              /* sorted index of the sector's curb point, 0 = none */
     bool running = last >= 1;
-    for (unsigned c0 = 0; c0 <= maxlast; c0 += URF_WALK_CHUNK) {
+    fetch(0);
+    park(0);
+    __syncthreads();
+    unsigned buf = 0;
+    for (unsigned c0 = 0; c0 <= maxlast; c0 += URF_WALK_CHUNK, buf ^= 1u) {
         if (!__any(running))
             break;
-        for (unsigned r = 0; r < 64; r += 4) {
-            const unsigned sec = r + (lane >> 4), e = c0 + (lane & 15);
-            if (e >= 1 && e <= slast[sec]) {
-                tS[sec][lane & 15] = a.wslp[sbase[sec] + e];
-                tG[sec][lane & 15] = a.wg[sbase[sec] + e];
-            }
-        }
-        __syncthreads();
+        const bool more = c0 + URF_WALK_CHUNK <= maxlast;
+        if (more)
+            fetch(c0 + URF_WALK_CHUNK);
         /* all lanes step through the chunk in lockstep (i is wave-uniform); a lane that is past
          * its sector's end or has found its curb point just stops updating its state */
 #pragma unroll
         for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
             const unsigned i = c0 + j;
             const bool active = running && i >= 1 && i <= last;
-            const float slp = tS[lane][j];
+            const float slp = tS[buf][lane][j];
             const bool isnan = slp != slp;
             if (__any(active && (isnan || nan != 0.0f))) {
                 /* rare: a NaN slope has been seen (star_shaped_search.cpp:131-132, 135-140 with nan > 0) */
@@ -1264,7 +1284,7 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
                 dev = active ? nd : dev;
             }
             const bool h = slp > slope_param ||                /* :142-143 */
-                           ((int)i > dmin && (slp * slp - avg * avg) * kdev * tG[lane][j] > dev);
+                           ((int)i > dmin && (slp * slp - avg * avg) * kdev * tG[buf][lane][j] > dev);
             if (active && h) {
                 hit_i = i;                                     /* :146 */
                 running = false;
@@ -1272,6 +1292,8 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
         }
         if (c0 + URF_WALK_CHUNK > last)
             running = false;
+        if (more)
+            park(buf ^ 1u);
         __syncthreads();
     }
     const int hit = hit_i ? (int)a.ssrt[base + hit_i] : -1;
