@@ -30,7 +30,8 @@ def cpu_ref(cfg, seeds, repeat):
     p = O.cfg_params(cfg)
     scans = [O.cfg_cloud(cfg, s) for s in seeds]
     _, infos, ms, ms_first = O.run_a(scans, p, repeat=repeat, timeout=1800)
-    return {"ms_per_scan": ms, "ms_first_call": ms_first, "scans_per_s": 1000.0 / ms, "info": infos[0]}
+    info = {k: int(v) for k, v in infos[0].items() if not hasattr(v, "shape") and v is not None}
+    return {"ms_per_scan": ms, "ms_first_call": ms_first, "scans_per_s": 1000.0 / ms, "info": info}
 
 
 def main(tag):
