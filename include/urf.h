@@ -267,6 +267,11 @@ int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
  * 3-operation division by pi against the IEEE division, exhaustively over all
  * floats in [0, 600]).  *n_mismatches must come back 0.  Synchronous. */
 int urf_selftest(urf_ctx* ctx, uint64_t* n_mismatches);
+/* Measured error of the float fast paths that settle ring and sector decisions (k_ingest) over
+ * n_samples pseudo-random points: err[0] = max |approx - exact| of the vertical angle [deg],
+ * err[1] of the polar angle [rad], err[2] of the scaled polar angle.  They must stay below the
+ * margins the kernels use (3e-4, 2e-6, 2.5e-4).  Synchronous. */
+int urf_selftest_fast(urf_ctx* ctx, uint64_t n_samples, float* err);
 const char* urf_strerror(int status);
 const char* urf_last_error(const urf_ctx* ctx);   /* text of the last HIP failure */
 int urf_abi_version(void);

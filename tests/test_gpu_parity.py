@@ -401,6 +401,14 @@ def test_device_arithmetic_selftest(ctx_big):
     assert ctx_big.selftest() == 0
 
 
+def test_fast_path_error_bounds(ctx_big):
+    """Ring and sector are decided from float approximations of the angles wherever the
+    approximation is clear of every decision boundary by a margin (urf_device.hpp); the margins
+    (3e-4 deg, 2e-6 rad, 2.5e-4) must dominate the error measured on 2^28 pseudo-random points."""
+    ev, ea, eu = ctx_big.selftest_fast(1 << 28)
+    assert ev < 1.0e-4 and ea < 0.7e-6 and eu < 0.85e-4, (ev, ea, eu)
+
+
 def test_capacity_and_argument_errors():
     with u.Context(4096, 2) as ctx:
         x, y, z = [a[:8192] for a in O.cfg_cloud("cfg2", 1)]

@@ -102,6 +102,7 @@ def lib():
         "urf_enable_stage_capture": [vp, C.c_int],
         "urf_enable_kernel_timing": [vp, C.c_int],
         "urf_selftest": [vp, C.c_void_p],
+        "urf_selftest_fast": [vp, C.c_uint64, C.c_void_p],
         "urf_kernel_timing": [vp, C.c_void_p, C.c_void_p],
         "urf_synth_cloud": [C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, fp, fp, fp],
         "urf_abi_version": [],
@@ -215,6 +216,12 @@ class Context:
         self._check(self._lib.urf_enable_stage_capture(self._h, int(on)), "urf_enable_stage_capture")
 
     NUM_KERNELS = 8
+
+    def selftest_fast(self, n_samples=1 << 27):
+        """max |approx - exact| of the float fast paths: (vertical angle [deg], polar angle [rad], fi*Kfi)."""
+        err = np.zeros(3, np.float32)
+        self._check(self._lib.urf_selftest_fast(self._h, n_samples, err.ctypes.data), "urf_selftest_fast")
+        return tuple(float(v) for v in err)
 
     def selftest(self):
         n = C.c_uint64(0)

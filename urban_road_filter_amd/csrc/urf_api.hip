@@ -304,6 +304,23 @@ extern "C" int urf_selftest(urf_ctx* c, uint64_t* n_mismatches)
     return URF_OK;
 }
 
+extern "C" int urf_selftest_fast(urf_ctx* c, uint64_t n_samples, float* err)
+{
+    if (!c || !err)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    unsigned* d = nullptr;
+    URF_HIP(c, hipMalloc((void**)&d, 3 * sizeof(unsigned)));
+    URF_HIP(c, hipMemsetAsync(d, 0, 3 * sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(k_selftest_fast, dim3(c->n_cus * 8), dim3(256), 0, c->stream, (unsigned long long)n_samples, c->dp.Kfi, d);
+    hipError_t e = hipMemcpyAsync(err, d, 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    URF_HIP(c, e);
+    return URF_OK;
+}
+
 extern "C" int urf_enable_kernel_timing(urf_ctx* c, int on)
 {
     if (!c)

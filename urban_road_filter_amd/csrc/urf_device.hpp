@@ -133,6 +133,74 @@ __device__ __forceinline__ unsigned urf_sector(float x, float y, float Kfi, unsi
     return ((unsigned)f >= sectors) ? 0u : (unsigned)f;
 }
 
+/* ---- float fast paths ---------------------------------------------------------
+ * Ring and sector of a point are DECISIONS (which table entry lies within `interval`, which
+ * integer the scaled polar angle truncates to).  A float approximation of the angle with a known
+ * error bound settles them whenever the approximation is farther from every decision boundary
+ * than the bound; only the rare point inside such a margin takes the reference's exact
+ * float/double sequence.  The result is identical by construction, the f64 square root, division
+ * and polynomials are skipped for almost every point.
+ *
+ * urf_fast_atan2f: |result - atan2(y, x)| <= 6e-7 rad (v_rcp_f32 is 1 ulp, degree-4 minimax of
+ * (atan t - t)/t^3 in t^2 is 1e-9, the rest is float rounding); urf_selftest measures it on the
+ * device and tests/ assert it stays below a third of the margins used. */
+#define URF_FAST_ATAN_ERR 2.0e-6f            /* claimed bound, rad */
+__device__ __forceinline__ float urf_fast_atan2f(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const bool big = t > 0.41421357f;
+    const float tt = big ? (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f) : t;
+    const float v = tt * tt;
+    float q = -0.06451718869358958f;
+    q = __builtin_fmaf(q, v, 0.10743668324830098f);
+    q = __builtin_fmaf(q, v, -0.14263949753605723f);
+    q = __builtin_fmaf(q, v, 0.1999954031495797f);
+    q = __builtin_fmaf(q, v, -0.33333331760434554f);
+    float r = __builtin_fmaf(tt * v, q, tt);
+    if (big)
+        r += 0.78539816339744831f;
+    if (ay > ax)
+        r = 1.57079632679489662f - r;
+    if (x < 0.0f)
+        r = 3.14159265358979324f - r;
+    return y < 0.0f ? -r : r;
+}
+
+/* Vertical angle [deg] of lidar_segmentation.cpp:148-166 (angle from the -z axis), approximately.
+ * The reference's own value deviates from the true angle by up to ~1.2e-7 * |z|/rho rad (it rounds
+ * |z|/d to float before the acos), hence the restriction to |z| <= 4 rho; within it
+ * |approx - reference| <= 3e-4 deg (URF_FAST_VALPHA_ERR, measured by urf_selftest). */
+#define URF_FAST_VALPHA_ERR 3.0e-4f
+__device__ __forceinline__ bool urf_fast_vertical_angle(float x, float y, float z, float* out)
+{
+    const float rho = __builtin_sqrtf(x * x + y * y);
+    if (!(rho > 0.0f) || !(__builtin_fabsf(z) <= 4.0f * rho))
+        return false;
+    *out = urf_fast_atan2f(rho, -z) * 57.295779513082323f;
+    return true;
+}
+
+/* Sector of star_shaped_search.cpp:164-171 when the scaled polar angle is clear of an integer by
+ * more than URF_FAST_SECTOR_ERR (reference: two float roundings of the angle, one of the product:
+ * <= 5e-5; approximation: URF_FAST_ATAN_ERR * Kfi + rounding <= 1.4e-4); -1 = undecided. */
+#define URF_FAST_SECTOR_ERR 2.5e-4f
+__device__ __forceinline__ int urf_fast_sector(float x, float y, float Kfi, unsigned sectors)
+{
+    if (x == 0.0f && y == 0.0f)
+        return -1;
+    float fi = urf_fast_atan2f(y, x);
+    if (fi < 0.0f)
+        fi += 6.28318530717958648f;
+    const float u = fi * Kfi;
+    const float f = __builtin_floorf(u);
+    const float fr = u - f;
+    if (!(fr > URF_FAST_SECTOR_ERR && fr < 1.0f - URF_FAST_SECTOR_ERR) || f < 0.0f || f >= (float)sectors)
+        return -1;
+    return (int)f;
+}
+
 /* star_shaped_search.cpp:73-107: is the point inside the rectangular beam of its sector */
 __device__ __forceinline__ bool urf_in_beam(const urf_beam& b, float x, float y)
 {

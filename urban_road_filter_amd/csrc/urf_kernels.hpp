@@ -118,22 +118,47 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
         float va = -1.0f;
         unsigned key = URF_SEC_NONE, rkey = URF_RING_NONE;
         if (roi) {
-            va = urf_vertical_angle(x, y, z);
-            /* lidar_segmentation.cpp:226-233: first sorted table entry within `interval`.
-             * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are contiguous
-             * and the first one is found by bisection with the very same float predicate. */
-            unsigned lo = 0, hi = nR;
-            while (lo < hi) {
-                const unsigned mid = (lo + hi) >> 1;
-                if (tab[mid] - va >= -interval)
-                    hi = mid;
-                else
-                    lo = mid + 1;
+            /* ring: float fast path (urf_device.hpp) unless the stage capture wants the exact angle */
+            bool decided = false;
+            float vt;
+            if (!a.valpha && urf_fast_vertical_angle(x, y, z, &vt)) {
+                /* with |vt - alpha| <= e: entries below vt - interval - e surely do not match, an entry
+                 * within interval - e surely does, one beyond interval + e surely does not */
+                const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;   /* + rounding of fl(angle[j] - alpha) */
+                unsigned lo = 0, hi = nR;
+                while (lo < hi) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if (tab[mid] - vt >= -(interval + e))
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                if (lo == nR || tab[lo] - vt > interval + e) {
+                    decided = true;                       /* no entry can match */
+                } else if (__builtin_fabsf(tab[lo] - vt) <= interval - e) {
+                    decided = true;                       /* the first candidate surely matches */
+                    rkey = lo;
+                }
             }
-            if (lo < nR && __builtin_fabsf(tab[lo] - va) <= interval)
-                rkey = lo;
+            if (!decided) {
+                va = urf_vertical_angle(x, y, z);
+                /* lidar_segmentation.cpp:226-233: first sorted table entry within `interval`.
+                 * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are contiguous
+                 * and the first one is found by bisection with the very same float predicate. */
+                unsigned lo = 0, hi = nR;
+                while (lo < hi) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if (tab[mid] - va >= -interval)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                if (lo < nR && __builtin_fabsf(tab[lo] - va) <= interval)
+                    rkey = lo;
+            }
             if (star) {
-                key = urf_sector(x, y, dp.Kfi, K);
+                const int fs = urf_fast_sector(x, y, dp.Kfi, K);
+                key = fs >= 0 ? (unsigned)fs : urf_sector(x, y, dp.Kfi, K);
                 if (dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
                     key = URF_SEC_NONE;
             }
@@ -2137,6 +2162,44 @@ __global__ __launch_bounds__(256) void k_selftest_div_pi(unsigned long long* mis
     }
     if (bad)
         atomicAdd(mismatches, bad);
+}
+
+/* max |fast - exact| of the float fast paths over pseudo-random points: out[0] = vertical angle
+ * [deg] (float bits), out[1] = polar angle [rad], out[2] = scaled polar angle fi*Kfi */
+__global__ __launch_bounds__(256) void k_selftest_fast(unsigned long long n, float Kfi, unsigned* out)
+{
+    float ev = 0.f, ea = 0.f, eu = 0.f;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long h = i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+        float c[3];
+        for (int k = 0; k < 3; k++) {
+            h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27; h *= 0x94D049BB133111EBull; h ^= h >> 31;
+            c[k] = ((float)(h >> 40) * (1.0f / 16777216.0f) - 0.5f) * ((i & 3) == 0 ? 400.0f : 20.0f);
+        }
+        const float x = c[0], y = c[1], z = c[2] * 0.25f;
+        float vt;
+        if (urf_fast_vertical_angle(x, y, z, &vt)) {
+            const float d = __builtin_fabsf(vt - urf_vertical_angle(x, y, z));
+            ev = d > ev ? d : ev;
+        }
+        if (x != 0.f || y != 0.f) {
+            float fe = urf_atan2f(y, x);
+            const float fa = urf_fast_atan2f(y, x);
+            const float da = __builtin_fabsf(fa - fe);
+            ea = da > ea ? da : ea;
+            if (fe < 0.0f)
+                fe = (float)((double)fe + 2.0 * URF_PI_D);
+            float ff = fa < 0.0f ? fa + 6.28318530717958648f : fa;
+            /* near the wrap the two may sit on opposite ends: the fast path never decides there */
+            const float du = __builtin_fabsf(ff * Kfi - fe * Kfi);
+            if (du < 180.0f)
+                eu = du > eu ? du : eu;
+        }
+    }
+    atomicMax(&out[0], __float_as_uint(ev));
+    atomicMax(&out[1], __float_as_uint(ea));
+    atomicMax(&out[2], __float_as_uint(eu));
 }
 
 #endif /* URF_KERNELS_HPP */
