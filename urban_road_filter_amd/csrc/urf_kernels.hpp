@@ -209,7 +209,7 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
  *   serial   one wave takes the next 64 points; a new leader costs one ballot
  *            (an organised sweep fills the table within its first firing);
  *   scan     when a 64-point step brought no new leader, all four waves look
- *            ahead 1024 points at a time for the first point that no leader
+ *            ahead 2048 points at a time for the first point that no leader
  *            matches (usually there is none: sweeps whose region of interest
  *            cuts off the outer rings never fill the table).
  * Matching "is there a leader within interval" is a bisection in a sorted copy
@@ -230,6 +230,31 @@ __device__ __forceinline__ bool urf_leader_match(const float* SL, unsigned nmatc
     return lo < nmatch && __builtin_fabsf(SL[lo] - v) <= interval;
 }
 
+/* Same question for a point, settled on the float approximation of its vertical angle whenever
+ * that is clear of the +-interval boundaries by the approximation's error (urf_device.hpp). */
+__device__ __forceinline__ bool urf_leader_match_point(const float* SL, unsigned nmatch, float x, float y, float z,
+                                                       float interval)
+{
+    float vt;
+    if (urf_fast_vertical_angle(x, y, z, &vt)) {
+        const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;
+        unsigned lo = 0, hi = nmatch;
+        while (lo < hi) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (SL[mid] - vt >= -(interval + e))
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        if (lo == nmatch || SL[lo] - vt > interval + e)
+            return false;
+        if (__builtin_fabsf(SL[lo] - vt) <= interval - e)
+            return true;
+    }
+    return urf_leader_match(SL, nmatch, urf_vertical_angle(x, y, z), interval);
+}
+
+#define URF_TABLE_SCAN_PPT 8
 __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params dp)
 {
     __shared__ float L[URF_MAX_CHANNELS];    /* leaders in insertion order (the reference's angle[]) */
@@ -318,14 +343,21 @@ __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params 
         const unsigned nmatch = sh_nmatch;
         while (pos < len) {
             unsigned first = 0xffffffffu;
+            float px[URF_TABLE_SCAN_PPT], py[URF_TABLE_SCAN_PPT], pz[URF_TABLE_SCAN_PPT];
 #pragma unroll
-            for (unsigned q = 0; q < 4; q++) {
+            for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++) {   /* all loads in flight first */
                 const unsigned i = pos + q * 256 + tid;
-                if (i < len && first == 0xffffffffu) {
-                    const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
-                    if (urf_in_roi(dp.p, x, y, z) && !urf_leader_match(SL, nmatch, urf_vertical_angle(x, y, z), interval))
-                        first = i;
-                }
+                const bool on = i < len;
+                px[q] = on ? a.x[off + i] : 0.f;
+                py[q] = on ? a.y[off + i] : 0.f;
+                pz[q] = on ? a.z[off + i] : 0.f;
+            }
+#pragma unroll
+            for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++) {
+                const unsigned i = pos + q * 256 + tid;
+                if (i < len && first == 0xffffffffu && urf_in_roi(dp.p, px[q], py[q], pz[q]) &&
+                    !urf_leader_match_point(SL, nmatch, px[q], py[q], pz[q], interval))
+                    first = i;
             }
             for (int o = 32; o > 0; o >>= 1) {
                 const unsigned w = __shfl_xor(first, o);
@@ -342,7 +374,7 @@ __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params 
                 pos = m;   /* the serial step resumes exactly there */
                 break;
             }
-            pos += 1024;
+            pos += 256 * URF_TABLE_SCAN_PPT;
         }
     }
     __syncthreads();
