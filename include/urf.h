@@ -238,8 +238,10 @@ typedef enum urf_stage {
                                  (n_rings = not blocked, -1 = beam not cast) */
 } urf_stage;
 int urf_read_stage(urf_ctx* ctx, urf_stage what, uint32_t scan, void* host_dst, size_t bytes);
-/* URF_STAGE_VALPHA and URF_STAGE_RANGE2D need one extra store per point each;
- * they are only kept when capture is on (default off). */
+/* URF_STAGE_VALPHA, URF_STAGE_AZIMUTH and URF_STAGE_RANGE2D are only available when capture is on
+ * (default off): without it the pipeline settles most ring / sector / road decisions on float
+ * approximations of these angles and never evaluates the reference's exact value for such a
+ * point; with it every point takes the exact sequence and the values are stored. */
 int urf_enable_stage_capture(urf_ctx* ctx, int on);
 
 /* ---- per-kernel timing (benchmark) ------------------------------------------
@@ -269,8 +271,9 @@ int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
 int urf_selftest(urf_ctx* ctx, uint64_t* n_mismatches);
 /* Measured error of the float fast paths that settle ring and sector decisions (k_ingest) over
  * n_samples pseudo-random points: err[0] = max |approx - exact| of the vertical angle [deg],
- * err[1] of the polar angle [rad], err[2] of the scaled polar angle.  They must stay below the
- * margins the kernels use (3e-4, 2e-6, 2.5e-4).  Synchronous. */
+ * err[1] of the polar angle [rad], err[2] of the scaled polar angle, err[3] of the azimuth [deg]
+ * (k_ring / k_label).  They must stay below the margins the kernels use (3e-4, 2e-6, 2.5e-4,
+ * 5e-4).  err has room for 4 floats.  Synchronous. */
 int urf_selftest_fast(urf_ctx* ctx, uint64_t n_samples, float* err);
 const char* urf_strerror(int status);
 const char* urf_last_error(const urf_ctx* ctx);   /* text of the last HIP failure */

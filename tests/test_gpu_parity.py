@@ -404,9 +404,9 @@ def test_device_arithmetic_selftest(ctx_big):
 def test_fast_path_error_bounds(ctx_big):
     """Ring and sector are decided from float approximations of the angles wherever the
     approximation is clear of every decision boundary by a margin (urf_device.hpp); the margins
-    (3e-4 deg, 2e-6 rad, 2.5e-4) must dominate the error measured on 2^28 pseudo-random points."""
-    ev, ea, eu = ctx_big.selftest_fast(1 << 28)
-    assert ev < 1.0e-4 and ea < 0.7e-6 and eu < 0.85e-4, (ev, ea, eu)
+    (3e-4 deg, 2e-6 rad, 2.5e-4, 5e-4 deg) must dominate the error measured on 2^28 pseudo-random points."""
+    ev, ea, eu, ez = ctx_big.selftest_fast(1 << 28)
+    assert ev < 1.0e-4 and ea < 0.7e-6 and eu < 0.85e-4 and ez < 1.7e-4, (ev, ea, eu, ez)
 
 
 def test_capacity_and_argument_errors():

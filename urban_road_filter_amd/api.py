@@ -218,8 +218,8 @@ class Context:
     NUM_KERNELS = 8
 
     def selftest_fast(self, n_samples=1 << 27):
-        """max |approx - exact| of the float fast paths: (vertical angle [deg], polar angle [rad], fi*Kfi)."""
-        err = np.zeros(3, np.float32)
+        """max |approx - exact| of the float fast paths: (vertical angle [deg], polar angle [rad], fi*Kfi, azimuth [deg])."""
+        err = np.zeros(4, np.float32)
         self._check(self._lib.urf_selftest_fast(self._h, n_samples, err.ctypes.data), "urf_selftest_fast")
         return tuple(float(v) for v in err)
 

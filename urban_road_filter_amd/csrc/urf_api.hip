@@ -310,10 +310,10 @@ extern "C" int urf_selftest_fast(urf_ctx* c, uint64_t n_samples, float* err)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
     unsigned* d = nullptr;
-    URF_HIP(c, hipMalloc((void**)&d, 3 * sizeof(unsigned)));
-    URF_HIP(c, hipMemsetAsync(d, 0, 3 * sizeof(unsigned), c->stream));
+    URF_HIP(c, hipMalloc((void**)&d, 4 * sizeof(unsigned)));
+    URF_HIP(c, hipMemsetAsync(d, 0, 4 * sizeof(unsigned), c->stream));
     hipLaunchKernelGGL(k_selftest_fast, dim3(c->n_cus * 8), dim3(256), 0, c->stream, (unsigned long long)n_samples, c->dp.Kfi, d);
-    hipError_t e = hipMemcpyAsync(err, d, 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipMemcpyAsync(err, d, 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess)
         e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
@@ -690,7 +690,7 @@ extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* h
     case URF_STAGE_AZIMUTH:
     case URF_STAGE_RANGE2D:
     case URF_STAGE_DETECT: {
-        if (what == URF_STAGE_RANGE2D && !c->debug_rd2) return URF_ERR_INVALID_ARG;
+        if (what != URF_STAGE_DETECT && !c->debug_rd2) return URF_ERR_INVALID_ARG;   /* exact values need the capture */
         const size_t esz = what == URF_STAGE_DETECT ? 1 : 4;
         if (bytes < len * esz) return URF_ERR_INVALID_ARG;
         std::memset(host_dst, 0, len * esz);
@@ -704,7 +704,7 @@ extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* h
             if ((rc = fetch(c, fl, k.rflag + off, nb)) != URF_OK) return rc;
             uint8_t* o = (uint8_t*)host_dst;
             for (uint32_t p = 0; p < nb; p++)
-                o[src[p]] = fl[p];
+                o[src[p]] = fl[p] & 7u;
         } else {
             std::vector<float> v;
             if ((rc = fetch(c, v, (what == URF_STAGE_AZIMUTH ? k.raz : k.rd2) + off, nb)) != URF_OK) return rc;

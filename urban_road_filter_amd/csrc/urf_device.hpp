@@ -201,6 +201,24 @@ __device__ __forceinline__ int urf_fast_sector(float x, float y, float Kfi, unsi
     return (int)f;
 }
 
+/* Azimuth [deg] of lidar_segmentation.cpp:245-269 (0 at -y, 90 at +x, 180 at +y, 270 at -x),
+ * approximately.  The reference takes asin(|x| / d) with |x| / d rounded to float, which is
+ * ill-conditioned towards the x axis: its own deviation from the true angle is up to
+ * 1.2e-7 * |x|/|y| rad.  Inside |y| >= |x| / 16 that is 1.1e-4 deg, and with the other roundings
+ * |approx - reference| <= URF_FAST_AZ_ERR (measured by urf_selftest_fast); closer to the x axis
+ * the caller takes the exact sequence.  Not valid across the 0/360 seam, which the users treat
+ * as undecided anyway (the approximation is then within the margin of an integer). */
+#define URF_FAST_AZ_ERR 5.0e-4f
+__device__ __forceinline__ bool urf_fast_azimuth(float x, float y, float* out)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    float r = urf_fast_atan2f(x, -y);
+    if (r < 0.0f)
+        r += 6.28318530717958648f;
+    *out = r * 57.295779513082323f;
+    return ay * 16.0f >= ax && ay > 0.0f;
+}
+
 /* star_shaped_search.cpp:73-107: is the point inside the rectangular beam of its sector */
 __device__ __forceinline__ bool urf_in_beam(const urf_beam& b, float x, float y)
 {

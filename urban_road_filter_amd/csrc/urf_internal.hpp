@@ -21,6 +21,7 @@
 #define URF_TILE_THREADS    512     /* k_scatter: one wave per 256 points of the tile */
 #define URF_TILE_GROUPS     (URF_TILE / 64)   /* wave-sized groups per tile */
 
+#define URF_RFLAG_AZ_APPROX 0x80u   /* rflag: raz holds the float approximation, not the reference value */
 #define URF_RING_NONE       0xFFu
 #define URF_SEC_NONE        0x3FFu
 

@@ -1362,27 +1362,149 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
 /* k_ring                                                                      */
 /* ------------------------------------------------------------------------- */
 /* One workgroup per (ring, scan).  The ring's points (input order) stream
- * through LDS in chunks of 1024 with a halo of curbPoints on both sides; every
+ * through LDS in chunks of 512 with a halo of curbPoints on both sides; every
  * thread owns four points per chunk and evaluates for each
  *   - x_zero for the triple (p - cp/2, p, p - cp/2 + cp) that marks p,
  *   - z_zero for the centre p,
  *   - azimuth and planar range of p,
  * then feeds the per-degree curb tables used by the beam march.
  * The star-shaped hits arrive as ring-major positions (k_scatter stores them in
- * the sector-major records), so the ring only has to collect the handful that
- * fall into its own range. */
+ * the sector-major records); the ring collects the handful that fall into its
+ * own range and turns them into one bit per point of the current chunk.
+ *
+ * Two point-to-thread mappings.  With the default curbPoints (5) a thread owns
+ * four CONSECUTIVE points: the 16 z values around them are read once (four
+ * 16-byte LDS loads) and every window maximum of z_zero and both z of x_zero
+ * come out of registers; chunks start at a multiple of four in the global
+ * ring-major index so that azimuth and flags leave as 16- and 4-byte stores.
+ * Any other curbPoints takes the generic mapping (points strided by the
+ * workgroup size, windows read from LDS). */
 #define URF_RING_PPT 4
 #define URF_RING_CHUNK (URF_RING_THREADS * URF_RING_PPT)
+#define URF_RING_PAD 32   /* LDS slots in front of a chunk, >= URF_MAX_CURB_POINTS, multiple of 4 */
+
+struct urf_ring_shared {
+    float xs[URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
+    float ys[URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
+    float zs[URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
+    int cmin[URF_DEG_CELLS], cmax[URF_DEG_CELLS];
+    int q[4];
+    unsigned long long maxs;
+    unsigned hits[URF_MAX_SECTORS + 2];
+    unsigned n_hits;
+    unsigned hb[2][URF_RING_CHUNK / 32];   /* star-hit bit per point of the chunk, double buffered */
+    /* quad mapping: points that need one of the expensive evaluations, compacted */
+    unsigned short cand[URF_RING_CHUNK];   /* chunk-local index | URF_CAND_* << 9 */
+    unsigned n_cand;
+    unsigned flg[URF_RING_CHUNK / 4];      /* byte per chunk point: detector bits | 0x80 = azx valid */
+    float azx[URF_RING_CHUNK];             /* exact azimuth of the points that needed it */
+};
+#define URF_CAND_XZERO 1u   /* passed the height tests of x_zero: angle test pending */
+#define URF_CAND_ZZERO 2u   /* same for z_zero */
+#define URF_CAND_EXACT 4u   /* no float approximation of the azimuth (near the x axis, stage capture) */
+#define URF_CAND_STAR 8u    /* star-shaped hit */
+
+/* x_zero_method.cpp:30-68 for the triple (j, p, j + cp), j = p - cp / 2, given the cheap height
+ * tests passed; lj = LDS slot (xs/ys) of j. */
+__device__ __forceinline__ bool urf_x_zero_angle(const urf_kargs& a, const urf_dev_params& dp, const urf_ring_shared& S,
+                                                 int j, int p, int lj, int cp, float zj, float pz, float z3)
+{
+    const int l3 = lj + cp;
+    const double dx = (double)(S.xs[l3] - S.xs[lj]), dy = (double)(S.ys[l3] - S.ys[lj]);
+    if (!(dx * dx + dy * dy < URF_DIST5_SQ))                                    /* :35-40 */
+        return false;
+    const float nyj = a.newY[j], ny2 = a.newY[p], ny3 = a.newY[j + cp];
+    double u, v;
+    u = (double)(ny2 - nyj); v = (double)(pz - zj);
+    const float x1 = (float)__builtin_sqrt(u * u + v * v);
+    u = (double)(ny3 - ny2); v = (double)(z3 - pz);
+    const float x2 = (float)__builtin_sqrt(u * u + v * v);
+    u = (double)(ny3 - nyj); v = (double)(z3 - zj);
+    const float x3 = (float)__builtin_sqrt(u * u + v * v);
+    const double num = (double)x3 * (double)x3 - (double)x1 * (double)x1 - (double)x2 * (double)x2;
+    const float den = (-2.0f * x1) * x2;
+    float br = (float)(num / (double)den);                                      /* :52 */
+    if (br < -1.0f)
+        br = -1.0f;
+    else if (br > 1.0f)
+        br = 1.0f;
+    const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));   /* :58 */
+    return alpha <= dp.p.angleFilter1;                                          /* :61 */
+}
+
+/* z_zero_method.cpp:21-66 for the centre p (LDS slot lp in xs/ys), given the height tests passed */
+__device__ __forceinline__ bool urf_z_zero_angle(const urf_dev_params& dp, const urf_ring_shared& S, int lp, int cp,
+                                                 float px, float py)
+{
+    const double dx = (double)(S.xs[lp + cp] - S.xs[lp - cp]), dy = (double)(S.ys[lp + cp] - S.ys[lp - cp]);
+    if (!(dx * dx + dy * dy < URF_DIST5_SQ))                                    /* :23-28 */
+        return false;
+    float va1 = 0.f, va2 = 0.f, vb1 = 0.f, vb2 = 0.f;
+    for (int k = 1; k <= cp; k++) {                                             /* :35-38 */
+        va1 = va1 + (S.xs[lp - k] - px);
+        va2 = va2 + (S.ys[lp - k] - py);
+    }
+    for (int k = 1; k <= cp; k++) {                                             /* :44-47 */
+        vb1 = vb1 + (S.xs[lp + k] - px);
+        vb2 = vb2 + (S.ys[lp + k] - py);
+    }
+    va1 = dp.inv_cp * va1;                                                      /* :52-55 */
+    va2 = dp.inv_cp * va2;
+    vb1 = dp.inv_cp * vb1;
+    vb2 = dp.inv_cp * vb2;
+    const float num = va1 * vb1 + va2 * vb2;
+    const double na = __builtin_sqrt((double)va1 * (double)va1 + (double)va2 * (double)va2);
+    const double nb = __builtin_sqrt((double)vb1 * (double)vb1 + (double)vb2 * (double)vb2);
+    float br = (float)((double)num / (na * nb));                                /* :57 */
+    if (br < -1.0f)
+        br = -1.0f;
+    else if (br > 1.0f)
+        br = 1.0f;
+    const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));   /* :63 */
+    return alpha <= dp.p.angleFilter2;                                          /* :66 */
+}
+
+/* exact azimuth (and planar range when captured) of one point and its entry in the curb tables
+ * (lidar_segmentation.cpp:245-269, blind_spots.cpp:19-56); returns the azimuth.
+ * maxDistance (:271-274) is the largest float(sqrt(double s)), s = x^2 + y^2: both roundings
+ * are monotone, so the callers track the largest s instead. */
+__device__ __forceinline__ float urf_ring_point(const urf_kargs& a, urf_ring_shared& S, size_t gpos, float px, float py,
+                                                unsigned flag, bool want_quad)
+{
+    float d2;
+    const float az = urf_azimuth(px, py, &d2);
+    if (a.rd2)
+        a.rd2[gpos] = d2;
+    if (flag && az == az) {
+        /* curb point: per-degree tables for the beam march.  The azimuth lies in [0,360];
+         * cell_lo = largest integer <= az, cell_hi = smallest integer >= az. */
+        int cl = (int)__builtin_floorf(az), ch = (int)__builtin_ceilf(az);
+        cl = cl < 0 ? 0 : (cl > 360 ? 360 : cl);
+        ch = ch < 0 ? 0 : (ch > 360 ? 360 : ch);
+        const int ab = (int)urf_fbits(az);
+        atomicMin(&S.cmin[cl], ab);
+        atomicMax(&S.cmax[ch], ab);
+        if (want_quad) {   /* blind_spots.cpp:19-56 */
+            if (az >= 0.f && az < 90.f)
+                atomicMax(&S.q[0], ab);
+            else if (az >= 90.f && az < 180.f)
+                atomicMin(&S.q[1], ab);
+            else if (az >= 180.f && az < 270.f)
+                atomicMax(&S.q[2], ab);
+            else if (az < 360.f)   /* "alpha < q4" with q4 starting at 360 */
+                atomicMin(&S.q[3], ab);
+        }
+    }
+    return az;
+}
+
 __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_params dp)
 {
-    constexpr int HALO = URF_MAX_CURB_POINTS;
-    constexpr int CH = URF_RING_CHUNK;
-    __shared__ float xs[CH + 2 * HALO], ys[CH + 2 * HALO], zs[CH + 2 * HALO];
-    __shared__ int cmin[URF_DEG_CELLS], cmax[URF_DEG_CELLS];
-    __shared__ int sh_q[4];
-    __shared__ int sh_maxd;
-    __shared__ unsigned hits[URF_MAX_SECTORS + 2];
-    __shared__ unsigned n_hits;
+    constexpr int CH = URF_RING_CHUNK, PAD = URF_RING_PAD;
+    __shared__ urf_ring_shared S;
+    int* const cmin = S.cmin;
+    int* const cmax = S.cmax;
+    int* const sh_q = S.q;
     const unsigned c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
     const urf_scan_info in = a.info[s];
     if (in.status != URF_OK || c >= in.n_rings)
@@ -1400,173 +1522,231 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
         cmin[i] = URF_INT_NONE_MIN;
         cmax[i] = -1;
     }
+    if (tid < 2 * (CH / 32))
+        (&S.hb[0][0])[tid] = 0;
     if (tid == 0) {
         sh_q[0] = (int)urf_fbits(0.f);
         sh_q[1] = (int)urf_fbits(180.f);
         sh_q[2] = (int)urf_fbits(180.f);
         sh_q[3] = (int)urf_fbits(360.f);
-        sh_maxd = 0;
-        n_hits = 0;
+        S.maxs = 0;
+        S.n_hits = 0;
+        S.n_cand = 0;
     }
     __syncthreads();
     if (star) {   /* lidar_segmentation.cpp:241-242: the star-shaped hits that lie on this ring */
         for (unsigned k = tid; k < K; k += URF_RING_THREADS) {
             const unsigned h = (unsigned)a.star_hit[(size_t)s * K + k];   /* ring-major position or 0xffffffff */
             if (h >= base && h < base + (unsigned)n)
-                hits[atomicAdd(&n_hits, 1u)] = h - base;
+                S.hits[atomicAdd(&S.n_hits, 1u)] = h - base;
         }
     }
-    int maxd_bits = 0;
+    __syncthreads();
+    const unsigned nh = S.n_hits;
+    double maxs = 0.0;
+    const bool quads = cp == 5;
+    /* quad mapping: chunk starts are multiples of 4 in the global ring-major index */
+    const int cs0 = quads ? -(int)(base & 3u) : 0;
+    const int zpad = PAD + (cp & 3);   /* z slot of chunk point 0: puts p - cp of a quad on a 16-byte boundary for cp = 5 */
+    unsigned buf = 0;
 
-    for (int cs = 0; cs < n; cs += CH) {
-        /* stage [cs - cp, cs + CH + cp) */
-        {
-            const int lo = cs - cp < 0 ? 0 : cs - cp;
-            const int hi = cs + CH + cp > n ? n : cs + CH + cp;
-            for (int j = lo + (int)tid; j < hi; j += URF_RING_THREADS) {
-                const int li = j - cs + cp;
-                xs[li] = a.rx[base + j];
-                ys[li] = a.ry[base + j];
-                zs[li] = a.rz[base + j];
-            }
-        }
-        __syncthreads();
-        const unsigned nh = n_hits;
+    /* The next chunk's points are requested from memory before the current chunk is evaluated and
+     * parked in LDS after it: the evaluation hides the latency. */
+    constexpr int NS = (CH + 2 * URF_MAX_CURB_POINTS + URF_RING_THREADS - 1) / URF_RING_THREADS;
+    float fx[NS], fy[NS], fz[NS];
+    auto fetch = [&](int cs) {
 #pragma unroll
-        for (int e = 0; e < URF_RING_PPT; e++) {
-            const int p = cs + e * URF_RING_THREADS + (int)tid;
-            if (p >= n)
-                continue;
-            const int lp = p - cs + cp;   /* LDS slot of p */
-            const float px = xs[lp], py = ys[lp], pz = zs[lp];
-            unsigned flag = 0;
-
-            for (unsigned i = 0; i < nh; i++)
-                if (hits[i] == (unsigned)p)
-                    flag |= 1u;
-
-            /* Both detectors are an && of an angle test (f64 sqrt/div, acos) and cheap float
-             * height tests.  The height tests run first: on road surface they fail for
-             * whole waves, which then skip the expensive part.  (Reordering an && chain of
-             * side-effect-free tests does not change its value.) */
-            if (dp.p.x_zero_method) {   /* x_zero_method.cpp:30-68, evaluated for the point it marks */
-                const int j = p - cp / 2;
-                if (j >= cp && j <= (n - 1) - cp) {
-                    const int lj = lp - cp / 2, l3 = lj + cp;
-                    const float zj = zs[lj], z3 = zs[l3];
-                    const bool heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight ||
-                                          __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
-                                         (double)__builtin_fabsf(zj - z3) >= 0.05;          /* :62-64 */
-                    if (heights) {
-                        const double dx = (double)(xs[l3] - xs[lj]), dy = (double)(ys[l3] - ys[lj]);
-                        if (dx * dx + dy * dy < URF_DIST5_SQ) {                             /* :35-40 */
-                            const float nyj = a.newY[j], ny2 = a.newY[p], ny3 = a.newY[j + cp];
-                            double u, v;
-                            u = (double)(ny2 - nyj); v = (double)(pz - zj);
-                            const float x1 = (float)__builtin_sqrt(u * u + v * v);
-                            u = (double)(ny3 - ny2); v = (double)(z3 - pz);
-                            const float x2 = (float)__builtin_sqrt(u * u + v * v);
-                            u = (double)(ny3 - nyj); v = (double)(z3 - zj);
-                            const float x3 = (float)__builtin_sqrt(u * u + v * v);
-                            const double num = (double)x3 * (double)x3 - (double)x1 * (double)x1 - (double)x2 * (double)x2;
-                            const float den = (-2.0f * x1) * x2;
-                            float br = (float)(num / (double)den);                          /* :52 */
-                            if (br < -1.0f)
-                                br = -1.0f;
-                            else if (br > 1.0f)
-                                br = 1.0f;
-                            const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));   /* :58 */
-                            if (alpha <= dp.p.angleFilter1)                                 /* :61 */
-                                flag |= 2u;
-                        }
-                    }
+        for (int m = 0; m < NS; m++) {
+            const int j = cs - cp + (int)tid + m * URF_RING_THREADS;
+            const bool on = j >= 0 && j < n && j < cs + CH + cp;
+            fx[m] = on ? a.rx[base + j] : 0.f;
+            fy[m] = on ? a.ry[base + j] : 0.f;
+            fz[m] = on ? a.rz[base + j] : 0.f;
+        }
+    };
+    fetch(cs0);
+    for (int cs = cs0; cs < n; cs += CH, buf ^= 1u) {
+        /* park [cs - cp, cs + CH + cp), mark the star hits of the chunk, clear the other bitmap */
+        {
+#pragma unroll
+            for (int m = 0; m < NS; m++) {
+                const int li = (int)tid + m * URF_RING_THREADS - cp, j = cs + li;
+                if (j >= 0 && j < n && li < CH + cp) {
+                    S.xs[li + PAD] = fx[m];
+                    S.ys[li + PAD] = fy[m];
+                    S.zs[li + zpad] = fz[m];
                 }
             }
-
-            if (dp.p.z_zero_method) {   /* z_zero_method.cpp:21-72 */
-                if (p >= cp && p <= (n - 1) - cp) {
-                    const float az = __builtin_fabsf(pz);
-                    float max1 = az, max2 = az;
-                    for (int k = 1; k <= cp; k++) {                                         /* :39-40, :48-49 */
-                        const float za = __builtin_fabsf(zs[lp - k]), zb = __builtin_fabsf(zs[lp + k]);
-                        if (za > max1)
-                            max1 = za;
-                        if (zb > max2)
-                            max2 = zb;
+            for (unsigned i = tid; i < nh; i += URF_RING_THREADS) {
+                const int h = (int)S.hits[i] - cs;
+                if (h >= 0 && h < CH)
+                    atomicOr(&S.hb[buf][h >> 5], 1u << (h & 31));
+            }
+            if (tid < CH / 32)
+                S.hb[buf ^ 1u][tid] = 0;
+            S.flg[tid] = 0;   /* CH / 4 == URF_RING_THREADS */
+        }
+        __syncthreads();
+        if (cs + CH < n)
+            fetch(cs + CH);
+        if (quads) {
+            /* ---- four consecutive points per thread, curbPoints == 5 ----
+             * A: cheap tests and the float azimuth for every point; the points that need an angle
+             *    test of a detector or the exact azimuth go to a list.
+             * B: the list, densely (all lanes busy instead of the two or three that sit on a curb).
+             * C: merge, store. */
+            const int q0 = cs + 4 * (int)tid;
+            float azf[4] = { 0.f, 0.f, 0.f, 0.f };
+            if (q0 < n) {
+                const float4* zp = (const float4*)(S.zs + 4 * tid + PAD - 4);   /* slot of q0 - 5 */
+                float w[16];
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const float4 t = zp[v];
+                    w[4 * v] = t.x; w[4 * v + 1] = t.y; w[4 * v + 2] = t.z; w[4 * v + 3] = t.w;
+                }
+                const float4 X = *(const float4*)(S.xs + 4 * tid + PAD), Y = *(const float4*)(S.ys + 4 * tid + PAD);
+                const float qx[4] = { X.x, X.y, X.z, X.w }, qy[4] = { Y.x, Y.y, Y.z, Y.w };
+                /* M[j] = max |z| over window slots j..j+5 (z_zero_method.cpp:39-40, :48-49: centre included) */
+                float T[12], M[9];
+#pragma unroll
+                for (int k = 0; k < 12; k++)
+                    T[k] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(w[k]), __builtin_fabsf(w[k + 1])), __builtin_fabsf(w[k + 2]));
+#pragma unroll
+                for (int j = 0; j < 9; j++)
+                    M[j] = __builtin_fmaxf(T[j], T[j + 3]);
+                const unsigned hbits = (S.hb[buf][tid >> 3] >> ((tid & 7u) * 4u)) & 15u;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int p = q0 + i;
+                    if (p < 0 || p >= n)
+                        continue;
+                    const float pz = w[5 + i];
+                    unsigned t = ((hbits >> i) & 1u) ? URF_CAND_STAR : 0u;
+                    if (dp.p.x_zero_method && p - 2 >= 5 && p - 2 <= (n - 1) - 5) {   /* j = p - cp/2 in [cp, n-1-cp] */
+                        const float zj = w[3 + i], z3 = w[8 + i];
+                        if ((__builtin_fabsf(zj - pz) >= dp.p.curbHeight || __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
+                            (double)__builtin_fabsf(zj - z3) >= 0.05)                            /* x_zero_method.cpp:62-64 */
+                            t |= URF_CAND_XZERO;
                     }
-                    const bool heights = (max1 - az >= dp.p.curbHeight || max2 - az >= dp.p.curbHeight) &&
-                                         (double)__builtin_fabsf(max1 - max2) >= 0.05;      /* :67-69 */
-                    if (heights) {
-                        const double dx = (double)(xs[lp + cp] - xs[lp - cp]), dy = (double)(ys[lp + cp] - ys[lp - cp]);
-                        if (dx * dx + dy * dy < URF_DIST5_SQ) {                             /* :23-28 */
-                            float va1 = 0.f, va2 = 0.f, vb1 = 0.f, vb2 = 0.f;
-                            for (int k = 1; k <= cp; k++) {                                 /* :35-38 */
-                                va1 = va1 + (xs[lp - k] - px);
-                                va2 = va2 + (ys[lp - k] - py);
-                            }
-                            for (int k = 1; k <= cp; k++) {                                 /* :44-47 */
-                                vb1 = vb1 + (xs[lp + k] - px);
-                                vb2 = vb2 + (ys[lp + k] - py);
-                            }
-                            va1 = dp.inv_cp * va1;                                          /* :52-55 */
-                            va2 = dp.inv_cp * va2;
-                            vb1 = dp.inv_cp * vb1;
-                            vb2 = dp.inv_cp * vb2;
-                            const float num = va1 * vb1 + va2 * vb2;
-                            const double na = __builtin_sqrt((double)va1 * (double)va1 + (double)va2 * (double)va2);
-                            const double nb = __builtin_sqrt((double)vb1 * (double)vb1 + (double)vb2 * (double)vb2);
-                            float br = (float)((double)num / (na * nb));                    /* :57 */
-                            if (br < -1.0f)
-                                br = -1.0f;
-                            else if (br > 1.0f)
-                                br = 1.0f;
-                            const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));   /* :63 */
-                            if (alpha <= dp.p.angleFilter2)                                 /* :66 */
-                                flag |= 4u;
-                        }
+                    if (dp.p.z_zero_method && p >= 5 && p <= (n - 1) - 5) {
+                        const float az = __builtin_fabsf(pz), max1 = M[i], max2 = M[5 + i];
+                        if ((max1 - az >= dp.p.curbHeight || max2 - az >= dp.p.curbHeight) &&
+                            (double)__builtin_fabsf(max1 - max2) >= 0.05)                        /* z_zero_method.cpp:67-69 */
+                            t |= URF_CAND_ZZERO;
                     }
+                    if (!urf_fast_azimuth(qx[i], qy[i], &azf[i]) || a.rd2)
+                        t |= URF_CAND_EXACT;
+                    const double s2 = (double)qx[i] * (double)qx[i] + (double)qy[i] * (double)qy[i];
+                    maxs = s2 > maxs ? s2 : maxs;
+                    if (t)
+                        S.cand[atomicAdd(&S.n_cand, 1u)] = (unsigned short)((unsigned)(4 * (int)tid + i) | (t << 9));
                 }
             }
-
-            float d2;
-            const float az = urf_azimuth(px, py, &d2);   /* lidar_segmentation.cpp:245-269 */
-            a.raz[base + p] = az;
-            a.rflag[base + p] = (uint8_t)flag;
-            if (a.rd2)
-                a.rd2[base + p] = d2;
-            const int db = (int)urf_fbits(d2);           /* :271-274, d2 >= 0 */
-            maxd_bits = db > maxd_bits ? db : maxd_bits;
-
-            if (flag && az == az) {
-                /* curb point: per-degree tables for the beam march.  The azimuth
-                 * lies in [0,360]; cell_lo = largest integer <= az, cell_hi =
-                 * smallest integer >= az. */
-                int cl = (int)__builtin_floorf(az), ch = (int)__builtin_ceilf(az);
-                cl = cl < 0 ? 0 : (cl > 360 ? 360 : cl);
-                ch = ch < 0 ? 0 : (ch > 360 ? 360 : ch);
-                const int ab = (int)urf_fbits(az);
-                atomicMin(&cmin[cl], ab);
-                atomicMax(&cmax[ch], ab);
+            __syncthreads();
+            const unsigned nc = S.n_cand;
+            for (unsigned e = tid; e < nc; e += URF_RING_THREADS) {
+                const unsigned v = S.cand[e], t = v >> 9;
+                const int lc = (int)(v & 511u), p = cs + lc;
+                const float px = S.xs[lc + PAD], py = S.ys[lc + PAD];
+                unsigned flag = (t & URF_CAND_STAR) ? 1u : 0u;
+                if (t & URF_CAND_XZERO) {
+                    const float zj = S.zs[lc + zpad - 2], pz = S.zs[lc + zpad], z3 = S.zs[lc + zpad + 3];
+                    if (urf_x_zero_angle(a, dp, S, p - 2, p, lc - 2 + PAD, 5, zj, pz, z3))
+                        flag |= 2u;
+                }
+                if ((t & URF_CAND_ZZERO) && urf_z_zero_angle(dp, S, lc + PAD, 5, px, py))
+                    flag |= 4u;
+                if (flag || (t & URF_CAND_EXACT)) {
+                    S.azx[lc] = urf_ring_point(a, S, (size_t)base + p, px, py, flag, want_quad);
+                    ((uint8_t*)S.flg)[lc] = (uint8_t)(flag | 0x80u);
+                }
             }
-            if (want_quad && flag) {   /* blind_spots.cpp:19-56 */
-                const int ab = (int)urf_fbits(az);
-                if (az >= 0.f && az < 90.f)
-                    atomicMax(&sh_q[0], ab);
-                else if (az >= 90.f && az < 180.f)
-                    atomicMin(&sh_q[1], ab);
-                else if (az >= 180.f && az < 270.f)
-                    atomicMax(&sh_q[2], ab);
-                else if (az < 360.f)   /* "alpha < q4" with q4 starting at 360; NaN fails */
-                    atomicMin(&sh_q[3], ab);
+            __syncthreads();
+            if (q0 < n) {
+                const unsigned f4 = S.flg[tid];
+                unsigned fl[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const unsigned f = (f4 >> (8 * i)) & 0xffu;
+                    if (f & 0x80u) {
+                        azf[i] = S.azx[4 * tid + i];
+                        fl[i] = f & 7u;
+                    } else {
+                        fl[i] = URF_RFLAG_AZ_APPROX;
+                    }
+                }
+                if (q0 >= 0 && q0 + 3 < n) {
+                    *(float4*)(a.raz + base + q0) = make_float4(azf[0], azf[1], azf[2], azf[3]);
+                    *(unsigned*)(a.rflag + base + q0) = fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (q0 + i >= 0 && q0 + i < n) {
+                            a.raz[base + q0 + i] = azf[i];
+                            a.rflag[base + q0 + i] = (uint8_t)fl[i];
+                        }
+                }
+            }
+            if (tid == 0)
+                S.n_cand = 0;   /* read by everyone before the previous barrier */
+        } else {
+#pragma unroll
+            for (int e = 0; e < URF_RING_PPT; e++) {
+                const int lc = e * URF_RING_THREADS + (int)tid;   /* chunk-relative index */
+                const int p = cs + lc;
+                if (p >= n)
+                    continue;
+                const int lp = lc + PAD, lz = lc + zpad;
+                const float px = S.xs[lp], py = S.ys[lp], pz = S.zs[lz];
+                unsigned flag = (S.hb[buf][lc >> 5] >> (lc & 31)) & 1u;
+
+                /* Both detectors are an && of an angle test (f64 sqrt/div, acos) and cheap float
+                 * height tests.  The height tests run first: on road surface they fail for
+                 * whole waves, which then skip the expensive part.  (Reordering an && chain of
+                 * side-effect-free tests does not change its value.) */
+                if (dp.p.x_zero_method) {   /* x_zero_method.cpp:30-68, evaluated for the point it marks */
+                    const int j = p - cp / 2;
+                    if (j >= cp && j <= (n - 1) - cp) {
+                        const float zj = S.zs[lz - cp / 2], z3 = S.zs[lz - cp / 2 + cp];
+                        const bool heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight ||
+                                              __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
+                                             (double)__builtin_fabsf(zj - z3) >= 0.05;          /* :62-64 */
+                        if (heights && urf_x_zero_angle(a, dp, S, j, p, lp - cp / 2, cp, zj, pz, z3))
+                            flag |= 2u;
+                    }
+                }
+                if (dp.p.z_zero_method) {   /* z_zero_method.cpp:21-72 */
+                    if (p >= cp && p <= (n - 1) - cp) {
+                        const float az = __builtin_fabsf(pz);
+                        float max1 = az, max2 = az;
+                        for (int k = 1; k <= cp; k++) {                                         /* :39-40, :48-49 */
+                            const float za = __builtin_fabsf(S.zs[lz - k]), zb = __builtin_fabsf(S.zs[lz + k]);
+                            if (za > max1)
+                                max1 = za;
+                            if (zb > max2)
+                                max2 = zb;
+                        }
+                        const bool heights = (max1 - az >= dp.p.curbHeight || max2 - az >= dp.p.curbHeight) &&
+                                             (double)__builtin_fabsf(max1 - max2) >= 0.05;      /* :67-69 */
+                        if (heights && urf_z_zero_angle(dp, S, lp, cp, px, py))
+                            flag |= 4u;
+                    }
+                }
+                const float az = urf_ring_point(a, S, (size_t)base + p, px, py, flag, want_quad);
+                const double s2 = (double)px * (double)px + (double)py * (double)py;
+                maxs = s2 > maxs ? s2 : maxs;
+                a.raz[base + p] = az;
+                a.rflag[base + p] = (uint8_t)flag;
             }
         }
         __syncthreads();
     }
 
-    atomicMax(&sh_maxd, maxd_bits);
+    atomicMax(&S.maxs, (unsigned long long)__double_as_longlong(maxs));   /* non-negative doubles order like integers */
     __syncthreads();
     if (tid == 0)
-        a.maxdist[(size_t)s * C + c] = __uint_as_float((unsigned)sh_maxd);
+        a.maxdist[(size_t)s * C + c] = (float)__builtin_sqrt(__longlong_as_double((long long)S.maxs));
     if (want_quad && tid < 4)
         a.quad[(size_t)s * 4 + tid] = __uint_as_float((unsigned)sh_q[tid]);
 
@@ -1736,6 +1916,54 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
 /* byte image of the tile's labels; consecutive ring-major slots of an organised sweep lie 64
  * bytes apart in input order, so the row (i >> 6) rotates the column (i & 63) to spread the
  * byte stores over the LDS banks */
+/* Is a non-curb point of ring c with azimuth az road?  af / ab: the ring's words of act_f / act_b.
+ * With eps > 0 the azimuth is only known to within eps: `unsure` is set when a decision taken
+ * here (floor, ceil, either window comparison) could come out differently for the true value. */
+__device__ __forceinline__ bool urf_road_test(const urf_dev_params& dp, const unsigned long long* af,
+                                              const unsigned long long* ab, unsigned c, double qkc, float az, float eps,
+                                              bool& unsure)
+{
+    unsure = false;
+    if (!(az == az))
+        return false;
+    bool road = false;
+    const float fl = __builtin_floorf(az);
+    if (eps > 0.0f)
+        unsure = az - fl <= eps || (fl + 1.0f) - az <= eps;
+    int cf = (int)fl;
+    cf = cf < 0 ? 0 : (cf > 360 ? 360 : cf);
+    {
+        int w = cf >> 6;
+        const int b = cf & 63;
+        unsigned long long mm = af[w] & (b == 63 ? ~0ull : ((2ull << b) - 1ull));
+        while (mm == 0 && w > 0)
+            mm = af[--w];
+        if (mm) {
+            const int i = w * 64 + 63 - __clzll((long long)mm);
+            const float hi = urf_fwd_hi(dp, i, c, qkc);
+            road = az <= hi;
+            unsure = unsure || (eps > 0.0f && __builtin_fabsf(az - hi) <= eps);
+        }
+    }
+    if (!road) {
+        int cb = (int)__builtin_ceilf(az);
+        cb = cb < 0 ? 0 : (cb > 360 ? 360 : cb);
+        int w = cb >> 6;
+        const int b = cb & 63;
+        unsigned long long mm = ab[w] & (~0ull << b);
+        while (mm == 0 && w < 5)
+            mm = ab[++w];
+        if (mm) {
+            const int i = w * 64 + __ffsll((long long)mm) - 1;
+            const float lo = urf_bwd_lo(dp, i, c, qkc);
+            road = az >= lo;
+            unsure = unsure || (eps > 0.0f && __builtin_fabsf(az - lo) <= eps);
+        }
+    }
+    return road;
+}
+
+#define URF_LABEL_UNSURE 256   /* capacity of the list of points decided on the exact azimuth */
 #define URF_IMG(i) (((i) & ~63u) | ((((i) & 63u) + ((i) >> 6)) & 63u))
 __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) void k_label(urf_kargs a, urf_dev_params dp)
 {
@@ -1743,7 +1971,8 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) void k_label(urf_kargs a, u
     __shared__ double qk[URF_MAX_CHANNELS];
     __shared__ unsigned base_r[URF_MAX_CHANNELS], koff[URF_MAX_CHANNELS + 1];
     __shared__ uint8_t img[URF_TILE];
-    __shared__ unsigned cnt_road, cnt_curb;
+    __shared__ unsigned cnt_road, cnt_curb, n_unsure;
+    __shared__ unsigned un_pos[URF_LABEL_UNSURE], un_key[URF_LABEL_UNSURE];   /* points to decide on the exact azimuth */
     const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
@@ -1775,6 +2004,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) void k_label(urf_kargs a, u
     if (tid == 0) {
         cnt_road = 0;
         cnt_curb = 0;
+        n_unsure = 0;
     }
     __syncthreads();
     if (tid < 64) {   /* exclusive scan of the run lengths (C <= 128) */
@@ -1828,48 +2058,51 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) void k_label(urf_kargs a, u
             continue;
         const unsigned c = rc[q];
         const unsigned flag = rfl[q];
-        const float az = raz[q];
         const unsigned src = rsr[q];
         uint8_t lab = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0);
-        if (flag) {
+        if (flag & 7u) {
             lab |= URF_LABEL_CURB;
             my_curb++;
-        } else if (az == az) {
-            bool road = false;
-            const unsigned long long* af = actf + c * 6;
-            const unsigned long long* ab = actb + c * 6;
-            int cf = (int)__builtin_floorf(az);
-            cf = cf < 0 ? 0 : (cf > 360 ? 360 : cf);
-            {
-                int w = cf >> 6;
-                const int b = cf & 63;
-                unsigned long long mm = af[w] & (b == 63 ? ~0ull : ((2ull << b) - 1ull));
-                while (mm == 0 && w > 0)
-                    mm = af[--w];
-                if (mm) {
-                    const int i = w * 64 + 63 - __clzll((long long)mm);
-                    road = az <= urf_fwd_hi(dp, i, c, qk[c]);
+        } else {
+            /* k_ring stored a float approximation of the azimuth for most points (error <=
+             * URF_FAST_AZ_ERR).  Every decision that the approximation clears by that margin is the
+             * reference's decision; the rare point that does not is listed and decided below on
+             * the exact azimuth. */
+            bool unsure;
+            const bool road = urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c], raz[q],
+                                            (flag & URF_RFLAG_AZ_APPROX) ? URF_FAST_AZ_ERR : 0.0f, unsure);
+            bool road_final = road;
+            if (unsure) {
+                const unsigned e = atomicAdd(&n_unsure, 1u);
+                if (e < URF_LABEL_UNSURE) {
+                    un_pos[e] = rpos[q];
+                    un_key[e] = (src - tbase) | (c << 16);
+                    continue;
                 }
+                float d2;   /* list full (pathological input): decide here */
+                road_final = urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c],
+                                           urf_azimuth(a.rx[rpos[q]], a.ry[rpos[q]], &d2), 0.0f, unsure);
             }
-            if (!road) {
-                int cb = (int)__builtin_ceilf(az);
-                cb = cb < 0 ? 0 : (cb > 360 ? 360 : cb);
-                int w = cb >> 6;
-                const int b = cb & 63;
-                unsigned long long mm = ab[w] & (~0ull << b);
-                while (mm == 0 && w < 5)
-                    mm = ab[++w];
-                if (mm) {
-                    const int i = w * 64 + __ffsll((long long)mm) - 1;
-                    road = az >= urf_bwd_lo(dp, i, c, qk[c]);
-                }
-            }
-            if (road) {
+            if (road_final) {
                 lab |= URF_LABEL_ROAD;
                 my_road++;
             }
         }
         img[URF_IMG(src - tbase)] = lab;
+    }
+    __syncthreads();
+    const unsigned nu = n_unsure < URF_LABEL_UNSURE ? n_unsure : URF_LABEL_UNSURE;
+    for (unsigned e = tid; e < nu; e += URF_LABEL_TILE_THREADS) {
+        const unsigned pos = un_pos[e], c = un_key[e] >> 16, li = un_key[e] & 0xffffu;
+        float d2;
+        bool unsure;
+        const float az = urf_azimuth(a.rx[pos], a.ry[pos], &d2);
+        uint8_t lab = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0);
+        if (urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c], az, 0.0f, unsure)) {
+            lab |= URF_LABEL_ROAD;
+            my_road++;
+        }
+        img[URF_IMG(li)] = lab;
     }
     if (my_road)
         atomicAdd(&cnt_road, my_road);
@@ -1888,6 +2121,15 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) void k_label(urf_kargs a, u
         if (cnt_curb)
             atomicAdd(&o->n_curb, cnt_curb);
     }
+}
+
+/* exact azimuth of the point at ring-major position pos (raz may hold the approximation) */
+__device__ __forceinline__ float urf_exact_az(const urf_kargs& a, size_t pos)
+{
+    if (!(a.rflag[pos] & URF_RFLAG_AZ_APPROX))
+        return a.raz[pos];
+    float d2;
+    return urf_azimuth(a.rx[pos], a.ry[pos], &d2);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1970,7 +2212,7 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++) {
             const unsigned i = tid + e * NT;
-            key[e] = i < n ? ((unsigned long long)urf_fbits(a.raz[base + i]) << 32) | i : ~0ull;
+            key[e] = i < n ? ((unsigned long long)urf_fbits(urf_exact_az(a, base + i)) << 32) | i : ~0ull;
         }
         urf_block_sort_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, false);
         for (unsigned i = tid; i < n; i += NT)
@@ -1978,7 +2220,7 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
     } else {
         unsigned long long* G = gkeys + rel;
         for (unsigned i = tid; i < n; i += NT)
-            G[i] = ((unsigned long long)urf_fbits(a.raz[base + i]) << 32) | i;
+            G[i] = ((unsigned long long)urf_fbits(urf_exact_az(a, base + i)) << 32) | i;
         __threadfence_block();
         __syncthreads();
         unsigned P = 1;
@@ -2097,7 +2339,7 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
     __syncthreads();
     /* pass 1: where does the scan of this ring stop in each degree (:318) */
     for (unsigned p = tid; p < n; p += 256) {
-        const float az = a.raz[base + p];
+        const float az = urf_exact_az(a, base + p);
         const unsigned lab = a.labels[off + a.rsrc[base + p]] & URF_LABEL_MASK;
         if (az == az && lab != URF_LABEL_ROAD) {
             int bin = (int)__builtin_floorf(az);
@@ -2109,7 +2351,7 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
     /* pass 2: farthest road point in front of it (:325-335); key = (d, first in azimuth order) */
     for (int pass = 0; pass < 2; pass++) {
         for (unsigned p = tid; p < n; p += 256) {
-            const float az = a.raz[base + p];
+            const float az = urf_exact_az(a, base + p);
             const unsigned lab = a.labels[off + a.rsrc[base + p]] & URF_LABEL_MASK;
             if (az == az && lab == URF_LABEL_ROAD) {
                 int bin = (int)__builtin_floorf(az);
@@ -2197,10 +2439,11 @@ __global__ __launch_bounds__(256) void k_selftest_div_pi(unsigned long long* mis
 }
 
 /* max |fast - exact| of the float fast paths over pseudo-random points: out[0] = vertical angle
- * [deg] (float bits), out[1] = polar angle [rad], out[2] = scaled polar angle fi*Kfi */
+ * [deg] (float bits), out[1] = polar angle [rad], out[2] = scaled polar angle fi*Kfi, out[3] =
+ * azimuth [deg] */
 __global__ __launch_bounds__(256) void k_selftest_fast(unsigned long long n, float Kfi, unsigned* out)
 {
-    float ev = 0.f, ea = 0.f, eu = 0.f;
+    float ev = 0.f, ea = 0.f, eu = 0.f, ez = 0.f;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
         unsigned long long h = i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
@@ -2214,6 +2457,13 @@ __global__ __launch_bounds__(256) void k_selftest_fast(unsigned long long n, flo
         if (urf_fast_vertical_angle(x, y, z, &vt)) {
             const float d = __builtin_fabsf(vt - urf_vertical_angle(x, y, z));
             ev = d > ev ? d : ev;
+        }
+        float azt;
+        if (urf_fast_azimuth(x, y, &azt)) {
+            float d2;
+            const float d = __builtin_fabsf(azt - urf_azimuth(x, y, &d2));
+            if (d < 180.0f)   /* the 0/360 seam is never decided on the approximation */
+                ez = d > ez ? d : ez;
         }
         if (x != 0.f || y != 0.f) {
             float fe = urf_atan2f(y, x);
@@ -2232,6 +2482,7 @@ __global__ __launch_bounds__(256) void k_selftest_fast(unsigned long long n, flo
     atomicMax(&out[0], __float_as_uint(ev));
     atomicMax(&out[1], __float_as_uint(ea));
     atomicMax(&out[2], __float_as_uint(eu));
+    atomicMax(&out[3], __float_as_uint(ez));
 }
 
 #endif /* URF_KERNELS_HPP */
