@@ -34,7 +34,9 @@
  * doubles s below this one: sqrt and the rounding to float are monotone, the threshold is the
  * smallest double whose rounded root reaches 5.0f (found by bisection, tools/check_dist5.c). */
 #define URF_DIST5_SQ 0x1.8ffffd800000fp+4
+#ifndef URF_RING_THREADS
 #define URF_RING_THREADS 128
+#endif
 #define URF_LABEL_THREADS 384
 #define URF_STAR_THREADS 64
 #define URF_INGEST_THREADS 256       /* tile kernels that need no big LDS tile run 8 workgroups per CU */
@@ -586,6 +588,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
     /* step 1: ranks inside the wave's own 256 points (LDS read-modify-write by the key's
      * leader lane; one wave touches only its own row, in program order) */
     unsigned rkey[Q], skey[Q], rrank[Q], srank[Q];
+    float px[Q], py[Q], pz[Q];   /* requested as soon as the keys are known, used in step 5 */
     uint16_t* my_r = wcnt_r + wave * C;
     uint16_t* my_s = wcnt_s + wave * K;
 #pragma unroll
@@ -618,6 +621,10 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
             }
             srank[q] = (unsigned)__shfl((int)old, (int)leader) + urf_popc_below(m);
         }
+        const bool used = rkey[q] != URF_RING_NONE || skey[q] != URF_SEC_NONE;
+        px[q] = used ? a.x[off + i] : 0.f;
+        py[q] = used ? a.y[off + i] : 0.f;
+        pz[q] = used ? a.z[off + i] : 0.f;
     }
     __syncthreads();
     /* step 2: exclusive scan over the waves, one thread per key */
@@ -676,10 +683,9 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
         const unsigned li = wave * 256 + q * 64 + lane;   /* index inside the tile, < 4096 */
-        const unsigned i = tbase + li;
         if (lp[q] == 0xffffffffu && sdst[q] == 0xffffffffu)
             continue;
-        const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
+        const float x = px[q], y = py[q], z = pz[q];
         if (lp[q] != 0xffffffffu) {
             const unsigned sl = URF_SLOT(lp[q]);
             stx[sl] = __float_as_uint(x);
@@ -1394,11 +1400,12 @@ struct urf_ring_shared {
     unsigned n_hits;
     unsigned hb[2][URF_RING_CHUNK / 32];   /* star-hit bit per point of the chunk, double buffered */
     /* quad mapping: points that need one of the expensive evaluations, compacted */
-    unsigned short cand[URF_RING_CHUNK];   /* chunk-local index | URF_CAND_* << 9 */
+    unsigned short cand[URF_RING_CHUNK];   /* chunk-local index | URF_CAND_* << URF_CAND_SHIFT */
     unsigned n_cand;
     unsigned flg[URF_RING_CHUNK / 4];      /* byte per chunk point: detector bits | 0x80 = azx valid */
     float azx[URF_RING_CHUNK];             /* exact azimuth of the points that needed it */
 };
+#define URF_CAND_SHIFT 12   /* chunk-local index below, URF_CAND_* above (chunk <= 4096 points) */
 #define URF_CAND_XZERO 1u   /* passed the height tests of x_zero: angle test pending */
 #define URF_CAND_ZZERO 2u   /* same for z_zero */
 #define URF_CAND_EXACT 4u   /* no float approximation of the azimuth (near the x axis, stage capture) */
@@ -1498,7 +1505,9 @@ __device__ __forceinline__ float urf_ring_point(const urf_kargs& a, urf_ring_sha
     return az;
 }
 
-__global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_params dp)
+/* 4 waves per SIMD (<= 128 VGPRs): the kernel hides its barrier and memory latencies with resident
+ * workgroups, measured 1.19 -> 1.00 ms against the compiler's own choice of 155 VGPRs */
+__global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ring(urf_kargs a, urf_dev_params dp)
 {
     constexpr int CH = URF_RING_CHUNK, PAD = URF_RING_PAD;
     __shared__ urf_ring_shared S;
@@ -1640,14 +1649,14 @@ __global__ __launch_bounds__(URF_RING_THREADS) void k_ring(urf_kargs a, urf_dev_
                     const double s2 = (double)qx[i] * (double)qx[i] + (double)qy[i] * (double)qy[i];
                     maxs = s2 > maxs ? s2 : maxs;
                     if (t)
-                        S.cand[atomicAdd(&S.n_cand, 1u)] = (unsigned short)((unsigned)(4 * (int)tid + i) | (t << 9));
+                        S.cand[atomicAdd(&S.n_cand, 1u)] = (unsigned short)((unsigned)(4 * (int)tid + i) | (t << URF_CAND_SHIFT));
                 }
             }
             __syncthreads();
             const unsigned nc = S.n_cand;
             for (unsigned e = tid; e < nc; e += URF_RING_THREADS) {
-                const unsigned v = S.cand[e], t = v >> 9;
-                const int lc = (int)(v & 511u), p = cs + lc;
+                const unsigned v = S.cand[e], t = v >> URF_CAND_SHIFT;
+                const int lc = (int)(v & (URF_RING_CHUNK - 1u)), p = cs + lc;
                 const float px = S.xs[lc + PAD], py = S.ys[lc + PAD];
                 unsigned flag = (t & URF_CAND_STAR) ? 1u : 0u;
                 if (t & URF_CAND_XZERO) {
