@@ -91,55 +91,68 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
         return;
     const unsigned K = (unsigned)dp.p.sectors, C = (unsigned)dp.p.channels;
     const bool star = dp.p.star_shaped_method != 0;
-    const unsigned nR = a.info[s].n_rings;
-    for (unsigned k = tid; k <= K; k += URF_INGEST_THREADS)
-        sh_hist[k] = 0;
-    if (tid < C) {
-        tab[tid] = tid < nR ? a.angle[(size_t)s * C + tid] : 0.f;
-        rhist[tid] = 0;
-    }
-    __syncthreads();
-
-    const float interval = dp.p.interval;
     constexpr unsigned Q = URF_TILE / URF_INGEST_THREADS;
     float px[Q], py[Q], pz[Q];
 #pragma unroll
-    for (unsigned q = 0; q < Q; q++) {   /* all loads of the tile in flight before any arithmetic */
+    for (unsigned q = 0; q < Q; q++) {   /* all loads of the tile in flight before anything else */
         const unsigned i = tbase + q * URF_INGEST_THREADS + tid;
         const bool valid = i < len;
         px[q] = valid ? a.x[off + i] : 0.f;
         py[q] = valid ? a.y[off + i] : 0.f;
         pz[q] = valid ? a.z[off + i] : 0.f;
     }
+    const unsigned nR = a.info[s].n_rings;
+    for (unsigned k = tid; k <= K; k += URF_INGEST_THREADS)
+        sh_hist[k] = 0;
+    if (tid < URF_MAX_CHANNELS) {
+        tab[tid] = tid < nR ? a.angle[(size_t)s * C + tid] : 0.f;
+        rhist[tid] = 0;
+    }
+    __syncthreads();
+
+    const float interval = dp.p.interval;
+    /* Ring, float fast path (urf_device.hpp) unless the stage capture wants the exact angle: with
+     * |vt - alpha| <= e, entries below vt - interval - e surely do not match, an entry within
+     * interval - e surely does, one beyond interval + e surely does not.  The bisections of the
+     * thread's eight points advance in lockstep, so that their LDS reads overlap. */
+    const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;   /* + rounding of fl(angle[j] - alpha) */
+    bool roi[Q], fast[Q];
+    float vt[Q];
+    unsigned lo[Q];
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned i = tbase + q * URF_INGEST_THREADS + tid;
+        roi[q] = i < len && urf_in_roi(dp.p, px[q], py[q], pz[q]);
+        vt[q] = 0.f;
+        fast[q] = roi[q] && !a.valpha && urf_fast_vertical_angle(px[q], py[q], pz[q], &vt[q]);
+        lo[q] = 0;
+    }
+#pragma unroll
+    for (unsigned step = URF_MAX_CHANNELS; step > 0; step >>= 1) {
+#pragma unroll
+        for (unsigned q = 0; q < Q; q++) {   /* lo = number of entries surely below the window */
+            const unsigned idx = lo[q] + step - 1;
+            const float tv = tab[idx & (URF_MAX_CHANNELS - 1)];
+            if (idx < nR && !(tv - vt[q] >= -(interval + e)))
+                lo[q] += step;
+        }
+    }
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
         const unsigned i = tbase + q * URF_INGEST_THREADS + tid;
         const bool valid = i < len;
         const float x = px[q], y = py[q], z = pz[q];
-        const bool roi = valid && urf_in_roi(dp.p, x, y, z);
         float va = -1.0f;
         unsigned key = URF_SEC_NONE, rkey = URF_RING_NONE;
-        if (roi) {
-            /* ring: float fast path (urf_device.hpp) unless the stage capture wants the exact angle */
+        if (roi[q]) {
             bool decided = false;
-            float vt;
-            if (!a.valpha && urf_fast_vertical_angle(x, y, z, &vt)) {
-                /* with |vt - alpha| <= e: entries below vt - interval - e surely do not match, an entry
-                 * within interval - e surely does, one beyond interval + e surely does not */
-                const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;   /* + rounding of fl(angle[j] - alpha) */
-                unsigned lo = 0, hi = nR;
-                while (lo < hi) {
-                    const unsigned mid = (lo + hi) >> 1;
-                    if (tab[mid] - vt >= -(interval + e))
-                        hi = mid;
-                    else
-                        lo = mid + 1;
-                }
-                if (lo == nR || tab[lo] - vt > interval + e) {
+            if (fast[q]) {
+                const float tv = tab[lo[q] & (URF_MAX_CHANNELS - 1)];
+                if (lo[q] >= nR || tv - vt[q] > interval + e) {
                     decided = true;                       /* no entry can match */
-                } else if (__builtin_fabsf(tab[lo] - vt) <= interval - e) {
+                } else if (__builtin_fabsf(tv - vt[q]) <= interval - e) {
                     decided = true;                       /* the first candidate surely matches */
-                    rkey = lo;
+                    rkey = lo[q];
                 }
             }
             if (!decided) {
@@ -147,16 +160,16 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
                 /* lidar_segmentation.cpp:226-233: first sorted table entry within `interval`.
                  * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are contiguous
                  * and the first one is found by bisection with the very same float predicate. */
-                unsigned lo = 0, hi = nR;
-                while (lo < hi) {
-                    const unsigned mid = (lo + hi) >> 1;
+                unsigned l2 = 0, h2 = nR;
+                while (l2 < h2) {
+                    const unsigned mid = (l2 + h2) >> 1;
                     if (tab[mid] - va >= -interval)
-                        hi = mid;
+                        h2 = mid;
                     else
-                        lo = mid + 1;
+                        l2 = mid + 1;
                 }
-                if (lo < nR && __builtin_fabsf(tab[lo] - va) <= interval)
-                    rkey = lo;
+                if (l2 < nR && __builtin_fabsf(tab[l2] - va) <= interval)
+                    rkey = l2;
             }
             if (star) {
                 const int fs = urf_fast_sector(x, y, dp.Kfi, K);
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
                 a.valpha[off + i] = va;   /* stage capture only */
             a.seckey[off + i] = (uint16_t)key;
             a.ringkey[off + i] = (uint8_t)rkey;
-            a.labels[off + i] = roi ? URF_FLAG_ROI : 0;
+            a.labels[off + i] = roi[q] ? URF_FLAG_ROI : 0;
         }
         {
             const unsigned long long m = urf_match_any_fast(rkey == URF_RING_NONE ? C : rkey, dp.ring_keybits);
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
             if (key != URF_SEC_NONE && urf_is_leader(m))
                 atomicAdd(&sh_hist[key], (unsigned)__popcll(m));
         }
-        const unsigned long long rb = __ballot(roi);
+        const unsigned long long rb = __ballot(roi[q]);
         if (urf_lane() == 0 && rb)
             atomicAdd(&sh_hist[K], (unsigned)__popcll(rb));
     }
