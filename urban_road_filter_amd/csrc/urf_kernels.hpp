@@ -39,6 +39,10 @@
 #endif
 #define URF_LABEL_THREADS 384
 #define URF_STAR_THREADS 64
+#ifndef URF_STAR_LOG_NB
+#define URF_STAR_LOG_NB 9u          /* k_star_sort_small: 512 range buckets */
+#endif
+#define URF_STAR_NB (1u << URF_STAR_LOG_NB)
 #define URF_INGEST_THREADS 256       /* tile kernels that need no big LDS tile run 8 workgroups per CU */
 #define URF_LABEL_TILE_THREADS 256   /* k_label: one tile per workgroup, 16 slots per thread, 8 workgroups per CU */
 #define URF_STAR_MID_CAP_ 2048
@@ -833,7 +837,7 @@ __device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_
 
 /* sectors with at most 512 points: one wave per (sector, scan).
  * Fast path: distribution sort.  The range bits are quantised monotonically
- * into 512 buckets ((bits - min) >> shift), a counting sort by bucket places
+ * into URF_STAR_NB buckets ((bits - min) >> shift), a counting sort by bucket places
  * every key next to the few keys sharing its bucket, and each key then counts
  * the smaller keys inside its own bucket -- exact for any input, and about five
  * times fewer instructions than a comparison network when the ranges are
@@ -847,17 +851,23 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
                                                      unsigned long long* A, unsigned* cnt, unsigned* sh_first,
                                                      uint32_t* star_first_out)
 {
-    constexpr unsigned NB = 512;
+    constexpr unsigned NB = URF_STAR_NB, PL = NB / 64;
     const unsigned lane = threadIdx.x;
     const unsigned B = (n + 63) >> 6;
     unsigned long long key[MAXB];
+    float zreg[MAXB];      /* height and ring-major position travel with the key: the tail */
+    unsigned sreg[MAXB];   /* then needs no dependent gathers from memory */
     unsigned rmin = 0xffffffffu, rmax = 0;
 #pragma unroll
     for (unsigned q = 0; q < MAXB; q++) {
         const unsigned i = q * 64 + lane;
         key[q] = ~0ull;
+        zreg[q] = 0.f;
+        sreg[q] = 0;
         if (q < B && i < n) {
             const unsigned rb = urf_fbits(a.sr[base + i]);
+            zreg[q] = a.sz[base + i];
+            sreg[q] = a.ssrc[base + i];
             key[q] = ((unsigned long long)rb << 32) | i;
             rmin = rb < rmin ? rb : rmin;
             rmax = rb > rmax ? rb : rmax;
@@ -871,7 +881,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
         rmax = hi > rmax ? hi : rmax;
     }
     const unsigned range = rmax - rmin;
-    const unsigned sh = range < NB ? 0u : (unsigned)(32 - __clz((int)range)) - 9u;   /* (range >> sh) < 512 */
+    const unsigned sh = range < NB ? 0u : (unsigned)(32 - __clz((int)range)) - URF_STAR_LOG_NB;   /* (range >> sh) < NB */
     __syncthreads();
 
     unsigned bkt[MAXB], wq[MAXB];
@@ -885,13 +895,13 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
         }
     }
     __syncthreads();
-    /* exclusive scan of the 512 counts: 8 consecutive counters per lane */
+    /* exclusive scan of the counts: NB / 64 consecutive counters per lane */
     unsigned maxc = 0;
     {
-        unsigned c8[8], sum = 0;
+        unsigned c8[PL], sum = 0;
 #pragma unroll
-        for (unsigned e = 0; e < 8; e++) {
-            c8[e] = cnt[lane * 8 + e];
+        for (unsigned e = 0; e < PL; e++) {
+            c8[e] = cnt[lane * PL + e];
             sum += c8[e];
             maxc = c8[e] > maxc ? c8[e] : maxc;
         }
@@ -903,8 +913,8 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
         }
         unsigned run = inc - sum;
 #pragma unroll
-        for (unsigned e = 0; e < 8; e++) {
-            cnt[lane * 8 + e] = run;
+        for (unsigned e = 0; e < PL; e++) {
+            cnt[lane * PL + e] = run;
             run += c8[e];
         }
         if (lane == 63)
@@ -941,6 +951,10 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
             if (q < B) {
                 key[q] = urf_wave_sort64(key[q]);
                 A[q * 64 + lane] = key[q];
+                if (key[q] != ~0ull) {   /* the key moved to another lane: fetch its companions again */
+                    zreg[q] = a.sz[base + (unsigned)key[q]];
+                    sreg[q] = a.ssrc[base + (unsigned)key[q]];
+                }
             }
         __syncthreads();
 #pragma unroll
@@ -952,14 +966,44 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
                         rank[q] += urf_count_less64(A + p * 64, key[q]);
         }
     }
-    __syncthreads();   /* every lane has its ranks: A may be overwritten */
+    __syncthreads();   /* every lane has its ranks: A and cnt may be overwritten */
+    unsigned* R = (unsigned*)A;      /* range bits, height, ring-major position in sorted order */
+    float* Z = (float*)A + 512;
+    unsigned* S = cnt;
 #pragma unroll
     for (unsigned q = 0; q < MAXB; q++)
-        if (q < B && key[q] != ~0ull)
-            A[rank[q]] = key[q];
+        if (q < B && key[q] != ~0ull) {
+            R[rank[q]] = (unsigned)(key[q] >> 32);
+            Z[rank[q]] = zreg[q];
+            S[rank[q]] = sreg[q];
+        }
     __syncthreads();
-    const unsigned long long* fin = A;
-    const unsigned first = urf_star_emit<URF_STAR_THREADS, MAXB>(a, dp, base, n, fin, nullptr, sh_first);
+    /* tail (see urf_star_emit): slopes / distance terms / ring positions in sorted order, stop
+     * after the 64-element chunk that holds the first static hit */
+    const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
+#pragma unroll
+    for (unsigned q = 0; q < MAXB; q++) {
+        const unsigned i = q * 64 + lane;
+        if (q * 64 >= n)
+            break;
+        if (i < n) {
+            float slp = 0.f, g = 0.f;
+            if (i >= 1) {
+                const float ax = __uint_as_float(R[i - 1]), bx = __uint_as_float(R[i]);
+                slp = (Z[i] - Z[i - 1]) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
+                g = (bx - ax) * kdist;
+                if (slp > slope_param)
+                    atomicMin(sh_first, i);
+            }
+            a.ssrt[base + i] = S[i];
+            a.wslp[base + i] = slp;
+            a.wg[base + i] = g;
+        }
+        __syncthreads();
+        if (*sh_first < (q + 1) * 64)
+            break;
+    }
+    const unsigned first = *sh_first;
     if (lane == 0)
         *star_first_out = first < n - 1 ? first : n - 1;   /* last index the walk may visit */
 }
@@ -967,15 +1011,17 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
 
 __global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs a, urf_dev_params dp)
 {
-    constexpr unsigned NB = 512;                    /* buckets */
-    __shared__ unsigned long long A[8 * 64];        /* keys by bucket, then the fully sorted sector */
-    __shared__ unsigned cnt[NB + 1];                /* bucket counts, then exclusive offsets */
+    constexpr unsigned NB = URF_STAR_NB;            /* buckets */
+    __shared__ unsigned long long A[8 * 64];        /* keys by bucket, then range / height of the sorted sector */
+    __shared__ unsigned cnt[NB + 1];                /* bucket counts, then exclusive offsets, then ring positions */
     __shared__ unsigned sh_first;
     const unsigned k = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
     if (a.info[s].status != URF_OK)
         return;
     const unsigned K = (unsigned)dp.p.sectors;
-    const unsigned n = a.sec_cnt[(size_t)s * K + k];
+    /* both ends of the sector in one round trip (sec_cnt, then sec_off would be two) */
+    const unsigned so0 = a.sec_off[(size_t)s * (K + 1) + k], so1 = a.sec_off[(size_t)s * (K + 1) + k + 1];
+    const unsigned n = so1 - so0;
     if (n > 512)
         return;   /* on a work list (k_offsets) */
     if (n < 2) {
@@ -985,7 +1031,7 @@ __global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs 
     }
     unsigned off, len;
     urf_scan_range(a, s, off, len);
-    const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
+    const unsigned base = off + so0;
     if (lane == 0)
         sh_first = n;
     /* per-lane element count fixed at compile time: 6 covers a sector of a 64 x 2048 sweep */
