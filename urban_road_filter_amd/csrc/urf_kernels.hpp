@@ -2145,11 +2145,12 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) void k_label(urf_kargs a, u
                 if (e < URF_LABEL_UNSURE) {
                     un_pos[e] = rpos[q];
                     un_key[e] = (src - tbase) | (c << 16);
-                    continue;
+                    road_final = false;   /* placeholder, corrected after the tile is written */
+                } else {
+                    float d2;   /* list full (pathological input): decide here */
+                    road_final = urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c],
+                                               urf_azimuth(a.rx[rpos[q]], a.ry[rpos[q]], &d2), 0.0f, unsure);
                 }
-                float d2;   /* list full (pathological input): decide here */
-                road_final = urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c],
-                                           urf_azimuth(a.rx[rpos[q]], a.ry[rpos[q]], &d2), 0.0f, unsure);
             }
             if (road_final) {
                 lab |= URF_LABEL_ROAD;
@@ -2159,29 +2160,38 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) void k_label(urf_kargs a, u
         img[URF_IMG(src - tbase)] = lab;
     }
     __syncthreads();
+    static_assert(URF_LABEL_UNSURE <= URF_LABEL_TILE_THREADS, "one listed point per thread");
+    /* The listed points: their coordinates are requested now and used after the tile has been
+     * written, so that the round trip hides behind the stores (URF_LABEL_UNSURE <= workgroup size). */
     const unsigned nu = n_unsure < URF_LABEL_UNSURE ? n_unsure : URF_LABEL_UNSURE;
-    for (unsigned e = tid; e < nu; e += URF_LABEL_TILE_THREADS) {
-        const unsigned pos = un_pos[e], c = un_key[e] >> 16, li = un_key[e] & 0xffffu;
+    const bool tail = tid < nu;
+    float tx = 0.f, ty = 0.f;
+    unsigned tkey = 0;
+    if (tail) {
+        tkey = un_key[tid];
+        tx = a.rx[un_pos[tid]];
+        ty = a.ry[un_pos[tid]];
+    }
+    for (unsigned i = tid; i < URF_TILE; i += URF_LABEL_TILE_THREADS) {
+        const uint8_t l = img[URF_IMG(i)];
+        if (l != 0xff && tbase + i < len)
+            a.labels[off + tbase + i] = l;   /* points on no ring keep the label k_ring_assign wrote */
+    }
+    __syncthreads();   /* the tile's stores come first, the corrections second */
+    if (tail) {
+        const unsigned c = tkey >> 16, li = tkey & 0xffffu;
         float d2;
         bool unsure;
-        const float az = urf_azimuth(a.rx[pos], a.ry[pos], &d2);
-        uint8_t lab = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0);
-        if (urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c], az, 0.0f, unsure)) {
-            lab |= URF_LABEL_ROAD;
+        if (urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c], urf_azimuth(tx, ty, &d2), 0.0f, unsure)) {
+            a.labels[off + tbase + li] = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0) | URF_LABEL_ROAD;
             my_road++;
         }
-        img[URF_IMG(li)] = lab;
     }
     if (my_road)
         atomicAdd(&cnt_road, my_road);
     if (my_curb)
         atomicAdd(&cnt_curb, my_curb);
     __syncthreads();
-    for (unsigned i = tid; i < URF_TILE; i += URF_LABEL_TILE_THREADS) {
-        const uint8_t l = img[URF_IMG(i)];
-        if (l != 0xff && tbase + i < len)
-            a.labels[off + tbase + i] = l;   /* points on no ring keep the label k_ring_assign wrote */
-    }
     if (tid == 0) {
         urf_scan_info* o = &a.info[s];
         if (cnt_road)
