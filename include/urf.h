@@ -249,7 +249,7 @@ int urf_enable_stage_capture(urf_ctx* ctx, int on);
  * with hipEvents on the context's stream.  urf_kernel_timing() synchronises,
  * adds the elapsed milliseconds of all calls since the last query to
  * ms_sum[0..URF_NUM_KERNELS) and the number of calls to *n_calls, then resets. */
-#define URF_NUM_KERNELS 8
+#define URF_NUM_KERNELS 9
 int urf_enable_kernel_timing(urf_ctx* ctx, int on);
 int urf_kernel_timing(urf_ctx* ctx, double* ms_sum, uint32_t* n_calls);
 const char* urf_kernel_name(int index);

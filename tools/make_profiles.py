@@ -54,8 +54,9 @@ def main(src, tag):
         return sum(v) / len(v)
     kernels = sorted({k for k, _ in vals if k.startswith("k_")})
     per = {k: int(2 * avg(k, "FETCH_SIZE") * 1024 + avg(k, "WRITE_SIZE") * 1024) for k in kernels}
-    # bench.py's timing slot "k_star" spans k_star_sort_* + k_star_walk; every other slot is one kernel
-    doms = [k for k in kernels if (k.startswith("k_star") if dom == "k_star" else k == dom)]
+    # bench.py's timing slot "k_star_sort" spans k_star_sort_small/mid/big (the latter two run over
+    # normally empty work lists); every other slot is one kernel
+    doms = [k for k in kernels if (k.startswith("k_star_sort") if dom == "k_star_sort" else k == dom)]
     out = {"kernel": dom, "scans_per_launch": bench["config"]["scans_per_gpu"],
            "hbm_bytes_per_launch": sum(per[k] for k in doms),
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",

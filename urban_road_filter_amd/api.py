@@ -215,7 +215,7 @@ class Context:
     def enable_stage_capture(self, on=True):
         self._check(self._lib.urf_enable_stage_capture(self._h, int(on)), "urf_enable_stage_capture")
 
-    NUM_KERNELS = 8
+    NUM_KERNELS = 9
 
     def selftest_fast(self, n_samples=1 << 27):
         """max |approx - exact| of the float fast paths: (vertical angle [deg], polar angle [rad], fi*Kfi, azimuth [deg])."""

@@ -332,7 +332,7 @@ extern "C" int urf_enable_kernel_timing(urf_ctx* c, int on)
 extern "C" const char* urf_kernel_name(int i)
 {
     static const char* names[URF_NUM_KERNELS] = { "k_ring_table", "k_ingest", "k_offsets", "k_scatter",
-                                                  "k_star", "k_ring", "k_beams", "k_label" };
+                                                  "k_star_sort", "k_star_walk", "k_ring", "k_beams", "k_label" };
     return (i >= 0 && i < URF_NUM_KERNELS) ? names[i] : "";
 }
 
@@ -425,8 +425,10 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         /* persistent workgroups over the (normally empty) work lists of oversized sectors */
         hipLaunchKernelGGL(k_star_sort_mid, dim3(c->n_cus * 4), dim3(URF_STAR_MID_THREADS), 0, st, a, dp);
         hipLaunchKernelGGL(k_star_sort_big, dim3(c->n_cus * 2), dim3(256), 0, st, a, dp);
-        hipLaunchKernelGGL(k_star_walk, dim3((K + 63) / 64, n_scans), dim3(64), 0, st, a, dp);
     }
+    mark();   /* "k_star_sort" = the three sort kernels (mid / big run over normally empty work lists) */
+    if (star)
+        hipLaunchKernelGGL(k_star_walk, dim3((K + 63) / 64, n_scans), dim3(64), 0, st, a, dp);
     mark();
     const dim3 g_ring(C, n_scans);
     hipLaunchKernelGGL(k_ring, g_ring, dim3(URF_RING_THREADS), 0, st, a, dp);
