@@ -1309,10 +1309,12 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
  * 16 steps of all its sectors cooperatively (16 consecutive floats = one line
  * per sector) into LDS and every lane then reads its own row. */
 #define URF_WALK_CHUNK 16
+#define URF_WALK_INV 512
 __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp)
 {
     __shared__ float tS[2][64][URF_WALK_CHUNK + 1], tG[2][64][URF_WALK_CHUNK + 1];
     __shared__ unsigned sbase[64], slast[64];
+    __shared__ float sinv[URF_WALK_INV];   /* 1.0f / (float)i, star_shaped_search.cpp:137 */
     const unsigned K = (unsigned)dp.p.sectors;
     const unsigned s = blockIdx.y, lane = threadIdx.x;
     const unsigned k = blockIdx.x * 64 + lane;
@@ -1336,13 +1338,19 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
     /* the next 16 steps of all 64 sectors: 32 loads in flight, then parked in registers until the
      * LDS buffer they belong to is free (double buffering: chunk c+1 loads while chunk c is walked) */
     float vs[16], vg[16];
+    unsigned rbase[16], rlast[16];   /* the 16 sectors this lane loads for: fixed for the whole walk */
+#pragma unroll
+    for (unsigned r = 0; r < 16; r++) {
+        rbase[r] = sbase[r * 4 + (lane >> 4)];
+        rlast[r] = slast[r * 4 + (lane >> 4)];
+    }
     auto fetch = [&](unsigned c0) {
+        const unsigned e = c0 + (lane & 15);
 #pragma unroll
         for (unsigned r = 0; r < 16; r++) {
-            const unsigned sec = r * 4 + (lane >> 4), e = c0 + (lane & 15);
-            const bool on = e >= 1 && e <= slast[sec];
-            vs[r] = on ? a.wslp[sbase[sec] + e] : 0.f;
-            vg[r] = on ? a.wg[sbase[sec] + e] : 0.f;
+            const bool on = e >= 1 && e <= rlast[r];
+            vs[r] = on ? a.wslp[rbase[r] + e] : 0.f;
+            vg[r] = on ? a.wg[rbase[r] + e] : 0.f;
         }
     };
     auto park = [&](unsigned buf) {
@@ -1358,30 +1366,73 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
     const int dmin = dp.p.dmin_param;
     float avg = 0.f, dev = 0.f, nan = 0.f;
     unsigned hit_i = 0;              /* sorted index of the sector's curb point, 0 = none */
-    bool running = last >= 1;
+    unsigned lim = last;             /* last index this lane still walks; 0 = done */
+    for (unsigned t = lane; t < URF_WALK_INV; t += 64)
+        sinv[t] = 1.0f / (float)(int)t;   /* [0] is never used */
     fetch(0);
     park(0);
     __syncthreads();
     unsigned buf = 0;
     for (unsigned c0 = 0; c0 <= maxlast; c0 += URF_WALK_CHUNK, buf ^= 1u) {
-        if (!__any(running))
+        if (!__any(lim != 0))
             break;
         const bool more = c0 + URF_WALK_CHUNK <= maxlast;
         if (more)
             fetch(c0 + URF_WALK_CHUNK);
-        /* all lanes step through the chunk in lockstep (i is wave-uniform); a lane that is past
-         * its sector's end or has found its curb point just stops updating its state */
+        /* the chunk's operands first: slopes, distance terms and the wave-uniform 1 / i (LDS
+         * table; anything fetched inside the dependent chain below would cost more than the step) */
+        float sl[URF_WALK_CHUNK], gg[URF_WALK_CHUNK], uu[URF_WALK_CHUNK];
+        bool anynan = nan != 0.0f;
 #pragma unroll
         for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
-            const unsigned i = c0 + j;
-            const bool active = running && i >= 1 && i <= last;
-            const float slp = tS[buf][lane][j];
-            const bool isnan = slp != slp;
-            if (__any(active && (isnan || nan != 0.0f))) {
-                /* rare: a NaN slope has been seen (star_shaped_search.cpp:131-132, 135-140 with nan > 0) */
+            sl[j] = tS[buf][lane][j];
+            gg[j] = tG[buf][lane][j];
+            anynan = anynan || sl[j] != sl[j];
+        }
+        if (c0 + URF_WALK_CHUNK <= URF_WALK_INV) {
+#pragma unroll
+            for (unsigned j = 0; j < URF_WALK_CHUNK; j++)
+                uu[j] = sinv[c0 + j];
+        } else {
+#pragma unroll
+            for (unsigned j = 0; j < URF_WALK_CHUNK; j++)
+                uu[j] = 1.0f / (float)(int)(c0 + j);
+        }
+        /* All lanes step through the chunk in lockstep (i is wave-uniform); a lane that is past its
+         * sector's end or has found its curb point just stops updating its state (lim = 0). */
+        if (!__any(anynan)) {
+            /* straight-line version: no NaN slope so far in any sector of the wave */
+#pragma unroll
+            for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
+                const unsigned i = c0 + j;
+                if (i == 0)
+                    continue;   /* the walk starts at 1 (compile-time j, uniform c0) */
+                const float slp = sl[j];
+                const float w = (float)(int)(i - 1);               /* == (float)i - 0 - 1, exact */
+                float na = avg * w;                                /* star_shaped_search.cpp:135-140 */
+                na = na + slp;
+                na = na * uu[j];
+                float nd = dev * w;
+                nd = nd + __builtin_fabsf(slp - na);
+                nd = nd * uu[j];
+                const bool active = i <= lim;
+                avg = active ? na : avg;
+                dev = active ? nd : dev;
+                const bool h = (slp > slope_param) |               /* :142-143 */
+                               (((int)i > dmin) & ((slp * slp - avg * avg) * kdev * gg[j] > dev));
+                const bool hit_now = active & h;
+                hit_i = hit_now ? i : hit_i;                       /* :146 */
+                lim = hit_now ? 0u : lim;
+            }
+        } else {
+#pragma unroll 1
+            for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
+                const unsigned i = c0 + j;
+                const bool active = i >= 1 && i <= lim;
+                const float slp = sl[j];
                 if (active) {
-                    if (isnan) {
-                        nan += 1.0f;
+                    if (slp != slp) {
+                        nan += 1.0f;                               /* :131-132 */
                     } else {
                         const float w = (float)(int)i - nan - 1.0f;
                         const float u = 1.0f / ((float)(int)i - nan);
@@ -1393,27 +1444,16 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
                         dev *= u;
                     }
                 }
-            } else {
-                const float w = (float)(int)(i - 1);           /* == (float)i - 0 - 1, exact */
-                const float u = a.inv_i[i];                    /* 1.0f / (float)i */
-                float na = avg * w;                            /* :135-140 */
-                na = na + slp;
-                na = na * u;
-                float nd = dev * w;
-                nd = nd + __builtin_fabsf(slp - na);
-                nd = nd * u;
-                avg = active ? na : avg;
-                dev = active ? nd : dev;
-            }
-            const bool h = slp > slope_param ||                /* :142-143 */
-                           ((int)i > dmin && (slp * slp - avg * avg) * kdev * tG[buf][lane][j] > dev);
-            if (active && h) {
-                hit_i = i;                                     /* :146 */
-                running = false;
+                const bool h = slp > slope_param ||
+                               ((int)i > dmin && (slp * slp - avg * avg) * kdev * gg[j] > dev);
+                if (active && h) {
+                    hit_i = i;
+                    lim = 0;
+                }
             }
         }
         if (c0 + URF_WALK_CHUNK > last)
-            running = false;
+            lim = 0;
         if (more)
             park(buf ^ 1u);
         __syncthreads();
