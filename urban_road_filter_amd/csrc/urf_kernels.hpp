@@ -452,6 +452,27 @@ __device__ void urf_scan_keys_256(const unsigned* cnt, unsigned* offs, unsigned 
     __syncthreads();
 }
 
+/* One key's column of the tile count matrix (element t at col[t * stride]) -> exclusive prefix over
+ * the tiles, in place; returns the total.  16 loads are in flight at a time: one load per tile in
+ * program order would cost a full memory round trip per tile. */
+__device__ __forceinline__ unsigned urf_tile_prefix(unsigned* col, unsigned stride, unsigned ntiles)
+{
+    unsigned run = 0;
+    for (unsigned t0 = 0; t0 < ntiles; t0 += 16) {
+        unsigned v[16];
+#pragma unroll
+        for (unsigned u = 0; u < 16; u++)
+            v[u] = t0 + u < ntiles ? col[(size_t)(t0 + u) * stride] : 0u;
+#pragma unroll
+        for (unsigned u = 0; u < 16; u++)
+            if (t0 + u < ntiles) {
+                col[(size_t)(t0 + u) * stride] = run;
+                run += v[u];
+            }
+    }
+    return run;
+}
+
 __global__ __launch_bounds__(256) void k_offsets(urf_kargs a, urf_dev_params dp)
 {
     __shared__ unsigned sh[8];
@@ -482,30 +503,14 @@ __global__ __launch_bounds__(256) void k_offsets(urf_kargs a, urf_dev_params dp)
             return;
     }
     /* rings */
-    for (unsigned k = tid; k < C; k += 256) {
-        unsigned run = 0;
-        for (unsigned t = 0; t < ntiles; t++) {
-            unsigned* p = &a.tile_ring[((size_t)s * a.tiles + t) * C + k];
-            const unsigned c = *p;
-            *p = run;
-            run += c;
-        }
-        a.ring_cnt[(size_t)s * C + k] = run;
-    }
+    for (unsigned k = tid; k < C; k += 256)
+        a.ring_cnt[(size_t)s * C + k] = urf_tile_prefix(&a.tile_ring[(size_t)s * a.tiles * C + k], C, ntiles);
     __syncthreads();
     urf_scan_keys_256(&a.ring_cnt[(size_t)s * C], &a.ring_off[(size_t)s * (C + 1)], C, sh);
     if (!dp.p.star_shaped_method)
         return;
-    for (unsigned k = tid; k < K; k += 256) {
-        unsigned run = 0;
-        for (unsigned t = 0; t < ntiles; t++) {
-            unsigned* p = &a.tile_sec[((size_t)s * a.tiles + t) * K + k];
-            const unsigned c = *p;
-            *p = run;
-            run += c;
-        }
-        a.sec_cnt[(size_t)s * K + k] = run;
-    }
+    for (unsigned k = tid; k < K; k += 256)
+        a.sec_cnt[(size_t)s * K + k] = urf_tile_prefix(&a.tile_sec[(size_t)s * a.tiles * K + k], K, ntiles);
     __syncthreads();
     urf_scan_keys_256(&a.sec_cnt[(size_t)s * K], &a.sec_off[(size_t)s * (K + 1)], K, sh);
     /* sectors too large for one wave's LDS tile go on the work lists of k_star_mid / k_star_big
@@ -1970,22 +1975,28 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     int sf = -1, sb = -1;
     if (fi <= dp.fwd_limit && !blind) {   /* blind_spots.cpp:68 */
         sf = (int)nR;
-        for (unsigned k = 0; k < nR; k++) {
-            const float m = a.sufmin[((size_t)s * C + k) * URF_DEG_CELLS + i];
-            if (m <= urf_fwd_hi(dp, i, k, qk[k])) {
-                sf = (int)k;
-                break;
-            }
+        for (unsigned k0 = 0; k0 < nR && sf == (int)nR; k0 += 8) {   /* 8 rings' table entries in flight */
+            float m[8];
+#pragma unroll
+            for (unsigned u = 0; u < 8; u++)
+                m[u] = k0 + u < nR ? a.sufmin[((size_t)s * C + k0 + u) * URF_DEG_CELLS + i] : __builtin_nanf("");
+#pragma unroll
+            for (unsigned u = 0; u < 8; u++)
+                if (sf == (int)nR && k0 + u < nR && m[u] <= urf_fwd_hi(dp, i, k0 + u, qk[k0 + u]))
+                    sf = (int)(k0 + u);
         }
     }
     if (fi >= dp.bwd_limit && !blind) {   /* blind_spots.cpp:177 */
         sb = (int)nR;
-        for (unsigned k = 0; k < nR; k++) {
-            const float m = a.premax[((size_t)s * C + k) * URF_DEG_CELLS + i];
-            if (m >= urf_bwd_lo(dp, i, k, qk[k])) {
-                sb = (int)k;
-                break;
-            }
+        for (unsigned k0 = 0; k0 < nR && sb == (int)nR; k0 += 8) {
+            float m[8];
+#pragma unroll
+            for (unsigned u = 0; u < 8; u++)
+                m[u] = k0 + u < nR ? a.premax[((size_t)s * C + k0 + u) * URF_DEG_CELLS + i] : __builtin_nanf("");
+#pragma unroll
+            for (unsigned u = 0; u < 8; u++)
+                if (sb == (int)nR && k0 + u < nR && m[u] >= urf_bwd_lo(dp, i, k0 + u, qk[k0 + u]))
+                    sb = (int)(k0 + u);
         }
     }
     if (inrange) {
