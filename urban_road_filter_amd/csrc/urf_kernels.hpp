@@ -1491,6 +1491,7 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
  * workgroup size, windows read from LDS). */
 #define URF_RING_PPT 4
 #define URF_RING_CHUNK (URF_RING_THREADS * URF_RING_PPT)
+#define URF_RING_CAND 1024   /* capacity of the candidate list; flushed when a chunk might not fit */
 #define URF_RING_PAD 32   /* LDS slots in front of a chunk, >= URF_MAX_CURB_POINTS, multiple of 4 */
 
 struct urf_ring_shared {
@@ -1503,25 +1504,23 @@ struct urf_ring_shared {
     unsigned hits[URF_MAX_SECTORS + 2];
     unsigned n_hits;
     unsigned hb[2][URF_RING_CHUNK / 32];   /* star-hit bit per point of the chunk, double buffered */
-    /* quad mapping: points that need one of the expensive evaluations, compacted */
-    unsigned short cand[URF_RING_CHUNK];   /* chunk-local index | URF_CAND_* << URF_CAND_SHIFT */
+    /* quad mapping: the ring's points that need one of the expensive evaluations, compacted */
+    unsigned cand[URF_RING_CAND];          /* ring-relative position | URF_CAND_* << URF_CAND_SHIFT */
     unsigned n_cand;
-    unsigned flg[URF_RING_CHUNK / 4];      /* byte per chunk point: detector bits | 0x80 = azx valid */
-    float azx[URF_RING_CHUNK];             /* exact azimuth of the points that needed it */
 };
-#define URF_CAND_SHIFT 12   /* chunk-local index below, URF_CAND_* above (chunk <= 4096 points) */
+#define URF_CAND_SHIFT 28   /* position below, URF_CAND_* above */
 #define URF_CAND_XZERO 1u   /* passed the height tests of x_zero: angle test pending */
 #define URF_CAND_ZZERO 2u   /* same for z_zero */
 #define URF_CAND_EXACT 4u   /* no float approximation of the azimuth (near the x axis, stage capture) */
 #define URF_CAND_STAR 8u    /* star-shaped hit */
 
 /* x_zero_method.cpp:30-68 for the triple (j, p, j + cp), j = p - cp / 2, given the cheap height
- * tests passed; lj = LDS slot (xs/ys) of j. */
-__device__ __forceinline__ bool urf_x_zero_angle(const urf_kargs& a, const urf_dev_params& dp, const urf_ring_shared& S,
-                                                 int j, int p, int lj, int cp, float zj, float pz, float z3)
+ * tests passed.  X / Y: the ring's coordinates indexed by ring-relative position (an LDS window or
+ * the ring-major arrays themselves). */
+__device__ __forceinline__ bool urf_x_zero_angle(const urf_kargs& a, const urf_dev_params& dp, const float* X, const float* Y,
+                                                 int j, int p, int cp, float zj, float pz, float z3)
 {
-    const int l3 = lj + cp;
-    const double dx = (double)(S.xs[l3] - S.xs[lj]), dy = (double)(S.ys[l3] - S.ys[lj]);
+    const double dx = (double)(X[j + cp] - X[j]), dy = (double)(Y[j + cp] - Y[j]);
     if (!(dx * dx + dy * dy < URF_DIST5_SQ))                                    /* :35-40 */
         return false;
     const float nyj = a.newY[j], ny2 = a.newY[p], ny3 = a.newY[j + cp];
@@ -1543,21 +1542,21 @@ __device__ __forceinline__ bool urf_x_zero_angle(const urf_kargs& a, const urf_d
     return alpha <= dp.p.angleFilter1;                                          /* :61 */
 }
 
-/* z_zero_method.cpp:21-66 for the centre p (LDS slot lp in xs/ys), given the height tests passed */
-__device__ __forceinline__ bool urf_z_zero_angle(const urf_dev_params& dp, const urf_ring_shared& S, int lp, int cp,
+/* z_zero_method.cpp:21-66 for the centre p, given the height tests passed */
+__device__ __forceinline__ bool urf_z_zero_angle(const urf_dev_params& dp, const float* X, const float* Y, int p, int cp,
                                                  float px, float py)
 {
-    const double dx = (double)(S.xs[lp + cp] - S.xs[lp - cp]), dy = (double)(S.ys[lp + cp] - S.ys[lp - cp]);
+    const double dx = (double)(X[p + cp] - X[p - cp]), dy = (double)(Y[p + cp] - Y[p - cp]);
     if (!(dx * dx + dy * dy < URF_DIST5_SQ))                                    /* :23-28 */
         return false;
     float va1 = 0.f, va2 = 0.f, vb1 = 0.f, vb2 = 0.f;
     for (int k = 1; k <= cp; k++) {                                             /* :35-38 */
-        va1 = va1 + (S.xs[lp - k] - px);
-        va2 = va2 + (S.ys[lp - k] - py);
+        va1 = va1 + (X[p - k] - px);
+        va2 = va2 + (Y[p - k] - py);
     }
     for (int k = 1; k <= cp; k++) {                                             /* :44-47 */
-        vb1 = vb1 + (S.xs[lp + k] - px);
-        vb2 = vb2 + (S.ys[lp + k] - py);
+        vb1 = vb1 + (X[p + k] - px);
+        vb2 = vb2 + (Y[p + k] - py);
     }
     va1 = dp.inv_cp * va1;                                                      /* :52-55 */
     va2 = dp.inv_cp * va2;
@@ -1697,19 +1696,17 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
             }
             if (tid < CH / 32)
                 S.hb[buf ^ 1u][tid] = 0;
-            S.flg[tid] = 0;   /* CH / 4 == URF_RING_THREADS */
         }
         __syncthreads();
         if (cs + CH < n)
             fetch(cs + CH);
         if (quads) {
             /* ---- four consecutive points per thread, curbPoints == 5 ----
-             * A: cheap tests and the float azimuth for every point; the points that need an angle
-             *    test of a detector or the exact azimuth go to a list.
-             * B: the list, densely (all lanes busy instead of the two or three that sit on a curb).
-             * C: merge, store. */
+             * Cheap tests and the float azimuth for every point, stored at once; the points that
+             * need an angle test of a detector or the exact azimuth go to the ring's candidate
+             * list, which is worked off densely (all lanes busy instead of the two or three that
+             * sit on a curb) when it fills up and at the end of the ring. */
             const int q0 = cs + 4 * (int)tid;
-            float azf[4] = { 0.f, 0.f, 0.f, 0.f };
             if (q0 < n) {
                 const float4* zp = (const float4*)(S.zs + 4 * tid + PAD - 4);   /* slot of q0 - 5 */
                 float w[16];
@@ -1729,6 +1726,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                 for (int j = 0; j < 9; j++)
                     M[j] = __builtin_fmaxf(T[j], T[j + 3]);
                 const unsigned hbits = (S.hb[buf][tid >> 3] >> ((tid & 7u) * 4u)) & 15u;
+                float azf[4] = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int p = q0 + i;
@@ -1753,56 +1751,47 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                     const double s2 = (double)qx[i] * (double)qx[i] + (double)qy[i] * (double)qy[i];
                     maxs = s2 > maxs ? s2 : maxs;
                     if (t)
-                        S.cand[atomicAdd(&S.n_cand, 1u)] = (unsigned short)((unsigned)(4 * (int)tid + i) | (t << URF_CAND_SHIFT));
+                        S.cand[atomicAdd(&S.n_cand, 1u)] = (unsigned)p | (t << URF_CAND_SHIFT);
                 }
-            }
-            __syncthreads();
-            const unsigned nc = S.n_cand;
-            for (unsigned e = tid; e < nc; e += URF_RING_THREADS) {
-                const unsigned v = S.cand[e], t = v >> URF_CAND_SHIFT;
-                const int lc = (int)(v & (URF_RING_CHUNK - 1u)), p = cs + lc;
-                const float px = S.xs[lc + PAD], py = S.ys[lc + PAD];
-                unsigned flag = (t & URF_CAND_STAR) ? 1u : 0u;
-                if (t & URF_CAND_XZERO) {
-                    const float zj = S.zs[lc + zpad - 2], pz = S.zs[lc + zpad], z3 = S.zs[lc + zpad + 3];
-                    if (urf_x_zero_angle(a, dp, S, p - 2, p, lc - 2 + PAD, 5, zj, pz, z3))
-                        flag |= 2u;
-                }
-                if ((t & URF_CAND_ZZERO) && urf_z_zero_angle(dp, S, lc + PAD, 5, px, py))
-                    flag |= 4u;
-                if (flag || (t & URF_CAND_EXACT)) {
-                    S.azx[lc] = urf_ring_point(a, S, (size_t)base + p, px, py, flag, want_quad);
-                    ((uint8_t*)S.flg)[lc] = (uint8_t)(flag | 0x80u);
-                }
-            }
-            __syncthreads();
-            if (q0 < n) {
-                const unsigned f4 = S.flg[tid];
-                unsigned fl[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const unsigned f = (f4 >> (8 * i)) & 0xffu;
-                    if (f & 0x80u) {
-                        azf[i] = S.azx[4 * tid + i];
-                        fl[i] = f & 7u;
-                    } else {
-                        fl[i] = URF_RFLAG_AZ_APPROX;
-                    }
-                }
+                /* every point leaves as "no curb, azimuth approximate"; the candidate pass rewrites
+                 * the ones for which that is not the whole truth */
+                const unsigned fl4 = URF_RFLAG_AZ_APPROX * 0x01010101u;
                 if (q0 >= 0 && q0 + 3 < n) {
                     *(float4*)(a.raz + base + q0) = make_float4(azf[0], azf[1], azf[2], azf[3]);
-                    *(unsigned*)(a.rflag + base + q0) = fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24);
+                    *(unsigned*)(a.rflag + base + q0) = fl4;
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
                         if (q0 + i >= 0 && q0 + i < n) {
                             a.raz[base + q0 + i] = azf[i];
-                            a.rflag[base + q0 + i] = (uint8_t)fl[i];
+                            a.rflag[base + q0 + i] = (uint8_t)URF_RFLAG_AZ_APPROX;
                         }
                 }
             }
-            if (tid == 0)
-                S.n_cand = 0;   /* read by everyone before the previous barrier */
+            __syncthreads();
+            if (S.n_cand > URF_RING_CAND - CH || cs + CH >= n) {   /* the next chunk might not fit / last chunk */
+                const unsigned nc = S.n_cand;
+                const float* GX = a.rx + base;
+                const float* GY = a.ry + base;
+                const float* GZ = a.rz + base;
+                for (unsigned e = tid; e < nc; e += URF_RING_THREADS) {
+                    const unsigned v = S.cand[e], t = v >> URF_CAND_SHIFT;
+                    const int p = (int)(v & ((1u << URF_CAND_SHIFT) - 1u));
+                    const float px = GX[p], py = GY[p];
+                    unsigned flag = (t & URF_CAND_STAR) ? 1u : 0u;
+                    if ((t & URF_CAND_XZERO) && urf_x_zero_angle(a, dp, GX, GY, p - 2, p, 5, GZ[p - 2], GZ[p], GZ[p + 3]))
+                        flag |= 2u;
+                    if ((t & URF_CAND_ZZERO) && urf_z_zero_angle(dp, GX, GY, p, 5, px, py))
+                        flag |= 4u;
+                    if (flag || (t & URF_CAND_EXACT)) {
+                        a.raz[base + p] = urf_ring_point(a, S, (size_t)base + p, px, py, flag, want_quad);
+                        a.rflag[base + p] = (uint8_t)flag;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0)
+                    S.n_cand = 0;
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < URF_RING_PPT; e++) {
@@ -1825,7 +1814,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                         const bool heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight ||
                                               __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
                                              (double)__builtin_fabsf(zj - z3) >= 0.05;          /* :62-64 */
-                        if (heights && urf_x_zero_angle(a, dp, S, j, p, lp - cp / 2, cp, zj, pz, z3))
+                        if (heights && urf_x_zero_angle(a, dp, S.xs + PAD - cs, S.ys + PAD - cs, j, p, cp, zj, pz, z3))
                             flag |= 2u;
                     }
                 }
@@ -1842,7 +1831,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                         }
                         const bool heights = (max1 - az >= dp.p.curbHeight || max2 - az >= dp.p.curbHeight) &&
                                              (double)__builtin_fabsf(max1 - max2) >= 0.05;      /* :67-69 */
-                        if (heights && urf_z_zero_angle(dp, S, lp, cp, px, py))
+                        if (heights && urf_z_zero_angle(dp, S.xs + PAD - cs, S.ys + PAD - cs, p, cp, px, py))
                             flag |= 4u;
                     }
                 }
