@@ -166,7 +166,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.rx, T) A(k.ry, T) A(k.rz, T) A(k.rsrc, T) A(k.raz, T) A(k.rd2, T) A(k.rflag, T)
     A(k.sr, T) A(k.sz, T) A(k.ssrc, T) A(k.ssrt, T) A(k.wslp, T) A(k.wg, T)
     A(k.tile_roi, S * tiles) A(k.tile_ring, S * tiles * C) A(k.tile_sec, S * tiles * K)
-    A(k.angle, S * C) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
+    A(k.angle, S * C) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
     A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 2)
     A(k.maxdist, S * C) A(k.quad, S * 4)

@@ -14,6 +14,8 @@
 #define URF_MAX_CHANNELS    128    /* ring keys fit 7 bits + "none" */
 #define URF_MAX_SECTORS     1022   /* sector keys fit 10 bits + "none" */
 #define URF_MAX_CURB_POINTS 30     /* cfg/LidarFilters.cfg:36 */
+#define URF_LUT_SCALE       16.0f  /* cells per degree of the ring lookup table (k_ring_table -> k_ingest) */
+#define URF_LUT_CELLS       2884   /* 180 * 16 + 1 cells, padded to a multiple of 4 */
 #define URF_DEG_CELLS       361    /* integer degrees 0..360 (blind_spots.cpp:68,177) */
 
 /* one tile = the unit of the stable multi-split by ring / by sector */
@@ -90,6 +92,7 @@ struct urf_kargs {
     uint32_t* tile_sec;         /* [S][tiles][sectors]  same for star sectors */
     /* per scan */
     float*    angle;            /* [S][channels] sorted ring-angle table */
+    uint8_t*  ring_lut;         /* [S][URF_LUT_CELLS] first table entry a vertical angle of the cell can match */
     uint32_t* ring_cnt;         /* [S][channels] */
     uint32_t* ring_off;         /* [S][channels+1] */
     uint32_t* sec_cnt;          /* [S][sectors] */

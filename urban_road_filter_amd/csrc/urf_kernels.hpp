@@ -87,6 +87,7 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
     extern __shared__ unsigned sh_hist[];   /* [sectors] sector histogram, [sectors] = ROI count */
     __shared__ float tab[URF_MAX_CHANNELS];
     __shared__ unsigned rhist[URF_MAX_CHANNELS];
+    __shared__ uint8_t lut[URF_LUT_CELLS] __attribute__((aligned(4)));   /* k_ring_table's lookup table */
     const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
@@ -112,13 +113,14 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
         tab[tid] = tid < nR ? a.angle[(size_t)s * C + tid] : 0.f;
         rhist[tid] = 0;
     }
+    for (unsigned i = tid; i < URF_LUT_CELLS / 4; i += URF_INGEST_THREADS)
+        ((unsigned*)lut)[i] = ((const unsigned*)(a.ring_lut + (size_t)s * URF_LUT_CELLS))[i];
     __syncthreads();
 
     const float interval = dp.p.interval;
     /* Ring, float fast path (urf_device.hpp) unless the stage capture wants the exact angle: with
      * |vt - alpha| <= e, entries below vt - interval - e surely do not match, an entry within
-     * interval - e surely does, one beyond interval + e surely does not.  The bisections of the
-     * thread's eight points advance in lockstep, so that their LDS reads overlap. */
+     * interval - e surely does, one beyond interval + e surely does not. */
     const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;   /* + rounding of fl(angle[j] - alpha) */
     bool roi[Q], fast[Q];
     float vt[Q];
@@ -131,16 +133,23 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
         fast[q] = roi[q] && !a.valpha && urf_fast_vertical_angle(px[q], py[q], pz[q], &vt[q]);
         lo[q] = 0;
     }
+    /* lo = number of table entries surely below the point's window: the cell's count from the
+     * lookup table, plus the (usually zero or one) entries between the cell's start and the angle */
 #pragma unroll
-    for (unsigned step = URF_MAX_CHANNELS; step > 0; step >>= 1) {
-#pragma unroll
-        for (unsigned q = 0; q < Q; q++) {   /* lo = number of entries surely below the window */
-            const unsigned idx = lo[q] + step - 1;
-            const float tv = tab[idx & (URF_MAX_CHANNELS - 1)];
-            if (idx < nR && !(tv - vt[q] >= -(interval + e)))
-                lo[q] += step;
-        }
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned cell = (unsigned)(vt[q] * URF_LUT_SCALE);   /* vt in [0, 180] */
+        lo[q] = lut[cell < URF_LUT_CELLS - 1 ? cell : URF_LUT_CELLS - 1];
     }
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const float tv = tab[lo[q] & (URF_MAX_CHANNELS - 1)];
+        if (lo[q] < nR && !(tv - vt[q] >= -(interval + e)))
+            lo[q]++;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++)
+        while (lo[q] < nR && !(tab[lo[q] & (URF_MAX_CHANNELS - 1)] - vt[q] >= -(interval + e)))
+            lo[q]++;
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
         const unsigned i = tbase + q * URF_INGEST_THREADS + tid;
@@ -408,9 +417,31 @@ __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params 
             rank += (w < v) || (w == v && j < tid);
         }
         a.angle[(size_t)s * C + rank] = v;
+        SL[rank] = v;   /* the matching copy is no longer needed */
     }
     if (tid == 0)
         a.info[s].n_rings = n;
+    __syncthreads();
+    /* Lookup table for k_ingest's float fast path: cell c covers the vertical angles
+     * [c / 16, (c + 1) / 16) deg; lut[c] = number of table entries that cannot match the cell's
+     * smallest angle (they lie below it by more than interval + the approximation's error).  The
+     * count only grows with the angle, so a point starts its search at lut[cell] and usually ends
+     * it there or one entry later, instead of bisecting the table. */
+    {
+        const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;
+        uint8_t* lut = a.ring_lut + (size_t)s * URF_LUT_CELLS;
+        for (unsigned cell = tid; cell < URF_LUT_CELLS; cell += 256) {
+            const float v0 = (float)cell * (1.0f / URF_LUT_SCALE);
+            unsigned lo = 0;
+#pragma unroll
+            for (unsigned step = URF_MAX_CHANNELS; step > 0; step >>= 1) {
+                const unsigned idx = lo + step - 1;
+                if (idx < n && !(SL[idx & (URF_MAX_CHANNELS - 1)] - v0 >= -(interval + e)))
+                    lo += step;
+            }
+            lut[cell] = (uint8_t)lo;
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------- */
