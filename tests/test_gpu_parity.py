@@ -82,6 +82,17 @@ def test_every_stage(ctx_big, cfg, seed, tweak):
         assert np.array_equal(lg, lb) and info_equal(ig, ib)
     finally:
         ctx_big.enable_stage_capture(False)
+    # the production configuration (capture off): ring, sector and window membership are decided on
+    # float approximations with margins; every integer stage must still be the reference's
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_RING, n), st["ring"])
+    if p.star_shaped_method:
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_SECTOR, n), st["sector"])
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, n), st["detect"])
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_MAXDIST, n), st["max_dist"])
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_QUADRANTS, n), st["quadrants"])
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_BEAM_STOP, n), st["beam_stop"])
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
 
 
 def run_batch(ctx, scans, p, ragged=False):
@@ -407,6 +418,61 @@ def test_fast_path_error_bounds(ctx_big):
     (3e-4 deg, 2e-6 rad, 2.5e-4, 5e-4 deg) must dominate the error measured on 2^28 pseudo-random points."""
     ev, ea, eu, ez = ctx_big.selftest_fast(1 << 28)
     assert ev < 1.0e-4 and ea < 0.7e-6 and eu < 0.85e-4 and ez < 1.7e-4, (ev, ea, eu, ez)
+
+
+def boundary_cloud(scale=1.0, seed=3):
+    """Points placed ON the decisions the float fast paths take: vertical angles at a ring-table
+    entry +- interval (in steps of the float resolution, out to beyond the fast path's margin), polar
+    angles at integer sector boundaries +- 0 .. 3e-4 deg, hence azimuths at integer degrees too."""
+    rng = np.random.default_rng(seed)
+    h = 1.8
+    lead = 62.0 + 1.7 * np.arange(14)                                   # table entries [deg from -z]
+    va = [lead]
+    offs = np.concatenate([np.arange(-120, 121) * 2.0e-6, [-3.2e-4, -3.0e-4, -2.8e-4, 2.8e-4, 3.0e-4, 3.2e-4]])
+    for sgn in (-1.0, 1.0):
+        for l in lead[::3]:
+            va.append(l + sgn * 0.18 + offs)
+    va = np.concatenate(va)
+    fi = rng.uniform(3.0, 357.0, len(va))
+    # sector / azimuth boundaries: every integer degree of a few decades, tiny offsets either side
+    deg = np.arange(1, 360, 7, dtype=np.float64)
+    d = np.array([0.0, 1e-7, 1e-6, 1e-5, 5e-5, 1e-4, 2e-4, 2.4e-4, 2.6e-4, 3e-4])
+    fb = (deg[:, None] + np.concatenate([-d[1:], d])[None, :]).ravel()
+    vb = lead[rng.integers(0, len(lead), len(fb))] + rng.uniform(-0.1, 0.1, len(fb))
+    va = np.concatenate([va, vb])
+    fi = np.concatenate([fi, fb])
+    rho = h * np.tan(np.deg2rad(va))
+    rho *= 1.0 + 1e-4 * np.arange(len(rho)) / len(rho)                   # no planar-range ties (and rings stay put)
+    z = np.full(len(rho), -h) * (1.0 + 1e-4 * np.arange(len(rho)) / len(rho))
+    x, y = rho * np.cos(np.deg2rad(fi)), rho * np.sin(np.deg2rad(fi))
+    return (x * scale).astype(np.float32), (y * scale).astype(np.float32), (z * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("log2_scale", [0, -30, 30, -62])
+@pytest.mark.parametrize("tweak", [{}, {"starbeam_filter": 1, "xDirection": 1}, {"channels": 20}])
+def test_decision_boundaries(ctx_big, log2_scale, tweak):
+    """Ring, sector and window membership are decided on float approximations wherever those are
+    clear of the boundary by a proven margin, and on the reference's exact sequence inside it.
+    This cloud sits on the boundaries (both sides of every margin), at the sensor's scale and at
+    2^-30, 2^30 and 2^-62 times it (the last one outside the range the fast paths accept)."""
+    sc = 2.0 ** log2_scale
+    x, y, z = boundary_cloud(sc)
+    p = u.default_params()
+    for k, v in tweak.items():
+        setattr(p, k, v)
+    p.min_X, p.max_X, p.min_Y, p.max_Y, p.min_Z, p.max_Z = -60 * sc, 60 * sc, -60 * sc, 60 * sc, -3 * sc, -1 * sc
+    p.channels = tweak.get("channels", 32)   # 20: the table fills up, later unmatched points stay without a ring
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    assert ib["status"] == 0 and ib["n_rings"] >= 14
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    n = len(x)
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_ANGLE_TABLE, n), st["angle_table"])
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_RING, n), st["ring"])
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_SECTOR, n), st["sector"])
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, n), st["detect"])
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_BEAM_STOP, n), st["beam_stop"])
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
 
 
 def test_capacity_and_argument_errors():

@@ -173,10 +173,14 @@ __device__ __forceinline__ float urf_fast_atan2f(float y, float x)
  * |z|/d to float before the acos), hence the restriction to |z| <= 4 rho; within it
  * |approx - reference| <= 3e-4 deg (URF_FAST_VALPHA_ERR, measured by urf_selftest). */
 #define URF_FAST_VALPHA_ERR 3.0e-4f
+/* magnitudes for which the float products, sums and reciprocals of the fast paths stay normal
+ * numbers with full precision (squares within [1e-30, 1e36]) */
+#define URF_FAST_MIN 1.0e-15f
+#define URF_FAST_MAX 1.0e18f
 __device__ __forceinline__ bool urf_fast_vertical_angle(float x, float y, float z, float* out)
 {
     const float rho = __builtin_sqrtf(x * x + y * y);
-    if (!(rho > 0.0f) || !(__builtin_fabsf(z) <= 4.0f * rho))
+    if (!(rho >= URF_FAST_MIN && rho <= URF_FAST_MAX) || !(__builtin_fabsf(z) <= 4.0f * rho))
         return false;
     *out = urf_fast_atan2f(rho, -z) * 57.295779513082323f;
     return true;
@@ -188,7 +192,8 @@ __device__ __forceinline__ bool urf_fast_vertical_angle(float x, float y, float 
 #define URF_FAST_SECTOR_ERR 2.5e-4f
 __device__ __forceinline__ int urf_fast_sector(float x, float y, float Kfi, unsigned sectors)
 {
-    if (x == 0.0f && y == 0.0f)
+    const float mx = __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y));
+    if (!(mx >= URF_FAST_MIN && mx <= URF_FAST_MAX))
         return -1;
     float fi = urf_fast_atan2f(y, x);
     if (fi < 0.0f)
@@ -216,7 +221,7 @@ __device__ __forceinline__ bool urf_fast_azimuth(float x, float y, float* out)
     if (r < 0.0f)
         r += 6.28318530717958648f;
     *out = r * 57.295779513082323f;
-    return ay * 16.0f >= ax && ay > 0.0f;
+    return ay * 16.0f >= ax && ay >= URF_FAST_MIN && ax <= URF_FAST_MAX && ay <= URF_FAST_MAX;
 }
 
 /* star_shaped_search.cpp:73-107: is the point inside the rectangular beam of its sector */

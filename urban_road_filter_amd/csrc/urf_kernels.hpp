@@ -2644,6 +2644,14 @@ __global__ __launch_bounds__(256) void k_selftest_fast(unsigned long long n, flo
             h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27; h *= 0x94D049BB133111EBull; h ^= h >> 31;
             c[k] = ((float)(h >> 40) * (1.0f / 16777216.0f) - 0.5f) * ((i & 3) == 0 ? 400.0f : 20.0f);
         }
+        /* an eighth of the samples at arbitrary magnitudes (2^-70 .. 2^70), with independent
+         * exponents per coordinate: the range guards of the fast paths have to hold there too */
+        if ((i & 7) == 1) {
+            for (int k = 0; k < 3; k++) {
+                h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27;
+                c[k] = __builtin_ldexpf(c[k], (int)(h % 141u) - 70);
+            }
+        }
         const float x = c[0], y = c[1], z = c[2] * 0.25f;
         float vt;
         if (urf_fast_vertical_angle(x, y, z, &vt)) {
