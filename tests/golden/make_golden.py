@@ -40,6 +40,12 @@ CASES = [
     ("cfg2_s1_cp9_bz45", "cfg2", 1, {"curbPoints": 9, "beamZone": 45.5}),
     ("default_roi_s1", "default_roi", 1, {}),
     ("cfg5_s1", "cfg5", 1, {}),
+    # points on the ring / sector / integer-degree decisions (tests/oracles.py boundary_cloud); the cloud
+    # itself is stored in the fixture
+    ("boundary_s3", "boundary", 3, {}),
+    ("boundary_s3_starbeam_xdir1", "boundary", 3, {"starbeam_filter": 1, "xDirection": 1}),
+    ("boundary_s3_ch20", "boundary", 3, {"channels": 20}),
+    ("boundary_hi_s3", "boundary_hi", 3, {}),
 ]
 
 
@@ -61,11 +67,18 @@ def main():
     for name, cfg, seed, tweak in CASES:
         p = case_params(cfg, tweak)
         x, y, z = O.cfg_cloud(cfg, seed)
-        labels, infos, ms, _ = O.run_a([(x, y, z)], p)
+        # boundary clouds sit on decisions that one ulp of acosf / asinf / atan2f flips, so their
+        # goldens come from the reference sources with the product's libm definition (oracle/shim/
+        # urf_libm_override.h); with the host's glibc 2.35 the reference labels 3 of the 3472
+        # points of boundary_s3 differently (asinf(0.8660254f) is 1 ulp high there: azimuth 60
+        # instead of 59.999996)
+        libm = cfg in O.BOUNDARY_SCALE
+        labels, infos, ms, _ = O.run_a([(x, y, z)], p, libm=libm)
         info = infos[0]
         out = os.path.join(HERE, name + ".npz")
+        extra = {"x": x, "y": y, "z": z, "oracle": "urf_ref_libm"} if libm else {}
         np.savez_compressed(out, labels=labels[0], cloud_sha=cloud_sha(x, y, z), params=np.frombuffer(bytes(p), np.uint8),
-                            **{"info_" + k: info[k] for k in ("status", "n_roi", "n_road", "n_curb", "n_ring10")})
+                            **{"info_" + k: info[k] for k in ("status", "n_roi", "n_road", "n_curb", "n_ring10")}, **extra)
         print("%-20s n=%d road=%d curb=%d roi=%d  labels sha256 %s  (%d bytes)" % (
             name, len(x), info["n_road"], info["n_curb"], info["n_roi"],
             hashlib.sha256(labels[0].tobytes()).hexdigest()[:16], os.path.getsize(out)))

@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_B = os.path.join(ORACLE_DIR, "liburf_oracle.so")
 ORACLE_A = os.path.join(ORACLE_DIR, "_ref", "urf_ref")
+ORACLE_A_LIBM = os.path.join(ORACLE_DIR, "_ref", "urf_ref_libm")   # same sources, float acos/asin/atan2 -> include/urf_libm.h
 REFERENCE = "/root/reference"
 
 
@@ -158,12 +159,15 @@ def run_b(x, y, z, params, debug=False):
     return labels, info.as_dict(), st
 
 
-def run_a(scans, params, repeat=1, timeout=1200, marker_params=None):
+def run_a(scans, params, repeat=1, timeout=1200, marker_params=None, libm=False):
     """scans: list of (x, y, z) with equal length.  Returns (list of labels, list of info dicts,
     ms_per_scan_steady, ms_first).  The RING bit is not observable from the reference.
     With marker_params the info dicts also carry "markers": the road_marker MarkerArray of the scan
     (list of dicts) or None when the reference published none; the scans run in sequence in one
-    Detector, as in the node."""
+    Detector, as in the node.
+    libm=True runs the variant whose float acos / asin / atan2 calls are mapped onto include/urf_libm.h
+    (oracle/shim/urf_libm_override.h): same reference sources, the product's definition of the three
+    functions instead of the host's glibc."""
     assert has_oracle_a(), "oracle A (reference build) not available"
     n = len(scans[0][0])
     with tempfile.TemporaryDirectory() as td:
@@ -179,7 +183,7 @@ def run_a(scans, params, repeat=1, timeout=1200, marker_params=None):
                 f.write(np.ascontiguousarray(x, np.float32).tobytes())
                 f.write(np.ascontiguousarray(y, np.float32).tobytes())
                 f.write(np.ascontiguousarray(z, np.float32).tobytes())
-        subprocess.run([ORACLE_A, fin, fout], check=True, timeout=timeout)
+        subprocess.run([ORACLE_A_LIBM if libm else ORACLE_A, fin, fout], check=True, timeout=timeout)
         with open(fout, "rb") as f:
             blob = f.read()
     assert blob[:8] == b"URFREFOU"
@@ -226,6 +230,11 @@ def cfg_params(name):
         p.channels, p.interval = 128, 0.05
     elif name == "default_roi":
         p = default_params()
+    elif name in ("boundary", "boundary_hi"):   # boundary_cloud(): points on the decisions of the float fast paths
+        sc = BOUNDARY_SCALE[name]
+        p = default_params()
+        p.min_X, p.max_X, p.min_Y, p.max_Y, p.min_Z, p.max_Z = -60 * sc, 60 * sc, -60 * sc, 60 * sc, -3 * sc, -1 * sc
+        p.channels = 32
     else:
         raise KeyError(name)
     return p
@@ -241,7 +250,51 @@ def cfg_cloud(name, seed=1):
         return synth_cloud(64, 2048, 2, seed)
     if name == "cfg5":
         return synth_cloud(128, 4096, 1, seed)
+    if name in BOUNDARY_SCALE:
+        return boundary_cloud(BOUNDARY_SCALE[name], seed)
     raise KeyError(name)
+
+
+def case_cloud(name, seed, fixture=None):
+    """cfg_cloud, except that clouds built with numpy transcendentals (boundary*) are taken from
+    the golden fixture that stores them: their last bits may depend on the numpy build."""
+    if fixture is not None and "x" in fixture:
+        return fixture["x"], fixture["y"], fixture["z"]
+    return cfg_cloud(name, seed)
+
+
+BOUNDARY_SCALE = {"boundary": 1.0, "boundary_hi": 2.0 ** 30}
+
+
+def boundary_cloud(scale=1.0, seed=3):
+    """Points placed ON the decisions the float fast paths take: vertical angles at a ring-table
+    entry +- interval (in steps of the float resolution, out to beyond the fast path's margin), polar
+    angles at integer sector boundaries +- 0 .. 3e-4 deg, hence azimuths at integer degrees too."""
+    rng = np.random.default_rng(seed)
+    h = 1.8
+    lead = 62.0 + 1.7 * np.arange(14)                                   # table entries [deg from -z]
+    va = [lead]
+    offs = np.concatenate([np.arange(-120, 121) * 2.0e-6, [-3.2e-4, -3.0e-4, -2.8e-4, 2.8e-4, 3.0e-4, 3.2e-4]])
+    for sgn in (-1.0, 1.0):
+        for l in lead[::3]:
+            va.append(l + sgn * 0.18 + offs)
+    va = np.concatenate(va)
+    fi = rng.uniform(3.0, 357.0, len(va))
+    # sector / azimuth boundaries: every integer degree of a few decades, tiny offsets either side
+    deg = np.arange(1, 360, 7, dtype=np.float64)
+    d = np.array([0.0, 1e-7, 1e-6, 1e-5, 5e-5, 1e-4, 2e-4, 2.4e-4, 2.6e-4, 3e-4])
+    fb = (deg[:, None] + np.concatenate([-d[1:], d])[None, :]).ravel()
+    vb = lead[rng.integers(0, len(lead), len(fb))] + rng.uniform(-0.1, 0.1, len(fb))
+    va = np.concatenate([va, vb])
+    fi = np.concatenate([fi, fb])
+    rho = h * np.tan(np.deg2rad(va))
+    rho *= 1.0 + 1e-4 * np.arange(len(rho)) / len(rho)                   # no planar-range ties (and rings stay put)
+    z = np.full(len(rho), -h) * (1.0 + 1e-4 * np.arange(len(rho)) / len(rho))
+    x, y = rho * np.cos(np.deg2rad(fi)), rho * np.sin(np.deg2rad(fi))
+    return (x * scale).astype(np.float32), (y * scale).astype(np.float32), (z * scale).astype(np.float32)
+
+
+
 
 
 MASK_NO_RING = 0xFF & ~0x08   # oracle A cannot report the RING bit

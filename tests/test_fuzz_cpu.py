@@ -18,3 +18,19 @@ def test_oracle_b_equals_reference_on_random_input(seed):
     if ib["status"] == 0:   # with < 30 ROI points the reference publishes nothing, not even its roi cloud
         for k in ("n_roi", "n_road", "n_curb", "n_ring10"):
             assert ia[0][k] == ib[k], k
+
+
+@pytest.mark.skipif(not O.has_oracle_a(), reason="oracle A binary (reference build) not available")
+@pytest.mark.parametrize("seed", range(100, 140))
+def test_oracle_b_equals_reference_with_shared_libm(seed):
+    """Same comparison against the reference sources built with the product's definition of
+    acosf / asinf / atan2f (oracle/shim/urf_libm_override.h): here equality has to hold for ANY
+    input, because no difference between libm implementations is left."""
+    (x, y, z), p = case(1000 + seed, for_reference=True)
+    la, ia, _, _ = O.run_a([(x, y, z)], p, libm=True)
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    assert ia[0]["status"] == ib["status"]
+    assert np.array_equal(la[0], lb & O.MASK_NO_RING)
+    if ib["status"] == 0:
+        for key in ("road_order", "curb_order", "ring10_order"):
+            assert np.array_equal(ia[0][key], st[key]), key

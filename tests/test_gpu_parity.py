@@ -40,7 +40,7 @@ def info_equal(ig, ib):
 def test_golden_cases(ctx_big, name, cfg, seed, tweak):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     p = case_params(cfg, tweak)
-    x, y, z = O.cfg_cloud(cfg, seed)
+    x, y, z = O.case_cloud(cfg, seed, g)
     assert cloud_sha(x, y, z) == str(g["cloud_sha"])
     ctx_big.set_params(p)
     lg, ig = ctx_big.classify_xyz(x, y, z)
@@ -420,34 +420,6 @@ def test_fast_path_error_bounds(ctx_big):
     assert ev < 1.0e-4 and ea < 0.7e-6 and eu < 0.85e-4 and ez < 1.7e-4, (ev, ea, eu, ez)
 
 
-def boundary_cloud(scale=1.0, seed=3):
-    """Points placed ON the decisions the float fast paths take: vertical angles at a ring-table
-    entry +- interval (in steps of the float resolution, out to beyond the fast path's margin), polar
-    angles at integer sector boundaries +- 0 .. 3e-4 deg, hence azimuths at integer degrees too."""
-    rng = np.random.default_rng(seed)
-    h = 1.8
-    lead = 62.0 + 1.7 * np.arange(14)                                   # table entries [deg from -z]
-    va = [lead]
-    offs = np.concatenate([np.arange(-120, 121) * 2.0e-6, [-3.2e-4, -3.0e-4, -2.8e-4, 2.8e-4, 3.0e-4, 3.2e-4]])
-    for sgn in (-1.0, 1.0):
-        for l in lead[::3]:
-            va.append(l + sgn * 0.18 + offs)
-    va = np.concatenate(va)
-    fi = rng.uniform(3.0, 357.0, len(va))
-    # sector / azimuth boundaries: every integer degree of a few decades, tiny offsets either side
-    deg = np.arange(1, 360, 7, dtype=np.float64)
-    d = np.array([0.0, 1e-7, 1e-6, 1e-5, 5e-5, 1e-4, 2e-4, 2.4e-4, 2.6e-4, 3e-4])
-    fb = (deg[:, None] + np.concatenate([-d[1:], d])[None, :]).ravel()
-    vb = lead[rng.integers(0, len(lead), len(fb))] + rng.uniform(-0.1, 0.1, len(fb))
-    va = np.concatenate([va, vb])
-    fi = np.concatenate([fi, fb])
-    rho = h * np.tan(np.deg2rad(va))
-    rho *= 1.0 + 1e-4 * np.arange(len(rho)) / len(rho)                   # no planar-range ties (and rings stay put)
-    z = np.full(len(rho), -h) * (1.0 + 1e-4 * np.arange(len(rho)) / len(rho))
-    x, y = rho * np.cos(np.deg2rad(fi)), rho * np.sin(np.deg2rad(fi))
-    return (x * scale).astype(np.float32), (y * scale).astype(np.float32), (z * scale).astype(np.float32)
-
-
 @pytest.mark.parametrize("log2_scale", [0, -30, 30, -62])
 @pytest.mark.parametrize("tweak", [{}, {"starbeam_filter": 1, "xDirection": 1}, {"channels": 20}])
 def test_decision_boundaries(ctx_big, log2_scale, tweak):
@@ -456,7 +428,7 @@ def test_decision_boundaries(ctx_big, log2_scale, tweak):
     This cloud sits on the boundaries (both sides of every margin), at the sensor's scale and at
     2^-30, 2^30 and 2^-62 times it (the last one outside the range the fast paths accept)."""
     sc = 2.0 ** log2_scale
-    x, y, z = boundary_cloud(sc)
+    x, y, z = O.boundary_cloud(sc)
     p = u.default_params()
     for k, v in tweak.items():
         setattr(p, k, v)

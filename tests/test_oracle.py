@@ -26,7 +26,7 @@ def test_oracle_b_equals_golden(name, cfg, seed, tweak):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     p = case_params(cfg, tweak)
     assert bytes(p) == g["params"].tobytes()
-    x, y, z = O.cfg_cloud(cfg, seed)
+    x, y, z = O.case_cloud(cfg, seed, g)
     assert cloud_sha(x, y, z) == str(g["cloud_sha"]), "synthetic generator drifted"
     lb, ib, _ = O.run_b(x, y, z, p)
     assert np.array_equal(lb & O.MASK_NO_RING, g["labels"])
@@ -58,6 +58,28 @@ def test_oracle_b_equals_oracle_a_live(cfg, seeds, tweak):
         # the clouds in the order the reference published them (ring-major, azimuth ascending)
         for key in ("road_order", "curb_order", "ring10_order"):
             assert np.array_equal(ia[k][key], st[key]), key
+
+
+@pytest.mark.skipif(not O.has_oracle_a(), reason="oracle A binary (reference build) not available")
+@pytest.mark.parametrize("log2_scale", [0, -30, 30, -62])
+@pytest.mark.parametrize("tweak", [{}, {"starbeam_filter": 1, "xDirection": 1}, {"channels": 20}, {"curbPoints": 9}])
+def test_boundary_cloud_live(log2_scale, tweak):
+    """Points ON the ring / sector / integer-degree decisions (O.boundary_cloud), at four scales: the
+    restatement must equal the reference sources exactly when both use the same definition of
+    acosf / asinf / atan2f.  (With the host's glibc the reference's own answer depends on the glibc
+    release there: 2.35 labels 3 of the 3472 points differently, asinf(0.8660254f) being 1 ulp high.)"""
+    sc = 2.0 ** log2_scale
+    x, y, z = O.boundary_cloud(sc)
+    p = u.default_params()
+    for k, v in tweak.items():
+        setattr(p, k, v)
+    p.min_X, p.max_X, p.min_Y, p.max_Y, p.min_Z, p.max_Z = -60 * sc, 60 * sc, -60 * sc, 60 * sc, -3 * sc, -1 * sc
+    p.channels = tweak.get("channels", 32)
+    la, ia, _, _ = O.run_a([(x, y, z)], p, libm=True)
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    assert np.array_equal(la[0], lb & O.MASK_NO_RING)
+    for key in ("road_order", "curb_order", "ring10_order"):
+        assert np.array_equal(ia[0][key], st[key]), key
 
 
 @pytest.mark.skipif(not O.has_oracle_a(), reason="oracle A binary (reference build) not available")
