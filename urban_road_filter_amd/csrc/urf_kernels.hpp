@@ -974,8 +974,12 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
             rank[q] = 0;
             if (q < B && key[q] != ~0ull) {
                 const unsigned b0 = cnt[bkt[q]], b1 = cnt[bkt[q] + 1];
-                unsigned r = b0;
-                for (unsigned t = b0; t < b1; t++)
+                unsigned r = b0, t = b0;
+                for (; t + 1 < b1; t += 2) {   /* two bucket-mates per trip (one ds_read2_b64) */
+                    const unsigned long long k0 = A[t], k1 = A[t + 1];
+                    r += (k0 < key[q]) + (k1 < key[q]);
+                }
+                if (t < b1)
                     r += A[t] < key[q];
                 rank[q] = r;
             }
@@ -1206,8 +1210,12 @@ __device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EP
             rank[e] = 0;
             if (key[e] != ~0ull) {
                 const unsigned b0 = cnt[bkt[e]], b1 = cnt[bkt[e] + 1];
-                unsigned r = b0;
-                for (unsigned t = b0; t < b1; t++)
+                unsigned r = b0, t = b0;
+                for (; t + 1 < b1; t += 2) {   /* two bucket-mates per trip */
+                    const unsigned long long k0 = A[t], k1 = A[t + 1];
+                    r += (k0 < key[e]) + (k1 < key[e]);
+                }
+                if (t < b1)
                     r += A[t] < key[e];
                 rank[e] = r;
             }
