@@ -447,6 +447,47 @@ def test_decision_boundaries(ctx_big, log2_scale, tweak):
     assert np.array_equal(lg, lb) and info_equal(ig, ib)
 
 
+def test_rough_ground_fills_the_candidate_list(ctx_big):
+    """k_ring collects the points that need a detector's angle test in a per-ring list and works it
+    off when it might overflow: on rough ground (noise above curbHeight) nearly every point is a
+    candidate, so the list is flushed in the middle of the rings."""
+    x, y, z = O.cfg_cloud("cfg2", 9)
+    rng = np.random.default_rng(9)
+    z = (z + 0.03 * rng.standard_normal(len(z))).astype(np.float32)
+    p = O.cfg_params("cfg2")
+    p.curbHeight = 0.01
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    assert ib["n_curb"] > 2000                      # the detectors fire all over the place
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, len(x)), st["detect"])
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+
+
+def test_whole_tiles_on_integer_degrees(ctx_big):
+    """k_label decides window membership on the approximate azimuth unless it is within the margin of
+    an integer degree or a window end; such points are listed (256 per tile) and decided on the
+    exact value, the overflow in place.  Here every point sits on an integer degree."""
+    rng = np.random.default_rng(11)
+    n = 6000
+    fi = rng.choice([31.0, 32.0, 60.0, 61.0, 119.0, 200.0, 271.0, 330.0], n)
+    va = 62.0 + 1.7 * rng.integers(0, 14, n)       # 14 rings
+    rho = 1.8 * np.tan(np.deg2rad(va)) * (1.0 + 1e-3 * np.arange(n) / n)
+    x = (rho * np.cos(np.deg2rad(fi - 90.0))).astype(np.float32)   # azimuth: 0 at -y, 90 at +x
+    y = (rho * np.sin(np.deg2rad(fi - 90.0))).astype(np.float32)
+    z = np.full(n, -1.8, np.float32)
+    z[rng.integers(0, n, 40)] += 0.3               # a few curb stones so that beams get blocked
+    p = u.default_params()
+    p.min_X, p.max_X, p.min_Y, p.max_Y = -60, 60, -60, 60
+    p.channels = 32
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    az = st["azimuth"][st["ring"] >= 0]
+    assert (np.abs(az - np.round(az)) < 5e-4).mean() > 0.9 and ib["n_road"] > 100
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+
+
 def test_capacity_and_argument_errors():
     with u.Context(4096, 2) as ctx:
         x, y, z = [a[:8192] for a in O.cfg_cloud("cfg2", 1)]
