@@ -41,7 +41,6 @@ struct urf_ctx {
     uint8_t* mk_red = nullptr;
     float* mk_out = nullptr;        /* 361 x 4 floats + 1 count */
     float* d_newY = nullptr;
-    float* d_inv_i = nullptr;
     urf_beam* d_beams = nullptr;
     uint32_t beams_cap = 0;
     bool debug_rd2 = false;
@@ -174,7 +173,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.stop_f, S * URF_DEG_CELLS) A(k.stop_b, S * URF_DEG_CELLS)
     A(k.act_f, S * C * 6) A(k.act_b, S * C * 6)
     A(k.info, S)
-    A(c->d_newY, (size_t)max_points) A(c->d_inv_i, (size_t)max_points) A(c->d_beams, K)
+    A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
     A(c->labels1, (size_t)max_points)
 #undef A
     /* x_zero_method.cpp:24-27: newY[j] = newY[j-1] + 0.0100 (float += double), a
@@ -187,16 +186,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
         if (hipMemcpy(c->d_newY, newY.data(), newY.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
             return fail(URF_ERR_HIP);
     }
-    {
-        std::vector<float> inv(max_points);
-        inv[0] = 0.0f;
-        for (uint32_t j = 1; j < max_points; j++)
-            inv[j] = 1.0f / (float)j;   /* star_shaped_search.cpp:137,140 with nan == 0 */
-        if (hipMemcpy(c->d_inv_i, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
-            return fail(URF_ERR_HIP);
-    }
     k.newY = c->d_newY;
-    k.inv_i = c->d_inv_i;
     k.beams = c->d_beams;
     if ((rc = upload_params(c)) != URF_OK)
         return fail(rc);

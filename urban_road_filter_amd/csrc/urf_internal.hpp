@@ -112,7 +112,6 @@ struct urf_kargs {
     unsigned long long* act_b;  /* [S][channels][6] same for backward beams */
     /* tables */
     const float*    newY;       /* [max_points] x_zero_method.cpp:24-27 */
-    const float*    inv_i;      /* [max_points] 1.0f / (float)i, star_shaped_search.cpp:137 */
     const urf_beam* beams;      /* [sectors] */
 };
 

@@ -975,9 +975,14 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
             if (q < B && key[q] != ~0ull) {
                 const unsigned b0 = cnt[bkt[q]], b1 = cnt[bkt[q] + 1];
                 unsigned r = b0, t = b0;
-                for (; t + 1 < b1; t += 2) {   /* two bucket-mates per trip (one ds_read2_b64) */
+                for (; t + 3 < b1; t += 4) {   /* four bucket-mates per trip */
+                    const unsigned long long k0 = A[t], k1 = A[t + 1], k2 = A[t + 2], k3 = A[t + 3];
+                    r += (k0 < key[q]) + (k1 < key[q]) + (k2 < key[q]) + (k3 < key[q]);
+                }
+                if (t + 1 < b1) {
                     const unsigned long long k0 = A[t], k1 = A[t + 1];
                     r += (k0 < key[q]) + (k1 < key[q]);
+                    t += 2;
                 }
                 if (t < b1)
                     r += A[t] < key[q];
