@@ -1361,7 +1361,7 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
 #define URF_WALK_INV 512
 __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp)
 {
-    __shared__ float tS[2][64][URF_WALK_CHUNK + 1], tG[2][64][URF_WALK_CHUNK + 1];
+    __shared__ float tS[64][URF_WALK_CHUNK + 1], tG[64][URF_WALK_CHUNK + 1];
     __shared__ unsigned sbase[64], slast[64];
     __shared__ float sinv[URF_WALK_INV];   /* 1.0f / (float)i, star_shaped_search.cpp:137 */
     const unsigned K = (unsigned)dp.p.sectors;
@@ -1385,7 +1385,8 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
     __syncthreads();
 
     /* the next 16 steps of all 64 sectors: 32 loads in flight, then parked in registers until the
-     * LDS buffer they belong to is free (double buffering: chunk c+1 loads while chunk c is walked) */
+     * LDS tile is free again (chunk c+1 loads while chunk c is walked; the walk itself runs out of
+     * registers, so one tile suffices -- a second one would halve the resident workgroups) */
     float vs[16], vg[16];
     unsigned rbase[16], rlast[16];   /* the 16 sectors this lane loads for: fixed for the whole walk */
 #pragma unroll
@@ -1402,12 +1403,12 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
             vg[r] = on ? a.wg[rbase[r] + e] : 0.f;
         }
     };
-    auto park = [&](unsigned buf) {
+    auto park = [&]() {
 #pragma unroll
         for (unsigned r = 0; r < 16; r++) {
             const unsigned sec = r * 4 + (lane >> 4);
-            tS[buf][sec][lane & 15] = vs[r];
-            tG[buf][sec][lane & 15] = vg[r];
+            tS[sec][lane & 15] = vs[r];
+            tG[sec][lane & 15] = vg[r];
         }
     };
 
@@ -1419,10 +1420,9 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
     for (unsigned t = lane; t < URF_WALK_INV; t += 64)
         sinv[t] = 1.0f / (float)(int)t;   /* [0] is never used */
     fetch(0);
-    park(0);
+    park();
     __syncthreads();
-    unsigned buf = 0;
-    for (unsigned c0 = 0; c0 <= maxlast; c0 += URF_WALK_CHUNK, buf ^= 1u) {
+    for (unsigned c0 = 0; c0 <= maxlast; c0 += URF_WALK_CHUNK) {
         if (!__any(lim != 0))
             break;
         const bool more = c0 + URF_WALK_CHUNK <= maxlast;
@@ -1434,8 +1434,8 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
         bool anynan = nan != 0.0f;
 #pragma unroll
         for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
-            sl[j] = tS[buf][lane][j];
-            gg[j] = tG[buf][lane][j];
+            sl[j] = tS[lane][j];
+            gg[j] = tG[lane][j];
             anynan = anynan || sl[j] != sl[j];
         }
         if (c0 + URF_WALK_CHUNK <= URF_WALK_INV) {
@@ -1447,6 +1447,7 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
             for (unsigned j = 0; j < URF_WALK_CHUNK; j++)
                 uu[j] = 1.0f / (float)(int)(c0 + j);
         }
+        __syncthreads();   /* the tile has been read: it may take the next chunk */
         /* All lanes step through the chunk in lockstep (i is wave-uniform); a lane that is past its
          * sector's end or has found its curb point just stops updating its state (lim = 0). */
         if (!__any(anynan)) {
@@ -1504,7 +1505,7 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
         if (c0 + URF_WALK_CHUNK > last)
             lim = 0;
         if (more)
-            park(buf ^ 1u);
+            park();
         __syncthreads();
     }
     const int hit = hit_i ? (int)a.ssrt[base + hit_i] : -1;
