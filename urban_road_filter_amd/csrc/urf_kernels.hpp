@@ -1958,20 +1958,14 @@ __device__ __forceinline__ bool urf_blind(const urf_params& p, const float* q, i
 __device__ __forceinline__ float urf_fwd_hi(const urf_dev_params& dp, int i, unsigned k, double qk)
 {
     const float fi = (float)i;
-    if (k == 0)
-        return fi + dp.p.beamZone;
-    if (fi == dp.fwd_limit)
-        return 360.0f;
-    return (float)((double)i + qk);
+    const float far = fi == dp.fwd_limit ? 360.0f : (float)((double)i + qk);   /* selects, not branches */
+    return k == 0 ? fi + dp.p.beamZone : far;
 }
 __device__ __forceinline__ float urf_bwd_lo(const urf_dev_params& dp, int i, unsigned k, double qk)
 {
     const float fi = (float)i;
-    if (k == 0)
-        return fi - dp.p.beamZone;
-    if (fi == dp.bwd_limit)
-        return 0.0f;
-    return (float)((double)i - qk);
+    const float far = fi == dp.bwd_limit ? 0.0f : (float)((double)i - qk);
+    return k == 0 ? fi - dp.p.beamZone : far;
 }
 /* arcDistance / ((maxDistance[k] * M_PI) / 180), blind_spots.cpp:65,142 */
 __device__ __forceinline__ double urf_arc_ratio(const urf_dev_params& dp, float maxd0, float maxdk)
