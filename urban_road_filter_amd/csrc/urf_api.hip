@@ -171,7 +171,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.maxdist, S * C) A(k.quad, S * 4)
     A(k.sufmin, S * C * URF_DEG_CELLS) A(k.premax, S * C * URF_DEG_CELLS)
     A(k.stop_f, S * URF_DEG_CELLS) A(k.stop_b, S * URF_DEG_CELLS)
-    A(k.act_f, S * C * 6) A(k.act_b, S * C * 6)
+    A(k.act_f, S * C * 6) A(k.act_b, S * C * 6) A(k.qk, S * C)
     A(k.info, S)
     A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
     A(c->labels1, (size_t)max_points)

@@ -108,6 +108,7 @@ struct urf_kargs {
     float*    premax;           /* [S][channels][361] */
     int16_t*  stop_f;           /* [S][361] */
     int16_t*  stop_b;           /* [S][361] */
+    double*   qk;               /* [S][channels] arcDistance / ((maxDistance[k] * pi) / 180), k_beams -> k_label */
     unsigned long long* act_f;  /* [S][channels][6] bit i: forward beam i reached beyond the ring */
     unsigned long long* act_b;  /* [S][channels][6] same for backward beams */
     /* tables */

@@ -1991,8 +1991,10 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
         /* q1..q4 come from sorted ring 1 (blind_spots.cpp:19) */
         q[tid] = (dp.p.blind_spots && nR > 1) ? a.quad[(size_t)s * 4 + tid] : init[tid];
     }
-    for (unsigned k = tid; k < nR; k += URF_LABEL_THREADS)
+    for (unsigned k = tid; k < nR; k += URF_LABEL_THREADS) {
         qk[k] = urf_arc_ratio(dp, maxd[0], maxd[k]);
+        a.qk[(size_t)s * C + k] = qk[k];   /* k_label's tiles need it too: computed once per scan, here */
+    }
     __syncthreads();
     if (tid < 4 && !(dp.p.blind_spots && nR > 1))
         a.quad[(size_t)s * 4 + tid] = q[tid];
@@ -2134,7 +2136,6 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) void k_label(urf_kargs a, u
     const unsigned C = (unsigned)dp.p.channels, nR = in.n_rings;
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     const size_t row = (size_t)s * a.tiles + t;
-    const float* maxd = a.maxdist + (size_t)s * C;
 
     if (tid < C) {
         /* run of ring `tid` that belongs to this tile: [first, first + n) inside the ring */
@@ -2142,7 +2143,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) void k_label(urf_kargs a, u
         const unsigned next = t + 1 < ntiles ? a.tile_ring[(row + 1) * C + tid] : a.ring_cnt[(size_t)s * C + tid];
         base_r[tid] = off + a.ring_off[(size_t)s * (C + 1) + tid] + first;
         koff[tid] = next - first;   /* count, scanned below */
-        qk[tid] = tid < nR ? urf_arc_ratio(dp, maxd[0], maxd[tid]) : 0.0;
+        qk[tid] = tid < nR ? a.qk[(size_t)s * C + tid] : 0.0;
     }
     for (unsigned w = tid; w < nR * 6; w += URF_LABEL_TILE_THREADS) {
         actf[w] = a.act_f[(size_t)s * C * 6 + w];
