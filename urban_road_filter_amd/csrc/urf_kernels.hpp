@@ -88,6 +88,8 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
     __shared__ float tab[URF_MAX_CHANNELS];
     __shared__ unsigned rhist[URF_MAX_CHANNELS];
     __shared__ uint8_t lut[URF_LUT_CELLS] __attribute__((aligned(4)));   /* k_ring_table's lookup table */
+    __shared__ uint16_t pending[URF_TILE];   /* tile-local indices of the points the approximations leave open */
+    __shared__ unsigned n_pending;
     const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
@@ -113,6 +115,8 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
         tab[tid] = tid < nR ? a.angle[(size_t)s * C + tid] : 0.f;
         rhist[tid] = 0;
     }
+    if (tid == 0)
+        n_pending = 0;
     for (unsigned i = tid; i < URF_LUT_CELLS / 4; i += URF_INGEST_THREADS)
         ((unsigned*)lut)[i] = ((const unsigned*)(a.ring_lut + (size_t)s * URF_LUT_CELLS))[i];
     __syncthreads();
@@ -150,53 +154,49 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
     for (unsigned q = 0; q < Q; q++)
         while (lo[q] < nR && !(tab[lo[q] & (URF_MAX_CHANNELS - 1)] - vt[q] >= -(interval + e)))
             lo[q]++;
+    /* Main pass: only what the approximations decide.  A point whose ring or sector they leave open
+     * (or every point, when the stage capture wants exact angles) is listed and takes the reference's
+     * exact sequence in a second, dense pass: the exact code exists once instead of sixteen times in
+     * the unrolled loop, and its f64 chains never run with two lanes of a wave. */
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned i = tbase + q * URF_INGEST_THREADS + tid;
+        const unsigned li = q * URF_INGEST_THREADS + tid, i = tbase + li;
         const bool valid = i < len;
-        const float x = px[q], y = py[q], z = pz[q];
-        float va = -1.0f;
+        const float x = px[q], y = py[q];
         unsigned key = URF_SEC_NONE, rkey = URF_RING_NONE;
+        bool open = false;
         if (roi[q]) {
-            bool decided = false;
+            open = true;
             if (fast[q]) {
                 const float tv = tab[lo[q] & (URF_MAX_CHANNELS - 1)];
                 if (lo[q] >= nR || tv - vt[q] > interval + e) {
-                    decided = true;                       /* no entry can match */
+                    open = false;                         /* no entry can match */
                 } else if (__builtin_fabsf(tv - vt[q]) <= interval - e) {
-                    decided = true;                       /* the first candidate surely matches */
+                    open = false;                         /* the first candidate surely matches */
                     rkey = lo[q];
                 }
             }
-            if (!decided) {
-                va = urf_vertical_angle(x, y, z);
-                /* lidar_segmentation.cpp:226-233: first sorted table entry within `interval`.
-                 * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are contiguous
-                 * and the first one is found by bisection with the very same float predicate. */
-                unsigned l2 = 0, h2 = nR;
-                while (l2 < h2) {
-                    const unsigned mid = (l2 + h2) >> 1;
-                    if (tab[mid] - va >= -interval)
-                        h2 = mid;
-                    else
-                        l2 = mid + 1;
-                }
-                if (l2 < nR && __builtin_fabsf(tab[l2] - va) <= interval)
-                    rkey = l2;
-            }
-            if (star) {
+            if (star && !open) {
                 const int fs = urf_fast_sector(x, y, dp.Kfi, K);
-                key = fs >= 0 ? (unsigned)fs : urf_sector(x, y, dp.Kfi, K);
-                if (dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
+                open = fs < 0;
+                key = (unsigned)fs;
+                if (!open && dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
                     key = URF_SEC_NONE;
+            }
+            if (open) {
+                pending[atomicAdd(&n_pending, 1u)] = (uint16_t)li;
+                key = URF_SEC_NONE;
+                rkey = URF_RING_NONE;
             }
         }
         if (valid) {
-            if (a.valpha)
-                a.valpha[off + i] = va;   /* stage capture only */
-            a.seckey[off + i] = (uint16_t)key;
-            a.ringkey[off + i] = (uint8_t)rkey;
+            if (!open) {
+                a.seckey[off + i] = (uint16_t)key;
+                a.ringkey[off + i] = (uint8_t)rkey;
+            }
             a.labels[off + i] = roi[q] ? URF_FLAG_ROI : 0;
+            if (a.valpha && !roi[q])
+                a.valpha[off + i] = -1.0f;   /* stage capture only */
         }
         {
             const unsigned long long m = urf_match_any_fast(rkey == URF_RING_NONE ? C : rkey, dp.ring_keybits);
@@ -211,6 +211,40 @@ __global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_
         const unsigned long long rb = __ballot(roi[q]);
         if (urf_lane() == 0 && rb)
             atomicAdd(&sh_hist[K], (unsigned)__popcll(rb));
+    }
+    __syncthreads();
+    const unsigned np = n_pending;
+    for (unsigned k = tid; k < np; k += URF_INGEST_THREADS) {
+        const unsigned i = tbase + pending[k];
+        const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
+        const float va = urf_vertical_angle(x, y, z);
+        /* lidar_segmentation.cpp:226-233: first sorted table entry within `interval`.
+         * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are contiguous
+         * and the first one is found by bisection with the very same float predicate. */
+        unsigned rkey = URF_RING_NONE, key = URF_SEC_NONE;
+        unsigned l2 = 0, h2 = nR;
+        while (l2 < h2) {
+            const unsigned mid = (l2 + h2) >> 1;
+            if (tab[mid] - va >= -interval)
+                h2 = mid;
+            else
+                l2 = mid + 1;
+        }
+        if (l2 < nR && __builtin_fabsf(tab[l2] - va) <= interval)
+            rkey = l2;
+        if (star) {
+            key = urf_sector(x, y, dp.Kfi, K);
+            if (dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
+                key = URF_SEC_NONE;
+        }
+        if (a.valpha)
+            a.valpha[off + i] = va;   /* stage capture only */
+        a.seckey[off + i] = (uint16_t)key;
+        a.ringkey[off + i] = (uint8_t)rkey;
+        if (rkey != URF_RING_NONE)
+            atomicAdd(&rhist[rkey], 1u);
+        if (key != URF_SEC_NONE)
+            atomicAdd(&sh_hist[key], 1u);
     }
     __syncthreads();
     const size_t row = (size_t)s * a.tiles + t;
