@@ -781,12 +781,12 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
             sts[sl] = (rkey[q] << 12) | li;
         }
         if (sdst[q] != 0xffffffffu) {
-            a.sr[sdst[q]] = __builtin_sqrtf(x * x + y * y);   /* star_shaped_search.cpp:164 */
-            a.sz[sdst[q]] = z;
+            __builtin_nontemporal_store(__builtin_sqrtf(x * x + y * y), &a.sr[sdst[q]]);   /* star_shaped_search.cpp:164 */
+            __builtin_nontemporal_store(z, &a.sz[sdst[q]]);
             /* where a star-shaped hit on this point has to be reported: its ring-major position
              * (none if the point lies on no ring: such a hit ends the walk but marks nothing
              * that reaches the output, lidar_segmentation.cpp:235-242) */
-            a.ssrc[sdst[q]] = rdst[q];
+            __builtin_nontemporal_store(rdst[q], &a.ssrc[sdst[q]]);
         }
     }
     __syncthreads();
@@ -795,10 +795,10 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_d
         const unsigned pk = sts[sl];
         const unsigned k = pk >> 12;
         const unsigned dst = base_r[k] + (j - koff[k]);
-        a.rx[dst] = __uint_as_float(stx[sl]);
-        a.ry[dst] = __uint_as_float(sty[sl]);
-        a.rz[dst] = __uint_as_float(stz[sl]);
-        a.rsrc[dst] = tbase + (pk & 0xfffu);
+        __builtin_nontemporal_store(__uint_as_float(stx[sl]), &a.rx[dst]);
+        __builtin_nontemporal_store(__uint_as_float(sty[sl]), &a.ry[dst]);
+        __builtin_nontemporal_store(__uint_as_float(stz[sl]), &a.rz[dst]);
+        __builtin_nontemporal_store(tbase + (pk & 0xfffu), &a.rsrc[dst]);
     }
 }
 
