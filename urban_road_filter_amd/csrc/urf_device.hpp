@@ -52,6 +52,58 @@ __device__ __forceinline__ bool urf_is_leader(unsigned long long m)
     return (unsigned)__ffsll((long long)m) - 1u == urf_lane();
 }
 
+/* Wave-wide minimum / maximum of an unsigned value, result in every lane.  DPP row shifts and the
+ * gfx9 row broadcasts (the cross-lane data path of the VALU) instead of six ds_bpermute round trips
+ * through the LDS crossbar: lanes without a source keep the identity passed as `old`. */
+#define URF_DPP_STEP(op, ident, ctrl, rowmask)                                                         \
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp((int)(ident), (int)v, (ctrl), (rowmask), 0xf, false))
+__device__ __forceinline__ unsigned urf_umin(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned urf_umax(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned urf_wave_min(unsigned v)
+{
+    URF_DPP_STEP(urf_umin, 0xffffffffu, 0x111, 0xf);   /* row_shr:1 */
+    URF_DPP_STEP(urf_umin, 0xffffffffu, 0x112, 0xf);   /* row_shr:2 */
+    URF_DPP_STEP(urf_umin, 0xffffffffu, 0x114, 0xf);   /* row_shr:4 */
+    URF_DPP_STEP(urf_umin, 0xffffffffu, 0x118, 0xf);   /* row_shr:8: lane 15 of a row holds the row's result */
+    URF_DPP_STEP(urf_umin, 0xffffffffu, 0x142, 0xa);   /* row_bcast:15 into rows 1 and 3 */
+    URF_DPP_STEP(urf_umin, 0xffffffffu, 0x143, 0xc);   /* row_bcast:31 into rows 2 and 3: lane 63 holds all */
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned urf_wave_max(unsigned v)
+{
+    URF_DPP_STEP(urf_umax, 0u, 0x111, 0xf);
+    URF_DPP_STEP(urf_umax, 0u, 0x112, 0xf);
+    URF_DPP_STEP(urf_umax, 0u, 0x114, 0xf);
+    URF_DPP_STEP(urf_umax, 0u, 0x118, 0xf);
+    URF_DPP_STEP(urf_umax, 0u, 0x142, 0xa);
+    URF_DPP_STEP(urf_umax, 0u, 0x143, 0xc);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+/* inclusive prefix sum / prefix maximum over the lanes of the wave (same data path; the sequence
+ * is the one LLVM's atomic optimizer emits for gfx9) */
+__device__ __forceinline__ unsigned urf_uadd(unsigned a, unsigned b) { return a + b; }
+__device__ __forceinline__ unsigned urf_wave_scan_add(unsigned v)
+{
+    URF_DPP_STEP(urf_uadd, 0u, 0x111, 0xf);
+    URF_DPP_STEP(urf_uadd, 0u, 0x112, 0xf);
+    URF_DPP_STEP(urf_uadd, 0u, 0x114, 0xf);
+    URF_DPP_STEP(urf_uadd, 0u, 0x118, 0xf);
+    URF_DPP_STEP(urf_uadd, 0u, 0x142, 0xa);
+    URF_DPP_STEP(urf_uadd, 0u, 0x143, 0xc);
+    return v;
+}
+__device__ __forceinline__ unsigned urf_wave_scan_max(unsigned v)
+{
+    URF_DPP_STEP(urf_umax, 0u, 0x111, 0xf);
+    URF_DPP_STEP(urf_umax, 0u, 0x112, 0xf);
+    URF_DPP_STEP(urf_umax, 0u, 0x114, 0xf);
+    URF_DPP_STEP(urf_umax, 0u, 0x118, 0xf);
+    URF_DPP_STEP(urf_umax, 0u, 0x142, 0xa);
+    URF_DPP_STEP(urf_umax, 0u, 0x143, 0xc);
+    return v;
+}
+
 /* scan s occupies [off, off+len) of every per-point array */
 __device__ __forceinline__ void urf_scan_range(const urf_kargs& a, unsigned s, unsigned& off, unsigned& len)
 {
