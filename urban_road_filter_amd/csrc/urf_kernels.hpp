@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void k_pc2_to_soa(const uint8_t* __restrict__ 
 /* ------------------------------------------------------------------------- */
 /* k_ingest                                                                    */
 /* ------------------------------------------------------------------------- */
-__global__ __launch_bounds__(URF_INGEST_THREADS) void k_ingest(urf_kargs a, urf_dev_params dp)
+/* amdgpu_waves_per_eu(8, 8): scheduling for full occupancy measured 0.69 -> 0.64 ms */
+__global__ __launch_bounds__(URF_INGEST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ingest(urf_kargs a, urf_dev_params dp)
 {
     extern __shared__ unsigned sh_hist[];   /* [sectors] sector histogram, [sectors] = ROI count */
     __shared__ float tab[URF_MAX_CHANNELS];
