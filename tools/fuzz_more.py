@@ -1,14 +1,15 @@
 """Extended differential fuzzing on the GPU (not part of the test suite): 2500 further random
 unorganised clouds / parameter sets (tests/fuzz.py), HIP path in its production configuration
 (float fast paths active) against oracle B: labels, ring, sector and detector stages.
-    python tools/fuzz_more.py            (on the GPU box; last run: 0 mismatches)"""
+    python tools/fuzz_more.py [first_seed last_seed]   (on the GPU box)
+Last runs: seeds 10000..12499 and 20000..29999, 0 mismatches."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
 import numpy as np, oracles as O, urban_road_filter_amd as u
 from fuzz import case
 ctx = u.Context(32768, 1)
 bad = 0
-for seed in range(10000, 12500):
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10000, int(sys.argv[2]) if len(sys.argv) > 2 else 12500):
     (x, y, z), p = case(seed)
     lb, ib, st = O.run_b(x, y, z, p, debug=True)
     ctx.set_params(p)
@@ -22,4 +23,4 @@ for seed in range(10000, 12500):
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, int((lg != lb).sum()), flush=True)
-print("extended fuzz: 2500 cases,", bad, "mismatches")
+print("extended fuzz:", bad, "mismatches")
