@@ -1235,7 +1235,9 @@ __device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EP
             cnt[NB] = run;
     }
     __syncthreads();
-    if (sh->maxc <= 64 && !force_general) {
+    /* in-bucket ranking is quadratic in the bucket size, but up to a few hundred keys per bucket it is
+     * still cheaper than the bitonic network below (128 x 4096 sweeps: 2.13 -> 1.74 ms with 256 instead of 64) */
+    if (sh->maxc <= 256 && !force_general) {
         unsigned rank[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; e++)
