@@ -996,29 +996,65 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
 
     unsigned rank[MAXB];
     if (maxc <= 64 && !(dp.exp_flags & 4u)) {
-#pragma unroll
-        for (unsigned q = 0; q < MAXB; q++)
-            if (q < B && key[q] != ~0ull)
-                A[cnt[bkt[q]] + wq[q]] = key[q];
-        __syncthreads();
+        /* Rank inside the bucket = number of smaller keys in it.  In an organised sweep the keys
+         * that share a bucket are the firings of ONE ring inside the sector, and those sit in the
+         * registers of one lane (element q * 64 + lane = firing q, ring lane): every lane first
+         * ranks its own keys against each other (15 register comparisons for 6 keys).  A key whose
+         * bucket holds nothing but keys of its own lane is done; only the others read the bucket
+         * from LDS.  The kernel is bound by the LDS pipe (PMC: 72 % of its cycles, a third of them
+         * bank conflicts), and this loop was most of its traffic. */
+        unsigned ol[MAXB];   /* keys of this lane in the same bucket (incl. itself) | smaller ones among them << 8 */
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
-            rank[q] = 0;
+            ol[q] = 1;
+            if (!(q < B && key[q] != ~0ull))
+                bkt[q] = 0xffff0000u + q;   /* matches nothing */
+        }
+#pragma unroll
+        for (unsigned q = 0; q < MAXB; q++)
+#pragma unroll
+            for (unsigned r = q + 1; r < MAXB; r++) {
+                const unsigned same = bkt[q] == bkt[r];
+                const unsigned lt = key[q] < key[r];   /* keys are distinct (the index is part of them) */
+                ol[q] += same + ((same & (lt ^ 1u)) << 8);
+                ol[r] += same + ((same & lt) << 8);
+            }
+        bool need = false;   /* does any key of this lane share its bucket with another lane? */
+        unsigned bb[MAXB];   /* bucket start | bucket size << 16 */
+#pragma unroll
+        for (unsigned q = 0; q < MAXB; q++) {
+            bb[q] = 0;
             if (q < B && key[q] != ~0ull) {
-                const unsigned b0 = cnt[bkt[q]], b1 = cnt[bkt[q] + 1];
-                unsigned r = b0, t = b0;
-                for (; t + 3 < b1; t += 4) {   /* four bucket-mates per trip */
-                    const unsigned long long k0 = A[t], k1 = A[t + 1], k2 = A[t + 2], k3 = A[t + 3];
-                    r += (k0 < key[q]) + (k1 < key[q]) + (k2 < key[q]) + (k3 < key[q]);
+                const unsigned b0 = cnt[bkt[q]];
+                bb[q] = b0 | ((cnt[bkt[q] + 1] - b0) << 16);
+                need = need || (bb[q] >> 16) != (ol[q] & 0xffu);
+            }
+            rank[q] = (bb[q] & 0xffffu) + (ol[q] >> 8);
+        }
+        if (__any(need)) {
+#pragma unroll
+            for (unsigned q = 0; q < MAXB; q++)
+                if (q < B && key[q] != ~0ull)
+                    A[(bb[q] & 0xffffu) + wq[q]] = key[q];
+            __syncthreads();
+#pragma unroll
+            for (unsigned q = 0; q < MAXB; q++) {
+                if (q < B && key[q] != ~0ull && (bb[q] >> 16) != (ol[q] & 0xffu)) {
+                    const unsigned b0 = bb[q] & 0xffffu, b1 = b0 + (bb[q] >> 16);
+                    unsigned r = b0, t = b0;
+                    for (; t + 3 < b1; t += 4) {   /* four bucket-mates per trip */
+                        const unsigned long long k0 = A[t], k1 = A[t + 1], k2 = A[t + 2], k3 = A[t + 3];
+                        r += (k0 < key[q]) + (k1 < key[q]) + (k2 < key[q]) + (k3 < key[q]);
+                    }
+                    if (t + 1 < b1) {
+                        const unsigned long long k0 = A[t], k1 = A[t + 1];
+                        r += (k0 < key[q]) + (k1 < key[q]);
+                        t += 2;
+                    }
+                    if (t < b1)
+                        r += A[t] < key[q];
+                    rank[q] = r;
                 }
-                if (t + 1 < b1) {
-                    const unsigned long long k0 = A[t], k1 = A[t + 1];
-                    r += (k0 < key[q]) + (k1 < key[q]);
-                    t += 2;
-                }
-                if (t < b1)
-                    r += A[t] < key[q];
-                rank[q] = r;
             }
         }
     } else {
@@ -1086,7 +1122,9 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
 }
 
 
-__global__ __launch_bounds__(URF_STAR_THREADS) void k_star_sort_small(urf_kargs a, urf_dev_params dp)
+/* amdgpu_waves_per_eu(6, 6): 6 KB of LDS allow 26 waves per CU; without the cap the register ranking
+ * below takes 98 VGPRs and halves the occupancy (0.75 -> 0.92 ms instead of 0.70) */
+__global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_star_sort_small(urf_kargs a, urf_dev_params dp)
 {
     constexpr unsigned NB = URF_STAR_NB;            /* buckets */
     __shared__ unsigned long long A[8 * 64];        /* keys by bucket, then range / height of the sorted sector */
