@@ -238,18 +238,24 @@ typedef enum urf_stage {
                                  (n_rings = not blocked, -1 = beam not cast) */
 } urf_stage;
 int urf_read_stage(urf_ctx* ctx, urf_stage what, uint32_t scan, void* host_dst, size_t bytes);
-/* URF_STAGE_VALPHA, URF_STAGE_AZIMUTH and URF_STAGE_RANGE2D are only available when capture is on
- * (default off): without it the pipeline settles most ring / sector / road decisions on float
- * approximations of these angles and never evaluates the reference's exact value for such a
- * point; with it every point takes the exact sequence and the values are stored. */
-int urf_enable_stage_capture(urf_ctx* ctx, int on);
+/* Capture mode (default 0 = off: the production path records nothing per input point):
+ *   1  every point takes the reference's exact arithmetic and the values are stored: all stages
+ *      can be read (URF_STAGE_VALPHA, URF_STAGE_AZIMUTH and URF_STAGE_RANGE2D only in this mode --
+ *      without it the pipeline settles most ring / sector / road decisions on float approximations
+ *      of these angles and never evaluates the reference's exact value for such a point);
+ *   2  the production decisions, with the ring and sector of every input point recorded
+ *      (URF_STAGE_RING, URF_STAGE_SECTOR; mode 0 keeps them only in sorted order).
+ * The other stages can be read in every mode.  urf_read_stage, urf_ordered_indices and
+ * urf_marker_points look at the LAST classify call of the context with the parameters that call
+ * ran with; the label buffer handed to that call must still be alive. */
+int urf_enable_stage_capture(urf_ctx* ctx, int mode);
 
 /* ---- per-kernel timing (benchmark) ------------------------------------------
  * With timing on, every classify call brackets each kernel of the pipeline
  * with hipEvents on the context's stream.  urf_kernel_timing() synchronises,
  * adds the elapsed milliseconds of all calls since the last query to
  * ms_sum[0..URF_NUM_KERNELS) and the number of calls to *n_calls, then resets. */
-#define URF_NUM_KERNELS 9
+#define URF_NUM_KERNELS 8
 int urf_enable_kernel_timing(urf_ctx* ctx, int on);
 int urf_kernel_timing(urf_ctx* ctx, double* ms_sum, uint32_t* n_calls);
 const char* urf_kernel_name(int index);
@@ -269,12 +275,16 @@ int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
  * 3-operation division by pi against the IEEE division, exhaustively over all
  * floats in [0, 600]).  *n_mismatches must come back 0.  Synchronous. */
 int urf_selftest(urf_ctx* ctx, uint64_t* n_mismatches);
-/* Measured error of the float fast paths that settle ring and sector decisions (k_ingest) over
+/* Measured error of the float fast paths that settle ring and sector decisions (k_split) over
  * n_samples pseudo-random points: err[0] = max |approx - exact| of the vertical angle [deg],
- * err[1] of the polar angle [rad], err[2] of the scaled polar angle, err[3] of the azimuth [deg]
- * (k_ring / k_label).  They must stay below the margins the kernels use (3e-4, 2e-6, 2.5e-4,
- * 5e-4).  err has room for 4 floats.  Synchronous. */
+ * err[1] of the polar angle [rad], err[2] of the scaled polar angle (at the configured number of
+ * sectors), err[3] of the azimuth [deg] (k_ring / k_label).  They must stay below the margins the
+ * kernels use (3e-4, 2e-6, 2.5e-4 * max(1, sectors / 360), 5e-4).  err has room for 4 floats.
+ * Synchronous. */
 int urf_selftest_fast(urf_ctx* ctx, uint64_t n_samples, float* err);
+/* Test hook: bit 2 (value 4) forces the general (comparison network) path of the star-shaped sort
+ * for every sector; 0 in production.  Takes effect with the next classify call. */
+int urf_set_debug_flags(urf_ctx* ctx, uint32_t flags);
 const char* urf_strerror(int status);
 const char* urf_last_error(const urf_ctx* ctx);   /* text of the last HIP failure */
 int urf_abi_version(void);

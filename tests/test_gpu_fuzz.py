@@ -22,7 +22,10 @@ def check_case(ctx, seed, capture):
     (x, y, z), p = case(2000 + seed)
     lb, ib, st = O.run_b(x, y, z, p, debug=True)
     ctx.set_params(p)
-    ctx.enable_stage_capture(capture)
+    if not capture:   # the production path proper (records nothing per input point)
+        lg, ig = ctx.classify_xyz(x, y, z)
+        assert np.array_equal(lg, lb), "seed %d: %d labels differ" % (seed, int((lg != lb).sum()))
+    ctx.enable_stage_capture(1 if capture else 2)   # 2: the production decisions, ring / sector recorded
     try:
         lg, ig = ctx.classify_xyz(x, y, z)
         n = len(x)
@@ -33,7 +36,7 @@ def check_case(ctx, seed, capture):
             assert np.array_equal(ctx.read_stage(u.STAGE_DETECT, n), st["detect"])
             assert np.array_equal(ctx.read_stage(u.STAGE_BEAM_STOP, n), st["beam_stop"])
     finally:
-        ctx.enable_stage_capture(False)
+        ctx.enable_stage_capture(0)
     assert np.array_equal(lg, lb), "seed %d: %d labels differ" % (seed, int((lg != lb).sum()))
     assert all(getattr(ig, k) == ib[k] for k in ("status", "n_roi", "n_rings", "n_ring_pts", "n_road", "n_curb", "n_ring10"))
 

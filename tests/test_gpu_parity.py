@@ -59,7 +59,7 @@ def test_every_stage(ctx_big, cfg, seed, tweak):
     n = len(x)
     lb, ib, st = O.run_b(x, y, z, p, debug=True)
     ctx_big.set_params(p)
-    ctx_big.enable_stage_capture(True)
+    ctx_big.enable_stage_capture(1)
     try:
         lg, ig = ctx_big.classify_xyz(x, y, z)
         roi = (lb & u.FLAG_ROI) != 0
@@ -81,13 +81,20 @@ def test_every_stage(ctx_big, cfg, seed, tweak):
         assert np.array_equal(ctx_big.read_stage(u.STAGE_BEAM_STOP, n), st["beam_stop"])
         assert np.array_equal(lg, lb) and info_equal(ig, ib)
     finally:
-        ctx_big.enable_stage_capture(False)
-    # the production configuration (capture off): ring, sector and window membership are decided on
-    # float approximations with margins; every integer stage must still be the reference's
+        ctx_big.enable_stage_capture(0)
+    # the production configuration: ring, sector and window membership are decided on float
+    # approximations with margins; every integer stage must still be the reference's (capture
+    # mode 2 = the production decisions, with ring and sector of every input point recorded)
+    ctx_big.enable_stage_capture(2)
+    try:
+        lg, ig = ctx_big.classify_xyz(x, y, z)
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_RING, n), st["ring"])
+        if p.star_shaped_method:
+            assert np.array_equal(ctx_big.read_stage(u.STAGE_SECTOR, n), st["sector"])
+        assert np.array_equal(lg, lb) and info_equal(ig, ib)
+    finally:
+        ctx_big.enable_stage_capture(0)
     lg, ig = ctx_big.classify_xyz(x, y, z)
-    assert np.array_equal(ctx_big.read_stage(u.STAGE_RING, n), st["ring"])
-    if p.star_shaped_method:
-        assert np.array_equal(ctx_big.read_stage(u.STAGE_SECTOR, n), st["sector"])
     assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, n), st["detect"])
     assert np.array_equal(ctx_big.read_stage(u.STAGE_MAXDIST, n), st["max_dist"])
     assert np.array_equal(ctx_big.read_stage(u.STAGE_QUADRANTS, n), st["quadrants"])
@@ -275,18 +282,19 @@ def test_equal_ranges_are_ordered_by_input_index(ctx_big, n_pts):
     assert np.array_equal(lg, lb) and info_equal(ig, ib)
 
 
-def test_star_sort_paths(ctx_big, monkeypatch):
+def test_star_sort_paths(ctx_big):
     """k_star_sort_small has a distribution-sort fast path and a general path (in-register block
     sorts merged by ranking).  (a) force the general path on a normal sweep; (b) a cloud whose
     ranges are so clustered that buckets overflow and the kernel falls back by itself."""
     p = O.cfg_params("cfg2")
     x, y, z = O.cfg_cloud("narrow", 91)
     lb, ib, st = O.run_b(x, y, z, p, debug=True)
-    monkeypatch.setenv("URF_EXP", "4")
     ctx_big.set_params(p)
-    lg, ig = ctx_big.classify_xyz(x, y, z)
-    monkeypatch.delenv("URF_EXP")
-    ctx_big.set_params(p)
+    ctx_big.set_debug_flags(4)
+    try:
+        lg, ig = ctx_big.classify_xyz(x, y, z)
+    finally:
+        ctx_big.set_debug_flags(0)
     assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, len(x)), st["detect"])
     assert np.array_equal(lg, lb) and info_equal(ig, ib)
     # (b) 3 rings; in sector 10: 300 points packed within a few hundred ulps of r = 10 m plus two far
@@ -323,9 +331,13 @@ def test_ring_table_zero_sentinel(ctx_big):
     z[3] = -1.8
     lb, ib, st = O.run_b(x, y, z, p, debug=True)
     ctx_big.set_params(p)
-    lg, ig = ctx_big.classify_xyz(x, y, z)
-    assert np.array_equal(ctx_big.read_stage(u.STAGE_ANGLE_TABLE, len(x)), st["angle_table"])
-    assert np.array_equal(ctx_big.read_stage(u.STAGE_RING, len(x)), st["ring"])
+    ctx_big.enable_stage_capture(2)
+    try:
+        lg, ig = ctx_big.classify_xyz(x, y, z)
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_ANGLE_TABLE, len(x)), st["angle_table"])
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_RING, len(x)), st["ring"])
+    finally:
+        ctx_big.enable_stage_capture(0)
     assert ig.n_rings == ib["n_rings"] and (lg[3] & 3) != 1
 
 
@@ -437,11 +449,17 @@ def test_decision_boundaries(ctx_big, log2_scale, tweak):
     lb, ib, st = O.run_b(x, y, z, p, debug=True)
     assert ib["status"] == 0 and ib["n_rings"] >= 14
     ctx_big.set_params(p)
-    lg, ig = ctx_big.classify_xyz(x, y, z)
     n = len(x)
-    assert np.array_equal(ctx_big.read_stage(u.STAGE_ANGLE_TABLE, n), st["angle_table"])
-    assert np.array_equal(ctx_big.read_stage(u.STAGE_RING, n), st["ring"])
-    assert np.array_equal(ctx_big.read_stage(u.STAGE_SECTOR, n), st["sector"])
+    ctx_big.enable_stage_capture(2)   # the production decisions, ring / sector per input point recorded
+    try:
+        lg, ig = ctx_big.classify_xyz(x, y, z)
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_ANGLE_TABLE, n), st["angle_table"])
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_RING, n), st["ring"])
+        assert np.array_equal(ctx_big.read_stage(u.STAGE_SECTOR, n), st["sector"])
+        assert np.array_equal(lg, lb) and info_equal(ig, ib)
+    finally:
+        ctx_big.enable_stage_capture(0)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
     assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, n), st["detect"])
     assert np.array_equal(ctx_big.read_stage(u.STAGE_BEAM_STOP, n), st["beam_stop"])
     assert np.array_equal(lg, lb) and info_equal(ig, ib)

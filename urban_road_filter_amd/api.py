@@ -100,6 +100,7 @@ def lib():
         "urf_ordered_indices": [vp, C.c_uint32, vp, vp, vp, vp],
         "urf_marker_points": [vp, C.c_uint32, vp, vp],
         "urf_enable_stage_capture": [vp, C.c_int],
+        "urf_set_debug_flags": [vp, C.c_uint32],
         "urf_enable_kernel_timing": [vp, C.c_int],
         "urf_selftest": [vp, C.c_void_p],
         "urf_selftest_fast": [vp, C.c_uint64, C.c_void_p],
@@ -212,10 +213,15 @@ class Context:
     def synchronize(self):
         self._check(self._lib.urf_synchronize(self._h), "urf_synchronize")
 
-    def enable_stage_capture(self, on=True):
-        self._check(self._lib.urf_enable_stage_capture(self._h, int(on)), "urf_enable_stage_capture")
+    def enable_stage_capture(self, mode=1):
+        """0 off; 1 exact arithmetic for every point, all stages readable; 2 production decisions with
+        the ring / sector of every input point recorded (STAGE_RING, STAGE_SECTOR)."""
+        self._check(self._lib.urf_enable_stage_capture(self._h, int(mode)), "urf_enable_stage_capture")
 
-    NUM_KERNELS = 9
+    def set_debug_flags(self, flags):
+        self._check(self._lib.urf_set_debug_flags(self._h, int(flags)), "urf_set_debug_flags")
+
+    NUM_KERNELS = 8
 
     def selftest_fast(self, n_samples=1 << 27):
         """max |approx - exact| of the float fast paths: (vertical angle [deg], polar angle [rad], fi*Kfi, azimuth [deg])."""

@@ -19,8 +19,10 @@
 struct urf_ctx {
     int device = 0;
     uint32_t max_points = 0, max_batch = 0;
-    size_t total = 0;               /* max_points * max_batch */
+    size_t total = 0;               /* scratch elements: sstride * max_batch */
     uint32_t max_tiles = 0;
+    uint32_t sstride = 0;           /* scratch elements per scan: max_tiles * URF_TILE + URF_SCAN_PAD */
+    uint32_t debug_flags = 0;       /* urf_set_debug_flags */
     unsigned n_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -43,14 +45,16 @@ struct urf_ctx {
     float* d_newY = nullptr;
     urf_beam* d_beams = nullptr;
     uint32_t beams_cap = 0;
-    bool debug_rd2 = false;
+    int capture = 0;                /* urf_enable_stage_capture */
     bool timing = false;
-    std::vector<std::vector<hipEvent_t>> timing_events;   /* one set of URF_NUM_KERNELS+1 events per call */
-    /* last call, for urf_read_stage */
-    uint32_t last_scans = 0, last_n = 0, last_max_len = 0;
-    bool last_ragged = false;
-    const uint32_t* last_offsets = nullptr;
-    const uint8_t* last_labels = nullptr;
+    std::vector<std::vector<hipEvent_t>> timing_events;   /* sets of URF_NUM_KERNELS+1 events, created once and reused */
+    size_t timing_used = 0;         /* sets recorded since the last urf_kernel_timing() */
+    uint32_t* offsets_copy = nullptr;   /* [max_batch + 1] the ragged offsets of the last call (context-owned) */
+    /* last call, for the entry points that read its intermediate results (urf_read_stage,
+     * urf_ordered_indices, urf_marker_points): the kernel arguments and parameters it ran with */
+    uint32_t last_scans = 0;
+    urf_kargs last_a;
+    urf_dev_params last_dp;
     std::string last_error;
 };
 
@@ -111,11 +115,23 @@ static int upload_params(urf_ctx* c)
     dp.ring_keybits = 1;
     while ((1u << dp.ring_keybits) <= (unsigned)p.channels)
         dp.ring_keybits++;
-    dp.exp_flags = std::getenv("URF_EXP") ? (uint32_t)std::strtoul(std::getenv("URF_EXP"), nullptr, 0) : 0u;
+    dp.exp_flags = c->debug_flags;
+    dp.sector_margin = URF_FAST_SECTOR_ERR * (p.sectors > 360 ? (float)p.sectors / 360.0f : 1.0f);
     std::vector<urf_beam> beams;
     beam_init(beams, p.sectors, p.beam_width);
     URF_HIP(c, hipMemcpyAsync(c->d_beams, beams.data(), beams.size() * sizeof(urf_beam), hipMemcpyHostToDevice, c->stream));
     URF_HIP(c, hipStreamSynchronize(c->stream));   /* `beams` is a stack object */
+    return URF_OK;
+}
+
+static int ensure_capture_arrays(urf_ctx* c)
+{
+    if (c->k.valpha)
+        return URF_OK;
+    int rc;
+    if ((rc = dev_alloc(c, &c->k.valpha, c->total)) != URF_OK || (rc = dev_alloc(c, &c->k.seckey, c->total)) != URF_OK ||
+        (rc = dev_alloc(c, &c->k.ringkey, c->total)) != URF_OK || (rc = dev_alloc(c, &c->k.rd2, c->total)) != URF_OK)
+        return rc;
     return URF_OK;
 }
 
@@ -124,7 +140,9 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     if (!out || max_points == 0 || max_batch == 0)
         return URF_ERR_INVALID_ARG;
     *out = nullptr;
-    if ((unsigned long long)max_points * max_batch >= (1ull << 32))
+    const unsigned long long max_tiles = ((unsigned long long)max_points + URF_TILE - 1) / URF_TILE;
+    const unsigned long long sstride = max_tiles * URF_TILE + URF_SCAN_PAD;
+    if (max_tiles > URF_MAX_TILES || sstride * max_batch >= (1ull << 32))
         return URF_ERR_CAPACITY;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
@@ -133,8 +151,9 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     c->device = device_id;
     c->max_points = max_points;
     c->max_batch = max_batch;
-    c->total = (size_t)max_points * max_batch;
-    c->max_tiles = (max_points + URF_TILE - 1) / URF_TILE;
+    c->max_tiles = (uint32_t)max_tiles;
+    c->sstride = (uint32_t)sstride;
+    c->total = (size_t)sstride * max_batch;
     int rc = URF_OK;
     auto fail = [&](int code) {
         urf_destroy(c);
@@ -150,21 +169,21 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
             c->n_cus = (unsigned)prop.multiProcessorCount;
     }
-    /* k_scatter stages a whole tile in LDS (> 64 KiB of the CU's 160 KiB) */
-    if (hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-        return fail(URF_ERR_HIP);
     urf_default_params(&c->params);
     std::memset(&c->k, 0, sizeof(c->k));
+    std::memset(&c->last_a, 0, sizeof(c->last_a));
     urf_kargs& k = c->k;
     const size_t T = c->total, S = max_batch, tiles = c->max_tiles;
     const size_t C = URF_MAX_CHANNELS, K = URF_MAX_SECTORS;
 #define A(ptr, count)                                     \
     if ((rc = dev_alloc(c, &(ptr), (count))) != URF_OK)   \
         return fail(rc);
-    A(k.valpha, T) A(k.seckey, T) A(k.ringkey, T)
-    A(k.rx, T) A(k.ry, T) A(k.rz, T) A(k.rsrc, T) A(k.raz, T) A(k.rd2, T) A(k.rflag, T)
-    A(k.sr, T) A(k.sz, T) A(k.ssrc, T) A(k.ssrt, T) A(k.wslp, T) A(k.wg, T)
-    A(k.tile_roi, S * tiles) A(k.tile_ring, S * tiles * C) A(k.tile_sec, S * tiles * K)
+    A(k.rx, T) A(k.ry, T) A(k.rz, T) A(k.rsrc, T) A(k.raz, T) A(k.rflag, T)
+    A(k.sr, T) A(k.sz, T) A(k.sslot, T) A(k.ssrt, T) A(k.wslp, T) A(k.wg, T)
+    A(k.big_r, T) A(k.big_z, T) A(k.big_i, T)
+    A(k.tile_roi, S * tiles) A(k.troff, S * tiles * (C + 1)) A(k.tsoff, S * tiles * (K + 1))
+    A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles) A(k.tpre, S * tiles * C)
+    A(k.spre, S * K * (tiles + 1)) A(k.sstart, S * K * tiles)
     A(k.angle, S * C) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
     A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 2)
@@ -173,9 +192,11 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.stop_f, S * URF_DEG_CELLS) A(k.stop_b, S * URF_DEG_CELLS)
     A(k.act_f, S * C * 6) A(k.act_b, S * C * 6) A(k.qk, S * C)
     A(k.info, S)
+    A(c->offsets_copy, S + 1)
     A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
     A(c->labels1, (size_t)max_points)
 #undef A
+    k.sstride = c->sstride;
     /* x_zero_method.cpp:24-27: newY[j] = newY[j-1] + 0.0100 (float += double), a
      * data-independent table shared by all rings */
     {
@@ -194,18 +215,8 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     return URF_OK;
 }
 
-extern "C" int urf_destroy(urf_ctx* c)
+static void free_lazy(urf_ctx* c)
 {
-    if (!c)
-        return URF_ERR_INVALID_ARG;
-    (void)hipSetDevice(c->device);
-    if (c->own_stream)
-        (void)hipStreamSynchronize(c->own_stream);
-    for (auto& set : c->timing_events)
-        for (hipEvent_t e : set)
-            (void)hipEventDestroy(e);
-    for (void* p : c->allocs)
-        (void)hipFree(p);
     if (c->raw)
         (void)hipFree(c->raw);
     if (c->mk_d) {
@@ -224,6 +235,21 @@ extern "C" int urf_destroy(urf_ctx* c)
         (void)hipFree(c->sy);
         (void)hipFree(c->sz);
     }
+}
+
+extern "C" int urf_destroy(urf_ctx* c)
+{
+    if (!c)
+        return URF_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream)
+        (void)hipStreamSynchronize(c->own_stream);
+    for (auto& set : c->timing_events)
+        for (hipEvent_t e : set)
+            (void)hipEventDestroy(e);
+    for (void* p : c->allocs)
+        (void)hipFree(p);
+    free_lazy(c);
     if (c->own_stream)
         (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -267,11 +293,26 @@ extern "C" int urf_synchronize(urf_ctx* c)
     return URF_OK;
 }
 
-extern "C" int urf_enable_stage_capture(urf_ctx* c, int on)
+extern "C" int urf_enable_stage_capture(urf_ctx* c, int mode)
+{
+    if (!c || mode < 0 || mode > 2)
+        return URF_ERR_INVALID_ARG;
+    if (mode) {
+        URF_HIP(c, hipSetDevice(c->device));
+        const int rc = ensure_capture_arrays(c);
+        if (rc != URF_OK)
+            return rc;
+    }
+    c->capture = mode;
+    return URF_OK;
+}
+
+extern "C" int urf_set_debug_flags(urf_ctx* c, uint32_t flags)
 {
     if (!c)
         return URF_ERR_INVALID_ARG;
-    c->debug_rd2 = on != 0;
+    c->debug_flags = flags;
+    c->dp.exp_flags = flags;
     return URF_OK;
 }
 
@@ -321,8 +362,8 @@ extern "C" int urf_enable_kernel_timing(urf_ctx* c, int on)
 
 extern "C" const char* urf_kernel_name(int i)
 {
-    static const char* names[URF_NUM_KERNELS] = { "k_ring_table", "k_ingest", "k_offsets", "k_scatter",
-                                                  "k_star_sort", "k_star_walk", "k_ring", "k_beams", "k_label" };
+    static const char* names[URF_NUM_KERNELS] = { "k_ring_table", "k_split", "k_index", "k_star_sort",
+                                                  "k_star_walk", "k_ring", "k_beams", "k_label" };
     return (i >= 0 && i < URF_NUM_KERNELS) ? names[i] : "";
 }
 
@@ -332,17 +373,16 @@ extern "C" int urf_kernel_timing(urf_ctx* c, double* ms_sum, uint32_t* n_calls)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
     URF_HIP(c, hipStreamSynchronize(c->stream));
-    for (auto& set : c->timing_events) {
+    for (size_t i = 0; i < c->timing_used; i++) {
+        auto& set = c->timing_events[i];
         for (int k = 0; k < URF_NUM_KERNELS; k++) {
             float ms = 0.f;
             URF_HIP(c, hipEventElapsedTime(&ms, set[k], set[k + 1]));
             ms_sum[k] += (double)ms;
         }
-        for (hipEvent_t e : set)
-            (void)hipEventDestroy(e);
         (*n_calls)++;
     }
-    c->timing_events.clear();
+    c->timing_used = 0;   /* the events stay allocated and are recorded again by the next calls */
     return URF_OK;
 }
 
@@ -360,34 +400,43 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     if (n_scans > c->max_batch || max_len > c->max_points)
         return URF_ERR_CAPACITY;
     URF_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
     urf_kargs a = c->k;
     a.x = d_x;
     a.y = d_y;
     a.z = d_z;
-    a.offsets = d_offsets;
+    a.offsets = nullptr;
+    if (d_offsets) {
+        /* the context keeps its own copy: the entry points that look at this call's results later
+         * (urf_read_stage, urf_ordered_indices, urf_marker_points) must not depend on the caller
+         * keeping d_offsets alive.  Scratch memory is indexed by scan, never by these offsets. */
+        URF_HIP(c, hipMemcpyAsync(c->offsets_copy, d_offsets, ((size_t)n_scans + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        a.offsets = c->offsets_copy;
+    }
     a.n_per_scan = n_per_scan;
     a.n_scans = n_scans;
     a.max_len = max_len;
     a.tiles = (max_len + URF_TILE - 1) / URF_TILE;
     if (a.tiles == 0)
         a.tiles = 1;
+    a.sstride = c->sstride;
+    a.capture = (uint32_t)c->capture;
     a.labels = d_labels;
-    if (!c->debug_rd2) {
+    if (c->capture != 1)
         a.rd2 = nullptr;
-        a.valpha = nullptr;
-    }
     const urf_dev_params dp = c->dp;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
-    hipStream_t st = c->stream;
     const dim3 g_tiles(a.tiles, n_scans), g_scan(n_scans);
 
     std::vector<hipEvent_t>* ev = nullptr;
     if (c->timing) {
-        c->timing_events.emplace_back(URF_NUM_KERNELS + 1);
-        ev = &c->timing_events.back();
-        for (hipEvent_t& e : *ev)
-            URF_HIP(c, hipEventCreate(&e));
+        if (c->timing_used == c->timing_events.size()) {
+            c->timing_events.emplace_back(URF_NUM_KERNELS + 1);
+            for (hipEvent_t& e : c->timing_events.back())
+                URF_HIP(c, hipEventCreate(&e));
+        }
+        ev = &c->timing_events[c->timing_used++];
     }
     int stage = 0;
     auto mark = [&]() {
@@ -398,16 +447,11 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     mark();
     hipLaunchKernelGGL(k_ring_table, g_scan, dim3(256), 0, st, a, dp);
     mark();
-    hipLaunchKernelGGL(k_ingest, g_tiles, dim3(URF_INGEST_THREADS), (K + 1) * sizeof(unsigned), st, a, dp);
+    hipLaunchKernelGGL(k_split, g_tiles, dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
     mark();
     if (star)
         URF_HIP(c, hipMemsetAsync(a.star_count, 0, 2 * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_offsets, g_scan, dim3(256), 0, st, a, dp);
-    mark();
-    {
-        const size_t lds = urf_scatter_lds_bytes(C, K, star);
-        hipLaunchKernelGGL(k_scatter, g_tiles, dim3(URF_TILE_THREADS), lds, st, a, dp);
-    }
+    hipLaunchKernelGGL(k_index, g_scan, dim3(256), 0, st, a, dp);
     mark();
     if (star) {
         const dim3 g_sec(K, n_scans);
@@ -421,7 +465,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         hipLaunchKernelGGL(k_star_walk, dim3((K + 63) / 64, n_scans), dim3(64), 0, st, a, dp);
     mark();
     const dim3 g_ring(C, n_scans);
-    hipLaunchKernelGGL(k_ring, g_ring, dim3(URF_RING_THREADS), 0, st, a, dp);
+    hipLaunchKernelGGL(k_ring, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
     mark();
     hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_LABEL_THREADS), 0, st, a, dp);
     mark();
@@ -431,11 +475,8 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     if (d_info)
         URF_HIP(c, hipMemcpyAsync(d_info, a.info, (size_t)n_scans * sizeof(urf_scan_info), hipMemcpyDeviceToDevice, st));
     c->last_scans = n_scans;
-    c->last_n = n_per_scan;
-    c->last_max_len = max_len;
-    c->last_ragged = d_offsets != nullptr;
-    c->last_offsets = d_offsets;
-    c->last_labels = d_labels;
+    c->last_a = a;
+    c->last_dp = dp;
     return URF_OK;
 }
 
@@ -460,21 +501,30 @@ static int ensure_soa_staging(urf_ctx* c)
 {
     if (c->sx)
         return URF_OK;
+    const size_t n = (size_t)c->max_points * c->max_batch;
     void *px = nullptr, *py = nullptr, *pz = nullptr;
-    URF_HIP(c, hipMalloc(&px, c->total * sizeof(float)));
-    URF_HIP(c, hipMalloc(&py, c->total * sizeof(float)));
-    URF_HIP(c, hipMalloc(&pz, c->total * sizeof(float)));
+    URF_HIP(c, hipMalloc(&px, n * sizeof(float)));
+    URF_HIP(c, hipMalloc(&py, n * sizeof(float)));
+    URF_HIP(c, hipMalloc(&pz, n * sizeof(float)));
     c->sx = (float*)px;
     c->sy = (float*)py;
     c->sz = (float*)pz;
     return URF_OK;
 }
 
+/* field offsets of a PointCloud2 record: every FLOAT32 field must lie inside the record
+ * (evaluated in 64 bits: the offsets come from an untrusted wire message) */
+static bool pc2_layout_ok(uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z)
+{
+    const uint64_t ps = point_step;
+    return ps >= 4 && (uint64_t)off_x + 4 <= ps && (uint64_t)off_y + 4 <= ps && (uint64_t)off_z + 4 <= ps;
+}
+
 extern "C" int urf_classify_batch_pc2(urf_ctx* c, const uint8_t* d_data, uint32_t n_per_scan, uint32_t n_scans,
                                       uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
                                       uint8_t* d_labels, urf_scan_info* d_info)
 {
-    if (!c || !d_data || point_step < 4 || off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step)
+    if (!c || !d_data || !pc2_layout_ok(point_step, off_x, off_y, off_z))
         return URF_ERR_INVALID_ARG;
     if (n_scans > c->max_batch || n_per_scan > c->max_points)
         return URF_ERR_CAPACITY;
@@ -493,8 +543,8 @@ extern "C" int urf_classify_batch_pc2(urf_ctx* c, const uint8_t* d_data, uint32_
 extern "C" int urf_classify_pc2(urf_ctx* c, const uint8_t* data, uint32_t n_points, uint32_t point_step,
                                 uint32_t off_x, uint32_t off_y, uint32_t off_z, uint8_t* labels_out, urf_scan_info* info)
 {
-    if (!c || !data || !labels_out)
-        return URF_ERR_INVALID_ARG;
+    if (!c || !data || !labels_out || !pc2_layout_ok(point_step, off_x, off_y, off_z))
+        return URF_ERR_INVALID_ARG;   /* before any byte of the message is copied */
     if (n_points > c->max_points)
         return URF_ERR_CAPACITY;
     if (n_points == 0) {
@@ -545,31 +595,28 @@ extern "C" int urf_compact_indices(urf_ctx* c, const uint8_t* d_labels, uint32_t
 extern "C" int urf_ordered_indices(urf_ctx* c, uint32_t scan, uint32_t* road, uint32_t* curb, uint32_t* ring10,
                                    uint32_t* counts)
 {
-    if (!c || !counts || scan >= c->last_scans || !c->last_labels)
+    if (!c || !counts || scan >= c->last_scans || !c->last_a.labels)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
+    const size_t mp = (size_t)c->max_points + URF_SCAN_PAD;   /* ring starts are padded to multiples of 4 */
     if (!c->ord_keys) {
         void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
-        URF_HIP(c, hipMalloc(&p0, (size_t)c->max_points * sizeof(unsigned long long)));
-        URF_HIP(c, hipMalloc(&p1, (size_t)c->max_points * sizeof(uint32_t)));
-        URF_HIP(c, hipMalloc(&p2, ((size_t)c->max_points * 3 + 4) * sizeof(uint32_t)));
+        URF_HIP(c, hipMalloc(&p0, mp * sizeof(unsigned long long)));
+        URF_HIP(c, hipMalloc(&p1, mp * sizeof(uint32_t)));
+        URF_HIP(c, hipMalloc(&p2, (mp * 3 + 4) * sizeof(uint32_t)));
         c->ord_keys = (unsigned long long*)p0;
         c->ord_pos = (uint32_t*)p1;
         c->ord_lists = (uint32_t*)p2;
     }
-    urf_kargs a = c->k;
-    a.offsets = c->last_offsets;
-    a.n_per_scan = c->last_n;
-    a.n_scans = c->last_scans;
-    a.labels = const_cast<uint8_t*>(c->last_labels);
-    const size_t mp = c->max_points;
+    const urf_kargs a = c->last_a;   /* the call's own arguments and parameters, whatever was set since */
+    const urf_dev_params dp = c->last_dp;
     uint32_t* d_road = c->ord_lists;
     uint32_t* d_curb = d_road + mp;
     uint32_t* d_r10 = d_curb + mp;
     uint32_t* d_cnt = d_r10 + mp;
     hipStream_t st = c->stream;
-    hipLaunchKernelGGL(k_ring_order, dim3((unsigned)c->dp.p.channels), dim3(256), 0, st, a, c->dp, scan, c->ord_keys, c->ord_pos);
-    hipLaunchKernelGGL(k_ordered_lists, dim3(1), dim3(1024), 0, st, a, c->dp, scan, c->ord_pos, d_road, d_curb, d_r10, d_cnt);
+    hipLaunchKernelGGL(k_ring_order, dim3((unsigned)dp.p.channels), dim3(256), 0, st, a, dp, scan, c->ord_keys, c->ord_pos);
+    hipLaunchKernelGGL(k_ordered_lists, dim3(1), dim3(1024), 0, st, a, dp, scan, c->ord_pos, d_road, d_curb, d_r10, d_cnt);
     URF_HIP(c, hipGetLastError());
     uint32_t h[3] = { 0, 0, 0 };
     URF_HIP(c, hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -588,7 +635,7 @@ extern "C" int urf_ordered_indices(urf_ctx* c, uint32_t scan, uint32_t* road, ui
 
 extern "C" int urf_marker_points(urf_ctx* c, uint32_t scan, float* pts, uint32_t* count)
 {
-    if (!c || !pts || !count || scan >= c->last_scans || !c->last_labels)
+    if (!c || !pts || !count || scan >= c->last_scans || !c->last_a.labels)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
     const size_t cells = (size_t)URF_MAX_CHANNELS * URF_DEG_CELLS;
@@ -603,15 +650,12 @@ extern "C" int urf_marker_points(urf_ctx* c, uint32_t scan, float* pts, uint32_t
         c->mk_red = (uint8_t*)p2;
         c->mk_out = (float*)p3;
     }
-    urf_kargs a = c->k;
-    a.offsets = c->last_offsets;
-    a.n_per_scan = c->last_n;
-    a.n_scans = c->last_scans;
-    a.labels = const_cast<uint8_t*>(c->last_labels);
+    const urf_kargs a = c->last_a;
+    const urf_dev_params dp = c->last_dp;
     hipStream_t st = c->stream;
     unsigned* d_cnt = (unsigned*)(c->mk_out + URF_DEG_CELLS * 4);
-    hipLaunchKernelGGL(k_marker_ring, dim3((unsigned)c->dp.p.channels), dim3(256), 0, st, a, c->dp, scan, c->mk_d, c->mk_pos, c->mk_red);
-    hipLaunchKernelGGL(k_marker_bins, dim3(1), dim3(384), 0, st, a, c->dp, scan, c->mk_d, c->mk_pos, c->mk_red, c->mk_out, d_cnt);
+    hipLaunchKernelGGL(k_marker_ring, dim3((unsigned)dp.p.channels), dim3(256), 0, st, a, dp, scan, c->mk_d, c->mk_pos, c->mk_red);
+    hipLaunchKernelGGL(k_marker_bins, dim3(1), dim3(384), 0, st, a, dp, scan, c->mk_d, c->mk_pos, c->mk_red, c->mk_out, d_cnt);
     URF_HIP(c, hipGetLastError());
     std::vector<float> h(URF_DEG_CELLS * 4 + 4);
     URF_HIP(c, hipMemcpyAsync(h.data(), c->mk_out, h.size() * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -630,7 +674,37 @@ template <class T>
 static int fetch(urf_ctx* c, std::vector<T>& dst, const T* src, size_t count)
 {
     dst.resize(count);
-    URF_HIP(c, hipMemcpy(dst.data(), src, count * sizeof(T), hipMemcpyDeviceToHost));
+    if (count)
+        URF_HIP(c, hipMemcpy(dst.data(), src, count * sizeof(T), hipMemcpyDeviceToHost));
+    return URF_OK;
+}
+
+/* For every ring-major position of scan `scan` that holds a point: the point's input index
+ * (relative to the scan).  Rebuilt on the host from k_split's per-tile tables: ring c, tile t
+ * contributes the ring-sorted slots [troff[t][c], troff[t][c+1]) of tile t, and the ring's points
+ * before tile t number rpre[c][t]. */
+static int ring_major_sources(urf_ctx* c, uint32_t scan, uint32_t len, std::vector<uint32_t>& pos, std::vector<uint32_t>& src)
+{
+    const urf_kargs& k = c->last_a;
+    const unsigned C = (unsigned)c->last_dp.p.channels;
+    const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
+    std::vector<uint16_t> troff, rsrc;
+    std::vector<uint32_t> roff, rpre;
+    int rc;
+    if ((rc = fetch(c, troff, k.troff + (size_t)scan * k.tiles * (C + 1), (size_t)ntiles * (C + 1))) != URF_OK) return rc;
+    if ((rc = fetch(c, rsrc, k.rsrc + (size_t)scan * k.sstride, (size_t)ntiles * URF_TILE)) != URF_OK) return rc;
+    if ((rc = fetch(c, roff, k.ring_off + (size_t)scan * (C + 1), C + 1)) != URF_OK) return rc;
+    if ((rc = fetch(c, rpre, k.rpre + (size_t)scan * C * (k.tiles + 1), (size_t)C * (k.tiles + 1))) != URF_OK) return rc;
+    pos.clear();
+    src.clear();
+    for (unsigned t = 0; t < ntiles; t++)
+        for (unsigned r = 0; r < C; r++) {
+            const unsigned j0 = troff[(size_t)t * (C + 1) + r], j1 = troff[(size_t)t * (C + 1) + r + 1];
+            for (unsigned j = j0; j < j1; j++) {
+                pos.push_back(roff[r] + rpre[(size_t)r * (k.tiles + 1) + t] + (j - j0));
+                src.push_back(t * URF_TILE + rsrc[(size_t)t * URF_TILE + j]);
+            }
+        }
     return URF_OK;
 }
 
@@ -640,40 +714,43 @@ extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* h
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
     URF_HIP(c, hipStreamSynchronize(c->stream));
-    uint32_t off, len;
-    if (c->last_ragged) {
+    const urf_kargs& k = c->last_a;   /* the arguments and parameters of the call whose results are read */
+    uint32_t len;
+    if (k.offsets) {
         uint32_t o2[2];
-        URF_HIP(c, hipMemcpy(o2, c->last_offsets + scan, sizeof(o2), hipMemcpyDeviceToHost));
-        off = o2[0];
+        URF_HIP(c, hipMemcpy(o2, k.offsets + scan, sizeof(o2), hipMemcpyDeviceToHost));
         len = o2[1] - o2[0];
+        if (len > k.max_len)
+            len = k.max_len;
     } else {
-        off = scan * c->last_n;
-        len = c->last_n;
+        len = k.n_per_scan;
     }
-    const unsigned C = (unsigned)c->params.channels;
-    const urf_kargs& k = c->k;
+    const unsigned C = (unsigned)c->last_dp.p.channels;
+    const size_t sb = (size_t)scan * k.sstride;
     urf_scan_info in;
     URF_HIP(c, hipMemcpy(&in, k.info + scan, sizeof(in), hipMemcpyDeviceToHost));
     int rc;
     switch (what) {
     case URF_STAGE_VALPHA:
-        if (!c->debug_rd2) return URF_ERR_INVALID_ARG;
+        if (k.capture != 1) return URF_ERR_INVALID_ARG;
         if (bytes < len * sizeof(float)) return URF_ERR_INVALID_ARG;
-        URF_HIP(c, hipMemcpy(host_dst, k.valpha + off, len * sizeof(float), hipMemcpyDeviceToHost));
+        URF_HIP(c, hipMemcpy(host_dst, k.valpha + sb, len * sizeof(float), hipMemcpyDeviceToHost));
         return URF_OK;
     case URF_STAGE_RING: {
+        if (k.capture == 0) return URF_ERR_INVALID_ARG;
         if (bytes < len * sizeof(int16_t)) return URF_ERR_INVALID_ARG;
         std::vector<uint8_t> rk;
-        if ((rc = fetch(c, rk, k.ringkey + off, len)) != URF_OK) return rc;
+        if ((rc = fetch(c, rk, k.ringkey + sb, len)) != URF_OK) return rc;
         int16_t* o = (int16_t*)host_dst;
         for (uint32_t i = 0; i < len; i++)
             o[i] = (in.status != URF_OK || rk[i] == URF_RING_NONE) ? (int16_t)-1 : (int16_t)rk[i];
         return URF_OK;
     }
     case URF_STAGE_SECTOR: {
+        if (k.capture == 0) return URF_ERR_INVALID_ARG;
         if (bytes < len * sizeof(int16_t)) return URF_ERR_INVALID_ARG;
         std::vector<uint16_t> sk;
-        if ((rc = fetch(c, sk, k.seckey + off, len)) != URF_OK) return rc;
+        if ((rc = fetch(c, sk, k.seckey + sb, len)) != URF_OK) return rc;
         int16_t* o = (int16_t*)host_dst;
         for (uint32_t i = 0; i < len; i++)
             o[i] = sk[i] == URF_SEC_NONE ? (int16_t)-1 : (int16_t)sk[i];
@@ -682,27 +759,27 @@ extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* h
     case URF_STAGE_AZIMUTH:
     case URF_STAGE_RANGE2D:
     case URF_STAGE_DETECT: {
-        if (what != URF_STAGE_DETECT && !c->debug_rd2) return URF_ERR_INVALID_ARG;   /* exact values need the capture */
+        if (what != URF_STAGE_DETECT && k.capture != 1) return URF_ERR_INVALID_ARG;   /* exact values need the capture */
         const size_t esz = what == URF_STAGE_DETECT ? 1 : 4;
         if (bytes < len * esz) return URF_ERR_INVALID_ARG;
         std::memset(host_dst, 0, len * esz);
         if (in.status != URF_OK) return URF_OK;
-        std::vector<uint32_t> src, roff;
-        if ((rc = fetch(c, roff, k.ring_off + (size_t)scan * (C + 1), C + 1)) != URF_OK) return rc;
-        const uint32_t nb = roff[C];   /* bucketed points */
-        if ((rc = fetch(c, src, k.rsrc + off, nb)) != URF_OK) return rc;
+        std::vector<uint32_t> pos, src;
+        if ((rc = ring_major_sources(c, scan, len, pos, src)) != URF_OK) return rc;
+        uint32_t padded_total = 0;
+        URF_HIP(c, hipMemcpy(&padded_total, k.ring_off + (size_t)scan * (C + 1) + C, sizeof(padded_total), hipMemcpyDeviceToHost));
         if (what == URF_STAGE_DETECT) {
             std::vector<uint8_t> fl;
-            if ((rc = fetch(c, fl, k.rflag + off, nb)) != URF_OK) return rc;
+            if ((rc = fetch(c, fl, k.rflag + sb, padded_total)) != URF_OK) return rc;
             uint8_t* o = (uint8_t*)host_dst;
-            for (uint32_t p = 0; p < nb; p++)
-                o[src[p]] = fl[p] & 7u;
+            for (size_t p = 0; p < pos.size(); p++)
+                o[src[p]] = fl[pos[p]] & 7u;
         } else {
             std::vector<float> v;
-            if ((rc = fetch(c, v, (what == URF_STAGE_AZIMUTH ? k.raz : k.rd2) + off, nb)) != URF_OK) return rc;
+            if ((rc = fetch(c, v, (what == URF_STAGE_AZIMUTH ? k.raz : k.rd2) + sb, padded_total)) != URF_OK) return rc;
             float* o = (float*)host_dst;
-            for (uint32_t p = 0; p < nb; p++)
-                o[src[p]] = v[p];
+            for (size_t p = 0; p < pos.size(); p++)
+                o[src[p]] = v[pos[p]];
         }
         return URF_OK;
     }

@@ -104,16 +104,40 @@ __device__ __forceinline__ unsigned urf_wave_scan_max(unsigned v)
     return v;
 }
 
-/* scan s occupies [off, off+len) of every per-point array */
+/* scan s occupies [off, off+len) of the CALLER's per-point arrays (x, y, z, labels); a scan longer
+ * than the max_len the host sized the grids and tables for is cut there */
 __device__ __forceinline__ void urf_scan_range(const urf_kargs& a, unsigned s, unsigned& off, unsigned& len)
 {
     if (a.offsets) {
         off = a.offsets[s];
         len = a.offsets[s + 1] - off;
+        len = len > a.max_len ? a.max_len : len;
     } else {
         off = s * a.n_per_scan;
         len = a.n_per_scan;
     }
+}
+
+/* first scratch element of scan s (urf_internal.hpp: scratch layout); urf_create keeps
+ * max_batch * sstride below 2^32 */
+__device__ __forceinline__ unsigned urf_sbase(const urf_kargs& a, unsigned s) { return s * a.sstride; }
+
+/* Ring c of scan s, position p inside the ring -> index of the point in the tile-local ring-sorted
+ * arrays (rx, ry, rz, rsrc), relative to the scan's scratch base.  Bisection in the ring's prefix
+ * over the tiles; for the kernels off the hot path (k_ring keeps the table in LDS). */
+__device__ __forceinline__ unsigned urf_ring_slot(const urf_kargs& a, unsigned s, unsigned C, unsigned c, unsigned ntiles,
+                                                  unsigned p)
+{
+    const unsigned* P = a.rpre + ((size_t)s * C + c) * (a.tiles + 1);
+    unsigned lo = 0, hi = ntiles;   /* largest t with P[t] <= p; P[0] = 0 */
+    while (hi - lo > 1) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (P[mid] <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo * URF_TILE + a.rstart[((size_t)s * C + c) * a.tiles + lo] + (p - P[lo]);
 }
 
 /* ---- per-point expressions ------------------------------------------------ */
@@ -238,11 +262,15 @@ __device__ __forceinline__ bool urf_fast_vertical_angle(float x, float y, float 
     return true;
 }
 
-/* Sector of star_shaped_search.cpp:164-171 when the scaled polar angle is clear of an integer by
- * more than URF_FAST_SECTOR_ERR (reference: two float roundings of the angle, one of the product:
- * <= 5e-5; approximation: URF_FAST_ATAN_ERR * Kfi + rounding <= 1.4e-4); -1 = undecided. */
+/* Sector of star_shaped_search.cpp:164-171 when the scaled polar angle u = fi * Kfi is clear of an
+ * integer by more than `margin`; -1 = undecided.  Both error sources grow with the number of sectors:
+ * the reference's own roundings (two of the angle, one of the product: <= 3 ulp of u, u < sectors) and
+ * the approximation (URF_FAST_ATAN_ERR * Kfi, Kfi = sectors / 2 pi).  At the reference's 360 sectors
+ * they add up to 5e-5 + 1.4e-4 < URF_FAST_SECTOR_ERR; upload_params scales the margin with
+ * sectors / 360 beyond that (urf_dev_params::sector_margin), and urf_selftest_fast measures the
+ * approximation's part at the configured Kfi. */
 #define URF_FAST_SECTOR_ERR 2.5e-4f
-__device__ __forceinline__ int urf_fast_sector(float x, float y, float Kfi, unsigned sectors)
+__device__ __forceinline__ int urf_fast_sector(float x, float y, float Kfi, unsigned sectors, float margin)
 {
     const float mx = __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y));
     if (!(mx >= URF_FAST_MIN && mx <= URF_FAST_MAX))
@@ -253,7 +281,7 @@ __device__ __forceinline__ int urf_fast_sector(float x, float y, float Kfi, unsi
     const float u = fi * Kfi;
     const float f = __builtin_floorf(u);
     const float fr = u - f;
-    if (!(fr > URF_FAST_SECTOR_ERR && fr < 1.0f - URF_FAST_SECTOR_ERR) || f < 0.0f || f >= (float)sectors)
+    if (!(fr > margin && fr < 1.0f - margin) || f < 0.0f || f >= (float)sectors)
         return -1;
     return (int)f;
 }

@@ -20,8 +20,11 @@
 
 /* one tile = the unit of the stable multi-split by ring / by sector */
 #define URF_TILE            2048
-#define URF_TILE_THREADS    512     /* k_scatter: one wave per 256 points of the tile */
+#define URF_TILE_THREADS    512     /* k_split: one wave per 256 points of the tile */
 #define URF_TILE_GROUPS     (URF_TILE / 64)   /* wave-sized groups per tile */
+#define URF_MAX_TILES       4096    /* tiles per scan (k_ring keeps one table entry per tile in LDS) */
+#define URF_SCAN_PAD        512     /* scratch elements per scan beyond its tiles: rings start at multiples of 4 */
+#define URF_SLOT_NONE       0xFFFFu
 
 #define URF_RFLAG_AZ_APPROX 0x80u   /* rflag: raz holds the float approximation, not the reference value */
 #define URF_RING_NONE       0xFFu
@@ -43,16 +46,33 @@ struct urf_dev_params {
     urf_params p;
     float    slope_param;   /* star_shaped_search.cpp:160 */
     float    Kfi;           /* star_shaped_search.cpp:65  */
+    float    sector_margin; /* urf_fast_sector: URF_FAST_SECTOR_ERR scaled with sectors / 360 */
     float    fwd_limit;     /* 360 - beamZone  (blind_spots.cpp:68)  */
     float    bwd_limit;     /* 0 + beamZone    (blind_spots.cpp:177) */
     float    inv_cp;        /* 1 / (float)curbPoints (z_zero_method.cpp:52) */
     uint32_t sec_keybits;   /* bits needed for sector keys incl. "none" */
     uint32_t ring_keybits;
-    uint32_t exp_flags;     /* test hook (env URF_EXP): bit 2 forces the general star sort path; 0 in production */
+    uint32_t exp_flags;     /* test hook (urf_set_debug_flags): bit 2 forces the general star sort path; 0 in production */
 };
 
 /* Everything a kernel needs to find a scan's data.  All pointers are device
- * memory owned by the context except x/y/z/labels/info (caller's). */
+ * memory owned by the context except x/y/z/labels (caller's).
+ *
+ * Scratch layout ("tile-local"): scan s owns the scratch elements
+ * [s * sstride, (s + 1) * sstride), sstride = tiles * URF_TILE + URF_SCAN_PAD, independent of where
+ * the caller keeps the scan (offsets[]).  Tile t of the scan (input points [t * URF_TILE, ...)) owns
+ * [s * sstride + t * URF_TILE, ... + URF_TILE) of every per-point array:
+ *   ring-sorted   rx ry rz rsrc   slot j = the tile's points that lie on a ring, ordered by ring,
+ *                                 input order inside a ring (stable); rsrc = index inside the tile
+ *   sector-sorted sr sz sslot     the tile's points that take part in the star-shaped search,
+ *                                 ordered by sector, input order inside; sslot = the point's
+ *                                 ring-sorted slot (URF_SLOT_NONE if it lies on no ring)
+ * so that ONE pass over x/y/z (k_split) can write both without knowing any total.  Ring c of the
+ * scan = the concatenation over the tiles of run [troff[t][c], troff[t][c+1]); k_index turns the
+ * per-tile run tables into per-ring / per-sector tables (prefix over the tiles, start inside the
+ * tile).  What the later kernels PRODUCE per point is contiguous per ring (raz, rflag: element p of
+ * ring c at s * sstride + ring_off[c] + p, ring_off padded to multiples of 4) resp. per sector
+ * (wslp, wg, ssrt: at s * sstride + sec_off[k] + i). */
 struct urf_kargs {
     /* input */
     const float* x;
@@ -62,39 +82,49 @@ struct urf_kargs {
     uint32_t n_per_scan;
     uint32_t n_scans;
     uint32_t max_len;
-    uint32_t tiles;             /* tiles per scan = ceil(max_len / URF_TILE) */
+    uint32_t tiles;             /* tiles per scan = ceil(max_len / URF_TILE): stride of the per-tile tables */
+    uint32_t sstride;           /* scratch elements per scan */
+    uint32_t capture;           /* 0 production; 1 every point takes the exact sequence, values recorded;
+                                   2 production decisions, ring / sector keys recorded */
     /* output */
     uint8_t* labels;
     urf_scan_info* info;        /* context copy, [n_scans] */
-    /* per point, input order */
+    /* per point, input order (scratch indexing), stage capture only */
     float*    valpha;
     uint16_t* seckey;
     uint8_t*  ringkey;
-    /* per point, ring-major */
+    /* per point, ring-sorted inside the tile */
     float*    rx;
     float*    ry;
     float*    rz;
-    uint32_t* rsrc;
+    uint16_t* rsrc;
+    /* per point, ring-major (padded ring starts) */
     float*    raz;
-    float*    rd2;              /* debug only (may be NULL) */
+    float*    rd2;              /* stage capture only (may be NULL) */
     uint8_t*  rflag;
-    /* per point, sector-major */
+    /* per point, sector-sorted inside the tile */
     float*    sr;
     float*    sz;
-    uint32_t* ssrc;
-    uint32_t* ssrt;             /* ring-major position of the i-th point of the sector in sorted order */
+    uint16_t* sslot;
+    /* per point, sector-major */
+    uint32_t* ssrt;             /* tile-local ring-sorted index (t * URF_TILE + slot) of the i-th point of the sector in sorted order */
     float*    wslp;             /* slope between the (i-1)-th and i-th point of the sector in sorted order */
     float*    wg;               /* (r_i - r_{i-1}) * kdist */
-    /* per scan x tile */
+    /* per scan x tile (k_split) */
     uint32_t* tile_roi;         /* [S][tiles] ROI points of the tile */
-    uint32_t* tile_ring;        /* [S][tiles][channels] per-tile ring counts; k_offsets turns them into the
-                                   position of the tile's first point of ring c inside ring c */
-    uint32_t* tile_sec;         /* [S][tiles][sectors]  same for star sectors */
+    uint16_t* troff;            /* [S][tiles][C+1] first ring-sorted slot of ring c in the tile; [C] = ring points of the tile */
+    uint16_t* tsoff;            /* [S][tiles][K+1] same for star sectors */
+    /* per scan x key x tile (k_index) */
+    uint32_t* rpre;             /* [S][C][tiles+1] points of ring c in the tiles before t; [ntiles] = ring_cnt */
+    uint16_t* rstart;           /* [S][C][tiles]   = troff[t][c] */
+    uint32_t* tpre;             /* [S][tiles][C]   = rpre[c][t] (the layout k_label reads) */
+    uint32_t* spre;             /* [S][K][tiles+1] */
+    uint16_t* sstart;           /* [S][K][tiles] */
     /* per scan */
     float*    angle;            /* [S][channels] sorted ring-angle table */
     uint8_t*  ring_lut;         /* [S][URF_LUT_CELLS] first table entry a vertical angle of the cell can match */
     uint32_t* ring_cnt;         /* [S][channels] */
-    uint32_t* ring_off;         /* [S][channels+1] */
+    uint32_t* ring_off;         /* [S][channels+1] start of ring c in the ring-major arrays, multiples of 4 */
     uint32_t* sec_cnt;          /* [S][sectors] */
     uint32_t* sec_off;          /* [S][sectors+1] */
     int32_t*  star_hit;         /* [S][sectors] ring-major position of the sector's curb point; -1 = none or on no ring */
@@ -102,6 +132,9 @@ struct urf_kargs {
     uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 513..2048 points */
     uint32_t* star_list_big;    /* [S*sectors] ... with more than 2048 points */
     uint32_t* star_count;       /* [2] lengths of the two lists (zeroed per call) */
+    float*    big_r;            /* sector-major copies of the sectors on the "big" list (sorted in place) */
+    float*    big_z;
+    uint32_t* big_i;
     float*    maxdist;          /* [S][channels] */
     float*    quad;             /* [S][4] */
     float*    sufmin;           /* [S][channels][361] */

@@ -80,185 +80,6 @@ __global__ __launch_bounds__(256) void k_pc2_to_soa(const uint8_t* __restrict__ 
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_ingest                                                                    */
-/* ------------------------------------------------------------------------- */
-/* amdgpu_waves_per_eu(8, 8): scheduling for full occupancy measured 0.69 -> 0.64 ms */
-__global__ __launch_bounds__(URF_INGEST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ingest(urf_kargs a, urf_dev_params dp)
-{
-    extern __shared__ unsigned sh_hist[];   /* [sectors] sector histogram, [sectors] = ROI count */
-    __shared__ float tab[URF_MAX_CHANNELS];
-    __shared__ unsigned rhist[URF_MAX_CHANNELS];
-    __shared__ uint8_t lut[URF_LUT_CELLS] __attribute__((aligned(4)));   /* k_ring_table's lookup table */
-    __shared__ uint16_t pending[URF_TILE];   /* tile-local indices of the points the approximations leave open */
-    __shared__ unsigned n_pending;
-    const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-    unsigned off, len;
-    urf_scan_range(a, s, off, len);
-    const unsigned tbase = t * URF_TILE;
-    if (tbase >= len)
-        return;
-    const unsigned K = (unsigned)dp.p.sectors, C = (unsigned)dp.p.channels;
-    const bool star = dp.p.star_shaped_method != 0;
-    constexpr unsigned Q = URF_TILE / URF_INGEST_THREADS;
-    float px[Q], py[Q], pz[Q];
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {   /* all loads of the tile in flight before anything else */
-        const unsigned i = tbase + q * URF_INGEST_THREADS + tid;
-        const bool valid = i < len;
-        px[q] = valid ? a.x[off + i] : 0.f;
-        py[q] = valid ? a.y[off + i] : 0.f;
-        pz[q] = valid ? a.z[off + i] : 0.f;
-    }
-    const unsigned nR = a.info[s].n_rings;
-    for (unsigned k = tid; k <= K; k += URF_INGEST_THREADS)
-        sh_hist[k] = 0;
-    if (tid < URF_MAX_CHANNELS) {
-        tab[tid] = tid < nR ? a.angle[(size_t)s * C + tid] : 0.f;
-        rhist[tid] = 0;
-    }
-    if (tid == 0)
-        n_pending = 0;
-    for (unsigned i = tid; i < URF_LUT_CELLS / 4; i += URF_INGEST_THREADS)
-        ((unsigned*)lut)[i] = ((const unsigned*)(a.ring_lut + (size_t)s * URF_LUT_CELLS))[i];
-    __syncthreads();
-
-    const float interval = dp.p.interval;
-    /* Ring, float fast path (urf_device.hpp) unless the stage capture wants the exact angle: with
-     * |vt - alpha| <= e, entries below vt - interval - e surely do not match, an entry within
-     * interval - e surely does, one beyond interval + e surely does not. */
-    const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;   /* + rounding of fl(angle[j] - alpha) */
-    bool roi[Q], fast[Q];
-    float vt[Q];
-    unsigned lo[Q];
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const unsigned i = tbase + q * URF_INGEST_THREADS + tid;
-        roi[q] = i < len && urf_in_roi(dp.p, px[q], py[q], pz[q]);
-        vt[q] = 0.f;
-        fast[q] = roi[q] && !a.valpha && urf_fast_vertical_angle(px[q], py[q], pz[q], &vt[q]);
-        lo[q] = 0;
-    }
-    /* lo = number of table entries surely below the point's window: the cell's count from the
-     * lookup table, plus the (usually zero or one) entries between the cell's start and the angle */
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const unsigned cell = (unsigned)(vt[q] * URF_LUT_SCALE);   /* vt in [0, 180] */
-        lo[q] = lut[cell < URF_LUT_CELLS - 1 ? cell : URF_LUT_CELLS - 1];
-    }
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const float tv = tab[lo[q] & (URF_MAX_CHANNELS - 1)];
-        if (lo[q] < nR && !(tv - vt[q] >= -(interval + e)))
-            lo[q]++;
-    }
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++)
-        while (lo[q] < nR && !(tab[lo[q] & (URF_MAX_CHANNELS - 1)] - vt[q] >= -(interval + e)))
-            lo[q]++;
-    /* Main pass: only what the approximations decide.  A point whose ring or sector they leave open
-     * (or every point, when the stage capture wants exact angles) is listed and takes the reference's
-     * exact sequence in a second, dense pass: the exact code exists once instead of sixteen times in
-     * the unrolled loop, and its f64 chains never run with two lanes of a wave. */
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const unsigned li = q * URF_INGEST_THREADS + tid, i = tbase + li;
-        const bool valid = i < len;
-        const float x = px[q], y = py[q];
-        unsigned key = URF_SEC_NONE, rkey = URF_RING_NONE;
-        bool open = false;
-        if (roi[q]) {
-            open = true;
-            if (fast[q]) {
-                const float tv = tab[lo[q] & (URF_MAX_CHANNELS - 1)];
-                if (lo[q] >= nR || tv - vt[q] > interval + e) {
-                    open = false;                         /* no entry can match */
-                } else if (__builtin_fabsf(tv - vt[q]) <= interval - e) {
-                    open = false;                         /* the first candidate surely matches */
-                    rkey = lo[q];
-                }
-            }
-            if (star && !open) {
-                const int fs = urf_fast_sector(x, y, dp.Kfi, K);
-                open = fs < 0;
-                key = (unsigned)fs;
-                if (!open && dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
-                    key = URF_SEC_NONE;
-            }
-            if (open) {
-                pending[atomicAdd(&n_pending, 1u)] = (uint16_t)li;
-                key = URF_SEC_NONE;
-                rkey = URF_RING_NONE;
-            }
-        }
-        if (valid) {
-            if (!open) {
-                a.seckey[off + i] = (uint16_t)key;
-                a.ringkey[off + i] = (uint8_t)rkey;
-            }
-            a.labels[off + i] = roi[q] ? URF_FLAG_ROI : 0;
-            if (a.valpha && !roi[q])
-                a.valpha[off + i] = -1.0f;   /* stage capture only */
-        }
-        {
-            const unsigned long long m = urf_match_any_fast(rkey == URF_RING_NONE ? C : rkey, dp.ring_keybits);
-            if (rkey != URF_RING_NONE && urf_is_leader(m))
-                atomicAdd(&rhist[rkey], (unsigned)__popcll(m));
-        }
-        if (star) {
-            const unsigned long long m = urf_match_any_fast(key == URF_SEC_NONE ? K : key, dp.sec_keybits);
-            if (key != URF_SEC_NONE && urf_is_leader(m))
-                atomicAdd(&sh_hist[key], (unsigned)__popcll(m));
-        }
-        const unsigned long long rb = __ballot(roi[q]);
-        if (urf_lane() == 0 && rb)
-            atomicAdd(&sh_hist[K], (unsigned)__popcll(rb));
-    }
-    __syncthreads();
-    const unsigned np = n_pending;
-    for (unsigned k = tid; k < np; k += URF_INGEST_THREADS) {
-        const unsigned i = tbase + pending[k];
-        const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
-        const float va = urf_vertical_angle(x, y, z);
-        /* lidar_segmentation.cpp:226-233: first sorted table entry within `interval`.
-         * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are contiguous
-         * and the first one is found by bisection with the very same float predicate. */
-        unsigned rkey = URF_RING_NONE, key = URF_SEC_NONE;
-        unsigned l2 = 0, h2 = nR;
-        while (l2 < h2) {
-            const unsigned mid = (l2 + h2) >> 1;
-            if (tab[mid] - va >= -interval)
-                h2 = mid;
-            else
-                l2 = mid + 1;
-        }
-        if (l2 < nR && __builtin_fabsf(tab[l2] - va) <= interval)
-            rkey = l2;
-        if (star) {
-            key = urf_sector(x, y, dp.Kfi, K);
-            if (dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
-                key = URF_SEC_NONE;
-        }
-        if (a.valpha)
-            a.valpha[off + i] = va;   /* stage capture only */
-        a.seckey[off + i] = (uint16_t)key;
-        a.ringkey[off + i] = (uint8_t)rkey;
-        if (rkey != URF_RING_NONE)
-            atomicAdd(&rhist[rkey], 1u);
-        if (key != URF_SEC_NONE)
-            atomicAdd(&sh_hist[key], 1u);
-    }
-    __syncthreads();
-    const size_t row = (size_t)s * a.tiles + t;
-    if (star)
-        for (unsigned k = tid; k < K; k += URF_INGEST_THREADS)
-            a.tile_sec[row * K + k] = sh_hist[k];
-    if (tid < C)
-        a.tile_ring[row * C + tid] = rhist[tid];
-    if (tid == 0)
-        a.tile_roi[row] = sh_hist[K];
-}
-
-/* ------------------------------------------------------------------------- */
 /* k_ring_table                                                                */
 /* ------------------------------------------------------------------------- */
 /* The reference walks the ROI points in order and appends a point's vertical
@@ -480,25 +301,368 @@ __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params 
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_offsets                                                                   */
+/* k_split                                                                     */
 /* ------------------------------------------------------------------------- */
-/* exclusive scan of cnt[0..K) (K <= 1024) by 256 threads -> off[0..K] */
-__device__ void urf_scan_keys_256(const unsigned* cnt, unsigned* offs, unsigned K, unsigned* sh /* [256+8] */)
+/* ONE pass over x/y/z per tile of 2048 input points: ROI test, ring of every point (float fast path
+ * with margins, exact sequence for the rare open point), star sector, then a stable multi-split of
+ * the tile by ring and by sector, written into the tile's own region of the scratch arrays
+ * (urf_internal.hpp: scratch layout) -- no total over the scan is needed before writing, so the
+ * points are read from HBM once.  Input order is preserved inside every ring, which x_zero /
+ * z_zero rely on (lidar_segmentation.cpp:280-283 run before the azimuth sort :289).
+ *
+ * Wave w of the workgroup owns the 256 consecutive points [w*256, w*256+256) of the tile and walks
+ * them 64 at a time.  A point's rank inside its key within the tile =
+ *     points of that key in earlier waves of this tile       (LDS matrix wcnt[wave][key], scanned per key)
+ *   + ... in earlier 64-point steps of its own wave          (running value of wcnt[wave][key])
+ *   + ... in lower lanes of its own step                     (match_any + popcount).
+ *
+ * Ring-sorted stores: in firing order the 64 lanes of a wave belong to 64 different rings.  The
+ * tile is therefore transposed through LDS (slot = position in the tile's ring-sorted order,
+ * row-padded against bank conflicts) and written out slot by slot, 2048 consecutive elements per
+ * array.  Sector-sorted stores go out directly (a firing shares one sector: consecutive ranks). */
+#define URF_SLOT(lp) ((lp) + ((lp) >> 6))
+#define URF_SLOTS (URF_TILE + URF_TILE / 64)
+#define URF_TILE_WAVES (URF_TILE_THREADS / 64)
+
+__host__ __device__ inline unsigned urf_align16(unsigned v) { return (v + 15u) & ~15u; }
+
+/* LDS carve of k_split: tab | lut | koff[C+1] | soff[Ks+1] | misc[16] |
+ * union { keyr[T] u8, keys[T] u16, pending[T] u16, wcnt_r[W][C] u16, wcnt_s[W][Ks] u16 ;
+ *         staging x y z src [URF_SLOTS] u32 } */
+__host__ __device__ inline size_t urf_split_lds_bytes(unsigned C, unsigned K, bool star)
+{
+    const unsigned Ks = star ? K : 0;
+    const size_t fixed = URF_MAX_CHANNELS * 4 + urf_align16(URF_LUT_CELLS) + urf_align16((C + 1) * 4) +
+                         urf_align16((Ks + 1) * 4) + 64;
+    const size_t phase_a = 5 * (size_t)URF_TILE + urf_align16(2 * URF_TILE_WAVES * (C + Ks));
+    const size_t phase_b = 4 * (size_t)URF_SLOTS * 4;
+    return fixed + (phase_a > phase_b ? phase_a : phase_b);
+}
+
+__global__ __launch_bounds__(URF_TILE_THREADS) void k_split(urf_kargs a, urf_dev_params dp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_raw[];
+    const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    const unsigned wave = tid >> 6, lane = tid & 63;
+    unsigned off, len;
+    urf_scan_range(a, s, off, len);
+    const unsigned tbase = t * URF_TILE;
+    if (tbase >= len)
+        return;
+    const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
+    const bool star = dp.p.star_shaped_method != 0;
+    const unsigned Ks = star ? K : 0;
+    float* tab = (float*)sh_raw;
+    uint8_t* lut = (uint8_t*)(tab + URF_MAX_CHANNELS);
+    unsigned* koff = (unsigned*)(lut + urf_align16(URF_LUT_CELLS));
+    unsigned* soff = koff + urf_align16((C + 1) * 4) / 4;
+    unsigned* misc = soff + urf_align16((Ks + 1) * 4) / 4;   /* [0] ROI points, [1] pending, [2..9] wave sums */
+    unsigned char* un = (unsigned char*)(misc + 16);
+    uint8_t* keyr = un;
+    uint16_t* keys = (uint16_t*)(un + URF_TILE);
+    uint16_t* pending = keys + URF_TILE;
+    uint16_t* wcnt_r = pending + URF_TILE;
+    uint16_t* wcnt_s = wcnt_r + (size_t)URF_TILE_WAVES * C;
+    const unsigned sb = urf_sbase(a, s);
+
+    constexpr unsigned Q = URF_TILE / URF_TILE_THREADS;
+    float px[Q], py[Q], pz[Q];
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {   /* all loads of the tile in flight before anything else */
+        const unsigned i = tbase + wave * 256 + q * 64 + lane;
+        const bool valid = i < len;
+        px[q] = valid ? a.x[off + i] : 0.f;
+        py[q] = valid ? a.y[off + i] : 0.f;
+        pz[q] = valid ? a.z[off + i] : 0.f;
+    }
+    const unsigned nR = a.info[s].n_rings;
+    for (unsigned k = tid; k < URF_TILE_WAVES * (C + Ks) / 2; k += URF_TILE_THREADS)
+        ((unsigned*)wcnt_r)[k] = 0;
+    if (tid < URF_MAX_CHANNELS)
+        tab[tid] = tid < nR ? a.angle[(size_t)s * C + tid] : 0.f;
+    if (tid < 16)
+        misc[tid] = 0;
+    for (unsigned i = tid; i < URF_LUT_CELLS / 4; i += URF_TILE_THREADS)
+        ((unsigned*)lut)[i] = ((const unsigned*)(a.ring_lut + (size_t)s * URF_LUT_CELLS))[i];
+    __syncthreads();
+
+    const float interval = dp.p.interval;
+    /* Ring, float fast path (urf_device.hpp) unless the stage capture wants the exact angle: with
+     * |vt - alpha| <= e, entries below vt - interval - e surely do not match, an entry within
+     * interval - e surely does, one beyond interval + e surely does not. */
+    const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;   /* + rounding of fl(angle[j] - alpha) */
+    const bool exact_all = a.capture == 1;
+    bool roi[Q], fast[Q];
+    float vt[Q];
+    unsigned lo[Q];
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned i = tbase + wave * 256 + q * 64 + lane;
+        roi[q] = i < len && urf_in_roi(dp.p, px[q], py[q], pz[q]);
+        vt[q] = 0.f;
+        fast[q] = roi[q] && !exact_all && urf_fast_vertical_angle(px[q], py[q], pz[q], &vt[q]);
+    }
+    /* lo = number of table entries surely below the point's window: the cell's count from the
+     * lookup table, plus the (usually zero or one) entries between the cell's start and the angle */
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned cell = (unsigned)(vt[q] * URF_LUT_SCALE);   /* vt in [0, 180] */
+        lo[q] = lut[cell < URF_LUT_CELLS - 1 ? cell : URF_LUT_CELLS - 1];
+    }
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const float tv = tab[lo[q] & (URF_MAX_CHANNELS - 1)];
+        if (lo[q] < nR && !(tv - vt[q] >= -(interval + e)))
+            lo[q]++;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++)
+        while (lo[q] < nR && !(tab[lo[q] & (URF_MAX_CHANNELS - 1)] - vt[q] >= -(interval + e)))
+            lo[q]++;
+    /* Main pass: only what the approximations decide.  A point whose ring or sector they leave open
+     * (or every point, when the stage capture wants exact angles) is listed and takes the reference's
+     * exact sequence in a second, dense pass: the exact code exists once instead of four times in
+     * the unrolled loop, and its f64 chains never run with two lanes of a wave. */
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned li = wave * 256 + q * 64 + lane, i = tbase + li;
+        const bool valid = i < len;
+        const float x = px[q], y = py[q];
+        unsigned key = URF_SEC_NONE, rkey = URF_RING_NONE;
+        bool open = false;
+        if (roi[q]) {
+            open = true;
+            if (fast[q]) {
+                const float tv = tab[lo[q] & (URF_MAX_CHANNELS - 1)];
+                if (lo[q] >= nR || tv - vt[q] > interval + e) {
+                    open = false;                         /* no entry can match */
+                } else if (__builtin_fabsf(tv - vt[q]) <= interval - e) {
+                    open = false;                         /* the first candidate surely matches */
+                    rkey = lo[q];
+                }
+            }
+            if (star && !open) {
+                const int fs = urf_fast_sector(x, y, dp.Kfi, K, dp.sector_margin);
+                open = fs < 0;
+                key = (unsigned)fs;
+                if (!open && dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
+                    key = URF_SEC_NONE;
+            }
+        }
+        if (open)
+            pending[atomicAdd(&misc[1], 1u)] = (uint16_t)li;
+        else {
+            keyr[li] = (uint8_t)rkey;
+            keys[li] = (uint16_t)key;
+        }
+        if (valid) {
+            a.labels[off + i] = roi[q] ? URF_FLAG_ROI : 0;
+            if (exact_all && !roi[q])
+                a.valpha[sb + i] = -1.0f;   /* stage capture only */
+        }
+        const unsigned long long rb = __ballot(roi[q]);
+        if (lane == 0 && rb)
+            atomicAdd(&misc[0], (unsigned)__popcll(rb));
+    }
+    __syncthreads();
+    const unsigned np = misc[1];
+    for (unsigned k = tid; k < np; k += URF_TILE_THREADS) {
+        const unsigned li = pending[k], i = tbase + li;
+        const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
+        const float va = urf_vertical_angle(x, y, z);
+        /* lidar_segmentation.cpp:226-233: first sorted table entry within `interval`.
+         * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are contiguous
+         * and the first one is found by bisection with the very same float predicate. */
+        unsigned rkey = URF_RING_NONE, key = URF_SEC_NONE;
+        unsigned l2 = 0, h2 = nR;
+        while (l2 < h2) {
+            const unsigned mid = (l2 + h2) >> 1;
+            if (tab[mid] - va >= -interval)
+                h2 = mid;
+            else
+                l2 = mid + 1;
+        }
+        if (l2 < nR && __builtin_fabsf(tab[l2] - va) <= interval)
+            rkey = l2;
+        if (star) {
+            key = urf_sector(x, y, dp.Kfi, K);
+            if (dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
+                key = URF_SEC_NONE;
+        }
+        if (exact_all)
+            a.valpha[sb + i] = va;   /* stage capture only */
+        keyr[li] = (uint8_t)rkey;
+        keys[li] = (uint16_t)key;
+    }
+    __syncthreads();
+
+    /* step 1: ranks inside the wave's own 256 points (LDS read-modify-write by the key's
+     * leader lane; one wave touches only its own row, in program order) */
+    unsigned rkey[Q], skey[Q], rrank[Q], srank[Q];
+    uint16_t* my_r = wcnt_r + wave * C;
+    uint16_t* my_s = wcnt_s + wave * K;
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned li = wave * 256 + q * 64 + lane, i = tbase + li;
+        rkey[q] = (unsigned)keyr[li];
+        skey[q] = star ? (unsigned)keys[li] : URF_SEC_NONE;
+        if (a.capture && i < len) {   /* stage capture only */
+            a.ringkey[sb + i] = (uint8_t)rkey[q];
+            a.seckey[sb + i] = (uint16_t)skey[q];
+        }
+        {
+            const unsigned mk = rkey[q] == URF_RING_NONE ? C : rkey[q];
+            const unsigned long long m = urf_match_any_fast(mk, dp.ring_keybits);
+            const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
+            unsigned old = 0;
+            if (rkey[q] != URF_RING_NONE && leader == lane) {
+                old = my_r[rkey[q]];
+                my_r[rkey[q]] = (uint16_t)(old + (unsigned)__popcll(m));
+            }
+            rrank[q] = (unsigned)__shfl((int)old, (int)leader) + urf_popc_below(m);
+        }
+        srank[q] = 0;
+        if (star) {
+            const unsigned mk = skey[q] == URF_SEC_NONE ? K : skey[q];
+            const unsigned long long m = urf_match_any_fast(mk, dp.sec_keybits);
+            const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
+            unsigned old = 0;
+            if (skey[q] != URF_SEC_NONE && leader == lane) {
+                old = my_s[skey[q]];
+                my_s[skey[q]] = (uint16_t)(old + (unsigned)__popcll(m));
+            }
+            srank[q] = (unsigned)__shfl((int)old, (int)leader) + urf_popc_below(m);
+        }
+    }
+    __syncthreads();
+    /* step 2: exclusive scan over the waves, one thread per key; totals to koff / soff */
+    for (unsigned k = tid; k < C; k += URF_TILE_THREADS) {
+        unsigned run = 0;
+        for (unsigned w = 0; w < URF_TILE_WAVES; w++) {
+            const unsigned c = wcnt_r[w * C + k];
+            wcnt_r[w * C + k] = (uint16_t)run;
+            run += c;
+        }
+        koff[k] = run;
+    }
+    for (unsigned k = tid; k < Ks; k += URF_TILE_THREADS) {
+        unsigned run = 0;
+        for (unsigned w = 0; w < URF_TILE_WAVES; w++) {
+            const unsigned c = wcnt_s[w * K + k];
+            wcnt_s[w * K + k] = (uint16_t)run;
+            run += c;
+        }
+        soff[k] = run;
+    }
+    __syncthreads();
+    /* step 3: first slot of every ring (C <= 128: wave 0) and of every sector (K <= 1022: two keys
+     * per thread) inside the tile */
+    unsigned sv0 = 0, sv1 = 0, sinc = 0;
+    if (star) {
+        sv0 = 2 * tid < K ? soff[2 * tid] : 0;
+        sv1 = 2 * tid + 1 < K ? soff[2 * tid + 1] : 0;
+        sinc = urf_wave_scan_add(sv0 + sv1);
+        if (lane == 63)
+            misc[2 + wave] = sinc;
+    }
+    if (tid < 64) {
+        const unsigned v0 = tid < C ? koff[tid] : 0, v1 = tid + 64 < C ? koff[tid + 64] : 0;
+        const unsigned i0 = urf_wave_scan_add(v0), i1 = urf_wave_scan_add(v1);
+        const unsigned total0 = __shfl(i0, 63), total1 = __shfl(i1, 63);
+        if (tid < C)
+            koff[tid] = i0 - v0;
+        if (tid + 64 < C)
+            koff[tid + 64] = total0 + i1 - v1;
+        if (tid == 0)
+            koff[C] = total0 + total1;
+    }
+    __syncthreads();
+    if (star) {
+        unsigned wb = 0, total = 0;
+#pragma unroll
+        for (unsigned w = 0; w < URF_TILE_WAVES; w++) {
+            wb += w < wave ? misc[2 + w] : 0;
+            total += misc[2 + w];
+        }
+        const unsigned run = wb + sinc - (sv0 + sv1);
+        if (2 * tid < K)
+            soff[2 * tid] = run;
+        if (2 * tid + 1 < K)
+            soff[2 * tid + 1] = run + sv0;
+        if (tid == 0)
+            soff[K] = total;
+    }
+    __syncthreads();
+
+    /* step 4: slot in the tile's ring-sorted order (lp) and sector-sorted order (sp) */
+    unsigned lp[Q], sp[Q];
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        lp[q] = rkey[q] != URF_RING_NONE ? koff[rkey[q]] + my_r[rkey[q]] + rrank[q] : 0xffffffffu;
+        sp[q] = skey[q] != URF_SEC_NONE ? soff[skey[q]] + my_s[skey[q]] + srank[q] : 0xffffffffu;
+    }
+    __syncthreads();   /* keys and wcnt are dead: their memory becomes the staging buffers */
+    unsigned* stx = (unsigned*)un;
+    unsigned* sty = stx + URF_SLOTS;
+    unsigned* stz = sty + URF_SLOTS;
+    unsigned* sts = stz + URF_SLOTS;
+    const unsigned tb = sb + tbase;
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned li = wave * 256 + q * 64 + lane;
+        const float x = px[q], y = py[q], z = pz[q];
+        if (lp[q] != 0xffffffffu) {
+            const unsigned sl = URF_SLOT(lp[q]);
+            stx[sl] = __float_as_uint(x);
+            sty[sl] = __float_as_uint(y);
+            stz[sl] = __float_as_uint(z);
+            sts[sl] = li;
+        }
+        if (sp[q] != 0xffffffffu) {
+            __builtin_nontemporal_store(__builtin_sqrtf(x * x + y * y), &a.sr[tb + sp[q]]);   /* star_shaped_search.cpp:164 */
+            __builtin_nontemporal_store(z, &a.sz[tb + sp[q]]);
+            /* where a star-shaped hit on this point has to be reported: its ring-sorted slot (none
+             * if the point lies on no ring: such a hit ends the walk but marks nothing that
+             * reaches the output, lidar_segmentation.cpp:235-242) */
+            __builtin_nontemporal_store((uint16_t)(lp[q] != 0xffffffffu ? lp[q] : URF_SLOT_NONE), &a.sslot[tb + sp[q]]);
+        }
+    }
+    __syncthreads();
+    const unsigned tile_ring_pts = koff[C];
+    for (unsigned j = tid; j < tile_ring_pts; j += URF_TILE_THREADS) {
+        const unsigned sl = URF_SLOT(j);
+        __builtin_nontemporal_store(__uint_as_float(stx[sl]), &a.rx[tb + j]);
+        __builtin_nontemporal_store(__uint_as_float(sty[sl]), &a.ry[tb + j]);
+        __builtin_nontemporal_store(__uint_as_float(stz[sl]), &a.rz[tb + j]);
+        __builtin_nontemporal_store((uint16_t)sts[sl], &a.rsrc[tb + j]);
+    }
+    const size_t row = (size_t)s * a.tiles + t;
+    for (unsigned k = tid; k <= C; k += URF_TILE_THREADS)
+        a.troff[row * (C + 1) + k] = (uint16_t)koff[k];
+    if (star)
+        for (unsigned k = tid; k <= K; k += URF_TILE_THREADS)
+            a.tsoff[row * (K + 1) + k] = (uint16_t)soff[k];
+    if (tid == 0)
+        a.tile_roi[row] = misc[0];
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_index                                                                     */
+/* ------------------------------------------------------------------------- */
+/* exclusive scan of f(cnt[0..K)) (K <= 1024) by 256 threads -> offs[0..K]; pad4: every count is
+ * rounded up to a multiple of 4 first (ring starts in the ring-major arrays) */
+__device__ void urf_scan_keys_256(const unsigned* cnt, unsigned* offs, unsigned K, unsigned* sh /* [8] */, bool pad4)
 {
     const unsigned tid = threadIdx.x;
     unsigned v[4], sum = 0;
     for (int e = 0; e < 4; e++) {
         const unsigned k = tid * 4 + e;
         v[e] = k < K ? cnt[k] : 0;
+        if (pad4)
+            v[e] = (v[e] + 3u) & ~3u;
         sum += v[e];
     }
-    /* inclusive scan of `sum` over the block */
-    unsigned inc = sum;
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned w = __shfl_up(inc, o);
-        if ((int)urf_lane() >= o)
-            inc += w;
-    }
+    const unsigned inc = urf_wave_scan_add(sum);
     __syncthreads();
     if (urf_lane() == 63)
         sh[tid >> 6] = inc;
@@ -518,29 +682,80 @@ __device__ void urf_scan_keys_256(const unsigned* cnt, unsigned* offs, unsigned 
     __syncthreads();
 }
 
-/* One key's column of the tile count matrix (element t at col[t * stride]) -> exclusive prefix over
- * the tiles, in place; returns the total.  16 loads are in flight at a time: one load per tile in
- * program order would cost a full memory round trip per tile. */
-__device__ __forceinline__ unsigned urf_tile_prefix(unsigned* col, unsigned stride, unsigned ntiles)
+/* One family of keys (rings or sectors) of one scan: turns k_split's per-tile run tables
+ * toff[tile][key] (first slot of the key's run inside the tile, row-major, rows of nkeys + 1 u16)
+ * into per-key tables: pre[key][tile] = points of the key in the tiles before (u32, [ntiles] =
+ * total), start[key][tile] = toff[tile][key], optionally tpre[tile][key] = pre[key][tile], and the
+ * totals cnt[key].  Blocks of 64 keys x 64 tiles are transposed through LDS so that both the
+ * reads (rows of toff) and the writes (rows of pre / start) are contiguous. */
+struct urf_index_shared {
+    unsigned pre[64][65];
+    uint16_t cnt[64][66];
+    uint16_t st[64][66];
+    unsigned carry[64];
+};
+__device__ void urf_index_family(urf_index_shared& L, const uint16_t* toff, unsigned nkeys, unsigned ntiles, unsigned tstride,
+                                 unsigned* pre, uint16_t* start, unsigned* tpre, unsigned* cnt)
 {
-    unsigned run = 0;
-    for (unsigned t0 = 0; t0 < ntiles; t0 += 16) {
-        unsigned v[16];
-#pragma unroll
-        for (unsigned u = 0; u < 16; u++)
-            v[u] = t0 + u < ntiles ? col[(size_t)(t0 + u) * stride] : 0u;
-#pragma unroll
-        for (unsigned u = 0; u < 16; u++)
-            if (t0 + u < ntiles) {
-                col[(size_t)(t0 + u) * stride] = run;
-                run += v[u];
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned rowlen = nkeys + 1;
+    for (unsigned k0 = 0; k0 < nkeys; k0 += 64) {
+        const unsigned key = k0 + lane;
+        if (tid < 64)
+            L.carry[tid] = 0;
+        for (unsigned t0 = 0; t0 < ntiles; t0 += 64) {
+            /* rows of toff -> counts and starts (wave w: tiles t0 + 4 * pass + w; lane = key) */
+#pragma unroll 4
+            for (unsigned pass = 0; pass < 16; pass++) {
+                const unsigned u = pass * 4 + wave, tt = t0 + u;
+                unsigned v0 = 0, v1 = 0;
+                if (tt < ntiles && key < nkeys) {
+                    v0 = toff[(size_t)tt * rowlen + key];
+                    v1 = toff[(size_t)tt * rowlen + key + 1];
+                }
+                L.cnt[lane][u] = (uint16_t)(v1 - v0);
+                L.st[lane][u] = (uint16_t)v0;
             }
+            __syncthreads();
+            if (tid < 64) {   /* prefix along the tiles, one key per lane */
+                unsigned run = L.carry[tid];
+                for (unsigned u = 0; u < 64; u++) {
+                    L.pre[tid][u] = run;
+                    run += L.cnt[tid][u];
+                }
+                L.carry[tid] = run;
+            }
+            __syncthreads();
+            /* rows of pre / start (wave w: keys k0 + 4 * pass + w; lane = tile) */
+            for (unsigned pass = 0; pass < 16; pass++) {
+                const unsigned r = pass * 4 + wave, kk = k0 + r, tt = t0 + lane;
+                if (kk < nkeys && tt < ntiles) {
+                    pre[(size_t)kk * (tstride + 1) + tt] = L.pre[r][lane];
+                    start[(size_t)kk * tstride + tt] = L.st[r][lane];
+                }
+            }
+            if (tpre)
+                for (unsigned pass = 0; pass < 16; pass++) {
+                    const unsigned u = pass * 4 + wave, tt = t0 + u;
+                    if (tt < ntiles && key < nkeys)
+                        tpre[(size_t)tt * nkeys + key] = L.pre[lane][u];
+                }
+            __syncthreads();
+        }
+        if (tid < 64 && key < nkeys) {
+            pre[(size_t)key * (tstride + 1) + ntiles] = L.carry[tid];
+            cnt[key] = L.carry[tid];
+        }
+        __syncthreads();
     }
-    return run;
 }
 
-__global__ __launch_bounds__(256) void k_offsets(urf_kargs a, urf_dev_params dp)
+/* One workgroup per scan: piece < 30 test (lidar_segmentation.cpp:120-126), the per-ring and
+ * per-sector run tables, where every ring / sector starts in the ring-major / sector-major arrays,
+ * and the work lists of the oversized sectors. */
+__global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
 {
+    __shared__ urf_index_shared L;
     __shared__ unsigned sh[8];
     const unsigned s = blockIdx.x, tid = threadIdx.x;
     unsigned off, len;
@@ -568,17 +783,29 @@ __global__ __launch_bounds__(256) void k_offsets(urf_kargs a, urf_dev_params dp)
         if (piece < 30)
             return;
     }
-    /* rings */
-    for (unsigned k = tid; k < C; k += 256)
-        a.ring_cnt[(size_t)s * C + k] = urf_tile_prefix(&a.tile_ring[(size_t)s * a.tiles * C + k], C, ntiles);
-    __syncthreads();
-    urf_scan_keys_256(&a.ring_cnt[(size_t)s * C], &a.ring_off[(size_t)s * (C + 1)], C, sh);
+    urf_index_family(L, a.troff + (size_t)s * a.tiles * (C + 1), C, ntiles, a.tiles, a.rpre + (size_t)s * C * (a.tiles + 1),
+                     a.rstart + (size_t)s * C * a.tiles, a.tpre + (size_t)s * a.tiles * C, a.ring_cnt + (size_t)s * C);
+    urf_scan_keys_256(&a.ring_cnt[(size_t)s * C], &a.ring_off[(size_t)s * (C + 1)], C, sh, true);
+    {   /* lidar_segmentation.cpp:605-608: road_probably = every point of sorted ring 10 */
+        unsigned tot = 0;
+        for (unsigned k = tid; k < C; k += 256)
+            tot += a.ring_cnt[(size_t)s * C + k];
+        for (int o = 32; o > 0; o >>= 1)
+            tot += __shfl_xor(tot, o);
+        if (urf_lane() == 0)
+            sh[4 + (tid >> 6)] = tot;
+        __syncthreads();
+        if (tid == 0) {
+            urf_scan_info* o = &a.info[s];
+            o->n_ring_pts = sh[4] + sh[5] + sh[6] + sh[7];
+            o->n_ring10 = o->n_rings > 10 ? a.ring_cnt[(size_t)s * C + 10] : 0;
+        }
+    }
     if (!dp.p.star_shaped_method)
         return;
-    for (unsigned k = tid; k < K; k += 256)
-        a.sec_cnt[(size_t)s * K + k] = urf_tile_prefix(&a.tile_sec[(size_t)s * a.tiles * K + k], K, ntiles);
-    __syncthreads();
-    urf_scan_keys_256(&a.sec_cnt[(size_t)s * K], &a.sec_off[(size_t)s * (K + 1)], K, sh);
+    urf_index_family(L, a.tsoff + (size_t)s * a.tiles * (K + 1), K, ntiles, a.tiles, a.spre + (size_t)s * K * (a.tiles + 1),
+                     a.sstart + (size_t)s * K * a.tiles, nullptr, a.sec_cnt + (size_t)s * K);
+    urf_scan_keys_256(&a.sec_cnt[(size_t)s * K], &a.sec_off[(size_t)s * (K + 1)], K, sh, false);
     /* sectors too large for one wave's LDS tile go on the work lists of k_star_mid / k_star_big
      * (one atomic per wave, not per sector) */
     for (unsigned k0 = 0; k0 < K; k0 += 256) {
@@ -599,207 +826,6 @@ __global__ __launch_bounds__(256) void k_offsets(urf_kargs a, urf_dev_params dp)
             a.star_list_mid[pm + urf_popc_below(bm)] = s * K + k;
         if (big)
             a.star_list_big[pb + urf_popc_below(bb)] = s * K + k;
-    }
-}
-
-/* ------------------------------------------------------------------------- */
-/* k_scatter                                                                   */
-/* ------------------------------------------------------------------------- */
-/* Stable multi-split of one tile by ring and by sector.  Wave w of the
- * workgroup owns the 256 consecutive points [w*256, w*256+256) of the tile and
- * walks them 64 at a time.  A point's rank inside its key =
- *     points of that key in earlier tiles                 (tile_ring / tile_sec, k_offsets)
- *   + ... in earlier waves of this tile                   (LDS matrix wcnt[wave][key], scanned per key)
- *   + ... in earlier 64-point steps of its own wave       (running value of wcnt[wave][key])
- *   + ... in lower lanes of its own step                  (match_any + popcount).
- * Input order is preserved inside every ring, which x_zero / z_zero rely on
- * (lidar_segmentation.cpp:280-283 run before the azimuth sort :289).
- *
- * Ring-major stores: in firing order the 64 lanes of a wave belong to 64
- * different rings, i.e. 64 different cache lines per store.  The tile is
- * therefore transposed through LDS first (slot = position of the point in the
- * tile's ring-sorted order, row-padded against bank conflicts) and written out
- * slot by slot, so that a wave stores runs of consecutive ring-major elements.
- * Sector-major stores are already contiguous (a firing shares one sector). */
-#define URF_SLOT(lp) ((lp) + ((lp) >> 6))
-#define URF_SLOTS (URF_TILE + URF_TILE / 64)
-#define URF_TILE_WAVES (URF_TILE_THREADS / 64)
-
-__host__ __device__ inline size_t urf_scatter_lds_bytes(unsigned C, unsigned K, bool star)
-{
-    const size_t keys = C + (star ? K : 0);
-    const size_t wcnt = 2 * (size_t)URF_TILE_WAVES * keys + 8;   /* uint16 matrices */
-    const size_t stage = 4 * (size_t)URF_SLOTS * 4;               /* x y z src staging, aliases wcnt */
-    return 4 * (keys + 2 * C) + (wcnt > stage ? wcnt : stage);
-}
-
-__global__ __launch_bounds__(URF_TILE_THREADS) void k_scatter(urf_kargs a, urf_dev_params dp)
-{
-    extern __shared__ unsigned sh_dyn[];
-    const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-    unsigned off, len;
-    urf_scan_range(a, s, off, len);
-    const unsigned tbase = t * URF_TILE;
-    if (tbase >= len)
-        return;
-    if (a.info[s].status != URF_OK) {
-        /* nothing is published for this scan (lidar_segmentation.cpp:124-126): all labels 0 */
-        for (unsigned i = tbase + tid; i < len && i < tbase + URF_TILE; i += URF_TILE_THREADS)
-            a.labels[off + i] = 0;
-        return;
-    }
-    const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
-    const bool star = dp.p.star_shaped_method != 0;
-    constexpr unsigned Q = 256 / 64;
-    /* LDS carve: base_r[C] koff[C] tot_r[C] base_s[K] (uint32) |
-     * union { wcnt_r[W][C] wcnt_s[W][K] (uint16), stage x y z src [URF_SLOTS] (uint32) } */
-    unsigned* base_r = sh_dyn;
-    unsigned* koff = base_r + C;
-    unsigned* tot_r = koff + C;
-    unsigned* base_s = tot_r + C;
-    unsigned* un = base_s + (star ? K : 0);
-    uint16_t* wcnt_r = (uint16_t*)un;
-    uint16_t* wcnt_s = wcnt_r + (size_t)URF_TILE_WAVES * C;
-    const unsigned keys = C + (star ? K : 0);
-    const size_t row = (size_t)s * a.tiles + t;
-    const unsigned wave = tid >> 6, lane = tid & 63;
-
-    for (unsigned k = tid; k < C; k += URF_TILE_THREADS)
-        base_r[k] = off + a.ring_off[(size_t)s * (C + 1) + k] + a.tile_ring[row * C + k];
-    if (star)
-        for (unsigned k = tid; k < K; k += URF_TILE_THREADS)
-            base_s[k] = off + a.sec_off[(size_t)s * (K + 1) + k] + a.tile_sec[row * K + k];
-    for (unsigned k = tid; k < (URF_TILE_WAVES * keys + 1) / 2; k += URF_TILE_THREADS)
-        un[k] = 0;
-    __syncthreads();
-
-    /* step 1: ranks inside the wave's own 256 points (LDS read-modify-write by the key's
-     * leader lane; one wave touches only its own row, in program order) */
-    unsigned rkey[Q], skey[Q], rrank[Q], srank[Q];
-    float px[Q], py[Q], pz[Q];   /* requested as soon as the keys are known, used in step 5 */
-    uint16_t* my_r = wcnt_r + wave * C;
-    uint16_t* my_s = wcnt_s + wave * K;
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const unsigned i = tbase + wave * 256 + q * 64 + lane;
-        const bool valid = i < len;
-        rkey[q] = valid ? (unsigned)a.ringkey[off + i] : URF_RING_NONE;
-        {
-            const unsigned mk = rkey[q] == URF_RING_NONE ? C : rkey[q];
-            const unsigned long long m = urf_match_any_fast(mk, dp.ring_keybits);
-            const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
-            unsigned old = 0;
-            if (rkey[q] != URF_RING_NONE && leader == lane) {
-                old = my_r[rkey[q]];
-                my_r[rkey[q]] = (uint16_t)(old + (unsigned)__popcll(m));
-            }
-            rrank[q] = (unsigned)__shfl((int)old, (int)leader) + urf_popc_below(m);
-        }
-        skey[q] = URF_SEC_NONE;
-        srank[q] = 0;
-        if (star) {
-            skey[q] = valid ? (unsigned)a.seckey[off + i] : URF_SEC_NONE;
-            const unsigned mk = skey[q] == URF_SEC_NONE ? K : skey[q];
-            const unsigned long long m = urf_match_any_fast(mk, dp.sec_keybits);
-            const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
-            unsigned old = 0;
-            if (skey[q] != URF_SEC_NONE && leader == lane) {
-                old = my_s[skey[q]];
-                my_s[skey[q]] = (uint16_t)(old + (unsigned)__popcll(m));
-            }
-            srank[q] = (unsigned)__shfl((int)old, (int)leader) + urf_popc_below(m);
-        }
-        const bool used = rkey[q] != URF_RING_NONE || skey[q] != URF_SEC_NONE;
-        px[q] = used ? a.x[off + i] : 0.f;
-        py[q] = used ? a.y[off + i] : 0.f;
-        pz[q] = used ? a.z[off + i] : 0.f;
-    }
-    __syncthreads();
-    /* step 2: exclusive scan over the waves, one thread per key */
-    for (unsigned k = tid; k < C; k += URF_TILE_THREADS) {
-        unsigned run = 0;
-        for (unsigned w = 0; w < URF_TILE_WAVES; w++) {
-            const unsigned c = wcnt_r[w * C + k];
-            wcnt_r[w * C + k] = (uint16_t)run;
-            run += c;
-        }
-        tot_r[k] = run;
-    }
-    if (star)
-        for (unsigned k = tid; k < K; k += URF_TILE_THREADS) {
-            unsigned run = 0;
-            for (unsigned w = 0; w < URF_TILE_WAVES; w++) {
-                const unsigned c = wcnt_s[w * K + k];
-                wcnt_s[w * K + k] = (uint16_t)run;
-                run += c;
-            }
-        }
-    __syncthreads();
-    /* step 3: offset of every ring's run inside the tile's ring-sorted order (C <= 128) */
-    if (tid < 64) {
-        const unsigned v0 = tid < C ? tot_r[tid] : 0, v1 = tid + 64 < C ? tot_r[tid + 64] : 0;
-        unsigned i0 = v0, i1 = v1;
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned w0 = __shfl_up(i0, o), w1 = __shfl_up(i1, o);
-            if ((int)tid >= o) {
-                i0 += w0;
-                i1 += w1;
-            }
-        }
-        const unsigned total0 = __shfl(i0, 63);
-        if (tid < C)
-            koff[tid] = i0 - v0;
-        if (tid + 64 < C)
-            koff[tid + 64] = total0 + i1 - v1;
-    }
-    __syncthreads();
-    const unsigned tile_ring_pts = koff[C - 1] + tot_r[C - 1];
-
-    /* step 4: ring slot inside the tile (lp), sector-major destination (sdst) */
-    unsigned lp[Q], sdst[Q], rdst[Q];
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        lp[q] = rkey[q] != URF_RING_NONE ? koff[rkey[q]] + my_r[rkey[q]] + rrank[q] : 0xffffffffu;
-        rdst[q] = rkey[q] != URF_RING_NONE ? base_r[rkey[q]] + my_r[rkey[q]] + rrank[q] : 0xffffffffu;
-        sdst[q] = skey[q] != URF_SEC_NONE ? base_s[skey[q]] + my_s[skey[q]] + srank[q] : 0xffffffffu;
-    }
-    __syncthreads();   /* wcnt is dead: its memory becomes the staging buffers */
-    unsigned* stx = un;
-    unsigned* sty = stx + URF_SLOTS;
-    unsigned* stz = sty + URF_SLOTS;
-    unsigned* sts = stz + URF_SLOTS;
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const unsigned li = wave * 256 + q * 64 + lane;   /* index inside the tile, < 4096 */
-        if (lp[q] == 0xffffffffu && sdst[q] == 0xffffffffu)
-            continue;
-        const float x = px[q], y = py[q], z = pz[q];
-        if (lp[q] != 0xffffffffu) {
-            const unsigned sl = URF_SLOT(lp[q]);
-            stx[sl] = __float_as_uint(x);
-            sty[sl] = __float_as_uint(y);
-            stz[sl] = __float_as_uint(z);
-            sts[sl] = (rkey[q] << 12) | li;
-        }
-        if (sdst[q] != 0xffffffffu) {
-            __builtin_nontemporal_store(__builtin_sqrtf(x * x + y * y), &a.sr[sdst[q]]);   /* star_shaped_search.cpp:164 */
-            __builtin_nontemporal_store(z, &a.sz[sdst[q]]);
-            /* where a star-shaped hit on this point has to be reported: its ring-major position
-             * (none if the point lies on no ring: such a hit ends the walk but marks nothing
-             * that reaches the output, lidar_segmentation.cpp:235-242) */
-            __builtin_nontemporal_store(rdst[q], &a.ssrc[sdst[q]]);
-        }
-    }
-    __syncthreads();
-    for (unsigned j = tid; j < tile_ring_pts; j += URF_TILE_THREADS) {
-        const unsigned sl = URF_SLOT(j);
-        const unsigned pk = sts[sl];
-        const unsigned k = pk >> 12;
-        const unsigned dst = base_r[k] + (j - koff[k]);
-        __builtin_nontemporal_store(__uint_as_float(stx[sl]), &a.rx[dst]);
-        __builtin_nontemporal_store(__uint_as_float(sty[sl]), &a.ry[dst]);
-        __builtin_nontemporal_store(__uint_as_float(stz[sl]), &a.rz[dst]);
-        __builtin_nontemporal_store(tbase + (pk & 0xfffu), &a.rsrc[dst]);
     }
 }
 
@@ -871,8 +897,8 @@ __device__ __forceinline__ unsigned urf_count_less64(const unsigned long long* b
  * meet the curb within their first third.  The heights are gathered from the unsorted
  * sector-major array (or from an LDS copy `zs`). */
 template <int NT, int EPT>
-__device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_dev_params& dp, unsigned base, unsigned n,
-                                                  const unsigned long long* fin, const float* zs, unsigned* sh_first)
+__device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_dev_params& dp, unsigned sb, unsigned obase, unsigned n,
+                                                  const unsigned long long* fin, unsigned* sh_first)
 {
     const unsigned tid = threadIdx.x;
     const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
@@ -883,27 +909,57 @@ __device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_
             break;
         if (i < n) {
             const unsigned long long kb = fin[i];
-            const unsigned pb = (unsigned)kb;
+            const unsigned pb = (unsigned)kb;   /* the point's index in the sector-sorted arrays, relative to the scan */
             float slp = 0.f, g = 0.f;
             if (i >= 1) {
                 const unsigned long long ka = fin[i - 1];
                 const float ax = __uint_as_float((unsigned)(ka >> 32)), bx = __uint_as_float((unsigned)(kb >> 32));
-                const float ay = zs ? zs[(unsigned)ka] : a.sz[base + (unsigned)ka];
-                const float by = zs ? zs[pb] : a.sz[base + pb];
+                const float ay = a.sz[sb + (unsigned)ka];
+                const float by = a.sz[sb + pb];
                 slp = (by - ay) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
                 g = (bx - ax) * kdist;
                 if (slp > slope_param)
                     atomicMin(sh_first, i);
             }
-            a.ssrt[base + i] = a.ssrc[base + pb];
-            a.wslp[base + i] = slp;
-            a.wg[base + i] = g;
+            const unsigned sl = a.sslot[sb + pb];
+            a.ssrt[obase + i] = sl == URF_SLOT_NONE ? 0xffffffffu : (pb & ~(URF_TILE - 1u)) + sl;
+            a.wslp[obase + i] = slp;
+            a.wg[obase + i] = g;
         }
         __syncthreads();
         if (*sh_first < ((unsigned)e + 1) * NT)
             break;
     }
     return *sh_first;
+}
+
+/* The runs of sector k: the non-empty pieces (tile, first slot, count) of the sector in tile order
+ * (k_index tables).  runP[r] = position inside the sector of the run's first point, runA[r] = index
+ * of that point in the sector-sorted arrays (relative to the scan) minus runP[r], so that point i
+ * of the sector lives at runA[r] + i.  One wave builds the list; returns the number of runs
+ * (<= number of points of the sector). */
+__device__ __forceinline__ unsigned urf_sector_runs(const urf_kargs& a, unsigned s, unsigned K, unsigned k, unsigned ntiles,
+                                                    unsigned* runP, unsigned* runA)
+{
+    const unsigned lane = urf_lane();
+    const unsigned* P = a.spre + ((size_t)s * K + k) * (a.tiles + 1);
+    const uint16_t* ST = a.sstart + ((size_t)s * K + k) * a.tiles;
+    unsigned nr = 0;
+    for (unsigned t0 = 0; t0 < ntiles; t0 += 64) {
+        const unsigned t = t0 + lane;
+        const bool in = t < ntiles;
+        const unsigned p0 = in ? P[t] : 0, p1 = in ? P[t + 1] : 0;
+        const unsigned st = in ? (unsigned)ST[t] : 0;
+        const bool ne = p1 > p0;
+        const unsigned long long m = __ballot(ne);
+        if (ne) {
+            const unsigned idx = nr + urf_popc_below(m);
+            runP[idx] = p0;
+            runA[idx] = t * URF_TILE + st - p0;
+        }
+        nr += (unsigned)__popcll(m);
+    }
+    return nr;
 }
 
 /* sectors with at most 512 points: one wave per (sector, scan).
@@ -918,8 +974,8 @@ __device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_
  * general path: every 64-key block is sorted in registers by an in-wave
  * bitonic network and the blocks are merged by ranking. */
 template <unsigned MAXB>
-__device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const urf_dev_params& dp, unsigned base, unsigned n,
-                                                     unsigned long long* A, unsigned* cnt, unsigned* sh_first,
+__device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const urf_dev_params& dp, unsigned sb, unsigned obase, unsigned n,
+                                                     unsigned nruns, unsigned long long* A, unsigned* cnt, unsigned* sh_first,
                                                      uint32_t* star_first_out)
 {
     constexpr unsigned NB = URF_STAR_NB, PL = NB / 64;
@@ -929,19 +985,33 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
     float zreg[MAXB];      /* height and ring-major position travel with the key: the tail */
     unsigned sreg[MAXB];   /* then needs no dependent gathers from memory */
     unsigned rmin = 0xffffffffu, rmax = 0;
+    {
+        /* the sector's points are gathered run by run (urf_sector_runs; the list sits in A's memory
+         * until the keys are in registers); a lane's positions grow with q, so does its run.  The
+         * low half of a key is the point's index in the sector-sorted arrays: it grows with the
+         * position inside the sector (tiles in order, input order inside), i.e. it breaks ties
+         * exactly as the position would, and it finds the point's companions again. */
+        const unsigned* runP = (const unsigned*)A;
+        const unsigned* runA = runP + 512;
+        unsigned r = 0;
 #pragma unroll
-    for (unsigned q = 0; q < MAXB; q++) {
-        const unsigned i = q * 64 + lane;
-        key[q] = ~0ull;
-        zreg[q] = 0.f;
-        sreg[q] = 0;
-        if (q < B && i < n) {
-            const unsigned rb = urf_fbits(a.sr[base + i]);
-            zreg[q] = a.sz[base + i];
-            sreg[q] = a.ssrc[base + i];
-            key[q] = ((unsigned long long)rb << 32) | i;
-            rmin = rb < rmin ? rb : rmin;
-            rmax = rb > rmax ? rb : rmax;
+        for (unsigned q = 0; q < MAXB; q++) {
+            const unsigned i = q * 64 + lane;
+            key[q] = ~0ull;
+            zreg[q] = 0.f;
+            sreg[q] = 0;
+            if (q < B && i < n) {
+                while (r + 1 < nruns && i >= runP[r + 1])
+                    r++;
+                const unsigned adr = runA[r] + i;
+                const unsigned rb = urf_fbits(a.sr[sb + adr]);
+                zreg[q] = a.sz[sb + adr];
+                const unsigned sl = a.sslot[sb + adr];
+                sreg[q] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+                key[q] = ((unsigned long long)rb << 32) | adr;
+                rmin = rb < rmin ? rb : rmin;
+                rmax = rb > rmax ? rb : rmax;
+            }
         }
     }
     for (unsigned c = lane; c <= NB; c += 64)
@@ -1065,8 +1135,10 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
                 key[q] = urf_wave_sort64(key[q]);
                 A[q * 64 + lane] = key[q];
                 if (key[q] != ~0ull) {   /* the key moved to another lane: fetch its companions again */
-                    zreg[q] = a.sz[base + (unsigned)key[q]];
-                    sreg[q] = a.ssrc[base + (unsigned)key[q]];
+                    const unsigned adr = (unsigned)key[q];
+                    zreg[q] = a.sz[sb + adr];
+                    const unsigned sl = a.sslot[sb + adr];
+                    sreg[q] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
                 }
             }
         __syncthreads();
@@ -1108,9 +1180,9 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
                 if (slp > slope_param)
                     atomicMin(sh_first, i);
             }
-            a.ssrt[base + i] = S[i];
-            a.wslp[base + i] = slp;
-            a.wg[base + i] = g;
+            a.ssrt[obase + i] = S[i];
+            a.wslp[obase + i] = slp;
+            a.wg[obase + i] = g;
         }
         __syncthreads();
         if (*sh_first < (q + 1) * 64)
@@ -1138,7 +1210,7 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
     const unsigned so0 = a.sec_off[(size_t)s * (K + 1) + k], so1 = a.sec_off[(size_t)s * (K + 1) + k + 1];
     const unsigned n = so1 - so0;
     if (n > 512)
-        return;   /* on a work list (k_offsets) */
+        return;   /* on a work list (k_index) */
     if (n < 2) {
         if (lane == 0)
             a.star_first[(size_t)s * K + k] = 0;   /* nothing to walk */
@@ -1146,14 +1218,16 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
     }
     unsigned off, len;
     urf_scan_range(a, s, off, len);
-    const unsigned base = off + so0;
+    const unsigned sb = urf_sbase(a, s), obase = sb + so0;
     if (lane == 0)
         sh_first = n;
+    const unsigned nruns = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, (unsigned*)A, (unsigned*)A + 512);
+    __syncthreads();
     /* per-lane element count fixed at compile time: 6 covers a sector of a 64 x 2048 sweep */
     if (n <= 384)
-        urf_star_sort_sector<6>(a, dp, base, n, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
+        urf_star_sort_sector<6>(a, dp, sb, obase, n, nruns, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
     else
-        urf_star_sort_sector<8>(a, dp, base, n, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
+        urf_star_sort_sector<8>(a, dp, sb, obase, n, nruns, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
 }
 
 template <int NT>
@@ -1316,7 +1390,7 @@ __device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EP
 }
 
 /* sectors with 513..2048 points (e.g. 128 rings x 4096 columns): persistent
- * workgroups of 256 threads walk the work list built by k_offsets. */
+ * workgroups of 256 threads walk the work list built by k_index. */
 #define URF_STAR_MID_THREADS 256
 #define URF_STAR_MID_CAP 2048
 __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_kargs a, urf_dev_params dp)
@@ -1325,7 +1399,7 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_karg
     __shared__ unsigned long long A[URF_STAR_MID_CAP];
     __shared__ unsigned cnt[NB + 1];
     __shared__ urf_sort_shared ssh;
-    __shared__ unsigned sh_first;
+    __shared__ unsigned sh_first, sh_nruns;
     const unsigned K = (unsigned)dp.p.sectors;
     const unsigned count = a.star_count[0];
     const unsigned tid = threadIdx.x;
@@ -1335,26 +1409,44 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_karg
         unsigned off, len;
         urf_scan_range(a, s, off, len);
         const unsigned n = a.sec_cnt[(size_t)s * K + k];
-        const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
-        if (tid == 0)
-            sh_first = n;
+        const unsigned sb = urf_sbase(a, s), obase = sb + a.sec_off[(size_t)s * (K + 1) + k];
+        /* the sector's runs (<= n <= 2048 of them) sit in A's memory until the keys are in registers */
+        unsigned* runP = (unsigned*)A;
+        unsigned* runA = runP + URF_STAR_MID_CAP;
+        if (tid < 64) {
+            const unsigned nr = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, runP, runA);
+            if (tid == 0) {
+                sh_nruns = nr;
+                sh_first = n;
+            }
+        }
+        __syncthreads();
+        const unsigned nruns = sh_nruns;
         unsigned long long key[EPT];
+        unsigned r = 0;
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++) {
             const unsigned i = tid + e * NT;
-            key[e] = i < n ? ((unsigned long long)urf_fbits(a.sr[base + i]) << 32) | i : ~0ull;
+            key[e] = ~0ull;
+            if (i < n) {
+                while (r + 1 < nruns && i >= runP[r + 1])
+                    r++;
+                const unsigned adr = runA[r] + i;   /* grows with i: the tie-break, and the way back to z / slot */
+                key[e] = ((unsigned long long)urf_fbits(a.sr[sb + adr]) << 32) | adr;
+            }
         }
+        __syncthreads();   /* the run list has been read: A is free */
         urf_block_sort_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, (dp.exp_flags & 4u) != 0);
-        const unsigned first = urf_star_emit<NT, EPT>(a, dp, base, n, A, nullptr, &sh_first);
+        const unsigned first = urf_star_emit<NT, EPT>(a, dp, sb, obase, n, A, &sh_first);
         if (tid == 0)
             a.star_first[sk] = first < n - 1 ? first : n - 1;
         __syncthreads();
     }
 }
 
-/* sectors with more than 2048 points (adversarial clouds): sorted in place in
- * global memory by one workgroup each, same network, keys (range, position in the
- * sector = input order); then slopes in a second sweep. */
+/* sectors with more than 2048 points (adversarial clouds): gathered into sector-major
+ * copies and sorted there, in global memory, by one workgroup each, same network, keys (range,
+ * position in the sector = input order); then slopes in a second sweep. */
 __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_params dp)
 {
     __shared__ unsigned sh_first;
@@ -1366,25 +1458,42 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
         const unsigned s = sk / K, k = sk % K;
         unsigned off, len;
         urf_scan_range(a, s, off, len);
+        const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
         const unsigned n = a.sec_cnt[(size_t)s * K + k];
-        const unsigned base = off + a.sec_off[(size_t)s * (K + 1) + k];
-        float* R = a.sr + base;
-        float* Z = a.sz + base;
-        unsigned* I = a.ssrc + base;
+        const unsigned sb = urf_sbase(a, s), base = sb + a.sec_off[(size_t)s * (K + 1) + k];
+        const unsigned* P = a.spre + ((size_t)s * K + k) * (a.tiles + 1);
+        const uint16_t* ST = a.sstart + ((size_t)s * K + k) * a.tiles;
+        float* R = a.big_r + base;
+        float* Z = a.big_z + base;
+        unsigned* I = a.big_i + base;
         unsigned* Pq = a.ssrt + base;   /* original position in the sector = input order: the tie-break */
         if (threadIdx.x == 0)
             sh_first = n;
-        for (unsigned i = threadIdx.x; i < n; i += 256)
+        for (unsigned i = threadIdx.x; i < n; i += 256) {
+            unsigned lo = 0, hi = ntiles;   /* largest tile t with P[t] <= i (its run is not empty) */
+            while (hi - lo > 1) {
+                const unsigned mid = (lo + hi) >> 1;
+                if (P[mid] <= i)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const unsigned adr = sb + lo * URF_TILE + ST[lo] + (i - P[lo]);
+            const unsigned sl = a.sslot[adr];
+            R[i] = a.sr[adr];
+            Z[i] = a.sz[adr];
+            I[i] = sl == URF_SLOT_NONE ? 0xffffffffu : lo * URF_TILE + sl;
             Pq[i] = i;
+        }
         __threadfence_block();
         __syncthreads();
-        unsigned P = 1;
-        while (P < n)
-            P <<= 1;
-        for (unsigned kk = 2; kk <= P; kk <<= 1) {
+        unsigned P2 = 1;
+        while (P2 < n)
+            P2 <<= 1;
+        for (unsigned kk = 2; kk <= P2; kk <<= 1) {
             for (unsigned j = kk >> 1; j > 0; j >>= 1) {
                 const bool flip = (j == (kk >> 1));
-                for (unsigned tt = threadIdx.x; tt < (P >> 1); tt += 256) {
+                for (unsigned tt = threadIdx.x; tt < (P2 >> 1); tt += 256) {
                     const unsigned lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
                     const unsigned hi = flip ? ((lo & ~(kk - 1)) + (kk - 1) - (lo & (kk - 1))) : lo + j;
                     if (hi < n) {
@@ -1413,8 +1522,10 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
             }
             a.wslp[base + i] = slp;
             a.wg[base + i] = g;
-            a.ssrt[base + i] = I[i];
         }
+        __syncthreads();   /* every Pq (= ssrt) has been read for the last time */
+        for (unsigned i = threadIdx.x; i < n; i += 256)
+            a.ssrt[base + i] = I[i];
         atomicMin(&sh_first, first);
         __syncthreads();
         if (threadIdx.x == 0)
@@ -1441,11 +1552,10 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
     const unsigned k = blockIdx.x * 64 + lane;
     if (a.info[s].status != URF_OK)
         return;
-    unsigned off, len;
-    urf_scan_range(a, s, off, len);
+    const unsigned C = (unsigned)dp.p.channels;
     const bool have = k < K;
     const unsigned n = have ? a.sec_cnt[(size_t)s * K + k] : 0;
-    const unsigned base = have ? off + a.sec_off[(size_t)s * (K + 1) + k] : 0;
+    const unsigned base = have ? urf_sbase(a, s) + a.sec_off[(size_t)s * (K + 1) + k] : 0;
     unsigned last = n >= 2 ? a.star_first[(size_t)s * K + k] : 0;
     sbase[lane] = base;
     slast[lane] = last;
@@ -1580,7 +1690,25 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
             park();
         __syncthreads();
     }
-    const int hit = hit_i ? (int)a.ssrt[base + hit_i] : -1;
+    /* the curb point of the sector, reported where k_ring looks for it: as a position in the
+     * ring-major arrays.  ssrt holds its tile-local ring-sorted index t * URF_TILE + slot; the ring
+     * is the run of tile t that contains the slot (bisection in the tile's run table). */
+    int hit = -1;
+    const unsigned v = hit_i ? a.ssrt[base + hit_i] : 0xffffffffu;
+    if (v != 0xffffffffu) {
+        const unsigned t = v / URF_TILE, j = v % URF_TILE;
+        const uint16_t* row = a.troff + ((size_t)s * a.tiles + t) * (C + 1);
+        unsigned lo = 0, hi = C;   /* largest c with row[c] <= j (its run is not empty) */
+        while (hi - lo > 1) {
+            const unsigned mid = (lo + hi) >> 1;
+            if ((unsigned)row[mid] <= j)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const unsigned p = a.rpre[((size_t)s * C + lo) * (a.tiles + 1) + t] + (j - (unsigned)row[lo]);
+        hit = (int)(a.ring_off[(size_t)s * (C + 1) + lo] + p);   /* relative to the scan's scratch base */
+    }
     if (have)
         a.star_hit[(size_t)s * K + k] = hit;
 }
@@ -1631,13 +1759,41 @@ struct urf_ring_shared {
 #define URF_CAND_EXACT 4u   /* no float approximation of the azimuth (near the x axis, stage capture) */
 #define URF_CAND_STAR 8u    /* star-shaped hit */
 
+/* Ring position -> index of the point in the tile-local ring-sorted arrays (rx, ry, rz).  P[t] =
+ * points of the ring in the tiles before t (P[ntiles] = n), radd[t] = scratch index of the first
+ * point of the ring's run in tile t, minus P[t]: position j of the ring lives at radd[tile(j)] + j.
+ * Both tables sit in LDS.  The tile is guessed from the ring's average run length (exact for an
+ * organised sweep: every firing adds one point to every ring) and found by bisection otherwise. */
+struct urf_ring_map {
+    const unsigned* P;
+    const unsigned* radd;
+    unsigned ntiles;
+    float scale;   /* ntiles / n */
+    __device__ __forceinline__ unsigned tile(unsigned j) const
+    {
+        unsigned t = (unsigned)((float)j * scale);
+        t = t < ntiles ? t : ntiles - 1;
+        if (P[t] <= j && j < P[t + 1])
+            return t;
+        unsigned lo = 0, hi = ntiles;   /* largest t with P[t] <= j */
+        while (hi - lo > 1) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (P[mid] <= j)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        return lo;
+    }
+    __device__ __forceinline__ unsigned at(unsigned j) const { return radd[tile(j)] + j; }
+};
+
 /* x_zero_method.cpp:30-68 for the triple (j, p, j + cp), j = p - cp / 2, given the cheap height
- * tests passed.  X / Y: the ring's coordinates indexed by ring-relative position (an LDS window or
- * the ring-major arrays themselves). */
-__device__ __forceinline__ bool urf_x_zero_angle(const urf_kargs& a, const urf_dev_params& dp, const float* X, const float* Y,
+ * tests passed.  (xj, yj) / (x3, y3): planar coordinates of the points j and j + cp. */
+__device__ __forceinline__ bool urf_x_zero_angle(const urf_kargs& a, const urf_dev_params& dp, float xj, float yj, float x3, float y3,
                                                  int j, int p, int cp, float zj, float pz, float z3)
 {
-    const double dx = (double)(X[j + cp] - X[j]), dy = (double)(Y[j + cp] - Y[j]);
+    const double dx = (double)(x3 - xj), dy = (double)(y3 - yj);
     if (!(dx * dx + dy * dy < URF_DIST5_SQ))                                    /* :35-40 */
         return false;
     const float nyj = a.newY[j], ny2 = a.newY[p], ny3 = a.newY[j + cp];
@@ -1647,8 +1803,8 @@ __device__ __forceinline__ bool urf_x_zero_angle(const urf_kargs& a, const urf_d
     u = (double)(ny3 - ny2); v = (double)(z3 - pz);
     const float x2 = (float)__builtin_sqrt(u * u + v * v);
     u = (double)(ny3 - nyj); v = (double)(z3 - zj);
-    const float x3 = (float)__builtin_sqrt(u * u + v * v);
-    const double num = (double)x3 * (double)x3 - (double)x1 * (double)x1 - (double)x2 * (double)x2;
+    const float x3s = (float)__builtin_sqrt(u * u + v * v);
+    const double num = (double)x3s * (double)x3s - (double)x1 * (double)x1 - (double)x2 * (double)x2;
     const float den = (-2.0f * x1) * x2;
     float br = (float)(num / (double)den);                                      /* :52 */
     if (br < -1.0f)
@@ -1659,21 +1815,29 @@ __device__ __forceinline__ bool urf_x_zero_angle(const urf_kargs& a, const urf_d
     return alpha <= dp.p.angleFilter1;                                          /* :61 */
 }
 
-/* z_zero_method.cpp:21-66 for the centre p, given the height tests passed */
-__device__ __forceinline__ bool urf_z_zero_angle(const urf_dev_params& dp, const float* X, const float* Y, int p, int cp,
-                                                 float px, float py)
+/* z_zero_method.cpp:21-66 for the centre p, given the height tests passed.  xy(r, x, y) delivers the
+ * planar coordinates of ring position r (an LDS window or a gather from the ring-sorted arrays). */
+template <class FXY>
+__device__ __forceinline__ bool urf_z_zero_angle(const urf_dev_params& dp, FXY xy, int p, int cp, float px, float py)
 {
-    const double dx = (double)(X[p + cp] - X[p - cp]), dy = (double)(Y[p + cp] - Y[p - cp]);
+    float xa, ya, xb, yb;
+    xy(p + cp, xb, yb);
+    xy(p - cp, xa, ya);
+    const double dx = (double)(xb - xa), dy = (double)(yb - ya);
     if (!(dx * dx + dy * dy < URF_DIST5_SQ))                                    /* :23-28 */
         return false;
     float va1 = 0.f, va2 = 0.f, vb1 = 0.f, vb2 = 0.f;
     for (int k = 1; k <= cp; k++) {                                             /* :35-38 */
-        va1 = va1 + (X[p - k] - px);
-        va2 = va2 + (Y[p - k] - py);
+        float x, y;
+        xy(p - k, x, y);
+        va1 = va1 + (x - px);
+        va2 = va2 + (y - py);
     }
     for (int k = 1; k <= cp; k++) {                                             /* :44-47 */
-        vb1 = vb1 + (X[p + k] - px);
-        vb2 = vb2 + (Y[p + k] - py);
+        float x, y;
+        xy(p + k, x, y);
+        vb1 = vb1 + (x - px);
+        vb2 = vb2 + (y - py);
     }
     va1 = dp.inv_cp * va1;                                                      /* :52-55 */
     va2 = dp.inv_cp * va2;
@@ -1731,6 +1895,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
 {
     constexpr int CH = URF_RING_CHUNK, PAD = URF_RING_PAD;
     __shared__ urf_ring_shared S;
+    extern __shared__ unsigned sh_ring_tab[];   /* P[tiles + 1], radd[tiles] (urf_ring_map) */
     int* const cmin = S.cmin;
     int* const cmax = S.cmax;
     int* const sh_q = S.q;
@@ -1740,12 +1905,28 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
         return;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
+    const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const int n = (int)a.ring_cnt[(size_t)s * C + c];
-    const unsigned base = off + a.ring_off[(size_t)s * (C + 1) + c];
+    const unsigned sb = urf_sbase(a, s);
+    const unsigned ro = a.ring_off[(size_t)s * (C + 1) + c];   /* multiple of 4 */
+    const unsigned base = sb + ro;                              /* the ring in the ring-major arrays (raz, rflag) */
     const int cp = dp.p.curbPoints;
     const bool star = dp.p.star_shaped_method != 0;
     const bool want_quad = (c == 1) && dp.p.blind_spots;
+    unsigned* const mapP = sh_ring_tab;
+    unsigned* const mapA = sh_ring_tab + a.tiles + 1;
+    {
+        const unsigned* gp = a.rpre + ((size_t)s * C + c) * (a.tiles + 1);
+        const uint16_t* gs = a.rstart + ((size_t)s * C + c) * a.tiles;
+        for (unsigned t = tid; t <= ntiles; t += URF_RING_THREADS) {
+            const unsigned pt = gp[t];
+            mapP[t] = pt;
+            if (t < ntiles)
+                mapA[t] = sb + t * URF_TILE + gs[t] - pt;
+        }
+    }
+    const urf_ring_map map = { mapP, mapA, ntiles, (float)ntiles / (float)(n > 0 ? n : 1) };
 
     for (unsigned i = tid; i < URF_DEG_CELLS; i += URF_RING_THREADS) {
         cmin[i] = URF_INT_NONE_MIN;
@@ -1765,17 +1946,18 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
     __syncthreads();
     if (star) {   /* lidar_segmentation.cpp:241-242: the star-shaped hits that lie on this ring */
         for (unsigned k = tid; k < K; k += URF_RING_THREADS) {
-            const unsigned h = (unsigned)a.star_hit[(size_t)s * K + k];   /* ring-major position or 0xffffffff */
-            if (h >= base && h < base + (unsigned)n)
-                S.hits[atomicAdd(&S.n_hits, 1u)] = h - base;
+            const unsigned h = (unsigned)a.star_hit[(size_t)s * K + k];   /* ring-major position (scan-relative) or 0xffffffff */
+            if (h >= ro && h < ro + (unsigned)n)
+                S.hits[atomicAdd(&S.n_hits, 1u)] = h - ro;
         }
     }
     __syncthreads();
     const unsigned nh = S.n_hits;
     double maxs = 0.0;
     const bool quads = cp == 5;
-    /* quad mapping: chunk starts are multiples of 4 in the global ring-major index */
-    const int cs0 = quads ? -(int)(base & 3u) : 0;
+    /* quad mapping: chunk starts are multiples of 4, and so is the ring's start in the ring-major
+     * arrays (k_index pads), so that azimuths and flags leave as 16- and 4-byte stores */
+    const int cs0 = 0;
     const int zpad = PAD + (cp & 3);   /* z slot of chunk point 0: puts p - cp of a quad on a 16-byte boundary for cp = 5 */
     unsigned buf = 0;
 
@@ -1788,9 +1970,12 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
         for (int m = 0; m < NS; m++) {
             const int j = cs - cp + (int)tid + m * URF_RING_THREADS;
             const bool on = j >= 0 && j < n && j < cs + CH + cp;
-            fx[m] = on ? a.rx[base + j] : 0.f;
-            fy[m] = on ? a.ry[base + j] : 0.f;
-            fz[m] = on ? a.rz[base + j] : 0.f;
+            unsigned idx = 0;
+            if (on)
+                idx = map.at((unsigned)j);
+            fx[m] = on ? a.rx[idx] : 0.f;
+            fy[m] = on ? a.ry[idx] : 0.f;
+            fz[m] = on ? a.rz[idx] : 0.f;
         }
     };
     fetch(cs0);
@@ -1888,17 +2073,23 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
             __syncthreads();
             if (S.n_cand > URF_RING_CAND - CH || cs + CH >= n) {   /* the next chunk might not fit / last chunk */
                 const unsigned nc = S.n_cand;
-                const float* GX = a.rx + base;
-                const float* GY = a.ry + base;
-                const float* GZ = a.rz + base;
+                auto gxy = [&](int r, float& x, float& y) {   /* operands come from the ring-sorted arrays (L2) */
+                    const unsigned idx = map.at((unsigned)r);
+                    x = a.rx[idx];
+                    y = a.ry[idx];
+                };
                 for (unsigned e = tid; e < nc; e += URF_RING_THREADS) {
                     const unsigned v = S.cand[e], t = v >> URF_CAND_SHIFT;
                     const int p = (int)(v & ((1u << URF_CAND_SHIFT) - 1u));
-                    const float px = GX[p], py = GY[p];
+                    const unsigned ip = map.at((unsigned)p);
+                    const float px = a.rx[ip], py = a.ry[ip];
                     unsigned flag = (t & URF_CAND_STAR) ? 1u : 0u;
-                    if ((t & URF_CAND_XZERO) && urf_x_zero_angle(a, dp, GX, GY, p - 2, p, 5, GZ[p - 2], GZ[p], GZ[p + 3]))
-                        flag |= 2u;
-                    if ((t & URF_CAND_ZZERO) && urf_z_zero_angle(dp, GX, GY, p, 5, px, py))
+                    if (t & URF_CAND_XZERO) {   /* j = p - 2 and j + cp = p + 3 exist (height tests passed) */
+                        const unsigned ij = map.at((unsigned)(p - 2)), i3 = map.at((unsigned)(p + 3));
+                        if (urf_x_zero_angle(a, dp, a.rx[ij], a.ry[ij], a.rx[i3], a.ry[i3], p - 2, p, 5, a.rz[ij], a.rz[ip], a.rz[i3]))
+                            flag |= 2u;
+                    }
+                    if ((t & URF_CAND_ZZERO) && urf_z_zero_angle(dp, gxy, p, 5, px, py))
                         flag |= 4u;
                     if (flag || (t & URF_CAND_EXACT)) {
                         a.raz[base + p] = urf_ring_point(a, S, (size_t)base + p, px, py, flag, want_quad);
@@ -1931,7 +2122,8 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                         const bool heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight ||
                                               __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
                                              (double)__builtin_fabsf(zj - z3) >= 0.05;          /* :62-64 */
-                        if (heights && urf_x_zero_angle(a, dp, S.xs + PAD - cs, S.ys + PAD - cs, j, p, cp, zj, pz, z3))
+                        if (heights && urf_x_zero_angle(a, dp, S.xs[j - cs + PAD], S.ys[j - cs + PAD], S.xs[j + cp - cs + PAD],
+                                                        S.ys[j + cp - cs + PAD], j, p, cp, zj, pz, z3))
                             flag |= 2u;
                     }
                 }
@@ -1948,7 +2140,11 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                         }
                         const bool heights = (max1 - az >= dp.p.curbHeight || max2 - az >= dp.p.curbHeight) &&
                                              (double)__builtin_fabsf(max1 - max2) >= 0.05;      /* :67-69 */
-                        if (heights && urf_z_zero_angle(dp, S.xs + PAD - cs, S.ys + PAD - cs, p, cp, px, py))
+                        auto lxy = [&](int r, float& x, float& y) {
+                            x = S.xs[r - cs + PAD];
+                            y = S.ys[r - cs + PAD];
+                        };
+                        if (heights && urf_z_zero_angle(dp, lxy, p, cp, px, py))
                             flag |= 4u;
                     }
                 }
@@ -2114,11 +2310,6 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
             a.act_b[((size_t)s * C + k) * 6 + (tid >> 6)] = bb;
         }
     }
-    if (tid == 0) {   /* lidar_segmentation.cpp:605-608: road_probably = every point of sorted ring 10 */
-        urf_scan_info* o = &a.info[s];
-        o->n_ring_pts = a.ring_off[(size_t)s * (C + 1) + C];
-        o->n_ring10 = nR > 10 ? a.ring_cnt[(size_t)s * C + 10] : 0;
-    }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -2204,19 +2395,24 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     if (tbase >= len)
         return;
     const urf_scan_info in = a.info[s];
-    if (in.status != URF_OK)
+    if (in.status != URF_OK) {
+        /* nothing is published for this scan (lidar_segmentation.cpp:124-126): all labels 0 */
+        for (unsigned i = tbase + tid; i < len && i < tbase + URF_TILE; i += URF_LABEL_TILE_THREADS)
+            a.labels[off + i] = 0;
         return;
+    }
     const unsigned C = (unsigned)dp.p.channels, nR = in.n_rings;
-    const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     const size_t row = (size_t)s * a.tiles + t;
+    const unsigned sb = urf_sbase(a, s);
 
-    if (tid < C) {
-        /* run of ring `tid` that belongs to this tile: [first, first + n) inside the ring */
-        const unsigned first = a.tile_ring[row * C + tid];
-        const unsigned next = t + 1 < ntiles ? a.tile_ring[(row + 1) * C + tid] : a.ring_cnt[(size_t)s * C + tid];
-        base_r[tid] = off + a.ring_off[(size_t)s * (C + 1) + tid] + first;
-        koff[tid] = next - first;   /* count, scanned below */
-        qk[tid] = tid < nR ? a.qk[(size_t)s * C + tid] : 0.0;
+    if (tid <= C) {
+        /* run of ring `tid` inside the tile's ring-sorted order: starts at slot troff[tid]; its first
+         * point is point tpre[tid] of the ring */
+        koff[tid] = a.troff[row * (C + 1) + tid];
+        if (tid < C) {
+            base_r[tid] = sb + a.ring_off[(size_t)s * (C + 1) + tid] + a.tpre[row * C + tid];
+            qk[tid] = tid < nR ? a.qk[(size_t)s * C + tid] : 0.0;
+        }
     }
     for (unsigned w = tid; w < nR * 6; w += URF_LABEL_TILE_THREADS) {
         actf[w] = a.act_f[(size_t)s * C * 6 + w];
@@ -2230,18 +2426,6 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         cnt_road = 0;
         cnt_curb = 0;
         n_unsure = 0;
-    }
-    __syncthreads();
-    if (tid < 64) {   /* exclusive scan of the run lengths (C <= 128) */
-        const unsigned v0 = tid < C ? koff[tid] : 0, v1 = tid + 64 < C ? koff[tid + 64] : 0;
-        const unsigned i0 = urf_wave_scan_add(v0), i1 = urf_wave_scan_add(v1);
-        const unsigned total0 = __shfl(i0, 63), total1 = __shfl(i1, 63);
-        if (tid < C)
-            koff[tid] = i0 - v0;
-        if (tid + 64 < C)
-            koff[tid + 64] = total0 + i1 - v1;
-        if (tid == 0)
-            koff[C] = total0 + total1;
     }
     __syncthreads();
     const unsigned npts = koff[C];
@@ -2302,7 +2486,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         const bool on = rpos[q] != 0xffffffffu;
         rfl[q] = on ? (unsigned)a.rflag[rpos[q]] : 0u;
         raz[q] = on ? a.raz[rpos[q]] : 0.f;
-        rsr[q] = on ? a.rsrc[rpos[q]] : 0u;
+        rsr[q] = on ? (unsigned)a.rsrc[sb + tbase + tid + q * URF_LABEL_TILE_THREADS] : 0u;   /* index inside the tile */
     }
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
@@ -2326,14 +2510,15 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
             bool road_final = road;
             if (unsure) {
                 const unsigned e = atomicAdd(&n_unsure, 1u);
+                const unsigned slot = sb + tbase + tid + q * URF_LABEL_TILE_THREADS;   /* the point in rx / ry */
                 if (e < URF_LABEL_UNSURE) {
-                    un_pos[e] = rpos[q];
-                    un_key[e] = (src - tbase) | (c << 16);
+                    un_pos[e] = slot;
+                    un_key[e] = src | (c << 16);
                     road_final = false;   /* placeholder, corrected after the tile is written */
                 } else {
                     float d2;   /* list full (pathological input): decide here */
                     road_final = urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c],
-                                               urf_azimuth(a.rx[rpos[q]], a.ry[rpos[q]], &d2), 0.0f, unsure);
+                                               urf_azimuth(a.rx[slot], a.ry[slot], &d2), 0.0f, unsure);
                 }
             }
             if (road_final) {
@@ -2341,7 +2526,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
                 my_road++;
             }
         }
-        img[URF_IMG(src - tbase)] = lab;
+        img[URF_IMG(src)] = lab;
     }
     __syncthreads();
     static_assert(URF_LABEL_UNSURE <= URF_LABEL_TILE_THREADS, "one listed point per thread");
@@ -2359,7 +2544,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     for (unsigned i = tid; i < URF_TILE; i += URF_LABEL_TILE_THREADS) {
         const uint8_t l = img[URF_IMG(i)];
         if (l != 0xff && tbase + i < len)
-            a.labels[off + tbase + i] = l;   /* points on no ring keep the label k_ring_assign wrote */
+            a.labels[off + tbase + i] = l;   /* points on no ring keep the label k_split wrote */
     }
     __syncthreads();   /* the tile's stores come first, the corrections second */
     if (tail) {
@@ -2385,13 +2570,14 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     }
 }
 
-/* exact azimuth of the point at ring-major position pos (raz may hold the approximation) */
-__device__ __forceinline__ float urf_exact_az(const urf_kargs& a, size_t pos)
+/* exact azimuth of the point at ring-major position pos (raz may hold the approximation); slot =
+ * the point's index in the ring-sorted arrays (urf_ring_slot) */
+__device__ __forceinline__ float urf_exact_az(const urf_kargs& a, unsigned pos, unsigned slot)
 {
     if (!(a.rflag[pos] & URF_RFLAG_AZ_APPROX))
         return a.raz[pos];
     float d2;
-    return urf_azimuth(a.rx[pos], a.ry[pos], &d2);
+    return urf_azimuth(a.rx[slot], a.ry[slot], &d2);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -2468,13 +2654,16 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
     const unsigned C = (unsigned)dp.p.channels;
     const unsigned n = a.ring_cnt[(size_t)s * C + c];
     const unsigned rel = a.ring_off[(size_t)s * (C + 1) + c];   /* scan-relative start of the ring */
-    const unsigned base = off + rel;
+    const unsigned sb = urf_sbase(a, s), base = sb + rel;
+    const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     if (n <= CAP) {
         unsigned long long key[EPT];
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++) {
             const unsigned i = tid + e * NT;
-            key[e] = i < n ? ((unsigned long long)urf_fbits(urf_exact_az(a, base + i)) << 32) | i : ~0ull;
+            key[e] = ~0ull;
+            if (i < n)
+                key[e] = ((unsigned long long)urf_fbits(urf_exact_az(a, base + i, sb + urf_ring_slot(a, s, C, c, ntiles, i))) << 32) | i;
         }
         urf_block_sort_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, false);
         for (unsigned i = tid; i < n; i += NT)
@@ -2482,7 +2671,7 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
     } else {
         unsigned long long* G = gkeys + rel;
         for (unsigned i = tid; i < n; i += NT)
-            G[i] = ((unsigned long long)urf_fbits(urf_exact_az(a, base + i)) << 32) | i;
+            G[i] = ((unsigned long long)urf_fbits(urf_exact_az(a, base + i, sb + urf_ring_slot(a, s, C, c, ntiles, i))) << 32) | i;
         __threadfence_block();
         __syncthreads();
         unsigned P = 1;
@@ -2518,27 +2707,47 @@ __global__ __launch_bounds__(1024) void k_ordered_lists(urf_kargs a, urf_dev_par
 {
     __shared__ unsigned wsum[3][16];
     __shared__ unsigned run[3];
+    __shared__ unsigned sroff[URF_MAX_CHANNELS + 1], srcnt[URF_MAX_CHANNELS];
     const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const urf_scan_info in = a.info[s];
+    const unsigned C = (unsigned)dp.p.channels;
     if (tid < 3)
         run[tid] = 0;
+    if (in.status == URF_OK && tid <= C) {
+        sroff[tid] = a.ring_off[(size_t)s * (C + 1) + tid];
+        if (tid < C)
+            srcnt[tid] = a.ring_cnt[(size_t)s * C + tid];
+    }
     __syncthreads();
     if (in.status == URF_OK) {
         unsigned off, len;
         urf_scan_range(a, s, off, len);
-        const unsigned C = (unsigned)dp.p.channels;
-        const unsigned* roff = a.ring_off + (size_t)s * (C + 1);
-        const unsigned total = roff[in.n_rings];
-        const unsigned r10lo = in.n_rings > 10 ? roff[10] : 0, r10hi = in.n_rings > 10 ? roff[11] : 0;
+        const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
+        const unsigned sb = urf_sbase(a, s);
+        const unsigned total = sroff[in.n_rings];   /* ring starts are padded to multiples of 4: positions behind a ring's last point are skipped */
         for (unsigned b0 = 0; b0 < total; b0 += 1024) {
             const unsigned p = b0 + tid;
-            unsigned src = 0, l = 0;
+            unsigned src = 0, l = 0, c = 0;
+            bool valid = false;
             if (p < total) {
-                src = a.rsrc[off + rord[p]];
+                unsigned lo = 0, hi = in.n_rings;   /* largest ring c with sroff[c] <= p */
+                while (hi - lo > 1) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if (sroff[mid] <= p)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                c = lo;
+                valid = p - sroff[c] < srcnt[c];
+            }
+            if (valid) {
+                const unsigned slot = urf_ring_slot(a, s, C, c, ntiles, rord[p] - sroff[c]);
+                src = (slot & ~(URF_TILE - 1u)) + a.rsrc[sb + slot];
                 l = a.labels[off + src];
             }
-            const bool f[3] = { p < total && (l & URF_LABEL_MASK) == URF_LABEL_ROAD,
-                                p < total && (l & URF_LABEL_MASK) == URF_LABEL_CURB, p >= r10lo && p < r10hi };
+            const bool f[3] = { valid && (l & URF_LABEL_MASK) == URF_LABEL_ROAD,
+                                valid && (l & URF_LABEL_MASK) == URF_LABEL_CURB, valid && c == 10 };
             unsigned below[3];
             for (int k = 0; k < 3; k++) {
                 const unsigned long long m = __ballot(f[k]);
@@ -2592,7 +2801,10 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
     urf_scan_range(a, s, off, len);
     const unsigned C = (unsigned)dp.p.channels;
     const unsigned n = a.ring_cnt[(size_t)s * C + c];
-    const unsigned base = off + a.ring_off[(size_t)s * (C + 1) + c];
+    const unsigned sb = urf_sbase(a, s), base = sb + a.ring_off[(size_t)s * (C + 1) + c];
+    const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
+    /* input index of the point in ring-sorted slot `slot` (relative to the scan) */
+    auto src_of = [&](unsigned slot) { return (slot & ~(URF_TILE - 1u)) + (unsigned)a.rsrc[sb + slot]; };
     for (unsigned i = tid; i < URF_DEG_CELLS; i += 256) {
         nrmin[i] = URF_INT_NONE_MIN;
         best[i] = 0;
@@ -2601,8 +2813,9 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
     __syncthreads();
     /* pass 1: where does the scan of this ring stop in each degree (:318) */
     for (unsigned p = tid; p < n; p += 256) {
-        const float az = urf_exact_az(a, base + p);
-        const unsigned lab = a.labels[off + a.rsrc[base + p]] & URF_LABEL_MASK;
+        const unsigned slot = urf_ring_slot(a, s, C, c, ntiles, p);
+        const float az = urf_exact_az(a, base + p, sb + slot);
+        const unsigned lab = a.labels[off + src_of(slot)] & URF_LABEL_MASK;
         if (az == az && lab != URF_LABEL_ROAD) {
             int bin = (int)__builtin_floorf(az);
             bin = bin < 0 ? 0 : (bin > 360 ? 360 : bin);
@@ -2613,13 +2826,14 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
     /* pass 2: farthest road point in front of it (:325-335); key = (d, first in azimuth order) */
     for (int pass = 0; pass < 2; pass++) {
         for (unsigned p = tid; p < n; p += 256) {
-            const float az = urf_exact_az(a, base + p);
-            const unsigned lab = a.labels[off + a.rsrc[base + p]] & URF_LABEL_MASK;
+            const unsigned slot = urf_ring_slot(a, s, C, c, ntiles, p);
+            const float az = urf_exact_az(a, base + p, sb + slot);
+            const unsigned lab = a.labels[off + src_of(slot)] & URF_LABEL_MASK;
             if (az == az && lab == URF_LABEL_ROAD) {
                 int bin = (int)__builtin_floorf(az);
                 bin = bin < 0 ? 0 : (bin > 360 ? 360 : bin);
                 if ((int)urf_fbits(az) < nrmin[bin]) {
-                    const float x = a.rx[base + p], y = a.ry[base + p];
+                    const float x = a.rx[sb + slot], y = a.ry[sb + slot];
                     const float d = (float)__builtin_sqrt((double)(0.f - x) * (double)(0.f - x) + (double)(0.f - y) * (double)(0.f - y));
                     if (d > 0.0f) {   /* "d > maxDistanceRoad" with maxDistanceRoad starting at 0 */
                         const unsigned long long key = ((unsigned long long)urf_fbits(d) << 32) | (0xffffffffu - urf_fbits(az));
@@ -2636,7 +2850,7 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
     for (unsigned i = tid; i < URF_DEG_CELLS; i += 256) {
         const size_t o = (size_t)c * URF_DEG_CELLS + i;
         m_d[o] = __uint_as_float((unsigned)(best[i] >> 32));
-        m_pos[o] = bestpos[i] == 0xffffffffu ? 0xffffffffu : base + bestpos[i];
+        m_pos[o] = bestpos[i] == 0xffffffffu ? 0xffffffffu : sb + urf_ring_slot(a, s, C, c, ntiles, bestpos[i]);
         m_red[o] = nrmin[i] != URF_INT_NONE_MIN;
     }
 }
