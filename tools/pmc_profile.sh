@@ -5,6 +5,7 @@
 set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+case "$OUT" in /*) ;; *) OUT="$REPO/$OUT";; esac
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --parity-scans 0 $*"

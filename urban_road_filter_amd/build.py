@@ -52,5 +52,22 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, defines, verbose=False):
+    """A/B builds for kernel experiments: tools/ab/liburf_hip_<name>.so compiled with extra -D flags
+    (select with URF_LIB_PATH; bench.py / the tests then run that library)."""
+    out_dir = os.path.join(ROOT, "tools", "ab")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "liburf_hip_%s.so" % name)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [_hipcc()] + FLAGS + ["-D" + d for d in defines] + srcs + ["-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":   # --variant NAME [DEFINE ...]
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        build(force="--force" in sys.argv)

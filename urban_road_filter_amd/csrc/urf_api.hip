@@ -183,7 +183,6 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.big_r, T) A(k.big_z, T) A(k.big_i, T)
     A(k.tile_roi, S * tiles) A(k.troff, S * tiles * (C + 1)) A(k.tsoff, S * tiles * (K + 1))
     A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles) A(k.tpre, S * tiles * C)
-    A(k.spre, S * K * (tiles + 1)) A(k.sstart, S * K * tiles)
     A(k.angle, S * C) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
     A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 2)

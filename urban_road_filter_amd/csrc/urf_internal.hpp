@@ -69,8 +69,8 @@ struct urf_dev_params {
  *                                 ring-sorted slot (URF_SLOT_NONE if it lies on no ring)
  * so that ONE pass over x/y/z (k_split) can write both without knowing any total.  Ring c of the
  * scan = the concatenation over the tiles of run [troff[t][c], troff[t][c+1]); k_index turns the
- * per-tile run tables into per-ring / per-sector tables (prefix over the tiles, start inside the
- * tile).  What the later kernels PRODUCE per point is contiguous per ring (raz, rflag: element p of
+ * rings' per-tile run tables into per-ring tables (prefix over the tiles, start inside the tile);
+ * a sector's runs are read from tsoff directly (it meets few tiles).  What the later kernels PRODUCE per point is contiguous per ring (raz, rflag: element p of
  * ring c at s * sstride + ring_off[c] + p, ring_off padded to multiples of 4) resp. per sector
  * (wslp, wg, ssrt: at s * sstride + sec_off[k] + i). */
 struct urf_kargs {
@@ -118,8 +118,6 @@ struct urf_kargs {
     uint32_t* rpre;             /* [S][C][tiles+1] points of ring c in the tiles before t; [ntiles] = ring_cnt */
     uint16_t* rstart;           /* [S][C][tiles]   = troff[t][c] */
     uint32_t* tpre;             /* [S][tiles][C]   = rpre[c][t] (the layout k_label reads) */
-    uint32_t* spre;             /* [S][K][tiles+1] */
-    uint16_t* sstart;           /* [S][K][tiles] */
     /* per scan */
     float*    angle;            /* [S][channels] sorted ring-angle table */
     uint8_t*  ring_lut;         /* [S][URF_LUT_CELLS] first table entry a vertical angle of the cell can match */

@@ -339,7 +339,43 @@ __host__ __device__ inline size_t urf_split_lds_bytes(unsigned C, unsigned K, bo
     return fixed + (phase_a > phase_b ? phase_a : phase_b);
 }
 
-__global__ __launch_bounds__(URF_TILE_THREADS) void k_split(urf_kargs a, urf_dev_params dp)
+/* The reference's exact sequence for one point: vertical angle (lidar_segmentation.cpp:148-166), first
+ * sorted table entry within `interval` (:226-233; fl(angle[j] - alpha) is monotone in angle[j], so
+ * the matching entries are contiguous and the first one is found by bisection with the very same
+ * float predicate), star sector (star_shaped_search.cpp:164-171; sectors == 0: not wanted).
+ * Deliberately NOT inlined: only the rare point the float approximations leave open gets here, and
+ * inlined its f64 polynomials would dictate the register allocation (and with it the occupancy)
+ * of the whole kernel. */
+struct urf_exact_key {
+    unsigned ring, sector;
+    float valpha;
+};
+__device__ __noinline__ urf_exact_key urf_exact_keys(const float* tab, unsigned nR, float interval, float x, float y, float z,
+                                                     unsigned sectors, float Kfi)
+{
+    urf_exact_key r;
+    r.valpha = urf_vertical_angle(x, y, z);
+    r.ring = URF_RING_NONE;
+    r.sector = URF_SEC_NONE;
+    unsigned l2 = 0, h2 = nR;
+    while (l2 < h2) {
+        const unsigned mid = (l2 + h2) >> 1;
+        if (tab[mid] - r.valpha >= -interval)
+            h2 = mid;
+        else
+            l2 = mid + 1;
+    }
+    if (l2 < nR && __builtin_fabsf(tab[l2] - r.valpha) <= interval)
+        r.ring = l2;
+    if (sectors)
+        r.sector = urf_sector(x, y, Kfi, sectors);
+    return r;
+}
+
+#ifndef URF_SPLIT_WAVES_PER_EU
+#define URF_SPLIT_WAVES_PER_EU 6   /* 73 VGPRs without spills; A/B on one box: 4 -> 1.39 ms, 6 -> 1.04 ms, 8 (32 B of scratch) -> 1.12 ms */
+#endif
+__global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_SPLIT_WAVES_PER_EU, URF_SPLIT_WAVES_PER_EU))) void k_split(urf_kargs a, urf_dev_params dp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_raw[];
     const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
@@ -389,149 +425,119 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_split(urf_kargs a, urf_dev
     const float interval = dp.p.interval;
     /* Ring, float fast path (urf_device.hpp) unless the stage capture wants the exact angle: with
      * |vt - alpha| <= e, entries below vt - interval - e surely do not match, an entry within
-     * interval - e surely does, one beyond interval + e surely does not. */
+     * interval - e surely does, one beyond interval + e surely does not.
+     *
+     * Main pass: only what the approximations decide, and without per-lane branches (every test is
+     * a select: the wave executes both sides of a divergent branch anyway, and the exec-mask
+     * bookkeeping of the branches cost more scalar instructions than the tests cost vector ones).
+     * A point whose ring or sector the approximations leave open (or every point, when the stage
+     * capture wants exact angles) is listed and takes the reference's exact sequence in a second,
+     * dense pass: the exact code exists once instead of four times in the unrolled loop, and its
+     * f64 chains never run with two lanes of a wave. */
     const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;   /* + rounding of fl(angle[j] - alpha) */
     const bool exact_all = a.capture == 1;
-    bool roi[Q], fast[Q];
-    float vt[Q];
-    unsigned lo[Q];
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const unsigned i = tbase + wave * 256 + q * 64 + lane;
-        roi[q] = i < len && urf_in_roi(dp.p, px[q], py[q], pz[q]);
-        vt[q] = 0.f;
-        fast[q] = roi[q] && !exact_all && urf_fast_vertical_angle(px[q], py[q], pz[q], &vt[q]);
-    }
-    /* lo = number of table entries surely below the point's window: the cell's count from the
-     * lookup table, plus the (usually zero or one) entries between the cell's start and the angle */
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const unsigned cell = (unsigned)(vt[q] * URF_LUT_SCALE);   /* vt in [0, 180] */
-        lo[q] = lut[cell < URF_LUT_CELLS - 1 ? cell : URF_LUT_CELLS - 1];
-    }
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const float tv = tab[lo[q] & (URF_MAX_CHANNELS - 1)];
-        if (lo[q] < nR && !(tv - vt[q] >= -(interval + e)))
-            lo[q]++;
-    }
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++)
-        while (lo[q] < nR && !(tab[lo[q] & (URF_MAX_CHANNELS - 1)] - vt[q] >= -(interval + e)))
-            lo[q]++;
-    /* Main pass: only what the approximations decide.  A point whose ring or sector they leave open
-     * (or every point, when the stage capture wants exact angles) is listed and takes the reference's
-     * exact sequence in a second, dense pass: the exact code exists once instead of four times in
-     * the unrolled loop, and its f64 chains never run with two lanes of a wave. */
+    unsigned rkey[Q], skey[Q];
+    unsigned openmask = 0;   /* bit q: point q of this thread is on the pending list */
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
         const unsigned li = wave * 256 + q * 64 + lane, i = tbase + li;
         const bool valid = i < len;
-        const float x = px[q], y = py[q];
-        unsigned key = URF_SEC_NONE, rkey = URF_RING_NONE;
-        bool open = false;
-        if (roi[q]) {
-            open = true;
-            if (fast[q]) {
-                const float tv = tab[lo[q] & (URF_MAX_CHANNELS - 1)];
-                if (lo[q] >= nR || tv - vt[q] > interval + e) {
-                    open = false;                         /* no entry can match */
-                } else if (__builtin_fabsf(tv - vt[q]) <= interval - e) {
-                    open = false;                         /* the first candidate surely matches */
-                    rkey = lo[q];
-                }
-            }
-            if (star && !open) {
-                const int fs = urf_fast_sector(x, y, dp.Kfi, K, dp.sector_margin);
-                open = fs < 0;
-                key = (unsigned)fs;
-                if (!open && dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
-                    key = URF_SEC_NONE;
-            }
+        const float x = px[q], y = py[q], z = pz[q];
+        const bool roi = valid & urf_in_roi(dp.p, x, y, z);
+        float vt;
+        const bool fast = urf_fast_vertical_angle(x, y, z, &vt) & roi & !exact_all;
+        vt = fast ? vt : 0.f;
+        /* lo = number of table entries surely below the point's window: the cell's count from the
+         * lookup table, plus up to two entries between the cell's start and the angle (a third one
+         * is rare and left to the exact pass) */
+        const unsigned cell = (unsigned)(vt * URF_LUT_SCALE);   /* vt in [0, 180] */
+        unsigned lo = lut[cell < URF_LUT_CELLS - 1 ? cell : URF_LUT_CELLS - 1];
+        float tv = tab[lo & (URF_MAX_CHANNELS - 1)];
+        lo += (lo < nR) & !(tv - vt >= -(interval + e));
+        tv = tab[lo & (URF_MAX_CHANNELS - 1)];
+        lo += (lo < nR) & !(tv - vt >= -(interval + e));
+        tv = tab[lo & (URF_MAX_CHANNELS - 1)];
+        const bool unsettled = (lo < nR) & !(tv - vt >= -(interval + e));
+        const float d = tv - vt;
+        const bool none = (lo >= nR) | (d > interval + e);                        /* no entry can match */
+        const bool match = !none & (__builtin_fabsf(d) <= interval - e);         /* the first candidate surely matches */
+        bool open = roi & (!fast | unsettled | !(none | match));
+        unsigned rk = match ? lo : URF_RING_NONE, sk = URF_SEC_NONE;
+        if (star) {
+            const int fs = urf_fast_sector(x, y, dp.Kfi, K, dp.sector_margin);
+            open = open | (roi & (fs < 0));
+            sk = (unsigned)fs;
+            if (dp.p.starbeam_filter && !urf_in_beam(a.beams[fs < 0 ? 0 : fs], x, y))
+                sk = URF_SEC_NONE;
         }
-        if (open)
+        const bool settled = roi & !open;
+        rkey[q] = settled ? rk : URF_RING_NONE;
+        skey[q] = settled ? sk : URF_SEC_NONE;
+        if (open) {
             pending[atomicAdd(&misc[1], 1u)] = (uint16_t)li;
-        else {
-            keyr[li] = (uint8_t)rkey;
-            keys[li] = (uint16_t)key;
+            openmask |= 1u << q;
         }
         if (valid) {
-            a.labels[off + i] = roi[q] ? URF_FLAG_ROI : 0;
-            if (exact_all && !roi[q])
+            a.labels[off + i] = roi ? URF_FLAG_ROI : 0;
+            if (exact_all && !roi)
                 a.valpha[sb + i] = -1.0f;   /* stage capture only */
         }
-        const unsigned long long rb = __ballot(roi[q]);
+        const unsigned long long rb = __ballot(roi);
         if (lane == 0 && rb)
             atomicAdd(&misc[0], (unsigned)__popcll(rb));
+#ifdef URF_SPLIT_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);   /* one point at a time: keeps the live ranges of the four unrolled iterations apart */
+#endif
     }
     __syncthreads();
     const unsigned np = misc[1];
     for (unsigned k = tid; k < np; k += URF_TILE_THREADS) {
         const unsigned li = pending[k], i = tbase + li;
         const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
-        const float va = urf_vertical_angle(x, y, z);
-        /* lidar_segmentation.cpp:226-233: first sorted table entry within `interval`.
-         * fl(angle[j] - alpha) is monotone in angle[j], so the matching entries are contiguous
-         * and the first one is found by bisection with the very same float predicate. */
-        unsigned rkey = URF_RING_NONE, key = URF_SEC_NONE;
-        unsigned l2 = 0, h2 = nR;
-        while (l2 < h2) {
-            const unsigned mid = (l2 + h2) >> 1;
-            if (tab[mid] - va >= -interval)
-                h2 = mid;
-            else
-                l2 = mid + 1;
-        }
-        if (l2 < nR && __builtin_fabsf(tab[l2] - va) <= interval)
-            rkey = l2;
-        if (star) {
-            key = urf_sector(x, y, dp.Kfi, K);
-            if (dp.p.starbeam_filter && !urf_in_beam(a.beams[key], x, y))
-                key = URF_SEC_NONE;
-        }
+        const urf_exact_key ek = urf_exact_keys(tab, nR, interval, x, y, z, star ? K : 0u, dp.Kfi);
+        unsigned sk = ek.sector;
+        if (star && dp.p.starbeam_filter && !urf_in_beam(a.beams[sk], x, y))
+            sk = URF_SEC_NONE;
         if (exact_all)
-            a.valpha[sb + i] = va;   /* stage capture only */
-        keyr[li] = (uint8_t)rkey;
-        keys[li] = (uint16_t)key;
+            a.valpha[sb + i] = ek.valpha;   /* stage capture only */
+        keyr[li] = (uint8_t)ek.ring;
+        keys[li] = (uint16_t)sk;
     }
     __syncthreads();
 
-    /* step 1: ranks inside the wave's own 256 points (LDS read-modify-write by the key's
-     * leader lane; one wave touches only its own row, in program order) */
-    unsigned rkey[Q], skey[Q], rrank[Q], srank[Q];
+    /* step 1: ranks inside the wave's own 256 points.  The lanes of a step that share a key read
+     * the key's running count (one LDS address: a broadcast), the first of them adds the group's
+     * size; a wave touches only its own row, in program order. */
+    unsigned rrank[Q], srank[Q];
     uint16_t* my_r = wcnt_r + wave * C;
     uint16_t* my_s = wcnt_s + wave * K;
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
         const unsigned li = wave * 256 + q * 64 + lane, i = tbase + li;
-        rkey[q] = (unsigned)keyr[li];
-        skey[q] = star ? (unsigned)keys[li] : URF_SEC_NONE;
+        if (openmask & (1u << q)) {   /* decided by the exact pass */
+            rkey[q] = (unsigned)keyr[li];
+            skey[q] = star ? (unsigned)keys[li] : URF_SEC_NONE;
+        }
         if (a.capture && i < len) {   /* stage capture only */
             a.ringkey[sb + i] = (uint8_t)rkey[q];
             a.seckey[sb + i] = (uint16_t)skey[q];
         }
         {
-            const unsigned mk = rkey[q] == URF_RING_NONE ? C : rkey[q];
-            const unsigned long long m = urf_match_any_fast(mk, dp.ring_keybits);
-            const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
-            unsigned old = 0;
-            if (rkey[q] != URF_RING_NONE && leader == lane) {
-                old = my_r[rkey[q]];
+            const bool on = rkey[q] != URF_RING_NONE;
+            const unsigned long long m = urf_match_any_fast(on ? rkey[q] : C, dp.ring_keybits);
+            const unsigned old = my_r[on ? rkey[q] : 0];
+            if (on && urf_is_leader(m))
                 my_r[rkey[q]] = (uint16_t)(old + (unsigned)__popcll(m));
-            }
-            rrank[q] = (unsigned)__shfl((int)old, (int)leader) + urf_popc_below(m);
+            rrank[q] = old + urf_popc_below(m);
         }
         srank[q] = 0;
         if (star) {
-            const unsigned mk = skey[q] == URF_SEC_NONE ? K : skey[q];
-            const unsigned long long m = urf_match_any_fast(mk, dp.sec_keybits);
-            const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
-            unsigned old = 0;
-            if (skey[q] != URF_SEC_NONE && leader == lane) {
-                old = my_s[skey[q]];
+            const bool on = skey[q] != URF_SEC_NONE;
+            const unsigned long long m = urf_match_any_fast(on ? skey[q] : K, dp.sec_keybits);
+            const unsigned old = my_s[on ? skey[q] : 0];
+            if (on && urf_is_leader(m))
                 my_s[skey[q]] = (uint16_t)(old + (unsigned)__popcll(m));
-            }
-            srank[q] = (unsigned)__shfl((int)old, (int)leader) + urf_popc_below(m);
+            srank[q] = old + urf_popc_below(m);
         }
     }
     __syncthreads();
@@ -597,9 +603,16 @@ __global__ __launch_bounds__(URF_TILE_THREADS) void k_split(urf_kargs a, urf_dev
     /* step 4: slot in the tile's ring-sorted order (lp) and sector-sorted order (sp) */
     unsigned lp[Q], sp[Q];
 #pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        lp[q] = rkey[q] != URF_RING_NONE ? koff[rkey[q]] + my_r[rkey[q]] + rrank[q] : 0xffffffffu;
-        sp[q] = skey[q] != URF_SEC_NONE ? soff[skey[q]] + my_s[skey[q]] + srank[q] : 0xffffffffu;
+    for (unsigned q = 0; q < Q; q++) {   /* unconditional reads (entry 0 for "none"), then a select */
+        const bool ron = rkey[q] != URF_RING_NONE, son = skey[q] != URF_SEC_NONE;
+        const unsigned rk = ron ? rkey[q] : 0, sk = son ? skey[q] : 0;
+        const unsigned lr = koff[rk] + my_r[rk] + rrank[q];
+        lp[q] = ron ? lr : 0xffffffffu;
+        sp[q] = 0xffffffffu;
+        if (star) {
+            const unsigned ls = soff[sk] + my_s[sk] + srank[q];
+            sp[q] = son ? ls : 0xffffffffu;
+        }
     }
     __syncthreads();   /* keys and wcnt are dead: their memory becomes the staging buffers */
     unsigned* stx = (unsigned*)un;
@@ -686,7 +699,7 @@ __device__ void urf_scan_keys_256(const unsigned* cnt, unsigned* offs, unsigned 
  * toff[tile][key] (first slot of the key's run inside the tile, row-major, rows of nkeys + 1 u16)
  * into per-key tables: pre[key][tile] = points of the key in the tiles before (u32, [ntiles] =
  * total), start[key][tile] = toff[tile][key], optionally tpre[tile][key] = pre[key][tile], and the
- * totals cnt[key].  Blocks of 64 keys x 64 tiles are transposed through LDS so that both the
+ * totals cnt[key], for the 64 keys from k0.  Blocks of 64 keys x 64 tiles are transposed through LDS so that both the
  * reads (rows of toff) and the writes (rows of pre / start) are contiguous. */
 struct urf_index_shared {
     unsigned pre[64][65];
@@ -694,12 +707,12 @@ struct urf_index_shared {
     uint16_t st[64][66];
     unsigned carry[64];
 };
-__device__ void urf_index_family(urf_index_shared& L, const uint16_t* toff, unsigned nkeys, unsigned ntiles, unsigned tstride,
-                                 unsigned* pre, uint16_t* start, unsigned* tpre, unsigned* cnt)
+__device__ void urf_index_family(urf_index_shared& L, const uint16_t* toff, unsigned nkeys, unsigned k0, unsigned ntiles,
+                                 unsigned tstride, unsigned* pre, uint16_t* start, unsigned* tpre, unsigned* cnt)
 {
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned rowlen = nkeys + 1;
-    for (unsigned k0 = 0; k0 < nkeys; k0 += 64) {
+    if (k0 < nkeys) {   /* the block of keys [k0, k0 + 64) */
         const unsigned key = k0 + lane;
         if (tid < 64)
             L.carry[tid] = 0;
@@ -727,6 +740,7 @@ __device__ void urf_index_family(urf_index_shared& L, const uint16_t* toff, unsi
             }
             __syncthreads();
             /* rows of pre / start (wave w: keys k0 + 4 * pass + w; lane = tile) */
+#pragma unroll 4
             for (unsigned pass = 0; pass < 16; pass++) {
                 const unsigned r = pass * 4 + wave, kk = k0 + r, tt = t0 + lane;
                 if (kk < nkeys && tt < ntiles) {
@@ -735,6 +749,7 @@ __device__ void urf_index_family(urf_index_shared& L, const uint16_t* toff, unsi
                 }
             }
             if (tpre)
+#pragma unroll 4
                 for (unsigned pass = 0; pass < 16; pass++) {
                     const unsigned u = pass * 4 + wave, tt = t0 + u;
                     if (tt < ntiles && key < nkeys)
@@ -750,9 +765,28 @@ __device__ void urf_index_family(urf_index_shared& L, const uint16_t* toff, unsi
     }
 }
 
-/* One workgroup per scan: piece < 30 test (lidar_segmentation.cpp:120-126), the per-ring and
- * per-sector run tables, where every ring / sector starts in the ring-major / sector-major arrays,
- * and the work lists of the oversized sectors. */
+/* piece = number of ROI points of the scan (lidar_segmentation.cpp:120), summed by all 256 threads */
+__device__ __forceinline__ unsigned urf_scan_piece(const urf_kargs& a, unsigned s, unsigned ntiles, unsigned* sh /* [4] */)
+{
+    const unsigned tid = threadIdx.x;
+    unsigned piece = 0;
+    for (unsigned t = tid; t < ntiles; t += 256)
+        piece += a.tile_roi[(size_t)s * a.tiles + t];
+    for (int o = 32; o > 0; o >>= 1)
+        piece += __shfl_xor(piece, o);
+    if (urf_lane() == 0)
+        sh[tid >> 6] = piece;
+    __syncthreads();
+    piece = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return piece;
+}
+
+/* One workgroup per scan: piece < 30 test (lidar_segmentation.cpp:120-126); the per-ring run tables
+ * (urf_index_family) and where every ring starts in the ring-major arrays; the size of every sector
+ * (the sort kernels read a sector's runs straight from k_split's per-tile tables: a sector meets
+ * only a few tiles) and where it starts in the sector-major arrays; the work lists of the oversized
+ * sectors. */
 __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
 {
     __shared__ urf_index_shared L;
@@ -762,17 +796,8 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
     urf_scan_range(a, s, off, len);
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
-    {   /* piece = number of ROI points (lidar_segmentation.cpp:120); < 30 => nothing is published (:124) */
-        unsigned piece = 0;
-        for (unsigned t = tid; t < ntiles; t += 256)
-            piece += a.tile_roi[(size_t)s * a.tiles + t];
-        for (int o = 32; o > 0; o >>= 1)
-            piece += __shfl_xor(piece, o);
-        if (urf_lane() == 0)
-            sh[tid >> 6] = piece;
-        __syncthreads();
-        piece = sh[0] + sh[1] + sh[2] + sh[3];
-        __syncthreads();
+    {
+        const unsigned piece = urf_scan_piece(a, s, ntiles, sh);
         if (tid == 0) {
             a.info[s].n_roi = piece;
             if (piece < 30) {
@@ -783,8 +808,30 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
         if (piece < 30)
             return;
     }
-    urf_index_family(L, a.troff + (size_t)s * a.tiles * (C + 1), C, ntiles, a.tiles, a.rpre + (size_t)s * C * (a.tiles + 1),
-                     a.rstart + (size_t)s * C * a.tiles, a.tpre + (size_t)s * a.tiles * C, a.ring_cnt + (size_t)s * C);
+    if (dp.p.star_shaped_method) {
+        /* sector sizes: column sums of the per-tile tables (rows are read contiguously: thread = key,
+         * 16 tiles in flight) */
+        const uint16_t* toff = a.tsoff + (size_t)s * a.tiles * (K + 1);
+        for (unsigned k = tid; k < K; k += 256) {
+            unsigned run = 0;
+            for (unsigned t0 = 0; t0 < ntiles; t0 += 16) {
+                unsigned v0[16], v1[16];
+#pragma unroll
+                for (unsigned u = 0; u < 16; u++) {
+                    const bool in = t0 + u < ntiles;
+                    v0[u] = in ? (unsigned)toff[(size_t)(t0 + u) * (K + 1) + k] : 0u;
+                    v1[u] = in ? (unsigned)toff[(size_t)(t0 + u) * (K + 1) + k + 1] : 0u;
+                }
+#pragma unroll
+                for (unsigned u = 0; u < 16; u++)
+                    run += v1[u] - v0[u];
+            }
+            a.sec_cnt[(size_t)s * K + k] = run;
+        }
+    }
+    for (unsigned k0 = 0; k0 < C; k0 += 64)
+        urf_index_family(L, a.troff + (size_t)s * a.tiles * (C + 1), C, k0, ntiles, a.tiles, a.rpre + (size_t)s * C * (a.tiles + 1),
+                         a.rstart + (size_t)s * C * a.tiles, a.tpre + (size_t)s * a.tiles * C, a.ring_cnt + (size_t)s * C);
     urf_scan_keys_256(&a.ring_cnt[(size_t)s * C], &a.ring_off[(size_t)s * (C + 1)], C, sh, true);
     {   /* lidar_segmentation.cpp:605-608: road_probably = every point of sorted ring 10 */
         unsigned tot = 0;
@@ -803,8 +850,6 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
     }
     if (!dp.p.star_shaped_method)
         return;
-    urf_index_family(L, a.tsoff + (size_t)s * a.tiles * (K + 1), K, ntiles, a.tiles, a.spre + (size_t)s * K * (a.tiles + 1),
-                     a.sstart + (size_t)s * K * a.tiles, nullptr, a.sec_cnt + (size_t)s * K);
     urf_scan_keys_256(&a.sec_cnt[(size_t)s * K], &a.sec_off[(size_t)s * (K + 1)], K, sh, false);
     /* sectors too large for one wave's LDS tile go on the work lists of k_star_mid / k_star_big
      * (one atomic per wave, not per sector) */
@@ -938,26 +983,42 @@ __device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_
  * of that point in the sector-sorted arrays (relative to the scan) minus runP[r], so that point i
  * of the sector lives at runA[r] + i.  One wave builds the list; returns the number of runs
  * (<= number of points of the sector). */
+struct urf_run_row {   /* lane t: the sector's run in tile t (first 64 tiles): first slot and size */
+    unsigned st, cnt;
+};
+__device__ __forceinline__ urf_run_row urf_sector_run_row(const urf_kargs& a, unsigned s, unsigned K, unsigned k, unsigned t0)
+{
+    const unsigned t = t0 + urf_lane();
+    const uint16_t* row = a.tsoff + ((size_t)s * a.tiles + (t < a.tiles ? t : 0)) * (K + 1) + k;
+    urf_run_row r;
+    r.st = (unsigned)row[0];
+    r.cnt = (unsigned)row[1] - r.st;
+    return r;
+}
+/* One wave builds the list from column k of k_split's per-tile tables (a sector of an organised
+ * sweep meets two or three tiles; the 64 two-byte reads of a column block hit 64 cache lines, all of
+ * them shared with the neighbouring sectors' waves) and a prefix sum over the tiles. */
 __device__ __forceinline__ unsigned urf_sector_runs(const urf_kargs& a, unsigned s, unsigned K, unsigned k, unsigned ntiles,
-                                                    unsigned* runP, unsigned* runA)
+                                                    const urf_run_row& first, unsigned* runP, unsigned* runA)
 {
     const unsigned lane = urf_lane();
-    const unsigned* P = a.spre + ((size_t)s * K + k) * (a.tiles + 1);
-    const uint16_t* ST = a.sstart + ((size_t)s * K + k) * a.tiles;
-    unsigned nr = 0;
+    unsigned nr = 0, carry = 0;
     for (unsigned t0 = 0; t0 < ntiles; t0 += 64) {
         const unsigned t = t0 + lane;
-        const bool in = t < ntiles;
-        const unsigned p0 = in ? P[t] : 0, p1 = in ? P[t + 1] : 0;
-        const unsigned st = in ? (unsigned)ST[t] : 0;
-        const bool ne = p1 > p0;
-        const unsigned long long m = __ballot(ne);
-        if (ne) {
+        urf_run_row r = first;   /* requested by the caller along with its other inputs */
+        if (t0)
+            r = urf_sector_run_row(a, s, K, k, t0);
+        const unsigned c = t < ntiles ? r.cnt : 0;
+        const unsigned inc = urf_wave_scan_add(c);
+        const unsigned p0 = carry + inc - c;
+        const unsigned long long m = __ballot(c != 0);
+        if (c) {
             const unsigned idx = nr + urf_popc_below(m);
             runP[idx] = p0;
-            runA[idx] = t * URF_TILE + st - p0;
+            runA[idx] = t * URF_TILE + r.st - p0;
         }
         nr += (unsigned)__popcll(m);
+        carry += (unsigned)__shfl((int)inc, 63);
     }
     return nr;
 }
@@ -1203,11 +1264,13 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
     __shared__ unsigned cnt[NB + 1];                /* bucket counts, then exclusive offsets, then ring positions */
     __shared__ unsigned sh_first;
     const unsigned k = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
-    if (a.info[s].status != URF_OK)
-        return;
     const unsigned K = (unsigned)dp.p.sectors;
-    /* both ends of the sector in one round trip (sec_cnt, then sec_off would be two) */
+    /* status, both ends of the sector and its run table in ONE round trip */
+    const int status = a.info[s].status;
     const unsigned so0 = a.sec_off[(size_t)s * (K + 1) + k], so1 = a.sec_off[(size_t)s * (K + 1) + k + 1];
+    const urf_run_row row = urf_sector_run_row(a, s, K, k, 0);
+    if (status != URF_OK)
+        return;
     const unsigned n = so1 - so0;
     if (n > 512)
         return;   /* on a work list (k_index) */
@@ -1221,7 +1284,7 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
     const unsigned sb = urf_sbase(a, s), obase = sb + so0;
     if (lane == 0)
         sh_first = n;
-    const unsigned nruns = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, (unsigned*)A, (unsigned*)A + 512);
+    const unsigned nruns = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, row, (unsigned*)A, (unsigned*)A + 512);
     __syncthreads();
     /* per-lane element count fixed at compile time: 6 covers a sector of a 64 x 2048 sweep */
     if (n <= 384)
@@ -1414,7 +1477,7 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_karg
         unsigned* runP = (unsigned*)A;
         unsigned* runA = runP + URF_STAR_MID_CAP;
         if (tid < 64) {
-            const unsigned nr = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, runP, runA);
+            const unsigned nr = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, urf_sector_run_row(a, s, K, k, 0), runP, runA);
             if (tid == 0) {
                 sh_nruns = nr;
                 sh_first = n;
@@ -1450,6 +1513,8 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_karg
 __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_params dp)
 {
     __shared__ unsigned sh_first;
+    __shared__ unsigned P[URF_MAX_TILES + 1];   /* the sector's points in the tiles before t */
+    __shared__ uint16_t ST[URF_MAX_TILES];      /* first slot of its run in tile t */
     const unsigned K = (unsigned)dp.p.sectors;
     const unsigned count = a.star_count[1];
     const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
@@ -1461,8 +1526,23 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
         const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
         const unsigned n = a.sec_cnt[(size_t)s * K + k];
         const unsigned sb = urf_sbase(a, s), base = sb + a.sec_off[(size_t)s * (K + 1) + k];
-        const unsigned* P = a.spre + ((size_t)s * K + k) * (a.tiles + 1);
-        const uint16_t* ST = a.sstart + ((size_t)s * K + k) * a.tiles;
+        if (threadIdx.x < 64) {   /* one wave: column k of the per-tile tables, prefix over the tiles */
+            unsigned carry = 0;
+            for (unsigned t0 = 0; t0 < ntiles; t0 += 64) {
+                const unsigned t = t0 + threadIdx.x;
+                const urf_run_row r = urf_sector_run_row(a, s, K, k, t0);
+                const unsigned c = t < ntiles ? r.cnt : 0;
+                const unsigned inc = urf_wave_scan_add(c);
+                if (t < ntiles) {
+                    P[t] = carry + inc - c;
+                    ST[t] = (uint16_t)r.st;
+                }
+                carry += (unsigned)__shfl((int)inc, 63);
+            }
+            if (threadIdx.x == 0)
+                P[ntiles] = carry;
+        }
+        __syncthreads();
         float* R = a.big_r + base;
         float* Z = a.big_z + base;
         unsigned* I = a.big_i + base;
@@ -1790,13 +1870,16 @@ struct urf_ring_map {
 
 /* x_zero_method.cpp:30-68 for the triple (j, p, j + cp), j = p - cp / 2, given the cheap height
  * tests passed.  (xj, yj) / (x3, y3): planar coordinates of the points j and j + cp. */
-__device__ __forceinline__ bool urf_x_zero_angle(const urf_kargs& a, const urf_dev_params& dp, float xj, float yj, float x3, float y3,
-                                                 int j, int p, int cp, float zj, float pz, float z3)
+/* (The angle tests and the exact azimuth are NOT inlined: only the few points that pass the cheap
+ * height tests get here, and inlined their f64 code dictates the kernel's register allocation --
+ * k_ring spilled 52..80 bytes per lane with them inside.) */
+__device__ __noinline__ bool urf_x_zero_angle(const float* newY, float angleFilter1, float xj, float yj, float x3, float y3,
+                                              int j, int p, int cp, float zj, float pz, float z3)
 {
     const double dx = (double)(x3 - xj), dy = (double)(y3 - yj);
     if (!(dx * dx + dy * dy < URF_DIST5_SQ))                                    /* :35-40 */
         return false;
-    const float nyj = a.newY[j], ny2 = a.newY[p], ny3 = a.newY[j + cp];
+    const float nyj = newY[j], ny2 = newY[p], ny3 = newY[j + cp];
     double u, v;
     u = (double)(ny2 - nyj); v = (double)(pz - zj);
     const float x1 = (float)__builtin_sqrt(u * u + v * v);
@@ -1812,13 +1895,13 @@ __device__ __forceinline__ bool urf_x_zero_angle(const urf_kargs& a, const urf_d
     else if (br > 1.0f)
         br = 1.0f;
     const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));   /* :58 */
-    return alpha <= dp.p.angleFilter1;                                          /* :61 */
+    return alpha <= angleFilter1;                                               /* :61 */
 }
 
 /* z_zero_method.cpp:21-66 for the centre p, given the height tests passed.  xy(r, x, y) delivers the
  * planar coordinates of ring position r (an LDS window or a gather from the ring-sorted arrays). */
 template <class FXY>
-__device__ __forceinline__ bool urf_z_zero_angle(const urf_dev_params& dp, FXY xy, int p, int cp, float px, float py)
+__device__ __forceinline__ bool urf_z_zero_angle(float inv_cp, float angleFilter2, FXY xy, int p, int cp, float px, float py)
 {
     float xa, ya, xb, yb;
     xy(p + cp, xb, yb);
@@ -1839,10 +1922,10 @@ __device__ __forceinline__ bool urf_z_zero_angle(const urf_dev_params& dp, FXY x
         vb1 = vb1 + (x - px);
         vb2 = vb2 + (y - py);
     }
-    va1 = dp.inv_cp * va1;                                                      /* :52-55 */
-    va2 = dp.inv_cp * va2;
-    vb1 = dp.inv_cp * vb1;
-    vb2 = dp.inv_cp * vb2;
+    va1 = inv_cp * va1;                                                         /* :52-55 */
+    va2 = inv_cp * va2;
+    vb1 = inv_cp * vb1;
+    vb2 = inv_cp * vb2;
     const float num = va1 * vb1 + va2 * vb2;
     const double na = __builtin_sqrt((double)va1 * (double)va1 + (double)va2 * (double)va2);
     const double nb = __builtin_sqrt((double)vb1 * (double)vb1 + (double)vb2 * (double)vb2);
@@ -1852,20 +1935,44 @@ __device__ __forceinline__ bool urf_z_zero_angle(const urf_dev_params& dp, FXY x
     else if (br > 1.0f)
         br = 1.0f;
     const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));   /* :63 */
-    return alpha <= dp.p.angleFilter2;                                          /* :66 */
+    return alpha <= angleFilter2;                                               /* :66 */
+}
+
+/* the two instances k_ring uses: operands gathered from the ring-sorted arrays through the ring's
+ * map (quad mapping), or read from an LDS window whose element 0 is ring position `origin` */
+__device__ __noinline__ bool urf_z_zero_angle_gather(const float* rx, const float* ry, const unsigned* P, const unsigned* A,
+                                                     unsigned ntiles, float scale, float inv_cp, float angleFilter2, int p, int cp,
+                                                     float px, float py)
+{
+    const urf_ring_map map = { P, A, ntiles, scale };
+    auto gxy = [&](int r, float& x, float& y) {
+        const unsigned idx = map.at((unsigned)r);
+        x = rx[idx];
+        y = ry[idx];
+    };
+    return urf_z_zero_angle(inv_cp, angleFilter2, gxy, p, cp, px, py);
+}
+__device__ __noinline__ bool urf_z_zero_angle_window(const float* xs, const float* ys, int origin, float inv_cp, float angleFilter2,
+                                                     int p, int cp, float px, float py)
+{
+    auto lxy = [&](int r, float& x, float& y) {
+        x = xs[r - origin];
+        y = ys[r - origin];
+    };
+    return urf_z_zero_angle(inv_cp, angleFilter2, lxy, p, cp, px, py);
 }
 
 /* exact azimuth (and planar range when captured) of one point and its entry in the curb tables
  * (lidar_segmentation.cpp:245-269, blind_spots.cpp:19-56); returns the azimuth.
  * maxDistance (:271-274) is the largest float(sqrt(double s)), s = x^2 + y^2: both roundings
  * are monotone, so the callers track the largest s instead. */
-__device__ __forceinline__ float urf_ring_point(const urf_kargs& a, urf_ring_shared& S, size_t gpos, float px, float py,
-                                                unsigned flag, bool want_quad)
+__device__ __noinline__ float urf_ring_point(float* rd2, urf_ring_shared& S, size_t gpos, float px, float py,
+                                             unsigned flag, bool want_quad)
 {
     float d2;
     const float az = urf_azimuth(px, py, &d2);
-    if (a.rd2)
-        a.rd2[gpos] = d2;
+    if (rd2)
+        rd2[gpos] = d2;
     if (flag && az == az) {
         /* curb point: per-degree tables for the beam march.  The azimuth lies in [0,360];
          * cell_lo = largest integer <= az, cell_hi = smallest integer >= az. */
@@ -1900,31 +2007,43 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
     int* const cmax = S.cmax;
     int* const sh_q = S.q;
     const unsigned c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
+    const bool star = dp.p.star_shaped_method != 0;
+    /* Everything the workgroup needs before it can start is requested at once (scan summary, the
+     * ring's size and place, the first 128 entries of its run table, the first 384 star-shaped
+     * hits): a chain of dependent round trips cost a fifth of a workgroup's life. */
     const urf_scan_info in = a.info[s];
-    if (in.status != URF_OK || c >= in.n_rings)
-        return;
+    const int n = (int)a.ring_cnt[(size_t)s * C + c];
+    const unsigned ro = a.ring_off[(size_t)s * (C + 1) + c];   /* multiple of 4 */
+    const unsigned* gp = a.rpre + ((size_t)s * C + c) * (a.tiles + 1);
+    const uint16_t* gs = a.rstart + ((size_t)s * C + c) * a.tiles;
+    const unsigned pt0 = tid <= a.tiles ? gp[tid] : 0;
+    const unsigned st0 = tid < a.tiles ? (unsigned)gs[tid] : 0;
+    unsigned h0[3];
+#pragma unroll
+    for (unsigned u = 0; u < 3; u++)
+        h0[u] = star && tid + u * URF_RING_THREADS < K ? (unsigned)a.star_hit[(size_t)s * K + tid + u * URF_RING_THREADS] : 0xffffffffu;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
+    if (in.status != URF_OK || c >= in.n_rings)
+        return;
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
-    const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
-    const int n = (int)a.ring_cnt[(size_t)s * C + c];
     const unsigned sb = urf_sbase(a, s);
-    const unsigned ro = a.ring_off[(size_t)s * (C + 1) + c];   /* multiple of 4 */
     const unsigned base = sb + ro;                              /* the ring in the ring-major arrays (raz, rflag) */
     const int cp = dp.p.curbPoints;
-    const bool star = dp.p.star_shaped_method != 0;
     const bool want_quad = (c == 1) && dp.p.blind_spots;
     unsigned* const mapP = sh_ring_tab;
     unsigned* const mapA = sh_ring_tab + a.tiles + 1;
-    {
-        const unsigned* gp = a.rpre + ((size_t)s * C + c) * (a.tiles + 1);
-        const uint16_t* gs = a.rstart + ((size_t)s * C + c) * a.tiles;
-        for (unsigned t = tid; t <= ntiles; t += URF_RING_THREADS) {
-            const unsigned pt = gp[t];
-            mapP[t] = pt;
-            if (t < ntiles)
-                mapA[t] = sb + t * URF_TILE + gs[t] - pt;
-        }
+    if (tid <= ntiles) {
+        mapP[tid] = pt0;
+        if (tid < ntiles)
+            mapA[tid] = sb + tid * URF_TILE + st0 - pt0;
+    }
+    for (unsigned t = tid + URF_RING_THREADS; t <= ntiles; t += URF_RING_THREADS) {
+        const unsigned pt = gp[t];
+        mapP[t] = pt;
+        if (t < ntiles)
+            mapA[t] = sb + t * URF_TILE + gs[t] - pt;
     }
     const urf_ring_map map = { mapP, mapA, ntiles, (float)ntiles / (float)(n > 0 ? n : 1) };
 
@@ -1945,8 +2064,12 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
     }
     __syncthreads();
     if (star) {   /* lidar_segmentation.cpp:241-242: the star-shaped hits that lie on this ring */
-        for (unsigned k = tid; k < K; k += URF_RING_THREADS) {
-            const unsigned h = (unsigned)a.star_hit[(size_t)s * K + k];   /* ring-major position (scan-relative) or 0xffffffff */
+#pragma unroll
+        for (unsigned u = 0; u < 3; u++)   /* ring-major positions (scan-relative) or 0xffffffff */
+            if (h0[u] >= ro && h0[u] < ro + (unsigned)n)
+                S.hits[atomicAdd(&S.n_hits, 1u)] = h0[u] - ro;
+        for (unsigned k = tid + 3 * URF_RING_THREADS; k < K; k += URF_RING_THREADS) {
+            const unsigned h = (unsigned)a.star_hit[(size_t)s * K + k];
             if (h >= ro && h < ro + (unsigned)n)
                 S.hits[atomicAdd(&S.n_hits, 1u)] = h - ro;
         }
@@ -1962,33 +2085,61 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
     unsigned buf = 0;
 
     /* The next chunk's points are requested from memory before the current chunk is evaluated and
-     * parked in LDS after it: the evaluation hides the latency. */
-    constexpr int NS = (CH + 2 * URF_MAX_CURB_POINTS + URF_RING_THREADS - 1) / URF_RING_THREADS;
-    float fx[NS], fy[NS], fz[NS];
+     * parked in LDS after it: the evaluation hides the latency.  A thread fetches quads of
+     * consecutive ring positions [cs - PAD + 4q, +4): inside one run of the tile-local layout and
+     * 16-byte aligned (an organised sweep: always) that is one 16-byte load per array, otherwise
+     * four mapped ones. */
+    constexpr int NSQ = (CH + 2 * PAD + 4 * URF_RING_THREADS - 1) / (4 * URF_RING_THREADS);
+    float4 fx[NSQ], fy[NSQ], fz[NSQ];
     auto fetch = [&](int cs) {
 #pragma unroll
-        for (int m = 0; m < NS; m++) {
-            const int j = cs - cp + (int)tid + m * URF_RING_THREADS;
-            const bool on = j >= 0 && j < n && j < cs + CH + cp;
-            unsigned idx = 0;
-            if (on)
-                idx = map.at((unsigned)j);
-            fx[m] = on ? a.rx[idx] : 0.f;
-            fy[m] = on ? a.ry[idx] : 0.f;
-            fz[m] = on ? a.rz[idx] : 0.f;
+        for (int m = 0; m < NSQ; m++) {
+            const int j = cs - PAD + 4 * ((int)tid + m * URF_RING_THREADS);
+            fx[m] = fy[m] = fz[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j + 3 < 0 || j >= n || j + 3 < cs - cp || j >= cs + CH + cp)
+                continue;   /* outside the ring or outside the chunk's halo */
+            bool wide = false;
+            if (j >= 0 && j + 3 < n) {
+                const unsigned t = map.tile((unsigned)j);
+                const unsigned idx = mapA[t] + (unsigned)j;
+                if ((unsigned)j + 3 < mapP[t + 1] && (idx & 3u) == 0) {
+                    wide = true;
+                    fx[m] = *(const float4*)(a.rx + idx);
+                    fy[m] = *(const float4*)(a.ry + idx);
+                    fz[m] = *(const float4*)(a.rz + idx);
+                }
+            }
+            if (!wide) {
+                float ex[4] = { 0.f, 0.f, 0.f, 0.f }, ey[4] = { 0.f, 0.f, 0.f, 0.f }, ez[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int e4 = 0; e4 < 4; e4++)
+                    if (j + e4 >= 0 && j + e4 < n) {
+                        const unsigned idx = map.at((unsigned)(j + e4));
+                        ex[e4] = a.rx[idx];
+                        ey[e4] = a.ry[idx];
+                        ez[e4] = a.rz[idx];
+                    }
+                fx[m] = make_float4(ex[0], ex[1], ex[2], ex[3]);
+                fy[m] = make_float4(ey[0], ey[1], ey[2], ey[3]);
+                fz[m] = make_float4(ez[0], ez[1], ez[2], ez[3]);
+            }
         }
     };
     fetch(cs0);
     for (int cs = cs0; cs < n; cs += CH, buf ^= 1u) {
-        /* park [cs - cp, cs + CH + cp), mark the star hits of the chunk, clear the other bitmap */
+        /* park [cs - PAD, cs + CH + PAD) (positions outside the ring hold zeros nobody reads), mark
+         * the star hits of the chunk, clear the other bitmap */
         {
 #pragma unroll
-            for (int m = 0; m < NS; m++) {
-                const int li = (int)tid + m * URF_RING_THREADS - cp, j = cs + li;
-                if (j >= 0 && j < n && li < CH + cp) {
-                    S.xs[li + PAD] = fx[m];
-                    S.ys[li + PAD] = fy[m];
-                    S.zs[li + zpad] = fz[m];
+            for (int m = 0; m < NSQ; m++) {
+                const int li = 4 * ((int)tid + m * URF_RING_THREADS);   /* slot of position cs - PAD + li */
+                if (li < CH + 2 * PAD) {
+                    *(float4*)(S.xs + li) = fx[m];
+                    *(float4*)(S.ys + li) = fy[m];
+                    S.zs[li + zpad - PAD] = fz[m].x;
+                    S.zs[li + zpad - PAD + 1] = fz[m].y;
+                    S.zs[li + zpad - PAD + 2] = fz[m].z;
+                    S.zs[li + zpad - PAD + 3] = fz[m].w;
                 }
             }
             for (unsigned i = tid; i < nh; i += URF_RING_THREADS) {
@@ -2073,11 +2224,6 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
             __syncthreads();
             if (S.n_cand > URF_RING_CAND - CH || cs + CH >= n) {   /* the next chunk might not fit / last chunk */
                 const unsigned nc = S.n_cand;
-                auto gxy = [&](int r, float& x, float& y) {   /* operands come from the ring-sorted arrays (L2) */
-                    const unsigned idx = map.at((unsigned)r);
-                    x = a.rx[idx];
-                    y = a.ry[idx];
-                };
                 for (unsigned e = tid; e < nc; e += URF_RING_THREADS) {
                     const unsigned v = S.cand[e], t = v >> URF_CAND_SHIFT;
                     const int p = (int)(v & ((1u << URF_CAND_SHIFT) - 1u));
@@ -2086,13 +2232,15 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                     unsigned flag = (t & URF_CAND_STAR) ? 1u : 0u;
                     if (t & URF_CAND_XZERO) {   /* j = p - 2 and j + cp = p + 3 exist (height tests passed) */
                         const unsigned ij = map.at((unsigned)(p - 2)), i3 = map.at((unsigned)(p + 3));
-                        if (urf_x_zero_angle(a, dp, a.rx[ij], a.ry[ij], a.rx[i3], a.ry[i3], p - 2, p, 5, a.rz[ij], a.rz[ip], a.rz[i3]))
+                        if (urf_x_zero_angle(a.newY, dp.p.angleFilter1, a.rx[ij], a.ry[ij], a.rx[i3], a.ry[i3], p - 2, p, 5, a.rz[ij],
+                                             a.rz[ip], a.rz[i3]))
                             flag |= 2u;
                     }
-                    if ((t & URF_CAND_ZZERO) && urf_z_zero_angle(dp, gxy, p, 5, px, py))
+                    if ((t & URF_CAND_ZZERO) &&   /* operands come from the ring-sorted arrays (L2) */
+                        urf_z_zero_angle_gather(a.rx, a.ry, mapP, mapA, ntiles, map.scale, dp.inv_cp, dp.p.angleFilter2, p, 5, px, py))
                         flag |= 4u;
                     if (flag || (t & URF_CAND_EXACT)) {
-                        a.raz[base + p] = urf_ring_point(a, S, (size_t)base + p, px, py, flag, want_quad);
+                        a.raz[base + p] = urf_ring_point(a.rd2, S, (size_t)base + p, px, py, flag, want_quad);
                         a.rflag[base + p] = (uint8_t)flag;
                     }
                 }
@@ -2122,8 +2270,8 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                         const bool heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight ||
                                               __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
                                              (double)__builtin_fabsf(zj - z3) >= 0.05;          /* :62-64 */
-                        if (heights && urf_x_zero_angle(a, dp, S.xs[j - cs + PAD], S.ys[j - cs + PAD], S.xs[j + cp - cs + PAD],
-                                                        S.ys[j + cp - cs + PAD], j, p, cp, zj, pz, z3))
+                        if (heights && urf_x_zero_angle(a.newY, dp.p.angleFilter1, S.xs[j - cs + PAD], S.ys[j - cs + PAD],
+                                                        S.xs[j + cp - cs + PAD], S.ys[j + cp - cs + PAD], j, p, cp, zj, pz, z3))
                             flag |= 2u;
                     }
                 }
@@ -2140,15 +2288,11 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                         }
                         const bool heights = (max1 - az >= dp.p.curbHeight || max2 - az >= dp.p.curbHeight) &&
                                              (double)__builtin_fabsf(max1 - max2) >= 0.05;      /* :67-69 */
-                        auto lxy = [&](int r, float& x, float& y) {
-                            x = S.xs[r - cs + PAD];
-                            y = S.ys[r - cs + PAD];
-                        };
-                        if (heights && urf_z_zero_angle(dp, lxy, p, cp, px, py))
+                        if (heights && urf_z_zero_angle_window(S.xs, S.ys, cs - PAD, dp.inv_cp, dp.p.angleFilter2, p, cp, px, py))
                             flag |= 4u;
                     }
                 }
-                const float az = urf_ring_point(a, S, (size_t)base + p, px, py, flag, want_quad);
+                const float az = urf_ring_point(a.rd2, S, (size_t)base + p, px, py, flag, want_quad);
                 const double s2 = (double)px * (double)px + (double)py * (double)py;
                 maxs = s2 > maxs ? s2 : maxs;
                 a.raz[base + p] = az;
@@ -2394,23 +2538,28 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     const unsigned tbase = t * URF_TILE;
     if (tbase >= len)
         return;
+    const unsigned C = (unsigned)dp.p.channels;
+    const size_t row = (size_t)s * a.tiles + t;
+    const unsigned sb = urf_sbase(a, s);
+    constexpr unsigned Q = URF_TILE / URF_LABEL_TILE_THREADS;
+    /* The scan summary and the tile's run table are requested together (run of ring `tid` inside the
+     * tile's ring-sorted order: starts at slot troff[tid]; its first point is point tpre[tid] of the
+     * ring).  (Also requesting the beam masks and the slots' input indices up front was measured:
+     * no gain, and beyond 72 registers the kernel loses a resident workgroup.) */
     const urf_scan_info in = a.info[s];
+    const unsigned v_koff = tid <= C ? (unsigned)a.troff[row * (C + 1) + tid] : 0;
+    const unsigned v_base = tid < C ? a.ring_off[(size_t)s * (C + 1) + tid] + a.tpre[row * C + tid] : 0;
     if (in.status != URF_OK) {
         /* nothing is published for this scan (lidar_segmentation.cpp:124-126): all labels 0 */
         for (unsigned i = tbase + tid; i < len && i < tbase + URF_TILE; i += URF_LABEL_TILE_THREADS)
             a.labels[off + i] = 0;
         return;
     }
-    const unsigned C = (unsigned)dp.p.channels, nR = in.n_rings;
-    const size_t row = (size_t)s * a.tiles + t;
-    const unsigned sb = urf_sbase(a, s);
-
+    const unsigned nR = in.n_rings;
     if (tid <= C) {
-        /* run of ring `tid` inside the tile's ring-sorted order: starts at slot troff[tid]; its first
-         * point is point tpre[tid] of the ring */
-        koff[tid] = a.troff[row * (C + 1) + tid];
+        koff[tid] = v_koff;
         if (tid < C) {
-            base_r[tid] = sb + a.ring_off[(size_t)s * (C + 1) + tid] + a.tpre[row * C + tid];
+            base_r[tid] = sb + v_base;
             qk[tid] = tid < nR ? a.qk[(size_t)s * C + tid] : 0.0;
         }
     }
@@ -2470,7 +2619,6 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     __syncthreads();
 
     unsigned my_road = 0, my_curb = 0;
-    constexpr unsigned Q = URF_TILE / URF_LABEL_TILE_THREADS;
     unsigned rc[Q], rpos[Q];
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
