@@ -182,7 +182,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.sr, T) A(k.sz, T) A(k.sslot, T) A(k.ssrt, T) A(k.wslp, T) A(k.wg, T)
     A(k.big_r, T) A(k.big_z, T) A(k.big_i, T)
     A(k.tile_roi, S * tiles) A(k.troff, S * tiles * (C + 1)) A(k.tsoff, S * tiles * (K + 1))
-    A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles) A(k.tpre, S * tiles * C)
+    A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles)
     A(k.angle, S * C) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
     A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 2)
@@ -678,31 +678,24 @@ static int fetch(urf_ctx* c, std::vector<T>& dst, const T* src, size_t count)
     return URF_OK;
 }
 
-/* For every ring-major position of scan `scan` that holds a point: the point's input index
- * (relative to the scan).  Rebuilt on the host from k_split's per-tile tables: ring c, tile t
- * contributes the ring-sorted slots [troff[t][c], troff[t][c+1]) of tile t, and the ring's points
- * before tile t number rpre[c][t]. */
-static int ring_major_sources(urf_ctx* c, uint32_t scan, uint32_t len, std::vector<uint32_t>& pos, std::vector<uint32_t>& src)
+/* The ring-sorted slots of scan `scan` that hold a point (index relative to the scan's scratch
+ * base) and the input index of each, rebuilt on the host from k_split's per-tile tables: tile t
+ * fills its first troff[t][C] slots. */
+static int ring_slot_sources(urf_ctx* c, uint32_t scan, uint32_t len, std::vector<uint32_t>& slot, std::vector<uint32_t>& src)
 {
     const urf_kargs& k = c->last_a;
     const unsigned C = (unsigned)c->last_dp.p.channels;
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     std::vector<uint16_t> troff, rsrc;
-    std::vector<uint32_t> roff, rpre;
     int rc;
     if ((rc = fetch(c, troff, k.troff + (size_t)scan * k.tiles * (C + 1), (size_t)ntiles * (C + 1))) != URF_OK) return rc;
     if ((rc = fetch(c, rsrc, k.rsrc + (size_t)scan * k.sstride, (size_t)ntiles * URF_TILE)) != URF_OK) return rc;
-    if ((rc = fetch(c, roff, k.ring_off + (size_t)scan * (C + 1), C + 1)) != URF_OK) return rc;
-    if ((rc = fetch(c, rpre, k.rpre + (size_t)scan * C * (k.tiles + 1), (size_t)C * (k.tiles + 1))) != URF_OK) return rc;
-    pos.clear();
+    slot.clear();
     src.clear();
     for (unsigned t = 0; t < ntiles; t++)
-        for (unsigned r = 0; r < C; r++) {
-            const unsigned j0 = troff[(size_t)t * (C + 1) + r], j1 = troff[(size_t)t * (C + 1) + r + 1];
-            for (unsigned j = j0; j < j1; j++) {
-                pos.push_back(roff[r] + rpre[(size_t)r * (k.tiles + 1) + t] + (j - j0));
-                src.push_back(t * URF_TILE + rsrc[(size_t)t * URF_TILE + j]);
-            }
+        for (unsigned j = 0; j < troff[(size_t)t * (C + 1) + C]; j++) {
+            slot.push_back(t * URF_TILE + j);
+            src.push_back(t * URF_TILE + rsrc[(size_t)t * URF_TILE + j]);
         }
     return URF_OK;
 }
@@ -763,22 +756,21 @@ extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* h
         if (bytes < len * esz) return URF_ERR_INVALID_ARG;
         std::memset(host_dst, 0, len * esz);
         if (in.status != URF_OK) return URF_OK;
-        std::vector<uint32_t> pos, src;
-        if ((rc = ring_major_sources(c, scan, len, pos, src)) != URF_OK) return rc;
-        uint32_t padded_total = 0;
-        URF_HIP(c, hipMemcpy(&padded_total, k.ring_off + (size_t)scan * (C + 1) + C, sizeof(padded_total), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> slot, src;
+        if ((rc = ring_slot_sources(c, scan, len, slot, src)) != URF_OK) return rc;
+        const size_t span = (size_t)((len + URF_TILE - 1) / URF_TILE) * URF_TILE;
         if (what == URF_STAGE_DETECT) {
             std::vector<uint8_t> fl;
-            if ((rc = fetch(c, fl, k.rflag + sb, padded_total)) != URF_OK) return rc;
+            if ((rc = fetch(c, fl, k.rflag + sb, span)) != URF_OK) return rc;
             uint8_t* o = (uint8_t*)host_dst;
-            for (size_t p = 0; p < pos.size(); p++)
-                o[src[p]] = fl[pos[p]] & 7u;
+            for (size_t p = 0; p < slot.size(); p++)
+                o[src[p]] = fl[slot[p]] & 7u;
         } else {
             std::vector<float> v;
-            if ((rc = fetch(c, v, (what == URF_STAGE_AZIMUTH ? k.raz : k.rd2) + sb, padded_total)) != URF_OK) return rc;
+            if ((rc = fetch(c, v, (what == URF_STAGE_AZIMUTH ? k.raz : k.rd2) + sb, span)) != URF_OK) return rc;
             float* o = (float*)host_dst;
-            for (size_t p = 0; p < pos.size(); p++)
-                o[src[p]] = v[pos[p]];
+            for (size_t p = 0; p < slot.size(); p++)
+                o[src[p]] = v[slot[p]];
         }
         return URF_OK;
     }

@@ -271,11 +271,14 @@ __device__ __forceinline__ bool urf_fast_vertical_angle(float x, float y, float 
  * sectors / 360 beyond that (urf_dev_params::sector_margin), and urf_selftest_fast measures the
  * approximation's part at the configured Kfi. */
 #define URF_FAST_SECTOR_ERR 2.5e-4f
-__device__ __forceinline__ int urf_fast_sector(float x, float y, float Kfi, unsigned sectors, float margin)
+__device__ __forceinline__ float urf_fast_polar(float x, float y)   /* polar angle in [0, 2 pi), approximately */
+{
+    const float fi = urf_fast_atan2f(y, x);
+    return fi < 0.0f ? fi + 6.28318530717958648f : fi;
+}
+__device__ __forceinline__ int urf_fast_sector_of(float fi, float x, float y, float Kfi, unsigned sectors, float margin)
 {
     const float mx = __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y));
-    float fi = urf_fast_atan2f(y, x);
-    fi = fi < 0.0f ? fi + 6.28318530717958648f : fi;
     const float u = fi * Kfi;
     const float f = __builtin_floorf(u);
     const float fr = u - f;
@@ -283,23 +286,34 @@ __device__ __forceinline__ int urf_fast_sector(float x, float y, float Kfi, unsi
                     (f < (float)sectors);
     return ok ? (int)f : -1;
 }
+__device__ __forceinline__ int urf_fast_sector(float x, float y, float Kfi, unsigned sectors, float margin)
+{
+    return urf_fast_sector_of(urf_fast_polar(x, y), x, y, Kfi, sectors, margin);
+}
 
 /* Azimuth [deg] of lidar_segmentation.cpp:245-269 (0 at -y, 90 at +x, 180 at +y, 270 at -x),
- * approximately.  The reference takes asin(|x| / d) with |x| / d rounded to float, which is
- * ill-conditioned towards the x axis: its own deviation from the true angle is up to
- * 1.2e-7 * |x|/|y| rad.  Inside |y| >= |x| / 16 that is 1.1e-4 deg, and with the other roundings
- * |approx - reference| <= URF_FAST_AZ_ERR (measured by urf_selftest_fast); closer to the x axis
- * the caller takes the exact sequence.  Not valid across the 0/360 seam, which the users treat
- * as undecided anyway (the approximation is then within the margin of an integer). */
+ * approximately: the polar angle (the one the sector comes from: k_split evaluates the arc tangent
+ * once per point) turned by a quarter.  The reference takes asin(|x| / d) with |x| / d rounded to
+ * float, which is ill-conditioned towards the x axis: its own deviation from the true angle is up
+ * to 1.2e-7 * |x|/|y| rad.  Inside |y| >= |x| / 16 (urf_fast_az_ok) that is 1.1e-4 deg, and with the
+ * other roundings |approx - reference| <= URF_FAST_AZ_ERR (measured by urf_selftest_fast); closer
+ * to the x axis the users take the exact sequence.  Not valid across the 0/360 seam, which the
+ * users treat as undecided anyway (the approximation is then within the margin of an integer). */
 #define URF_FAST_AZ_ERR 5.0e-4f
-__device__ __forceinline__ bool urf_fast_azimuth(float x, float y, float* out)
+__device__ __forceinline__ float urf_fast_azimuth_of(float fi)
+{
+    const float az = fi * 57.295779513082323f + 90.0f;
+    return az >= 360.0f ? az - 360.0f : az;
+}
+__device__ __forceinline__ bool urf_fast_az_ok(float x, float y)
 {
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-    float r = urf_fast_atan2f(x, -y);
-    if (r < 0.0f)
-        r += 6.28318530717958648f;
-    *out = r * 57.295779513082323f;
-    return ay * 16.0f >= ax && ay >= URF_FAST_MIN && ax <= URF_FAST_MAX && ay <= URF_FAST_MAX;
+    return (ay * 16.0f >= ax) & (ay >= URF_FAST_MIN) & (ax <= URF_FAST_MAX) & (ay <= URF_FAST_MAX);
+}
+__device__ __forceinline__ bool urf_fast_azimuth(float x, float y, float* out)
+{
+    *out = urf_fast_azimuth_of(urf_fast_polar(x, y));
+    return urf_fast_az_ok(x, y);
 }
 
 /* star_shaped_search.cpp:73-107: is the point inside the rectangular beam of its sector */

@@ -63,16 +63,16 @@ struct urf_dev_params {
  * the caller keeps the scan (offsets[]).  Tile t of the scan (input points [t * URF_TILE, ...)) owns
  * [s * sstride + t * URF_TILE, ... + URF_TILE) of every per-point array:
  *   ring-sorted   rx ry rz rsrc   slot j = the tile's points that lie on a ring, ordered by ring,
- *                                 input order inside a ring (stable); rsrc = index inside the tile
+ *                 raz rflag       input order inside a ring (stable); rsrc = index inside the tile
  *   sector-sorted sr sz sslot     the tile's points that take part in the star-shaped search,
  *                                 ordered by sector, input order inside; sslot = the point's
  *                                 ring-sorted slot (URF_SLOT_NONE if it lies on no ring)
  * so that ONE pass over x/y/z (k_split) can write both without knowing any total.  Ring c of the
  * scan = the concatenation over the tiles of run [troff[t][c], troff[t][c+1]); k_index turns the
  * rings' per-tile run tables into per-ring tables (prefix over the tiles, start inside the tile);
- * a sector's runs are read from tsoff directly (it meets few tiles).  What the later kernels PRODUCE per point is contiguous per ring (raz, rflag: element p of
- * ring c at s * sstride + ring_off[c] + p, ring_off padded to multiples of 4) resp. per sector
- * (wslp, wg, ssrt: at s * sstride + sec_off[k] + i). */
+ * a sector's runs are read from tsoff directly (it meets few tiles).  What k_ring produces per point
+ * (rflag, exact azimuths) goes into the point's ring-sorted slot; what the star sort produces is
+ * contiguous per sector (wslp, wg, ssrt: at s * sstride + sec_off[k] + i). */
 struct urf_kargs {
     /* input */
     const float* x;
@@ -98,10 +98,9 @@ struct urf_kargs {
     float*    ry;
     float*    rz;
     uint16_t* rsrc;
-    /* per point, ring-major (padded ring starts) */
-    float*    raz;
-    float*    rd2;              /* stage capture only (may be NULL) */
-    uint8_t*  rflag;
+    float*    raz;              /* azimuth: k_split's approximation, k_ring's exact value where rflag says so */
+    float*    rd2;              /* planar range, stage capture only (may be NULL) */
+    uint8_t*  rflag;            /* k_ring: detector hits (bits 0-2) | URF_RFLAG_AZ_APPROX */
     /* per point, sector-sorted inside the tile */
     float*    sr;
     float*    sz;
@@ -117,12 +116,11 @@ struct urf_kargs {
     /* per scan x key x tile (k_index) */
     uint32_t* rpre;             /* [S][C][tiles+1] points of ring c in the tiles before t; [ntiles] = ring_cnt */
     uint16_t* rstart;           /* [S][C][tiles]   = troff[t][c] */
-    uint32_t* tpre;             /* [S][tiles][C]   = rpre[c][t] (the layout k_label reads) */
     /* per scan */
     float*    angle;            /* [S][channels] sorted ring-angle table */
     uint8_t*  ring_lut;         /* [S][URF_LUT_CELLS] first table entry a vertical angle of the cell can match */
     uint32_t* ring_cnt;         /* [S][channels] */
-    uint32_t* ring_off;         /* [S][channels+1] start of ring c in the ring-major arrays, multiples of 4 */
+    uint32_t* ring_off;         /* [S][channels+1] ring points of the scan in front of ring c (exclusive scan of ring_cnt) */
     uint32_t* sec_cnt;          /* [S][sectors] */
     uint32_t* sec_off;          /* [S][sectors+1] */
     int32_t*  star_hit;         /* [S][sectors] ring-major position of the sector's curb point; -1 = none or on no ring */

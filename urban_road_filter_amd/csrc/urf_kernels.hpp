@@ -328,14 +328,14 @@ __host__ __device__ inline unsigned urf_align16(unsigned v) { return (v + 15u) &
 
 /* LDS carve of k_split: tab | lut | koff[C+1] | soff[Ks+1] | misc[16] |
  * union { keyr[T] u8, keys[T] u16, pending[T] u16, wcnt_r[W][C] u16, wcnt_s[W][Ks] u16 ;
- *         staging x y z src [URF_SLOTS] u32 } */
+ *         staging x y z azimuth src [URF_SLOTS] u32 } */
 __host__ __device__ inline size_t urf_split_lds_bytes(unsigned C, unsigned K, bool star)
 {
     const unsigned Ks = star ? K : 0;
     const size_t fixed = URF_MAX_CHANNELS * 4 + urf_align16(URF_LUT_CELLS) + urf_align16((C + 1) * 4) +
                          urf_align16((Ks + 1) * 4) + 64;
     const size_t phase_a = 5 * (size_t)URF_TILE + urf_align16(2 * URF_TILE_WAVES * (C + Ks));
-    const size_t phase_b = 4 * (size_t)URF_SLOTS * 4;
+    const size_t phase_b = 5 * (size_t)URF_SLOTS * 4;
     return fixed + (phase_a > phase_b ? phase_a : phase_b);
 }
 
@@ -437,6 +437,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
     const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;   /* + rounding of fl(angle[j] - alpha) */
     const bool exact_all = a.capture == 1;
     unsigned rkey[Q], skey[Q];
+    float azf[Q];            /* approximate azimuth [deg] (urf_device.hpp), consumed by k_label */
     unsigned openmask = 0;   /* bit q: point q of this thread is on the pending list */
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
@@ -463,8 +464,10 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
         const bool match = !none & (__builtin_fabsf(d) <= interval - e);         /* the first candidate surely matches */
         bool open = roi & (!fast | unsettled | !(none | match));
         unsigned rk = match ? lo : URF_RING_NONE, sk = URF_SEC_NONE;
+        const float fi = urf_fast_polar(x, y);   /* one arc tangent: the star sector and the azimuth */
+        azf[q] = urf_fast_azimuth_of(fi);
         if (star) {
-            const int fs = urf_fast_sector(x, y, dp.Kfi, K, dp.sector_margin);
+            const int fs = urf_fast_sector_of(fi, x, y, dp.Kfi, K, dp.sector_margin);
             open = open | (roi & (fs < 0));
             sk = (unsigned)fs;
             if (dp.p.starbeam_filter && !urf_in_beam(a.beams[fs < 0 ? 0 : fs], x, y))
@@ -618,7 +621,8 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
     unsigned* stx = (unsigned*)un;
     unsigned* sty = stx + URF_SLOTS;
     unsigned* stz = sty + URF_SLOTS;
-    unsigned* sts = stz + URF_SLOTS;
+    unsigned* sta = stz + URF_SLOTS;
+    unsigned* sts = sta + URF_SLOTS;
     const unsigned tb = sb + tbase;
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
@@ -629,6 +633,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
             stx[sl] = __float_as_uint(x);
             sty[sl] = __float_as_uint(y);
             stz[sl] = __float_as_uint(z);
+            sta[sl] = __float_as_uint(azf[q]);
             sts[sl] = li;
         }
         if (sp[q] != 0xffffffffu) {
@@ -647,6 +652,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
         __builtin_nontemporal_store(__uint_as_float(stx[sl]), &a.rx[tb + j]);
         __builtin_nontemporal_store(__uint_as_float(sty[sl]), &a.ry[tb + j]);
         __builtin_nontemporal_store(__uint_as_float(stz[sl]), &a.rz[tb + j]);
+        __builtin_nontemporal_store(__uint_as_float(sta[sl]), &a.raz[tb + j]);
         __builtin_nontemporal_store((uint16_t)sts[sl], &a.rsrc[tb + j]);
     }
     const size_t row = (size_t)s * a.tiles + t;
@@ -662,17 +668,14 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
 /* ------------------------------------------------------------------------- */
 /* k_index                                                                     */
 /* ------------------------------------------------------------------------- */
-/* exclusive scan of f(cnt[0..K)) (K <= 1024) by 256 threads -> offs[0..K]; pad4: every count is
- * rounded up to a multiple of 4 first (ring starts in the ring-major arrays) */
-__device__ void urf_scan_keys_256(const unsigned* cnt, unsigned* offs, unsigned K, unsigned* sh /* [8] */, bool pad4)
+/* exclusive scan of cnt[0..K) (K <= 1024) by 256 threads -> offs[0..K] */
+__device__ void urf_scan_keys_256(const unsigned* cnt, unsigned* offs, unsigned K, unsigned* sh /* [8] */)
 {
     const unsigned tid = threadIdx.x;
     unsigned v[4], sum = 0;
     for (int e = 0; e < 4; e++) {
         const unsigned k = tid * 4 + e;
         v[e] = k < K ? cnt[k] : 0;
-        if (pad4)
-            v[e] = (v[e] + 3u) & ~3u;
         sum += v[e];
     }
     const unsigned inc = urf_wave_scan_add(sum);
@@ -698,8 +701,7 @@ __device__ void urf_scan_keys_256(const unsigned* cnt, unsigned* offs, unsigned 
 /* One family of keys (rings or sectors) of one scan: turns k_split's per-tile run tables
  * toff[tile][key] (first slot of the key's run inside the tile, row-major, rows of nkeys + 1 u16)
  * into per-key tables: pre[key][tile] = points of the key in the tiles before (u32, [ntiles] =
- * total), start[key][tile] = toff[tile][key], optionally tpre[tile][key] = pre[key][tile], and the
- * totals cnt[key], for the 64 keys from k0.  Blocks of 64 keys x 64 tiles are transposed through LDS so that both the
+ * total), start[key][tile] = toff[tile][key], and the totals cnt[key], for the 64 keys from k0.  Blocks of 64 keys x 64 tiles are transposed through LDS so that both the
  * reads (rows of toff) and the writes (rows of pre / start) are contiguous. */
 struct urf_index_shared {
     unsigned pre[64][65];
@@ -708,7 +710,7 @@ struct urf_index_shared {
     unsigned carry[64];
 };
 __device__ void urf_index_family(urf_index_shared& L, const uint16_t* toff, unsigned nkeys, unsigned k0, unsigned ntiles,
-                                 unsigned tstride, unsigned* pre, uint16_t* start, unsigned* tpre, unsigned* cnt)
+                                 unsigned tstride, unsigned* pre, uint16_t* start, unsigned* cnt)
 {
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned rowlen = nkeys + 1;
@@ -748,13 +750,6 @@ __device__ void urf_index_family(urf_index_shared& L, const uint16_t* toff, unsi
                     start[(size_t)kk * tstride + tt] = L.st[r][lane];
                 }
             }
-            if (tpre)
-#pragma unroll 4
-                for (unsigned pass = 0; pass < 16; pass++) {
-                    const unsigned u = pass * 4 + wave, tt = t0 + u;
-                    if (tt < ntiles && key < nkeys)
-                        tpre[(size_t)tt * nkeys + key] = L.pre[lane][u];
-                }
             __syncthreads();
         }
         if (tid < 64 && key < nkeys) {
@@ -831,8 +826,8 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
     }
     for (unsigned k0 = 0; k0 < C; k0 += 64)
         urf_index_family(L, a.troff + (size_t)s * a.tiles * (C + 1), C, k0, ntiles, a.tiles, a.rpre + (size_t)s * C * (a.tiles + 1),
-                         a.rstart + (size_t)s * C * a.tiles, a.tpre + (size_t)s * a.tiles * C, a.ring_cnt + (size_t)s * C);
-    urf_scan_keys_256(&a.ring_cnt[(size_t)s * C], &a.ring_off[(size_t)s * (C + 1)], C, sh, true);
+                         a.rstart + (size_t)s * C * a.tiles, a.ring_cnt + (size_t)s * C);
+    urf_scan_keys_256(&a.ring_cnt[(size_t)s * C], &a.ring_off[(size_t)s * (C + 1)], C, sh);
     {   /* lidar_segmentation.cpp:605-608: road_probably = every point of sorted ring 10 */
         unsigned tot = 0;
         for (unsigned k = tid; k < C; k += 256)
@@ -850,7 +845,7 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
     }
     if (!dp.p.star_shaped_method)
         return;
-    urf_scan_keys_256(&a.sec_cnt[(size_t)s * K], &a.sec_off[(size_t)s * (K + 1)], K, sh, false);
+    urf_scan_keys_256(&a.sec_cnt[(size_t)s * K], &a.sec_off[(size_t)s * (K + 1)], K, sh);
     /* sectors too large for one wave's LDS tile go on the work lists of k_star_mid / k_star_big
      * (one atomic per wave, not per sector) */
     for (unsigned k0 = 0; k0 < K; k0 += 256) {
@@ -1966,7 +1961,7 @@ __device__ __noinline__ bool urf_z_zero_angle_window(const float* xs, const floa
  * (lidar_segmentation.cpp:245-269, blind_spots.cpp:19-56); returns the azimuth.
  * maxDistance (:271-274) is the largest float(sqrt(double s)), s = x^2 + y^2: both roundings
  * are monotone, so the callers track the largest s instead. */
-__device__ __noinline__ float urf_ring_point(float* rd2, urf_ring_shared& S, size_t gpos, float px, float py,
+__device__ __noinline__ float urf_ring_point(float* rd2, urf_ring_shared& S, unsigned gpos, float px, float py,
                                              unsigned flag, bool want_quad)
 {
     float d2;
@@ -2014,7 +2009,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
      * hits): a chain of dependent round trips cost a fifth of a workgroup's life. */
     const urf_scan_info in = a.info[s];
     const int n = (int)a.ring_cnt[(size_t)s * C + c];
-    const unsigned ro = a.ring_off[(size_t)s * (C + 1) + c];   /* multiple of 4 */
+    const unsigned ro = a.ring_off[(size_t)s * (C + 1) + c];   /* the ring's first position among the scan's ring points (star hits) */
     const unsigned* gp = a.rpre + ((size_t)s * C + c) * (a.tiles + 1);
     const uint16_t* gs = a.rstart + ((size_t)s * C + c) * a.tiles;
     const unsigned pt0 = tid <= a.tiles ? gp[tid] : 0;
@@ -2029,7 +2024,6 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
         return;
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     const unsigned sb = urf_sbase(a, s);
-    const unsigned base = sb + ro;                              /* the ring in the ring-major arrays (raz, rflag) */
     const int cp = dp.p.curbPoints;
     const bool want_quad = (c == 1) && dp.p.blind_spots;
     unsigned* const mapP = sh_ring_tab;
@@ -2078,8 +2072,6 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
     const unsigned nh = S.n_hits;
     double maxs = 0.0;
     const bool quads = cp == 5;
-    /* quad mapping: chunk starts are multiples of 4, and so is the ring's start in the ring-major
-     * arrays (k_index pads), so that azimuths and flags leave as 16- and 4-byte stores */
     const int cs0 = 0;
     const int zpad = PAD + (cp & 3);   /* z slot of chunk point 0: puts p - cp of a quad on a 16-byte boundary for cp = 5 */
     unsigned buf = 0;
@@ -2179,7 +2171,6 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                 for (int j = 0; j < 9; j++)
                     M[j] = __builtin_fmaxf(T[j], T[j + 3]);
                 const unsigned hbits = (S.hb[buf][tid >> 3] >> ((tid & 7u) * 4u)) & 15u;
-                float azf[4] = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int p = q0 + i;
@@ -2199,26 +2190,25 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                             (double)__builtin_fabsf(max1 - max2) >= 0.05)                        /* z_zero_method.cpp:67-69 */
                             t |= URF_CAND_ZZERO;
                     }
-                    if (!urf_fast_azimuth(qx[i], qy[i], &azf[i]) || a.rd2)
+                    if (!urf_fast_az_ok(qx[i], qy[i]) || a.rd2)   /* k_split's approximate azimuth is no good here */
                         t |= URF_CAND_EXACT;
                     const double s2 = (double)qx[i] * (double)qx[i] + (double)qy[i] * (double)qy[i];
                     maxs = s2 > maxs ? s2 : maxs;
                     if (t)
                         S.cand[atomicAdd(&S.n_cand, 1u)] = (unsigned)p | (t << URF_CAND_SHIFT);
                 }
-                /* every point leaves as "no curb, azimuth approximate"; the candidate pass rewrites
-                 * the ones for which that is not the whole truth */
-                const unsigned fl4 = URF_RFLAG_AZ_APPROX * 0x01010101u;
-                if (q0 >= 0 && q0 + 3 < n) {
-                    *(float4*)(a.raz + base + q0) = make_float4(azf[0], azf[1], azf[2], azf[3]);
-                    *(unsigned*)(a.rflag + base + q0) = fl4;
+                /* every point leaves as "no curb, azimuth approximate" (the approximation is the
+                 * one k_split stored next to the point); the candidate pass rewrites the ones for
+                 * which that is not the whole truth.  Flags live in the point's ring-sorted slot. */
+                const unsigned t0 = map.tile((unsigned)q0);
+                const unsigned idx0 = mapA[t0] + (unsigned)q0;
+                if (q0 + 3 < n && (unsigned)q0 + 3 < mapP[t0 + 1] && (idx0 & 3u) == 0) {
+                    *(unsigned*)(a.rflag + idx0) = URF_RFLAG_AZ_APPROX * 0x01010101u;
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        if (q0 + i >= 0 && q0 + i < n) {
-                            a.raz[base + q0 + i] = azf[i];
-                            a.rflag[base + q0 + i] = (uint8_t)URF_RFLAG_AZ_APPROX;
-                        }
+                        if (q0 + i < n)
+                            a.rflag[map.at((unsigned)(q0 + i))] = (uint8_t)URF_RFLAG_AZ_APPROX;
                 }
             }
             __syncthreads();
@@ -2240,8 +2230,8 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                         urf_z_zero_angle_gather(a.rx, a.ry, mapP, mapA, ntiles, map.scale, dp.inv_cp, dp.p.angleFilter2, p, 5, px, py))
                         flag |= 4u;
                     if (flag || (t & URF_CAND_EXACT)) {
-                        a.raz[base + p] = urf_ring_point(a.rd2, S, (size_t)base + p, px, py, flag, want_quad);
-                        a.rflag[base + p] = (uint8_t)flag;
+                        a.raz[ip] = urf_ring_point(a.rd2, S, ip, px, py, flag, want_quad);
+                        a.rflag[ip] = (uint8_t)flag;
                     }
                 }
                 __syncthreads();
@@ -2292,11 +2282,12 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                             flag |= 4u;
                     }
                 }
-                const float az = urf_ring_point(a.rd2, S, (size_t)base + p, px, py, flag, want_quad);
+                const unsigned ip = map.at((unsigned)p);
+                const float az = urf_ring_point(a.rd2, S, ip, px, py, flag, want_quad);
                 const double s2 = (double)px * (double)px + (double)py * (double)py;
                 maxs = s2 > maxs ? s2 : maxs;
-                a.raz[base + p] = az;
-                a.rflag[base + p] = (uint8_t)flag;
+                a.raz[ip] = az;
+                a.rflag[ip] = (uint8_t)flag;
             }
         }
         __syncthreads();
@@ -2526,7 +2517,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
 {
     __shared__ unsigned long long actf[URF_MAX_CHANNELS * 6], actb[URF_MAX_CHANNELS * 6];
     __shared__ double qk[URF_MAX_CHANNELS];
-    __shared__ unsigned base_r[URF_MAX_CHANNELS], koff[URF_MAX_CHANNELS + 1];
+    __shared__ unsigned koff[URF_MAX_CHANNELS + 1];
     __shared__ uint8_t img[URF_TILE];
     __shared__ uint8_t ring_of[URF_TILE] __attribute__((aligned(8)));
     __shared__ unsigned wave_max[URF_LABEL_TILE_THREADS / 64];
@@ -2542,13 +2533,12 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     const size_t row = (size_t)s * a.tiles + t;
     const unsigned sb = urf_sbase(a, s);
     constexpr unsigned Q = URF_TILE / URF_LABEL_TILE_THREADS;
-    /* The scan summary and the tile's run table are requested together (run of ring `tid` inside the
-     * tile's ring-sorted order: starts at slot troff[tid]; its first point is point tpre[tid] of the
-     * ring).  (Also requesting the beam masks and the slots' input indices up front was measured:
-     * no gain, and beyond 72 registers the kernel loses a resident workgroup.) */
+    /* The scan summary and the tile's run table are requested together (the run of ring `tid` inside
+     * the tile's ring-sorted order starts at slot troff[tid]).  (Also requesting the beam masks and
+     * the slots' input indices up front was measured: no gain, and beyond 72 registers the kernel
+     * loses a resident workgroup.) */
     const urf_scan_info in = a.info[s];
     const unsigned v_koff = tid <= C ? (unsigned)a.troff[row * (C + 1) + tid] : 0;
-    const unsigned v_base = tid < C ? a.ring_off[(size_t)s * (C + 1) + tid] + a.tpre[row * C + tid] : 0;
     if (in.status != URF_OK) {
         /* nothing is published for this scan (lidar_segmentation.cpp:124-126): all labels 0 */
         for (unsigned i = tbase + tid; i < len && i < tbase + URF_TILE; i += URF_LABEL_TILE_THREADS)
@@ -2558,10 +2548,8 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     const unsigned nR = in.n_rings;
     if (tid <= C) {
         koff[tid] = v_koff;
-        if (tid < C) {
-            base_r[tid] = sb + v_base;
+        if (tid < C)
             qk[tid] = tid < nR ? a.qk[(size_t)s * C + tid] : 0.0;
-        }
     }
     for (unsigned w = tid; w < nR * 6; w += URF_LABEL_TILE_THREADS) {
         actf[w] = a.act_f[(size_t)s * C * 6 + w];
@@ -2623,9 +2611,8 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
         const unsigned j = tid + q * URF_LABEL_TILE_THREADS;
-        const unsigned c = j < npts ? (unsigned)ring_of[j] - 1u : 0u;
-        rc[q] = c;
-        rpos[q] = j < npts ? base_r[c] + (j - koff[c]) : 0xffffffffu;
+        rc[q] = j < npts ? (unsigned)ring_of[j] - 1u : 0u;
+        rpos[q] = j < npts ? sb + tbase + j : 0xffffffffu;   /* the point's ring-sorted slot: flag, azimuth, source, x, y */
     }
     unsigned rfl[Q], rsr[Q];
     float raz[Q];
@@ -2634,7 +2621,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         const bool on = rpos[q] != 0xffffffffu;
         rfl[q] = on ? (unsigned)a.rflag[rpos[q]] : 0u;
         raz[q] = on ? a.raz[rpos[q]] : 0.f;
-        rsr[q] = on ? (unsigned)a.rsrc[sb + tbase + tid + q * URF_LABEL_TILE_THREADS] : 0u;   /* index inside the tile */
+        rsr[q] = on ? (unsigned)a.rsrc[rpos[q]] : 0u;   /* index inside the tile */
     }
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
@@ -2658,7 +2645,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
             bool road_final = road;
             if (unsure) {
                 const unsigned e = atomicAdd(&n_unsure, 1u);
-                const unsigned slot = sb + tbase + tid + q * URF_LABEL_TILE_THREADS;   /* the point in rx / ry */
+                const unsigned slot = rpos[q];
                 if (e < URF_LABEL_UNSURE) {
                     un_pos[e] = slot;
                     un_key[e] = src | (c << 16);
@@ -2718,12 +2705,11 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     }
 }
 
-/* exact azimuth of the point at ring-major position pos (raz may hold the approximation); slot =
- * the point's index in the ring-sorted arrays (urf_ring_slot) */
-__device__ __forceinline__ float urf_exact_az(const urf_kargs& a, unsigned pos, unsigned slot)
+/* exact azimuth of the point in ring-sorted slot `slot` (raz may hold the approximation) */
+__device__ __forceinline__ float urf_exact_az(const urf_kargs& a, unsigned slot)
 {
-    if (!(a.rflag[pos] & URF_RFLAG_AZ_APPROX))
-        return a.raz[pos];
+    if (!(a.rflag[slot] & URF_RFLAG_AZ_APPROX))
+        return a.raz[slot];
     float d2;
     return urf_azimuth(a.rx[slot], a.ry[slot], &d2);
 }
@@ -2802,7 +2788,7 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
     const unsigned C = (unsigned)dp.p.channels;
     const unsigned n = a.ring_cnt[(size_t)s * C + c];
     const unsigned rel = a.ring_off[(size_t)s * (C + 1) + c];   /* scan-relative start of the ring */
-    const unsigned sb = urf_sbase(a, s), base = sb + rel;
+    const unsigned sb = urf_sbase(a, s);
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     if (n <= CAP) {
         unsigned long long key[EPT];
@@ -2811,7 +2797,7 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
             const unsigned i = tid + e * NT;
             key[e] = ~0ull;
             if (i < n)
-                key[e] = ((unsigned long long)urf_fbits(urf_exact_az(a, base + i, sb + urf_ring_slot(a, s, C, c, ntiles, i))) << 32) | i;
+                key[e] = ((unsigned long long)urf_fbits(urf_exact_az(a, sb + urf_ring_slot(a, s, C, c, ntiles, i))) << 32) | i;
         }
         urf_block_sort_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, false);
         for (unsigned i = tid; i < n; i += NT)
@@ -2819,7 +2805,7 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
     } else {
         unsigned long long* G = gkeys + rel;
         for (unsigned i = tid; i < n; i += NT)
-            G[i] = ((unsigned long long)urf_fbits(urf_exact_az(a, base + i, sb + urf_ring_slot(a, s, C, c, ntiles, i))) << 32) | i;
+            G[i] = ((unsigned long long)urf_fbits(urf_exact_az(a, sb + urf_ring_slot(a, s, C, c, ntiles, i))) << 32) | i;
         __threadfence_block();
         __syncthreads();
         unsigned P = 1;
@@ -2949,7 +2935,7 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
     urf_scan_range(a, s, off, len);
     const unsigned C = (unsigned)dp.p.channels;
     const unsigned n = a.ring_cnt[(size_t)s * C + c];
-    const unsigned sb = urf_sbase(a, s), base = sb + a.ring_off[(size_t)s * (C + 1) + c];
+    const unsigned sb = urf_sbase(a, s);
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     /* input index of the point in ring-sorted slot `slot` (relative to the scan) */
     auto src_of = [&](unsigned slot) { return (slot & ~(URF_TILE - 1u)) + (unsigned)a.rsrc[sb + slot]; };
@@ -2962,7 +2948,7 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
     /* pass 1: where does the scan of this ring stop in each degree (:318) */
     for (unsigned p = tid; p < n; p += 256) {
         const unsigned slot = urf_ring_slot(a, s, C, c, ntiles, p);
-        const float az = urf_exact_az(a, base + p, sb + slot);
+        const float az = urf_exact_az(a, sb + slot);
         const unsigned lab = a.labels[off + src_of(slot)] & URF_LABEL_MASK;
         if (az == az && lab != URF_LABEL_ROAD) {
             int bin = (int)__builtin_floorf(az);
@@ -2975,7 +2961,7 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
     for (int pass = 0; pass < 2; pass++) {
         for (unsigned p = tid; p < n; p += 256) {
             const unsigned slot = urf_ring_slot(a, s, C, c, ntiles, p);
-            const float az = urf_exact_az(a, base + p, sb + slot);
+            const float az = urf_exact_az(a, sb + slot);
             const unsigned lab = a.labels[off + src_of(slot)] & URF_LABEL_MASK;
             if (az == az && lab == URF_LABEL_ROAD) {
                 int bin = (int)__builtin_floorf(az);
