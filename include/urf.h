@@ -73,7 +73,8 @@ typedef enum urf_status {
     URF_ERR_HIP = -3,            /* HIP runtime failure, see urf_last_error() */
     URF_ERR_CAPACITY = -4,       /* scan or batch larger than urf_create() sizes */
     URF_ERR_OOM = -5,
-    URF_ERR_PARAMS = -6          /* parameter outside the supported range */
+    URF_ERR_PARAMS = -6,         /* parameter outside the supported range */
+    URF_ERR_BUSY = -7            /* both slots of the asynchronous single-scan path are in flight */
 } urf_status;
 
 /* ---- parameters ----------------------------------------------------------
@@ -112,6 +113,33 @@ typedef struct urf_params {
 /* Fills *p with the reference defaults (cfg/LidarFilters.cfg) and the
  * reference's compile-time globals (channels 64, rep 360, width 0.2). */
 int urf_default_params(urf_params* p);
+
+/* ---- the live parameter surface ---------------------------------------------
+ * One descriptor per gen.add() of cfg/LidarFilters.cfg:10-84 (the node's dynamic_reconfigure
+ * interface): the reference's parameter name, type, default and range, the xDirection enum
+ * (:22-27), and where the value lives in urf_params / urf_marker_params (`field`, `offset`).
+ * fixed_frame / topic_name configure the ROS node, not the classification (URF_PARAM_NODE_ONLY).
+ * urf_clamp_params() does what the dynamic_reconfigure server does to a request before
+ * paramsCallback (src/main.cpp:4-34) sees it: every value is clamped to [min, max], bools become
+ * 0/1; *n_clamped (optional) = number of values it changed.  mp may be NULL.  (urf_set_params still
+ * rejects what the kernels cannot run: channels, sectors, curbPoints outside their limits.) */
+typedef enum urf_param_type { URF_PARAM_BOOL = 0, URF_PARAM_INT = 1, URF_PARAM_DOUBLE = 2, URF_PARAM_STR = 3 } urf_param_type;
+typedef enum urf_param_where { URF_PARAM_IN_PARAMS = 0, URF_PARAM_IN_MARKER_PARAMS = 1, URF_PARAM_NODE_ONLY = 2 } urf_param_where;
+typedef struct urf_param_desc {
+    const char* cfg_name;    /* name in cfg/LidarFilters.cfg */
+    const char* field;       /* member of urf_params / urf_marker_params ("" = node only) */
+    int32_t     where;       /* urf_param_where */
+    uint32_t    offset;      /* byte offset of the member (float for double_t, int32_t for int_t / bool_t) */
+    int32_t     type;        /* urf_param_type (the cfg's type) */
+    double      def, min, max;
+    const char* def_str;     /* default of a str_t, else NULL */
+    const char* enum_values; /* "name=value,..." where the cfg defines an enum, else NULL */
+    int32_t     cfg_line;    /* line of the gen.add() */
+} urf_param_desc;
+struct urf_marker_params;
+int urf_param_count(void);
+const urf_param_desc* urf_param_table(void);
+int urf_clamp_params(urf_params* p, struct urf_marker_params* mp, uint32_t* n_clamped);
 
 /* ---- per-scan summary ---------------------------------------------------- */
 typedef struct urf_scan_info {
@@ -156,6 +184,26 @@ int urf_synchronize(urf_ctx* ctx);
 int urf_classify_pc2(urf_ctx* ctx, const uint8_t* data, uint32_t n_points,
                      uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
                      uint8_t* labels_out, urf_scan_info* info);
+
+/* The same, asynchronously: the message is copied to pinned memory and sent to the device on a
+ * copy stream, classified on the context's stream by ONE graph launch (the kernel sequence of a
+ * sweep of this shape is captured once and replayed), and the labels come back to pinned memory.
+ * Two sweeps may be in flight (the copy of sweep i+1 overlaps the kernels of sweep i):
+ *     urf_classify_pc2_async(ctx, msg_a, ..., &ta);
+ *     urf_classify_pc2_async(ctx, msg_b, ..., &tb);      // a third one returns URF_ERR_BUSY
+ *     urf_classify_pc2_wait(ctx, ta, labels_a, &info_a);  // blocks until sweep a is done
+ * labels_out may be NULL: urf_result_labels() then gives read access to the pinned result buffer,
+ * valid until the ticket's slot is used again (two submissions later).  A producer that can fill a
+ * buffer of the library's choosing (a driver, a deserialiser) saves the staging copy: it asks for
+ * the pinned input buffer of slot (next ticket & 1) with urf_pinned_input() and passes that very
+ * pointer as `data`.  Reference: the subscriber callback, lidar_segmentation.cpp:53,95-100, and
+ * the publishers, :612-621. */
+int urf_classify_pc2_async(urf_ctx* ctx, const uint8_t* data, uint32_t n_points,
+                           uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                           uint32_t* ticket);
+int urf_classify_pc2_wait(urf_ctx* ctx, uint32_t ticket, uint8_t* labels_out, urf_scan_info* info);
+int urf_result_labels(urf_ctx* ctx, uint32_t ticket, const uint8_t** labels);
+int urf_pinned_input(urf_ctx* ctx, uint32_t slot, size_t bytes, uint8_t** ptr);
 
 /* ---- batch of scans, device-resident ---------------------------------------
  * n_scans independent scans of n_per_scan points each; scan s owns elements
@@ -212,12 +260,21 @@ int urf_marker_points(urf_ctx* ctx, uint32_t scan, float* pts, uint32_t* count);
 /* The polygon parameters of the reference (cfg/LidarFilters.cfg:75-84 -> main.cpp:29-32). */
 typedef struct urf_marker_params {
     uint32_t size;              /* = sizeof(urf_marker_params) */
-    int32_t  simple_poly_allow; /* cfg:76  bool, default true */
-    float    poly_s_param;      /* cfg:79  Douglas-Peucker distance, default 0.7 */
-    float    poly_z_manual;     /* cfg:82  default -1.5 */
-    int32_t  poly_z_avg_allow;  /* cfg:85  bool, default true */
+    int32_t  simple_poly_allow; /* cfg:75  bool, default true */
+    float    poly_s_param;      /* cfg:78  Douglas-Peucker distance, default 0.7 */
+    float    poly_z_manual;     /* cfg:81  default -1.5 */
+    int32_t  poly_z_avg_allow;  /* cfg:84  bool, default true */
 } urf_marker_params;
 int urf_default_marker_params(urf_marker_params* p);
+
+/* The line simplification of the polygon step (lidar_segmentation.cpp:475,512,548 call
+ * boost::geometry::simplify(line, out, poly_s_param)): Douglas-Peucker with the distance of a point
+ * to the SEGMENT between the span's ends, first and last point kept, an interior point kept iff it
+ * is the farthest of its span and strictly farther than max_distance; float coordinates
+ * (point_xy<float>, data_structures.hpp:38).  xy = n points (x0, y0, x1, y1, ...); keep[i] = 1 for
+ * the points of the simplified line.  Boost.Geometry itself is not in the reference checkout:
+ * the behaviour is pinned by the worked example of its documentation (tests/test_simplify_kat.py). */
+int urf_simplify_line(const float* xy, uint32_t n, float max_distance, uint8_t* keep);
 
 /* ---- stage-wise inspection (parity tests) ----------------------------------
  * After a classify call, copies one intermediate array of scan `scan` to host

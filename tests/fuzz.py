@@ -34,6 +34,10 @@ def random_params(rng, for_reference=False):
     p.dmin_param = int(rng.choice([3, 10, 30]))
     # the reference reads array3D[1] / array3D[10] unconditionally: keep channels > 10 when it is the judge
     p.channels = int(rng.choice([16, 64, 128] if for_reference else [1, 2, 7, 11, 16, 64, 128]))
+    if not for_reference:
+        # the reference's `rep` is a compile-time 360 (star_shaped_search.cpp:8); the restatement and the
+        # kernels take it as a parameter, and the float fast path's margin scales with it
+        p.sectors = int(rng.choice([360, 360, 90, 720, 1022]))
     return p
 
 

@@ -47,7 +47,7 @@ def test_defaults_are_the_reference_defaults():
 
 def test_strerror_covers_all_codes():
     L = u.lib()
-    for code in (0, 1, -1, -2, -3, -4, -5, -6):
+    for code in (0, 1, -1, -2, -3, -4, -5, -6, -7):
         assert L.urf_strerror(code) and b"unknown" not in L.urf_strerror(code)
     assert b"unknown" in L.urf_strerror(-99)
 

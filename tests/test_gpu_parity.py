@@ -130,6 +130,50 @@ def run_batch(ctx, scans, p, ragged=False):
     return out, infos
 
 
+def test_ragged_batch_inside_a_larger_buffer(ctx_big):
+    """The scans of a ragged batch may lie anywhere in the caller's arrays: offsets that do not start
+    at 0, gaps between scans, and a scan longer than max_len (cut there).  Scratch memory is indexed
+    by scan, not by these offsets."""
+    p = O.cfg_params("cfg2")
+    scans = [O.cfg_cloud("cfg2", 30 + k) for k in range(3)]
+    scans = [tuple(a[:n].copy() for a in s) for s, n in zip(scans, (40000, 131072, 9000))]
+    lead, gap = 777, 1234
+    X = np.full(lead + sum(len(s[0]) for s in scans) + 2 * gap + 50, 7.5, np.float32)
+    Y, Z = X.copy(), X.copy()
+    offs, pos = [], lead
+    for x, y, z in scans:
+        offs.append(pos)
+        X[pos:pos + len(x)], Y[pos:pos + len(x)], Z[pos:pos + len(x)] = x, y, z
+        pos += len(x) + gap
+    # offsets[s+1] - offsets[s] is the length: the gap belongs to the previous scan as junk points
+    # (7.5, 7.5, 7.5: outside the z ROI), except for the last scan
+    offs.append(pos - gap)
+    dx, dy, dz = DevBuf.from_numpy(X), DevBuf.from_numpy(Y), DevBuf.from_numpy(Z)
+    do = DevBuf.from_numpy(np.array(offs, np.uint32))
+    dl = DevBuf(len(X))
+    dl.fill(0xEE)
+    with u.Context(131072 + gap, 3, params=p) as ctx:
+        ctx.classify_batch_soa_ragged(dx, dy, dz, do, 131072 + gap, 3, dl, None)
+        ctx.synchronize()
+        L = dl.to_numpy(np.uint8)
+        assert (L[:lead] == 0xEE).all() and (L[offs[3]:] == 0xEE).all()        # nothing outside the scans is touched
+        for k, (x, y, z) in enumerate(scans):
+            n = offs[k + 1] - offs[k]
+            xx, yy, zz = X[offs[k]:offs[k] + n], Y[offs[k]:offs[k] + n], Z[offs[k]:offs[k] + n]
+            lb, _, _ = O.run_b(xx, yy, zz, p)
+            assert np.array_equal(L[offs[k]:offs[k] + n], lb), k
+        # a scan longer than max_len is cut at max_len: labels behind it stay untouched
+        dl.fill(0xEE)
+        ctx.classify_batch_soa_ragged(dx, dy, dz, do, 20000, 3, dl, None)
+        ctx.synchronize()
+        L = dl.to_numpy(np.uint8)
+        for k in range(3):
+            n = min(offs[k + 1] - offs[k], 20000)
+            lb, _, _ = O.run_b(X[offs[k]:offs[k] + n], Y[offs[k]:offs[k] + n], Z[offs[k]:offs[k] + n], p)
+            assert np.array_equal(L[offs[k]:offs[k] + n], lb), k
+            assert (L[offs[k] + n:offs[k + 1]] == 0xEE).all()
+
+
 def check_against_b(labels, infos, scans, p):
     for k, (x, y, z) in enumerate(scans):
         lb, ib, _ = O.run_b(x, y, z, p)
@@ -428,8 +472,17 @@ def test_fast_path_error_bounds(ctx_big):
     """Ring and sector are decided from float approximations of the angles wherever the
     approximation is clear of every decision boundary by a margin (urf_device.hpp); the margins
     (3e-4 deg, 2e-6 rad, 2.5e-4, 5e-4 deg) must dominate the error measured on 2^28 pseudo-random points."""
+    ctx_big.set_params(u.default_params())
     ev, ea, eu, ez = ctx_big.selftest_fast(1 << 28)
     assert ev < 1.0e-4 and ea < 0.7e-6 and eu < 0.85e-4 and ez < 1.7e-4, (ev, ea, eu, ez)
+    # the sector margin scales with the number of sectors (urf_dev_params::sector_margin): at the
+    # largest supported count the measured error of the scaled polar angle must stay below a third of it
+    p = u.default_params()
+    p.sectors = 1022
+    ctx_big.set_params(p)
+    _, _, eu, _ = ctx_big.selftest_fast(1 << 26)
+    assert eu < 2.5e-4 * (1022 / 360) / 3, eu
+    ctx_big.set_params(u.default_params())
 
 
 @pytest.mark.parametrize("log2_scale", [0, -30, 30, -62])

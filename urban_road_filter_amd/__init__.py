@@ -6,10 +6,16 @@ package is plumbing for tests and the benchmark: a ctypes binding of that ABI.
 """
 from .api import (  # noqa: F401
     Context,
+    MarkerParams,
+    ParamDesc,
     Params,
     ScanInfo,
     UrfError,
+    clamp_params,
+    default_marker_params,
     default_params,
+    param_table,
+    PARAM_BOOL, PARAM_INT, PARAM_DOUBLE, PARAM_STR,
     lib,
     lib_path,
     synth_cloud,

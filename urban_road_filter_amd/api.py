@@ -63,6 +63,21 @@ class ScanInfo(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+class MarkerParams(C.Structure):
+    """struct urf_marker_params: the polygon parameters of the road_marker output."""
+    _fields_ = [("size", C.c_uint32), ("simple_poly_allow", C.c_int32), ("poly_s_param", C.c_float),
+                ("poly_z_manual", C.c_float), ("poly_z_avg_allow", C.c_int32)]
+
+
+class ParamDesc(C.Structure):
+    """struct urf_param_desc: one row of the reference's dynamic_reconfigure interface."""
+    _fields_ = [("cfg_name", C.c_char_p), ("field", C.c_char_p), ("where", C.c_int32), ("offset", C.c_uint32),
+                ("type", C.c_int32), ("default", C.c_double), ("min", C.c_double), ("max", C.c_double),
+                ("def_str", C.c_char_p), ("enum_values", C.c_char_p), ("cfg_line", C.c_int32)]
+
+
+PARAM_BOOL, PARAM_INT, PARAM_DOUBLE, PARAM_STR = range(4)
+
 _LIB = None
 
 
@@ -85,6 +100,7 @@ def lib():
     vp, u8p, u32p, fp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     sig = {
         "urf_default_params": [C.POINTER(Params)],
+        "urf_default_marker_params": [C.POINTER(MarkerParams)],
         "urf_create": [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_uint32],
         "urf_destroy": [vp],
         "urf_set_params": [vp, C.POINTER(Params)],
@@ -92,6 +108,12 @@ def lib():
         "urf_set_stream": [vp, vp],
         "urf_synchronize": [vp],
         "urf_classify_pc2": [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.POINTER(ScanInfo)],
+        "urf_classify_pc2_async": [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)],
+        "urf_classify_pc2_wait": [vp, C.c_uint32, u8p, C.POINTER(ScanInfo)],
+        "urf_result_labels": [vp, C.c_uint32, C.POINTER(C.c_void_p)],
+        "urf_pinned_input": [vp, C.c_uint32, C.c_size_t, C.POINTER(C.c_void_p)],
+        "urf_param_count": [],
+        "urf_clamp_params": [C.POINTER(Params), C.POINTER(MarkerParams), C.POINTER(C.c_uint32)],
         "urf_classify_batch_soa": [vp, fp, fp, fp, C.c_uint32, C.c_uint32, u8p, vp],
         "urf_classify_batch_soa_ragged": [vp, fp, fp, fp, u32p, C.c_uint32, C.c_uint32, u8p, vp],
         "urf_classify_batch_pc2": [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p, vp],
@@ -112,6 +134,8 @@ def lib():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = C.c_int
+    L.urf_param_table.argtypes = []
+    L.urf_param_table.restype = C.POINTER(ParamDesc)
     L.urf_strerror.argtypes = [C.c_int]
     L.urf_strerror.restype = C.c_char_p
     L.urf_kernel_name.argtypes = [C.c_int]
@@ -135,6 +159,36 @@ def default_params():
     if rc != 0:
         raise UrfError(rc)
     return p
+
+
+def default_marker_params():
+    p = MarkerParams()
+    rc = lib().urf_default_marker_params(C.byref(p))
+    if rc != 0:
+        raise UrfError(rc)
+    return p
+
+
+def param_table():
+    """The reference's parameter surface (cfg/LidarFilters.cfg) as a list of dicts."""
+    L = lib()
+    t = L.urf_param_table()
+    rows = []
+    for i in range(L.urf_param_count()):
+        d = t[i]
+        rows.append(dict(cfg_name=d.cfg_name.decode(), field=d.field.decode(), where=d.where, offset=d.offset, type=d.type,
+                         default=d.default, min=d.min, max=d.max, def_str=d.def_str.decode() if d.def_str else None,
+                         enum_values=d.enum_values.decode() if d.enum_values else None, cfg_line=d.cfg_line))
+    return rows
+
+
+def clamp_params(p, mp=None):
+    """dynamic_reconfigure's clamping of a request; returns the number of values it changed."""
+    n = C.c_uint32(0)
+    rc = lib().urf_clamp_params(C.byref(p), C.byref(mp) if mp is not None else None, C.byref(n))
+    if rc != 0:
+        raise UrfError(rc, "urf_clamp_params")
+    return n.value
 
 
 def synth_cloud(rings, cols, scene=1, seed=1):
@@ -244,6 +298,33 @@ class Context:
         self._check(self._lib.urf_kernel_timing(self._h, ms, C.byref(n)), "urf_kernel_timing")
         names = [self._lib.urf_kernel_name(i).decode() for i in range(self.NUM_KERNELS)]
         return dict(zip(names, list(ms))), n.value
+
+    # -- single scan, asynchronous (two slots: copy of sweep i+1 overlaps kernels of sweep i) ----
+    def classify_pc2_async(self, data, n_points, point_step, off_x, off_y, off_z):
+        """data: uint8 array (or the int address urf_pinned_input returned).  Returns a ticket."""
+        ptr = data if isinstance(data, int) else np.ascontiguousarray(data).view(np.uint8).ctypes.data
+        t = C.c_uint32(0)
+        self._check(self._lib.urf_classify_pc2_async(self._h, ptr, n_points, point_step, off_x, off_y, off_z, C.byref(t)),
+                    "urf_classify_pc2_async")
+        return t.value
+
+    def classify_pc2_wait(self, ticket, labels=None):
+        """Blocks until the sweep is done; labels: optional uint8 array to receive the label bytes."""
+        info = ScanInfo()
+        self._check(self._lib.urf_classify_pc2_wait(self._h, ticket, labels.ctypes.data if labels is not None else None,
+                                                    C.byref(info)), "urf_classify_pc2_wait")
+        return info
+
+    def pinned_input(self, slot, nbytes):
+        """uint8 numpy view of the pinned input buffer of `slot` (0 / 1), at least nbytes long."""
+        p = C.c_void_p()
+        self._check(self._lib.urf_pinned_input(self._h, slot, nbytes, C.byref(p)), "urf_pinned_input")
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def result_labels(self, ticket, n_points):
+        p = C.c_void_p()
+        self._check(self._lib.urf_result_labels(self._h, ticket, C.byref(p)), "urf_result_labels")
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n_points,))
 
     # -- single scan, host, PointCloud2 layout ------------------------------------
     def classify_pc2(self, data, n_points, point_step, off_x, off_y, off_z):

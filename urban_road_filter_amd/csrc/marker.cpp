@@ -57,6 +57,27 @@ std::vector<std::array<float, 2>> simplifyLine(const std::vector<std::array<floa
     return out;
 }
 
+}   // namespace urf
+
+/* C view of simplifyLine (include/urf.h): known-answer tests bind it without a C++ compiler */
+extern "C" int urf_simplify_line(const float* xy, uint32_t n, float max_distance, uint8_t* keep)
+{
+    if ((!xy || !keep) && n)
+        return URF_ERR_INVALID_ARG;
+    std::vector<std::array<float, 2>> line(n);
+    for (uint32_t i = 0; i < n; i++)
+        line[i] = { xy[2 * i], xy[2 * i + 1] };
+    const auto out = urf::simplifyLine(line, max_distance);
+    size_t k = 0;   /* the result is a subsequence of the input: mark its members */
+    for (uint32_t i = 0; i < n; i++) {
+        keep[i] = k < out.size() && out[k] == line[i];
+        k += keep[i];
+    }
+    return k == out.size() ? URF_OK : URF_ERR_INVALID_ARG;
+}
+
+namespace urf {
+
 MarkerBuilder::MarkerBuilder() { urf_default_marker_params(&params_); }
 
 /* lidar_segmentation.cpp:471-489 (and :508-526, :544-562): optionally replace the strip's points by the

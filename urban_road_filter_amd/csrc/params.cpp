@@ -2,6 +2,7 @@
  * params.cpp -- parameter defaults, validation and status strings of the C ABI.
  * Host code.
  */
+#include <cstddef>
 #include <cstring>
 
 #include "urf.h"
@@ -49,10 +50,10 @@ extern "C" int urf_default_marker_params(urf_marker_params* p)
     if (!p)
         return URF_ERR_INVALID_ARG;
     p->size = sizeof(urf_marker_params);
-    p->simple_poly_allow = 1;    /* cfg:76 */
-    p->poly_s_param = 0.7f;      /* cfg:79 */
-    p->poly_z_manual = -1.5f;    /* cfg:82 */
-    p->poly_z_avg_allow = 1;     /* cfg:85 */
+    p->simple_poly_allow = 1;    /* cfg:75 */
+    p->poly_s_param = 0.7f;      /* cfg:78 */
+    p->poly_z_manual = -1.5f;    /* cfg:81 */
+    p->poly_z_avg_allow = 1;     /* cfg:84 */
     return URF_OK;
 }
 
@@ -75,6 +76,90 @@ int urf_validate_params(const urf_params* p)
     return URF_OK;
 }
 
+/* ---- the live parameter surface -------------------------------------------------
+ * cfg/LidarFilters.cfg:10-84, one row per gen.add(): name, type, default, range (dynamic_reconfigure
+ * fills in 0..1 for bool_t), the enum of xDirection (:22-27), and where the value lives here. */
+#define P_(f) "" #f, URF_PARAM_IN_PARAMS, (uint32_t)offsetof(urf_params, f)
+#define M_(f) "" #f, URF_PARAM_IN_MARKER_PARAMS, (uint32_t)offsetof(urf_marker_params, f)
+static const urf_param_desc g_param_table[] = {
+    /* cfg name            member                 type               default  min     max   string default / enum */
+    { "fixed_frame", "", URF_PARAM_NODE_ONLY, 0, URF_PARAM_STR, 0, 0, 0, "left_os1/os1_lidar", nullptr, 10 },
+    { "topic_name", "", URF_PARAM_NODE_ONLY, 0, URF_PARAM_STR, 0, 0, 0, "/left_os1/os1_cloud_node/points", nullptr, 13 },
+    { "x_zero_method", P_(x_zero_method), URF_PARAM_BOOL, 1, 0, 1, nullptr, nullptr, 16 },
+    { "z_zero_method", P_(z_zero_method), URF_PARAM_BOOL, 1, 0, 1, nullptr, nullptr, 17 },
+    { "star_shaped_method", P_(star_shaped_method), URF_PARAM_BOOL, 1, 0, 1, nullptr, nullptr, 18 },
+    { "blind_spots", P_(blind_spots), URF_PARAM_BOOL, 1, 0, 1, nullptr, nullptr, 19 },
+    { "xDirection", P_(xDirection), URF_PARAM_INT, 0, 0, 2, nullptr, "bothX=0,positiveX=1,negativeX=2", 27 },
+    { "interval", P_(interval), URF_PARAM_DOUBLE, 0.1800, 0.0100, 10, nullptr, nullptr, 30 },
+    { "curb_height", P_(curbHeight), URF_PARAM_DOUBLE, 0.0500, 0.0100, 0.5000, nullptr, nullptr, 33 },
+    { "curb_points", P_(curbPoints), URF_PARAM_INT, 5, 1, 30, nullptr, nullptr, 36 },
+    { "beamZone", P_(beamZone), URF_PARAM_DOUBLE, 30, 10, 100, nullptr, nullptr, 39 },
+    { "min_x", P_(min_X), URF_PARAM_DOUBLE, 0, -200, 200, nullptr, nullptr, 42 },
+    { "max_x", P_(max_X), URF_PARAM_DOUBLE, 30, -200, 200, nullptr, nullptr, 43 },
+    { "min_y", P_(min_Y), URF_PARAM_DOUBLE, -10, -200, 200, nullptr, nullptr, 46 },
+    { "max_y", P_(max_Y), URF_PARAM_DOUBLE, 10, -200, 200, nullptr, nullptr, 47 },
+    { "min_z", P_(min_Z), URF_PARAM_DOUBLE, -3, -200, 200, nullptr, nullptr, 50 },
+    { "max_z", P_(max_Z), URF_PARAM_DOUBLE, -1, -200, 200, nullptr, nullptr, 51 },
+    { "cylinder_deg_x", P_(angleFilter1), URF_PARAM_DOUBLE, 150, 0, 180, nullptr, nullptr, 54 },
+    { "cylinder_deg_z", P_(angleFilter2), URF_PARAM_DOUBLE, 140, 0, 180, nullptr, nullptr, 57 },
+    { "curb_slope_deg", P_(angleFilter3), URF_PARAM_DOUBLE, 50, 0, 180, nullptr, nullptr, 60 },
+    { "kdev_param", P_(kdev_param), URF_PARAM_DOUBLE, 1.225, 0.5, 5, nullptr, nullptr, 63 },
+    { "kdist_param", P_(kdist_param), URF_PARAM_DOUBLE, 2, 0.4, 10, nullptr, nullptr, 66 },
+    { "starbeam_filter", P_(starbeam_filter), URF_PARAM_BOOL, 0, 0, 1, nullptr, nullptr, 69 },
+    { "dmin_param", P_(dmin_param), URF_PARAM_INT, 10, 3, 30, nullptr, nullptr, 72 },
+    { "simple_poly_allow", M_(simple_poly_allow), URF_PARAM_BOOL, 1, 0, 1, nullptr, nullptr, 75 },
+    { "poly_s_param", M_(poly_s_param), URF_PARAM_DOUBLE, 0.7, 0, 1, nullptr, nullptr, 78 },
+    { "poly_z_manual", M_(poly_z_manual), URF_PARAM_DOUBLE, -1.5, -5, 5, nullptr, nullptr, 81 },
+    { "poly_z_avg_allow", M_(poly_z_avg_allow), URF_PARAM_BOOL, 1, 0, 1, nullptr, nullptr, 84 },
+};
+#undef P_
+#undef M_
+
+extern "C" int urf_param_count(void) { return (int)(sizeof(g_param_table) / sizeof(g_param_table[0])); }
+extern "C" const urf_param_desc* urf_param_table(void) { return g_param_table; }
+
+/* dynamic_reconfigure's server clamps a request to [min, max] before the callback sees it
+ * (src/main.cpp:4-34 then stores double -> float, int -> int, bool -> bool). */
+extern "C" int urf_clamp_params(urf_params* p, urf_marker_params* mp, uint32_t* n_clamped)
+{
+    if (!p || p->size != sizeof(urf_params) || (mp && mp->size != sizeof(urf_marker_params)))
+        return URF_ERR_INVALID_ARG;
+    uint32_t changed = 0;
+    for (const urf_param_desc& d : g_param_table) {
+        unsigned char* base = d.where == URF_PARAM_IN_PARAMS ? (unsigned char*)p : d.where == URF_PARAM_IN_MARKER_PARAMS ? (unsigned char*)mp : nullptr;
+        if (!base)
+            continue;
+        if (d.type == URF_PARAM_DOUBLE) {
+            float v;
+            std::memcpy(&v, base + d.offset, sizeof(v));
+            float w = v;
+            if (!(w >= (float)d.min))   /* NaN goes to the lower bound */
+                w = (float)d.min;
+            if (w > (float)d.max)
+                w = (float)d.max;
+            if (std::memcmp(&w, &v, sizeof(v)) != 0) {
+                std::memcpy(base + d.offset, &w, sizeof(w));
+                changed++;
+            }
+        } else {
+            int32_t v;
+            std::memcpy(&v, base + d.offset, sizeof(v));
+            int32_t w = v;
+            if (d.type == URF_PARAM_BOOL)
+                w = v != 0;
+            else
+                w = v < (int32_t)d.min ? (int32_t)d.min : (v > (int32_t)d.max ? (int32_t)d.max : v);
+            if (w != v) {
+                std::memcpy(base + d.offset, &w, sizeof(w));
+                changed++;
+            }
+        }
+    }
+    if (n_clamped)
+        *n_clamped = changed;
+    return URF_OK;
+}
+
 extern "C" const char* urf_strerror(int status)
 {
     switch (status) {
@@ -86,6 +171,7 @@ extern "C" const char* urf_strerror(int status)
     case URF_ERR_CAPACITY: return "scan or batch exceeds the capacity given to urf_create";
     case URF_ERR_OOM: return "out of device memory";
     case URF_ERR_PARAMS: return "parameter outside the supported range";
+    case URF_ERR_BUSY: return "both slots of the asynchronous single-scan path are in flight";
     default: return "unknown status";
     }
 }

@@ -32,9 +32,29 @@ struct urf_ctx {
     /* owned device memory */
     std::vector<void*> allocs;
     float *sx = nullptr, *sy = nullptr, *sz = nullptr;   /* SoA staging for PointCloud2 input */
-    uint8_t* raw = nullptr;         /* PointCloud2 staging (single scan) */
-    size_t raw_bytes = 0;
-    uint8_t* labels1 = nullptr;     /* labels of the single-scan entry point */
+    /* The single-scan (callback) path: two slots, so that the H2D copy of sweep i+1 runs on the copy
+     * stream while sweep i is being classified.  Per slot: pinned host staging for the message
+     * bytes and for the results, device copies of both, the captured launch sequence. */
+    struct slot_t {
+        uint8_t* h_in = nullptr;        /* pinned, h_in_cap bytes */
+        size_t h_in_cap = 0;
+        uint8_t* d_raw = nullptr;       /* device, d_raw_cap bytes */
+        size_t d_raw_cap = 0;
+        uint8_t* h_labels = nullptr;    /* pinned, max_points */
+        uint8_t* d_labels = nullptr;    /* device, max_points */
+        urf_scan_info* h_info = nullptr;   /* pinned */
+        hipEvent_t ev_h2d = nullptr, ev_done = nullptr;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        uint64_t key[3] = { 0, 0, 0 };  /* what the captured sequence was built for */
+        urf_kargs cap_a;                /* ... and the kernel arguments / parameters it runs with */
+        urf_dev_params cap_dp;
+        bool pending = false;
+        uint32_t n_points = 0, ticket = 0;
+    } slots[2];
+    hipStream_t copy_stream = nullptr;
+    uint32_t next_ticket = 0;
+    uint64_t epoch = 1;             /* bumped by everything a captured sequence depends on */
     unsigned long long* ord_keys = nullptr;   /* lazily: scratch of urf_ordered_indices, max_points each */
     uint32_t* ord_pos = nullptr;
     uint32_t* ord_lists = nullptr;  /* 3 x max_points + 4 */
@@ -193,7 +213,6 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.info, S)
     A(c->offsets_copy, S + 1)
     A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
-    A(c->labels1, (size_t)max_points)
 #undef A
     k.sstride = c->sstride;
     /* x_zero_method.cpp:24-27: newY[j] = newY[j-1] + 0.0100 (float += double), a
@@ -216,8 +235,28 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
 
 static void free_lazy(urf_ctx* c)
 {
-    if (c->raw)
-        (void)hipFree(c->raw);
+    for (auto& sl : c->slots) {
+        if (sl.exec)
+            (void)hipGraphExecDestroy(sl.exec);
+        if (sl.graph)
+            (void)hipGraphDestroy(sl.graph);
+        if (sl.ev_h2d)
+            (void)hipEventDestroy(sl.ev_h2d);
+        if (sl.ev_done)
+            (void)hipEventDestroy(sl.ev_done);
+        if (sl.h_in)
+            (void)hipHostFree(sl.h_in);
+        if (sl.h_labels)
+            (void)hipHostFree(sl.h_labels);
+        if (sl.h_info)
+            (void)hipHostFree(sl.h_info);
+        if (sl.d_raw)
+            (void)hipFree(sl.d_raw);
+        if (sl.d_labels)
+            (void)hipFree(sl.d_labels);
+    }
+    if (c->copy_stream)
+        (void)hipStreamDestroy(c->copy_stream);
     if (c->mk_d) {
         (void)hipFree(c->mk_d);
         (void)hipFree(c->mk_pos);
@@ -264,6 +303,7 @@ extern "C" int urf_set_params(urf_ctx* c, const urf_params* p)
         return rc;
     URF_HIP(c, hipSetDevice(c->device));
     c->params = *p;
+    c->epoch++;
     return upload_params(c);
 }
 
@@ -280,6 +320,7 @@ extern "C" int urf_set_stream(urf_ctx* c, void* hip_stream)
     if (!c)
         return URF_ERR_INVALID_ARG;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->epoch++;
     return URF_OK;
 }
 
@@ -303,6 +344,7 @@ extern "C" int urf_enable_stage_capture(urf_ctx* c, int mode)
             return rc;
     }
     c->capture = mode;
+    c->epoch++;
     return URF_OK;
 }
 
@@ -312,6 +354,7 @@ extern "C" int urf_set_debug_flags(urf_ctx* c, uint32_t flags)
         return URF_ERR_INVALID_ARG;
     c->debug_flags = flags;
     c->dp.exp_flags = flags;
+    c->epoch++;
     return URF_OK;
 }
 
@@ -356,6 +399,7 @@ extern "C" int urf_enable_kernel_timing(urf_ctx* c, int on)
     if (!c)
         return URF_ERR_INVALID_ARG;
     c->timing = on != 0;
+    c->epoch++;
     return URF_OK;
 }
 
@@ -539,6 +583,168 @@ extern "C" int urf_classify_batch_pc2(urf_ctx* c, const uint8_t* d_data, uint32_
     return run_pipeline(c, c->sx, c->sy, c->sz, nullptr, n_per_scan, n_per_scan, n_scans, d_labels, d_info);
 }
 
+/* ---- the callback path: one sweep, host buffers ------------------------------- */
+static int slot_prepare(urf_ctx* c, urf_ctx::slot_t& sl, size_t bytes)
+{
+    if (!c->copy_stream)
+        URF_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!sl.ev_h2d) {
+        URF_HIP(c, hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
+        URF_HIP(c, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+        void *hl = nullptr, *hi = nullptr, *dl = nullptr;
+        URF_HIP(c, hipHostMalloc(&hl, c->max_points, hipHostMallocDefault));
+        URF_HIP(c, hipHostMalloc(&hi, sizeof(urf_scan_info), hipHostMallocDefault));
+        URF_HIP(c, hipMalloc(&dl, c->max_points));
+        sl.h_labels = (uint8_t*)hl;
+        sl.h_info = (urf_scan_info*)hi;
+        sl.d_labels = (uint8_t*)dl;
+    }
+    if (bytes > sl.h_in_cap) {   /* grows to the largest message seen (a new buffer invalidates the captured sequence) */
+        URF_HIP(c, hipStreamSynchronize(c->copy_stream));
+        if (sl.h_in)
+            (void)hipHostFree(sl.h_in);
+        if (sl.d_raw)
+            (void)hipFree(sl.d_raw);
+        sl.h_in = nullptr;
+        sl.d_raw = nullptr;
+        sl.h_in_cap = sl.d_raw_cap = 0;
+        sl.key[0] = 0;
+        void *h = nullptr, *d = nullptr;
+        URF_HIP(c, hipHostMalloc(&h, bytes, hipHostMallocDefault));
+        sl.h_in = (uint8_t*)h;
+        sl.h_in_cap = bytes;
+        URF_HIP(c, hipMalloc(&d, bytes));
+        sl.d_raw = (uint8_t*)d;
+        sl.d_raw_cap = bytes;
+    }
+    return URF_OK;
+}
+
+/* what one sweep of the callback path launches on the compute stream: records -> SoA, the
+ * pipeline, results to the pinned host buffers */
+static int slot_launch(urf_ctx* c, urf_ctx::slot_t& sl, uint32_t n_points, uint32_t point_step, uint32_t off_x,
+                       uint32_t off_y, uint32_t off_z)
+{
+    hipLaunchKernelGGL(k_pc2_to_soa, dim3((n_points + 255) / 256), dim3(256), 0, c->stream, sl.d_raw, (unsigned long long)n_points,
+                       point_step, off_x, off_y, off_z, c->sx, c->sy, c->sz);
+    const int rc = run_pipeline(c, c->sx, c->sy, c->sz, nullptr, n_points, n_points, 1, sl.d_labels, nullptr);
+    if (rc != URF_OK)
+        return rc;
+    URF_HIP(c, hipMemcpyAsync(sl.h_labels, sl.d_labels, n_points, hipMemcpyDeviceToHost, c->stream));
+    URF_HIP(c, hipMemcpyAsync(sl.h_info, c->k.info, sizeof(urf_scan_info), hipMemcpyDeviceToHost, c->stream));
+    return URF_OK;
+}
+
+extern "C" int urf_pinned_input(urf_ctx* c, uint32_t slot, size_t bytes, uint8_t** ptr)
+{
+    if (!c || slot > 1 || !ptr || bytes == 0)
+        return URF_ERR_INVALID_ARG;
+    if (c->slots[slot].pending)
+        return URF_ERR_BUSY;
+    URF_HIP(c, hipSetDevice(c->device));
+    const int rc = slot_prepare(c, c->slots[slot], bytes);
+    if (rc != URF_OK)
+        return rc;
+    *ptr = c->slots[slot].h_in;
+    return URF_OK;
+}
+
+extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t n_points, uint32_t point_step,
+                                      uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t* ticket)
+{
+    if (!c || !data || !ticket || n_points == 0 || !pc2_layout_ok(point_step, off_x, off_y, off_z))
+        return URF_ERR_INVALID_ARG;   /* before any byte of the message is copied */
+    if (n_points > c->max_points)
+        return URF_ERR_CAPACITY;
+    urf_ctx::slot_t& sl = c->slots[c->next_ticket & 1u];
+    if (sl.pending)
+        return URF_ERR_BUSY;          /* both slots in flight: urf_classify_pc2_wait() the older one first */
+    URF_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n_points * point_step;
+    int rc = slot_prepare(c, sl, bytes);
+    if (rc == URF_OK)
+        rc = ensure_soa_staging(c);
+    if (rc != URF_OK)
+        return rc;
+    if (data != sl.h_in)
+        std::memcpy(sl.h_in, data, bytes);   /* urf_pinned_input() lets a producer write there directly */
+    URF_HIP(c, hipMemcpyAsync(sl.d_raw, sl.h_in, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    URF_HIP(c, hipEventRecord(sl.ev_h2d, c->copy_stream));
+    URF_HIP(c, hipStreamWaitEvent(c->stream, sl.ev_h2d, 0));
+    /* the launch sequence of a sweep of this shape is captured once and replayed (one graph launch
+     * instead of a dozen kernel launches per callback); anything it depends on bumps the epoch */
+    const uint64_t key[3] = { c->epoch, ((uint64_t)n_points << 32) | point_step,
+                              ((uint64_t)off_x << 42) ^ ((uint64_t)off_y << 21) ^ off_z };
+    const bool use_graph = !c->timing && !(c->debug_flags & 8u);
+    if (use_graph && (sl.key[0] != key[0] || sl.key[1] != key[1] || sl.key[2] != key[2] || !sl.exec)) {
+        if (sl.exec)
+            (void)hipGraphExecDestroy(sl.exec);
+        if (sl.graph)
+            (void)hipGraphDestroy(sl.graph);
+        sl.exec = nullptr;
+        sl.graph = nullptr;
+        URF_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+        rc = slot_launch(c, sl, n_points, point_step, off_x, off_y, off_z);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc != URF_OK || e != hipSuccess) {
+            if (g)
+                (void)hipGraphDestroy(g);
+            if (rc == URF_OK)
+                URF_HIP(c, e);
+            return rc;
+        }
+        sl.graph = g;
+        URF_HIP(c, hipGraphInstantiate(&sl.exec, sl.graph, nullptr, nullptr, 0));
+        sl.key[0] = key[0];
+        sl.key[1] = key[1];
+        sl.key[2] = key[2];
+        sl.cap_a = c->last_a;   /* (run_pipeline recorded them while capturing) */
+        sl.cap_dp = c->last_dp;
+    }
+    if (use_graph) {
+        URF_HIP(c, hipGraphLaunch(sl.exec, c->stream));
+        c->last_scans = 1;      /* what urf_read_stage / urf_marker_points / urf_ordered_indices look at */
+        c->last_a = sl.cap_a;
+        c->last_dp = sl.cap_dp;
+    } else {
+        rc = slot_launch(c, sl, n_points, point_step, off_x, off_y, off_z);
+        if (rc != URF_OK)
+            return rc;
+    }
+    URF_HIP(c, hipEventRecord(sl.ev_done, c->stream));
+    sl.pending = true;
+    sl.n_points = n_points;
+    sl.ticket = c->next_ticket;
+    *ticket = c->next_ticket++;
+    return URF_OK;
+}
+
+extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* labels_out, urf_scan_info* info)
+{
+    if (!c)
+        return URF_ERR_INVALID_ARG;
+    urf_ctx::slot_t& sl = c->slots[ticket & 1u];
+    if (!sl.pending || sl.ticket != ticket)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    URF_HIP(c, hipEventSynchronize(sl.ev_done));
+    if (labels_out)
+        std::memcpy(labels_out, sl.h_labels, sl.n_points);
+    if (info)
+        *info = *sl.h_info;
+    sl.pending = false;
+    return URF_OK;
+}
+
+extern "C" int urf_result_labels(urf_ctx* c, uint32_t ticket, const uint8_t** labels)
+{
+    if (!c || !labels)
+        return URF_ERR_INVALID_ARG;
+    *labels = c->slots[ticket & 1u].h_labels;
+    return URF_OK;
+}
+
 extern "C" int urf_classify_pc2(urf_ctx* c, const uint8_t* data, uint32_t n_points, uint32_t point_step,
                                 uint32_t off_x, uint32_t off_y, uint32_t off_z, uint8_t* labels_out, urf_scan_info* info)
 {
@@ -553,29 +759,11 @@ extern "C" int urf_classify_pc2(urf_ctx* c, const uint8_t* data, uint32_t n_poin
         }
         return URF_OK;
     }
-    URF_HIP(c, hipSetDevice(c->device));
-    const size_t bytes = (size_t)n_points * point_step;
-    if (bytes > c->raw_bytes) {
-        if (c->raw)
-            (void)hipFree(c->raw);
-        c->raw = nullptr;
-        c->raw_bytes = 0;
-        void* p = nullptr;
-        URF_HIP(c, hipMalloc(&p, bytes));
-        c->raw = (uint8_t*)p;
-        c->raw_bytes = bytes;
-    }
-    URF_HIP(c, hipMemcpyAsync(c->raw, data, bytes, hipMemcpyHostToDevice, c->stream));
-    int rc = urf_classify_batch_pc2(c, c->raw, n_points, 1, point_step, off_x, off_y, off_z, c->labels1, nullptr);
+    uint32_t ticket = 0;
+    const int rc = urf_classify_pc2_async(c, data, n_points, point_step, off_x, off_y, off_z, &ticket);
     if (rc != URF_OK)
         return rc;
-    URF_HIP(c, hipMemcpyAsync(labels_out, c->labels1, n_points, hipMemcpyDeviceToHost, c->stream));
-    urf_scan_info tmp;
-    URF_HIP(c, hipMemcpyAsync(&tmp, c->k.info, sizeof(tmp), hipMemcpyDeviceToHost, c->stream));
-    URF_HIP(c, hipStreamSynchronize(c->stream));
-    if (info)
-        *info = tmp;
-    return URF_OK;
+    return urf_classify_pc2_wait(c, ticket, labels_out, info);
 }
 
 extern "C" int urf_compact_indices(urf_ctx* c, const uint8_t* d_labels, uint32_t n_points,
