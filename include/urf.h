@@ -150,8 +150,18 @@ typedef struct urf_scan_info {
     uint32_t n_road;     /* size of the "road" cloud */
     uint32_t n_curb;     /* size of the "curb" cloud */
     uint32_t n_ring10;   /* size of "road_probably" */
-    uint32_t reserved;
+    uint32_t n_nan_azimuth; /* ring points with x == y == 0 (azimuth NaN): the one input on which this
+                               library deliberately differs from the reference, see below */
 } urf_scan_info;
+/* Deviation D5.  A ring point with x == y == 0 has d = 0 and azimuth asin(0/0) = NaN
+ * (lidar_segmentation.cpp:245-269).  In the reference that NaN goes through the per-ring Lomuto
+ * quicksort (:70-93), where every comparison with it is false: the point ends up at an
+ * input-order-dependent place and the beam scans of blind_spots.cpp stop or resume there.  That
+ * behaviour is deterministic but an accident of the sort; here such a point simply never becomes
+ * road and never blocks or truncates a beam (its curb flags and its effect on the ring table are
+ * the reference's).  n_nan_azimuth counts these points so that a caller can tell when a sweep's
+ * labels may differ from the reference's for this reason (0 on every real sweep: a return at the
+ * sensor's own axis). */
 
 typedef struct urf_ctx urf_ctx;
 
@@ -195,15 +205,15 @@ int urf_classify_pc2(urf_ctx* ctx, const uint8_t* data, uint32_t n_points,
  * labels_out may be NULL: urf_result_labels() then gives read access to the pinned result buffer,
  * valid until the ticket's slot is used again (two submissions later).  A producer that can fill a
  * buffer of the library's choosing (a driver, a deserialiser) saves the staging copy: it asks for
- * the pinned input buffer of slot (next ticket & 1) with urf_pinned_input() and passes that very
- * pointer as `data`.  Reference: the subscriber callback, lidar_segmentation.cpp:53,95-100, and
+ * the pinned input buffer of the NEXT submission with urf_pinned_input() (URF_ERR_BUSY while that
+ * slot is still in flight), writes the message there and passes that very pointer as `data`.  Reference: the subscriber callback, lidar_segmentation.cpp:53,95-100, and
  * the publishers, :612-621. */
 int urf_classify_pc2_async(urf_ctx* ctx, const uint8_t* data, uint32_t n_points,
                            uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
                            uint32_t* ticket);
 int urf_classify_pc2_wait(urf_ctx* ctx, uint32_t ticket, uint8_t* labels_out, urf_scan_info* info);
 int urf_result_labels(urf_ctx* ctx, uint32_t ticket, const uint8_t** labels);
-int urf_pinned_input(urf_ctx* ctx, uint32_t slot, size_t bytes, uint8_t** ptr);
+int urf_pinned_input(urf_ctx* ctx, size_t bytes, uint8_t** ptr);
 
 /* ---- batch of scans, device-resident ---------------------------------------
  * n_scans independent scans of n_per_scan points each; scan s owns elements

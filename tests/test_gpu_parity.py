@@ -383,6 +383,13 @@ def test_ring_table_zero_sentinel(ctx_big):
     finally:
         ctx_big.enable_stage_capture(0)
     assert ig.n_rings == ib["n_rings"] and (lg[3] & 3) != 1
+    assert ig.n_nan_azimuth == int(st["ring"][3] >= 0)   # deviation D5 is counted (include/urf.h)
+    x2, y2, z2 = [a.copy() for a in (x, y, z)]
+    x2[100:103] = 0.0
+    y2[100:103] = 0.0
+    lb2, ib2, st2 = O.run_b(x2, y2, z2, p, debug=True)
+    _, ig2 = ctx_big.classify_xyz(x2, y2, z2)
+    assert ig2.n_nan_azimuth == int((st2["ring"][[3, 100, 101, 102]] >= 0).sum())
 
 
 def test_storage_order_invariance(ctx_big):

@@ -57,10 +57,10 @@ class Params(C.Structure):
 class ScanInfo(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_roi", C.c_uint32), ("n_rings", C.c_uint32),
                 ("n_ring_pts", C.c_uint32), ("n_road", C.c_uint32), ("n_curb", C.c_uint32),
-                ("n_ring10", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_ring10", C.c_uint32), ("n_nan_azimuth", C.c_uint32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "n_nan_azimuth"}
 
 
 class MarkerParams(C.Structure):
@@ -111,7 +111,7 @@ def lib():
         "urf_classify_pc2_async": [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)],
         "urf_classify_pc2_wait": [vp, C.c_uint32, u8p, C.POINTER(ScanInfo)],
         "urf_result_labels": [vp, C.c_uint32, C.POINTER(C.c_void_p)],
-        "urf_pinned_input": [vp, C.c_uint32, C.c_size_t, C.POINTER(C.c_void_p)],
+        "urf_pinned_input": [vp, C.c_size_t, C.POINTER(C.c_void_p)],
         "urf_param_count": [],
         "urf_clamp_params": [C.POINTER(Params), C.POINTER(MarkerParams), C.POINTER(C.c_uint32)],
         "urf_classify_batch_soa": [vp, fp, fp, fp, C.c_uint32, C.c_uint32, u8p, vp],
@@ -315,10 +315,10 @@ class Context:
                                                     C.byref(info)), "urf_classify_pc2_wait")
         return info
 
-    def pinned_input(self, slot, nbytes):
-        """uint8 numpy view of the pinned input buffer of `slot` (0 / 1), at least nbytes long."""
+    def pinned_input(self, nbytes):
+        """uint8 numpy view (nbytes long) of the pinned input buffer the NEXT submission will use."""
         p = C.c_void_p()
-        self._check(self._lib.urf_pinned_input(self._h, slot, nbytes, C.byref(p)), "urf_pinned_input")
+        self._check(self._lib.urf_pinned_input(self._h, nbytes, C.byref(p)), "urf_pinned_input")
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
 
     def result_labels(self, ticket, n_points):

@@ -635,17 +635,18 @@ static int slot_launch(urf_ctx* c, urf_ctx::slot_t& sl, uint32_t n_points, uint3
     return URF_OK;
 }
 
-extern "C" int urf_pinned_input(urf_ctx* c, uint32_t slot, size_t bytes, uint8_t** ptr)
+extern "C" int urf_pinned_input(urf_ctx* c, size_t bytes, uint8_t** ptr)
 {
-    if (!c || slot > 1 || !ptr || bytes == 0)
+    if (!c || !ptr || bytes == 0)
         return URF_ERR_INVALID_ARG;
-    if (c->slots[slot].pending)
+    urf_ctx::slot_t& sl = c->slots[c->next_ticket & 1u];   /* the slot the next submission uses */
+    if (sl.pending)
         return URF_ERR_BUSY;
     URF_HIP(c, hipSetDevice(c->device));
-    const int rc = slot_prepare(c, c->slots[slot], bytes);
+    const int rc = slot_prepare(c, sl, bytes);
     if (rc != URF_OK)
         return rc;
-    *ptr = c->slots[slot].h_in;
+    *ptr = sl.h_in;
     return URF_OK;
 }
 

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params 
         in.n_road = 0;
         in.n_curb = 0;
         in.n_ring10 = 0;
-        in.reserved = 0;
+        in.n_nan_azimuth = 0;
         a.info[s] = in;
         sh_nL = 0;
         sh_nmatch = 0;
@@ -2230,8 +2230,11 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                         urf_z_zero_angle_gather(a.rx, a.ry, mapP, mapA, ntiles, map.scale, dp.inv_cp, dp.p.angleFilter2, p, 5, px, py))
                         flag |= 4u;
                     if (flag || (t & URF_CAND_EXACT)) {
-                        a.raz[ip] = urf_ring_point(a.rd2, S, ip, px, py, flag, want_quad);
+                        const float az = urf_ring_point(a.rd2, S, ip, px, py, flag, want_quad);
+                        a.raz[ip] = az;
                         a.rflag[ip] = (uint8_t)flag;
+                        if (!(az == az))   /* x == y == 0: deviation D5 (include/urf.h), counted per scan */
+                            atomicAdd(&a.info[s].n_nan_azimuth, 1u);
                     }
                 }
                 __syncthreads();
@@ -2288,6 +2291,8 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                 maxs = s2 > maxs ? s2 : maxs;
                 a.raz[ip] = az;
                 a.rflag[ip] = (uint8_t)flag;
+                if (!(az == az))
+                    atomicAdd(&a.info[s].n_nan_azimuth, 1u);
             }
         }
         __syncthreads();

@@ -27,11 +27,13 @@ COUNTER_NAMES = ("scans", "points_in", "roi_points", "road", "curb", "ok_scans")
 
 
 def local_counters(info, n_points_per_scan, steps=1):
-    """info: int array [S, 8] of urf_scan_info rows of the last step."""
+    """Totals over the whole run, every entry in the same unit (summed over all `steps` passes over
+    the batch).  info: int array [S, 8] of urf_scan_info rows of ONE step; the batch is the same in
+    every step, so each per-step sum counts `steps` times."""
     info = np.asarray(info, dtype=np.int64)
     s = info.shape[0]
-    return np.array([s * steps, s * n_points_per_scan * steps, info[:, 1].sum(), info[:, 4].sum(), info[:, 5].sum(),
-                     (info[:, 0] == 0).sum()], dtype=np.int64)
+    return steps * np.array([s, s * n_points_per_scan, info[:, 1].sum(), info[:, 4].sum(), info[:, 5].sum(),
+                             (info[:, 0] == 0).sum()], dtype=np.int64)
 
 
 def reduce_run(counters, elapsed_s, device=None):
