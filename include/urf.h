@@ -243,6 +243,13 @@ int urf_classify_batch_pc2(urf_ctx* ctx, const uint8_t* d_data, uint32_t n_per_s
 int urf_compact_indices(urf_ctx* ctx, const uint8_t* d_labels, uint32_t n_points,
                         uint32_t* d_road, uint32_t* d_curb, uint32_t* d_roi, uint32_t* d_ring10,
                         uint32_t* d_counts);
+/* The same for every scan of a batch in one launch (grid over tiles x scans, asynchronous on the
+ * context's stream): scan s owns [s*n_per_scan, (s+1)*n_per_scan) of d_labels and of every list
+ * (indices are relative to the scan), and d_counts[4*s .. 4*s+3].  The reference builds these sets
+ * for every sweep (lidar_segmentation.cpp:354-367, 605-608). */
+int urf_compact_indices_batch(urf_ctx* ctx, const uint8_t* d_labels, uint32_t n_per_scan, uint32_t n_scans,
+                              uint32_t* d_road, uint32_t* d_curb, uint32_t* d_roi, uint32_t* d_ring10,
+                              uint32_t* d_counts);
 
 /* ---- the published clouds, in the reference's order ------------------------
  * The reference fills "road", "curb" and "road_probably" ring by ring (sorted
@@ -255,6 +262,11 @@ int urf_compact_indices(urf_ctx* ctx, const uint8_t* d_labels, uint32_t n_points
  * road_probably}.  Synchronous; costs one extra per-ring sort. */
 int urf_ordered_indices(urf_ctx* ctx, uint32_t scan, uint32_t* road, uint32_t* curb, uint32_t* ring10,
                         uint32_t* counts);
+/* Every scan of the last classify call at once, results on the DEVICE (asynchronous on the
+ * context's stream): list l of scan s at d_l + s*stride (stride >= the call's scan length; any list
+ * may be NULL), d_counts[3*s .. 3*s+2] = {road, curb, road_probably}. */
+int urf_ordered_indices_batch(urf_ctx* ctx, uint32_t* d_road, uint32_t* d_curb, uint32_t* d_ring10,
+                              uint32_t stride, uint32_t* d_counts);
 
 /* ---- road_marker: the marker points ------------------------------------------
  * lidar_segmentation.cpp:295-351: for every integer degree i = 0..360 the farthest road point
@@ -266,6 +278,9 @@ int urf_ordered_indices(urf_ctx* ctx, uint32_t scan, uint32_t* road, uint32_t* c
  * simplification, ghost deletion, :369-602) are host code: urf::Detector::road_marker().
  * Synchronous; costs one extra per-ring sort. */
 int urf_marker_points(urf_ctx* ctx, uint32_t scan, float* pts, uint32_t* count);
+/* Every scan of the last classify call at once, results on the DEVICE (asynchronous): the marker
+ * points of scan s at d_pts + s*361*4 (x, y, z, red per point), their number in d_counts[s]. */
+int urf_marker_points_batch(urf_ctx* ctx, float* d_pts, uint32_t* d_counts);
 
 /* The polygon parameters of the reference (cfg/LidarFilters.cfg:75-84 -> main.cpp:29-32). */
 typedef struct urf_marker_params {

@@ -438,6 +438,51 @@ def test_index_lists(ctx_big):
         assert np.array_equal(bufs[k].to_numpy(np.uint32, int(cnt[k])), want[k])
 
 
+def test_batch_outputs_equal_the_single_scan_outputs():
+    """the index sets, the published order and the marker points of EVERY scan of a batch
+    in one launch sequence each (grid over tiles | rings x scans) -- against numpy on the label bytes
+    and against the single-scan entry points."""
+    p = O.cfg_params("cfg2")
+    n = 20000   # not a multiple of the 2048-label tile
+    scans = [tuple(a[:n].copy() for a in O.cfg_cloud("narrow" if k % 2 else "cfg2", 60 + k)) for k in range(5)]
+    S = len(scans)
+    with u.Context(n, S, params=p) as ctx:
+        X, Y, Z = (np.concatenate([s[k] for s in scans]) for k in range(3))
+        dx, dy, dz = DevBuf.from_numpy(X), DevBuf.from_numpy(Y), DevBuf.from_numpy(Z)
+        dl = DevBuf(S * n)
+        ctx.classify_batch_soa(dx, dy, dz, n, S, dl, None)
+        ctx.synchronize()
+        L = dl.to_numpy(np.uint8).reshape(S, n)
+        # index sets
+        bufs = [DevBuf(4 * S * n) for _ in range(4)]
+        dc = DevBuf(16 * S)
+        ctx.compact_indices_batch(dl, n, S, *bufs, dc)
+        ctx.synchronize()
+        cnt = dc.to_numpy(np.uint32).reshape(S, 4)
+        lists = [b.to_numpy(np.uint32).reshape(S, n) for b in bufs]
+        for s in range(S):
+            want = [np.nonzero((L[s] & 3) == 1)[0], np.nonzero((L[s] & 3) == 2)[0], np.nonzero(L[s] & 4)[0], np.nonzero(L[s] & 16)[0]]
+            for k in range(4):
+                assert cnt[s, k] == len(want[k]) and np.array_equal(lists[k][s, :cnt[s, k]], want[k]), (s, k)
+        # published order and marker points: batch == scan by scan
+        ob = [DevBuf(4 * S * n) for _ in range(3)]
+        oc = DevBuf(12 * S)
+        ctx.ordered_indices_batch(*ob, n, oc)
+        mp, mc = DevBuf(4 * S * 361 * 4), DevBuf(4 * S)
+        ctx.marker_points_batch(mp, mc)
+        ctx.synchronize()
+        ocnt = oc.to_numpy(np.uint32).reshape(S, 3)
+        olists = [b.to_numpy(np.uint32).reshape(S, n) for b in ob]
+        mpts, mcnt = mp.to_numpy(np.float32).reshape(S, 361, 4), mc.to_numpy(np.uint32)
+        for s in range(S):
+            single = ctx.ordered_indices(n, scan=s)
+            for k in range(3):
+                assert np.array_equal(olists[k][s, :ocnt[s, k]], single[k]), (s, k)
+            lb, ib, st = O.run_b(*scans[s], p, debug=True)
+            assert np.array_equal(single[0], st["road_order"]) and np.array_equal(single[1], st["curb_order"])
+            assert np.array_equal(mpts[s, :mcnt[s]], ctx.marker_points(scan=s))
+
+
 def test_full_size_batch_properties():
     """BASELINE cfg3 size (1024 scans of 64x2048): 64 distinct sweeps repeated 16 times.
     Properties: every copy of a sweep gets identical labels wherever it sits in the batch;

@@ -118,6 +118,9 @@ def lib():
         "urf_classify_batch_soa_ragged": [vp, fp, fp, fp, u32p, C.c_uint32, C.c_uint32, u8p, vp],
         "urf_classify_batch_pc2": [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p, vp],
         "urf_compact_indices": [vp, u8p, C.c_uint32, u32p, u32p, u32p, u32p, u32p],
+        "urf_compact_indices_batch": [vp, u8p, C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p, u32p],
+        "urf_ordered_indices_batch": [vp, u32p, u32p, u32p, C.c_uint32, u32p],
+        "urf_marker_points_batch": [vp, vp, u32p],
         "urf_read_stage": [vp, C.c_int, C.c_uint32, vp, C.c_size_t],
         "urf_ordered_indices": [vp, C.c_uint32, vp, vp, vp, vp],
         "urf_marker_points": [vp, C.c_uint32, vp, vp],
@@ -364,6 +367,17 @@ class Context:
     def compact_indices(self, d_labels, n_points, d_road, d_curb, d_roi, d_ring10, d_counts):
         self._check(self._lib.urf_compact_indices(self._h, _ptr(d_labels), n_points, _ptr(d_road), _ptr(d_curb),
                                                   _ptr(d_roi), _ptr(d_ring10), _ptr(d_counts)), "urf_compact_indices")
+
+    def compact_indices_batch(self, d_labels, n_per_scan, n_scans, d_road, d_curb, d_roi, d_ring10, d_counts):
+        self._check(self._lib.urf_compact_indices_batch(self._h, _ptr(d_labels), n_per_scan, n_scans, _ptr(d_road), _ptr(d_curb),
+                                                        _ptr(d_roi), _ptr(d_ring10), _ptr(d_counts)), "urf_compact_indices_batch")
+
+    def ordered_indices_batch(self, d_road, d_curb, d_ring10, stride, d_counts):
+        self._check(self._lib.urf_ordered_indices_batch(self._h, _ptr(d_road), _ptr(d_curb), _ptr(d_ring10), stride, _ptr(d_counts)),
+                    "urf_ordered_indices_batch")
+
+    def marker_points_batch(self, d_pts, d_counts):
+        self._check(self._lib.urf_marker_points_batch(self._h, _ptr(d_pts), _ptr(d_counts)), "urf_marker_points_batch")
 
     def ordered_indices(self, n_points, scan=0):
         """Input indices of the road / curb / road_probably clouds of scan `scan` in the order the

@@ -55,13 +55,18 @@ struct urf_ctx {
     hipStream_t copy_stream = nullptr;
     uint32_t next_ticket = 0;
     uint64_t epoch = 1;             /* bumped by everything a captured sequence depends on */
-    unsigned long long* ord_keys = nullptr;   /* lazily: scratch of urf_ordered_indices, max_points each */
+    /* lazily, sized for the largest number of scans asked for so far: scratch of the index-list and
+     * marker-point outputs (sstride entries resp. channels x 361 cells per scan) */
+    unsigned long long* ord_keys = nullptr;
     uint32_t* ord_pos = nullptr;
-    uint32_t* ord_lists = nullptr;  /* 3 x max_points + 4 */
-    float* mk_d = nullptr;          /* lazily: scratch of urf_marker_points */
+    uint32_t ord_scans = 0;
+    uint32_t* ord_lists = nullptr;  /* single-scan entry point: 3 x sstride + 4 */
+    float* mk_d = nullptr;
     uint32_t* mk_pos = nullptr;
     uint8_t* mk_red = nullptr;
-    float* mk_out = nullptr;        /* 361 x 4 floats + 1 count */
+    uint32_t mk_scans = 0;
+    float* mk_out = nullptr;        /* single-scan entry point: 361 x 4 floats + 1 count */
+    uint32_t* compact_cnt = nullptr;   /* [max_batch][max_tiles][4] */
     float* d_newY = nullptr;
     urf_beam* d_beams = nullptr;
     uint32_t beams_cap = 0;
@@ -212,6 +217,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.act_f, S * C * 6) A(k.act_b, S * C * 6) A(k.qk, S * C)
     A(k.info, S)
     A(c->offsets_copy, S + 1)
+    A(c->compact_cnt, S * tiles * 4)
     A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
 #undef A
     k.sstride = c->sstride;
@@ -257,17 +263,10 @@ static void free_lazy(urf_ctx* c)
     }
     if (c->copy_stream)
         (void)hipStreamDestroy(c->copy_stream);
-    if (c->mk_d) {
-        (void)hipFree(c->mk_d);
-        (void)hipFree(c->mk_pos);
-        (void)hipFree(c->mk_red);
-        (void)hipFree(c->mk_out);
-    }
-    if (c->ord_keys) {
-        (void)hipFree(c->ord_keys);
-        (void)hipFree(c->ord_pos);
-        (void)hipFree(c->ord_lists);
-    }
+    for (void* p : { (void*)c->mk_d, (void*)c->mk_pos, (void*)c->mk_red, (void*)c->mk_out, (void*)c->ord_keys,
+                     (void*)c->ord_pos, (void*)c->ord_lists })
+        if (p)
+            (void)hipFree(p);
     if (c->sx) {
         (void)hipFree(c->sx);
         (void)hipFree(c->sy);
@@ -767,17 +766,78 @@ extern "C" int urf_classify_pc2(urf_ctx* c, const uint8_t* data, uint32_t n_poin
     return urf_classify_pc2_wait(c, ticket, labels_out, info);
 }
 
+/* ---- index-set and marker outputs: every scan of a batch in one launch sequence ------------- */
+extern "C" int urf_compact_indices_batch(urf_ctx* c, const uint8_t* d_labels, uint32_t n_per_scan, uint32_t n_scans,
+                                         uint32_t* d_road, uint32_t* d_curb, uint32_t* d_roi, uint32_t* d_ring10,
+                                         uint32_t* d_counts)
+{
+    if (!c || !d_labels)
+        return URF_ERR_INVALID_ARG;
+    if (n_scans > c->max_batch || n_per_scan > c->max_points)
+        return URF_ERR_CAPACITY;
+    if (n_scans == 0 || n_per_scan == 0)
+        return URF_OK;
+    URF_HIP(c, hipSetDevice(c->device));
+    const unsigned tiles = (n_per_scan + URF_TILE - 1) / URF_TILE;
+    const dim3 grid(tiles, n_scans);
+    hipLaunchKernelGGL(k_compact_count, grid, dim3(URF_COMPACT_THREADS), 0, c->stream, d_labels, n_per_scan, tiles, c->compact_cnt);
+    hipLaunchKernelGGL(k_compact_write, grid, dim3(URF_COMPACT_THREADS), 0, c->stream, d_labels, n_per_scan, tiles, c->compact_cnt,
+                       d_road, d_curb, d_roi, d_ring10, d_counts);
+    URF_HIP(c, hipGetLastError());
+    return URF_OK;
+}
+
 extern "C" int urf_compact_indices(urf_ctx* c, const uint8_t* d_labels, uint32_t n_points,
                                    uint32_t* d_road, uint32_t* d_curb, uint32_t* d_roi, uint32_t* d_ring10,
                                    uint32_t* d_counts)
 {
-    if (!c || !d_labels)
-        return URF_ERR_INVALID_ARG;
-    URF_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, c->stream, d_labels, n_points, d_road, d_curb, d_roi, d_ring10,
+    return urf_compact_indices_batch(c, d_labels, n_points, 1, d_road, d_curb, d_roi, d_ring10, d_counts);
+}
+
+static int ensure_order_scratch(urf_ctx* c, uint32_t n_scans)
+{
+    if (n_scans <= c->ord_scans)
+        return URF_OK;
+    URF_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->ord_keys) {
+        (void)hipFree(c->ord_keys);
+        (void)hipFree(c->ord_pos);
+        c->ord_keys = nullptr;
+        c->ord_pos = nullptr;
+        c->ord_scans = 0;
+    }
+    void *p0 = nullptr, *p1 = nullptr;
+    URF_HIP(c, hipMalloc(&p0, (size_t)n_scans * c->sstride * sizeof(unsigned long long)));
+    URF_HIP(c, hipMalloc(&p1, (size_t)n_scans * c->sstride * sizeof(uint32_t)));
+    c->ord_keys = (unsigned long long*)p0;
+    c->ord_pos = (uint32_t*)p1;
+    c->ord_scans = n_scans;
+    return URF_OK;
+}
+
+/* scans [s0, s0 + n) of the last classify call, lists of `stride` entries per scan on the device */
+static int launch_ordered(urf_ctx* c, uint32_t s0, uint32_t n, uint32_t* d_road, uint32_t* d_curb, uint32_t* d_r10,
+                          uint32_t stride, uint32_t* d_counts)
+{
+    const int rc = ensure_order_scratch(c, n);
+    if (rc != URF_OK)
+        return rc;
+    const urf_kargs a = c->last_a;   /* the call's own arguments and parameters, whatever was set since */
+    const urf_dev_params dp = c->last_dp;
+    hipLaunchKernelGGL(k_ring_order, dim3((unsigned)dp.p.channels, n), dim3(256), 0, c->stream, a, dp, s0, c->ord_keys, c->ord_pos);
+    hipLaunchKernelGGL(k_ordered_lists, dim3(n), dim3(1024), 0, c->stream, a, dp, s0, c->ord_pos, d_road, d_curb, d_r10, stride,
                        d_counts);
     URF_HIP(c, hipGetLastError());
     return URF_OK;
+}
+
+extern "C" int urf_ordered_indices_batch(urf_ctx* c, uint32_t* d_road, uint32_t* d_curb, uint32_t* d_ring10, uint32_t stride,
+                                         uint32_t* d_counts)
+{
+    if (!c || !d_counts || c->last_scans == 0 || !c->last_a.labels || stride < c->last_a.max_len)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    return launch_ordered(c, 0, c->last_scans, d_road, d_curb, d_ring10, stride, d_counts);
 }
 
 extern "C" int urf_ordered_indices(urf_ctx* c, uint32_t scan, uint32_t* road, uint32_t* curb, uint32_t* ring10,
@@ -786,26 +846,20 @@ extern "C" int urf_ordered_indices(urf_ctx* c, uint32_t scan, uint32_t* road, ui
     if (!c || !counts || scan >= c->last_scans || !c->last_a.labels)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
-    const size_t mp = (size_t)c->max_points + URF_SCAN_PAD;   /* ring starts are padded to multiples of 4 */
-    if (!c->ord_keys) {
-        void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
-        URF_HIP(c, hipMalloc(&p0, mp * sizeof(unsigned long long)));
-        URF_HIP(c, hipMalloc(&p1, mp * sizeof(uint32_t)));
+    const size_t mp = c->sstride;
+    if (!c->ord_lists) {
+        void* p2 = nullptr;
         URF_HIP(c, hipMalloc(&p2, (mp * 3 + 4) * sizeof(uint32_t)));
-        c->ord_keys = (unsigned long long*)p0;
-        c->ord_pos = (uint32_t*)p1;
         c->ord_lists = (uint32_t*)p2;
     }
-    const urf_kargs a = c->last_a;   /* the call's own arguments and parameters, whatever was set since */
-    const urf_dev_params dp = c->last_dp;
     uint32_t* d_road = c->ord_lists;
     uint32_t* d_curb = d_road + mp;
     uint32_t* d_r10 = d_curb + mp;
     uint32_t* d_cnt = d_r10 + mp;
     hipStream_t st = c->stream;
-    hipLaunchKernelGGL(k_ring_order, dim3((unsigned)dp.p.channels), dim3(256), 0, st, a, dp, scan, c->ord_keys, c->ord_pos);
-    hipLaunchKernelGGL(k_ordered_lists, dim3(1), dim3(1024), 0, st, a, dp, scan, c->ord_pos, d_road, d_curb, d_r10, d_cnt);
-    URF_HIP(c, hipGetLastError());
+    const int rc = launch_ordered(c, scan, 1, d_road, d_curb, d_r10, (uint32_t)mp, d_cnt);
+    if (rc != URF_OK)
+        return rc;
     uint32_t h[3] = { 0, 0, 0 };
     URF_HIP(c, hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
     URF_HIP(c, hipStreamSynchronize(st));
@@ -821,30 +875,58 @@ extern "C" int urf_ordered_indices(urf_ctx* c, uint32_t scan, uint32_t* road, ui
     return URF_OK;
 }
 
+static int launch_markers(urf_ctx* c, uint32_t s0, uint32_t n, float* d_pts, uint32_t* d_counts)
+{
+    const size_t cells = (size_t)URF_MAX_CHANNELS * URF_DEG_CELLS;
+    if (n > c->mk_scans) {
+        URF_HIP(c, hipStreamSynchronize(c->stream));
+        for (void* p : { (void*)c->mk_d, (void*)c->mk_pos, (void*)c->mk_red })
+            if (p)
+                (void)hipFree(p);
+        c->mk_d = nullptr;
+        c->mk_pos = nullptr;
+        c->mk_red = nullptr;
+        c->mk_scans = 0;
+        void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+        URF_HIP(c, hipMalloc(&p0, n * cells * sizeof(float)));
+        URF_HIP(c, hipMalloc(&p1, n * cells * sizeof(uint32_t)));
+        URF_HIP(c, hipMalloc(&p2, n * cells));
+        c->mk_d = (float*)p0;
+        c->mk_pos = (uint32_t*)p1;
+        c->mk_red = (uint8_t*)p2;
+        c->mk_scans = n;
+    }
+    const urf_kargs a = c->last_a;
+    const urf_dev_params dp = c->last_dp;
+    hipLaunchKernelGGL(k_marker_ring, dim3((unsigned)dp.p.channels, n), dim3(256), 0, c->stream, a, dp, s0, c->mk_d, c->mk_pos, c->mk_red);
+    hipLaunchKernelGGL(k_marker_bins, dim3(n), dim3(384), 0, c->stream, a, dp, s0, c->mk_d, c->mk_pos, c->mk_red, d_pts, d_counts);
+    URF_HIP(c, hipGetLastError());
+    return URF_OK;
+}
+
+extern "C" int urf_marker_points_batch(urf_ctx* c, float* d_pts, uint32_t* d_counts)
+{
+    if (!c || !d_pts || !d_counts || c->last_scans == 0 || !c->last_a.labels)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    return launch_markers(c, 0, c->last_scans, d_pts, d_counts);
+}
+
 extern "C" int urf_marker_points(urf_ctx* c, uint32_t scan, float* pts, uint32_t* count)
 {
     if (!c || !pts || !count || scan >= c->last_scans || !c->last_a.labels)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
-    const size_t cells = (size_t)URF_MAX_CHANNELS * URF_DEG_CELLS;
-    if (!c->mk_d) {
-        void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
-        URF_HIP(c, hipMalloc(&p0, cells * sizeof(float)));
-        URF_HIP(c, hipMalloc(&p1, cells * sizeof(uint32_t)));
-        URF_HIP(c, hipMalloc(&p2, cells));
+    if (!c->mk_out) {
+        void* p3 = nullptr;
         URF_HIP(c, hipMalloc(&p3, (URF_DEG_CELLS * 4 + 4) * sizeof(float)));
-        c->mk_d = (float*)p0;
-        c->mk_pos = (uint32_t*)p1;
-        c->mk_red = (uint8_t*)p2;
         c->mk_out = (float*)p3;
     }
-    const urf_kargs a = c->last_a;
-    const urf_dev_params dp = c->last_dp;
     hipStream_t st = c->stream;
     unsigned* d_cnt = (unsigned*)(c->mk_out + URF_DEG_CELLS * 4);
-    hipLaunchKernelGGL(k_marker_ring, dim3((unsigned)dp.p.channels), dim3(256), 0, st, a, dp, scan, c->mk_d, c->mk_pos, c->mk_red);
-    hipLaunchKernelGGL(k_marker_bins, dim3(1), dim3(384), 0, st, a, dp, scan, c->mk_d, c->mk_pos, c->mk_red, c->mk_out, d_cnt);
-    URF_HIP(c, hipGetLastError());
+    const int rc = launch_markers(c, scan, 1, c->mk_out, d_cnt);
+    if (rc != URF_OK)
+        return rc;
     std::vector<float> h(URF_DEG_CELLS * 4 + 4);
     URF_HIP(c, hipMemcpyAsync(h.data(), c->mk_out, h.size() * sizeof(float), hipMemcpyDeviceToHost, st));
     URF_HIP(c, hipStreamSynchronize(st));

@@ -2722,49 +2722,91 @@ __device__ __forceinline__ float urf_exact_az(const urf_kargs& a, unsigned slot)
 /* ------------------------------------------------------------------------- */
 /* index lists                                                                 */
 /* ------------------------------------------------------------------------- */
-/* Single workgroup, ascending index order (ballot + prefix per 1024 points). */
-__global__ __launch_bounds__(1024) void k_compact(const uint8_t* __restrict__ labels, unsigned n,
-                                                  unsigned* road, unsigned* curb, unsigned* roi, unsigned* ring10,
-                                                  unsigned* counts)
+/* lidar_segmentation.cpp:354-367, 605-608, 620 as index sets: for every scan of a batch the
+ * ascending lists of the input indices of its road / curb / roi / road_probably points.
+ * Workgroup (t, s) = tile t (2048 labels) of scan s.  k_compact_count: the tile's four counts;
+ * k_compact_write: the tile's first position in each list = the counts of the tiles before it, then
+ * ranks inside the tile by ballot + prefix, eight rounds of 256 labels (ascending order kept). */
+#define URF_COMPACT_THREADS 256
+__device__ __forceinline__ unsigned urf_label_classes(unsigned l)
 {
-    __shared__ unsigned wsum[4][16];
-    __shared__ unsigned run[4];
-    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    return ((l & URF_LABEL_MASK) == URF_LABEL_ROAD ? 1u : 0u) | ((l & URF_LABEL_MASK) == URF_LABEL_CURB ? 2u : 0u) |
+           ((l & URF_FLAG_ROI) ? 4u : 0u) | ((l & URF_FLAG_RING10) ? 8u : 0u);
+}
+__global__ __launch_bounds__(URF_COMPACT_THREADS) void k_compact_count(const uint8_t* __restrict__ labels, unsigned n_per_scan,
+                                                                         unsigned tiles, unsigned* __restrict__ tile_cnt)
+{
+    __shared__ unsigned sh[4];
+    const unsigned t = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    const uint8_t* L = labels + (size_t)s * n_per_scan;
     if (tid < 4)
-        run[tid] = 0;
+        sh[tid] = 0;
     __syncthreads();
-    for (unsigned b0 = 0; b0 < n; b0 += 1024) {
-        const unsigned i = b0 + tid;
-        const unsigned l = i < n ? labels[i] : 0;
-        const bool f[4] = { (l & URF_LABEL_MASK) == URF_LABEL_ROAD, (l & URF_LABEL_MASK) == URF_LABEL_CURB,
-                            (l & URF_FLAG_ROI) != 0, (l & URF_FLAG_RING10) != 0 };
+    unsigned c[4] = { 0, 0, 0, 0 };
+    for (unsigned r = 0; r < URF_TILE / URF_COMPACT_THREADS; r++) {
+        const unsigned i = t * URF_TILE + r * URF_COMPACT_THREADS + tid;
+        const unsigned f = i < n_per_scan ? urf_label_classes(L[i]) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            c[k] += (unsigned)__popcll(__ballot((f >> k) & 1u));
+    }
+    if (urf_lane() == 0)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            atomicAdd(&sh[k], c[k]);
+    __syncthreads();
+    if (tid < 4)
+        tile_cnt[((size_t)s * tiles + t) * 4 + tid] = sh[tid];
+}
+__global__ __launch_bounds__(URF_COMPACT_THREADS) void k_compact_write(const uint8_t* __restrict__ labels, unsigned n_per_scan,
+                                                                         unsigned tiles, const unsigned* __restrict__ tile_cnt,
+                                                                         unsigned* road, unsigned* curb, unsigned* roi,
+                                                                         unsigned* ring10, unsigned* counts)
+{
+    __shared__ unsigned run[4], wsum[4][URF_COMPACT_THREADS / 64];
+    const unsigned t = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t* L = labels + (size_t)s * n_per_scan;
+    if (tid < 64) {   /* the tiles before this one: lane k + 4 j sums every 16th tile of class k */
+        const unsigned k = tid & 3u;
+        unsigned sum = 0;
+        for (unsigned u = tid >> 2; u < t; u += 16)
+            sum += tile_cnt[((size_t)s * tiles + u) * 4 + k];
+        sum += __shfl_xor(sum, 4);
+        sum += __shfl_xor(sum, 8);
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (tid < 4)
+            run[tid] = sum;
+    }
+    __syncthreads();
+    unsigned* outs[4] = { road, curb, roi, ring10 };
+    for (unsigned r = 0; r < URF_TILE / URF_COMPACT_THREADS; r++) {
+        const unsigned i = t * URF_TILE + r * URF_COMPACT_THREADS + tid;
+        const unsigned f = i < n_per_scan ? urf_label_classes(L[i]) : 0u;
         unsigned below[4];
+#pragma unroll
         for (int k = 0; k < 4; k++) {
-            const unsigned long long m = __ballot(f[k]);
-            below[k] = __popcll(m & ((1ull << lane) - 1ull));
+            const unsigned long long m = __ballot((f >> k) & 1u);
+            below[k] = urf_popc_below(m);
             if (lane == 0)
-                wsum[k][wave] = __popcll(m);
+                wsum[k][wave] = (unsigned)__popcll(m);
         }
         __syncthreads();
-        unsigned* outs[4] = { road, curb, roi, ring10 };
+#pragma unroll
         for (int k = 0; k < 4; k++) {
             unsigned pre = run[k];
             for (unsigned w = 0; w < wave; w++)
                 pre += wsum[k][w];
-            if (f[k] && outs[k])
-                outs[k][pre + below[k]] = i;
+            if (((f >> k) & 1u) && outs[k])
+                outs[k][(size_t)s * n_per_scan + pre + below[k]] = i;
         }
         __syncthreads();
-        if (tid < 4) {
-            unsigned t = 0;
-            for (int w = 0; w < 16; w++)
-                t += wsum[tid][w];
-            run[tid] += t;
-        }
+        if (tid < 4)
+            run[tid] += wsum[tid][0] + wsum[tid][1] + wsum[tid][2] + wsum[tid][3];
         __syncthreads();
     }
-    if (tid < 4 && counts)
-        counts[tid] = run[tid];
+    if (t + 1 == tiles && tid < 4 && counts)
+        counts[(size_t)s * 4 + tid] = run[tid];
 }
 
 /* ------------------------------------------------------------------------- */
@@ -2777,14 +2819,16 @@ __global__ __launch_bounds__(1024) void k_compact(const uint8_t* __restrict__ la
  * -- equal azimuths stay in input order, where the reference's unstable quicksort leaves their
  * order open -- and writes the ring-major position of the i-th point of the ring in azimuth
  * order.  Rings of up to 2048 points sort in LDS, longer ones in global memory. */
-__global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params dp, unsigned s,
-                                                    unsigned long long* gkeys, unsigned* rord)
+__global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params dp, unsigned s0,
+                                                    unsigned long long* gkeys_all, unsigned* rord_all)
 {
     constexpr unsigned NT = 256, NB = 2048, EPT = 8, CAP = NT * EPT;
     __shared__ unsigned long long A[CAP];
     __shared__ unsigned cnt[NB + 1];
     __shared__ urf_sort_shared ssh;
-    const unsigned c = blockIdx.x, tid = threadIdx.x;
+    const unsigned c = blockIdx.x, s = s0 + blockIdx.y, tid = threadIdx.x;
+    unsigned long long* gkeys = gkeys_all + (size_t)blockIdx.y * a.sstride;   /* per scan of the launch: sstride entries */
+    unsigned* rord = rord_all + (size_t)blockIdx.y * a.sstride;
     const urf_scan_info in = a.info[s];
     if (in.status != URF_OK || c >= in.n_rings)
         return;
@@ -2841,9 +2885,16 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
 /* Walks the rings of one scan in order, every ring in azimuth order (rord), and appends the
  * input index of each point to the list(s) its label puts it in.  Single workgroup; order is
  * kept by ballot + prefix per 1024 points. */
-__global__ __launch_bounds__(1024) void k_ordered_lists(urf_kargs a, urf_dev_params dp, unsigned s, const unsigned* rord,
-                                                        unsigned* road, unsigned* curb, unsigned* ring10, unsigned* counts)
+__global__ __launch_bounds__(1024) void k_ordered_lists(urf_kargs a, urf_dev_params dp, unsigned s0, const unsigned* rord_all,
+                                                        unsigned* road_all, unsigned* curb_all, unsigned* ring10_all,
+                                                        unsigned stride, unsigned* counts_all)
 {
+    const unsigned s = s0 + blockIdx.x;
+    const unsigned* rord = rord_all + (size_t)blockIdx.x * a.sstride;
+    unsigned* road = road_all ? road_all + (size_t)blockIdx.x * stride : nullptr;
+    unsigned* curb = curb_all ? curb_all + (size_t)blockIdx.x * stride : nullptr;
+    unsigned* ring10 = ring10_all ? ring10_all + (size_t)blockIdx.x * stride : nullptr;
+    unsigned* counts = counts_all + (size_t)blockIdx.x * 3;
     __shared__ unsigned wsum[3][16];
     __shared__ unsigned run[3];
     __shared__ unsigned sroff[URF_MAX_CHANNELS + 1], srcnt[URF_MAX_CHANNELS];
@@ -2926,13 +2977,17 @@ __global__ __launch_bounds__(1024) void k_ordered_lists(urf_kargs a, urf_dev_par
  * point (where the scan of this ring stops, and with it the whole scan), and the farthest road point
  * in front of it (ties: the first in azimuth order).  k_marker_ring builds these two tables per ring
  * in LDS (no sort needed), k_marker_bins walks the rings per degree. */
-__global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params dp, unsigned s,
-                                                     float* m_d, unsigned* m_pos, uint8_t* m_red)
+__global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params dp, unsigned s0,
+                                                     float* m_d_all, unsigned* m_pos_all, uint8_t* m_red_all)
 {
     __shared__ int nrmin[URF_DEG_CELLS];
     __shared__ unsigned long long best[URF_DEG_CELLS];
     __shared__ unsigned bestpos[URF_DEG_CELLS];
-    const unsigned c = blockIdx.x, tid = threadIdx.x;
+    const unsigned c = blockIdx.x, s = s0 + blockIdx.y, tid = threadIdx.x;
+    const size_t cells = (size_t)URF_MAX_CHANNELS * URF_DEG_CELLS;   /* per scan of the launch */
+    float* m_d = m_d_all + blockIdx.y * cells;
+    unsigned* m_pos = m_pos_all + blockIdx.y * cells;
+    uint8_t* m_red = m_red_all + blockIdx.y * cells;
     const urf_scan_info in = a.info[s];
     if (in.status != URF_OK || c >= in.n_rings)
         return;
@@ -2994,10 +3049,18 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
     }
 }
 
-__global__ __launch_bounds__(384) void k_marker_bins(urf_kargs a, urf_dev_params dp, unsigned s, const float* m_d,
-                                                     const unsigned* m_pos, const uint8_t* m_red, float* out, unsigned* count)
+__global__ __launch_bounds__(384) void k_marker_bins(urf_kargs a, urf_dev_params dp, unsigned s0, const float* m_d_all,
+                                                     const unsigned* m_pos_all, const uint8_t* m_red_all, float* out_all,
+                                                     unsigned* count_all)
 {
     __shared__ unsigned wsum[6];
+    const unsigned s = s0 + blockIdx.x;
+    const size_t cells = (size_t)URF_MAX_CHANNELS * URF_DEG_CELLS;
+    const float* m_d = m_d_all + blockIdx.x * cells;
+    const unsigned* m_pos = m_pos_all + blockIdx.x * cells;
+    const uint8_t* m_red = m_red_all + blockIdx.x * cells;
+    float* out = out_all + (size_t)blockIdx.x * URF_DEG_CELLS * 4;
+    unsigned* count = count_all + blockIdx.x;
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const urf_scan_info in = a.info[s];
     const unsigned nR = in.status == URF_OK ? in.n_rings : 0;
