@@ -296,6 +296,27 @@ def main():
     kms, kcalls = ctx.kernel_timing()
     ctx.enable_kernel_timing(False)
 
+    # the optional outputs of SURVEY.md 8f for the whole batch (not part of `value`): index sets,
+    # published order, marker points
+    outputs_ms = None
+    if world == 1 and args.workload == "cfg3" and not args.no_e2e:
+        idx = [torch.empty((S, N_PTS), dtype=torch.int32, device=dev) for _ in range(4)]
+        cnt = torch.zeros((S, 4), dtype=torch.int32, device=dev)
+        mpts = torch.empty((S, 361, 4), dtype=torch.float32, device=dev)
+        outputs_ms = {}
+        with torch.cuda.stream(stream):
+            for name, fn in (("compact_indices", lambda: ctx.compact_indices_batch(dl, N_PTS, S, idx[0], idx[1], idx[2], idx[3], cnt)),
+                             ("ordered_indices", lambda: ctx.ordered_indices_batch(idx[0], idx[1], idx[2], N_PTS, cnt)),
+                             ("marker_points", lambda: ctx.marker_points_batch(mpts, cnt))):
+                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                fn()
+                e1.record(stream)
+                torch.cuda.synchronize()
+                outputs_ms[name] = round(e0.elapsed_time(e1), 4)
+        del idx, mpts
+
     # bookkeeping only: all-reduce(SUM) of six 64-bit counters + all-reduce(MAX) of the elapsed time
     # over RCCL; no point data ever crosses xGMI
     counters = sharding.local_counters(di.cpu().numpy(), N_PTS, steps=args.steps)
@@ -332,6 +353,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "whole_pipeline_achieved": round(whole, 2), "whole_pipeline_frac": round(whole / HBM_PEAK_GBS, 5)},
             "kernel_ms": {k: round(v / max(kcalls, 1), 4) for k, v in kms.items()},
+            "outputs_ms_per_batch": outputs_ms,
             "counters": dict(zip(sharding.COUNTER_NAMES, [int(v) for v in counters])),
             "parity_checked_scans": picked,
             "backend": args.backend if world > 1 else None,

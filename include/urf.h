@@ -360,9 +360,10 @@ int urf_selftest(urf_ctx* ctx, uint64_t* n_mismatches);
 /* Measured error of the float fast paths that settle ring and sector decisions (k_split) over
  * n_samples pseudo-random points: err[0] = max |approx - exact| of the vertical angle [deg],
  * err[1] of the polar angle [rad], err[2] of the scaled polar angle (at the configured number of
- * sectors), err[3] of the azimuth [deg] (k_ring / k_label).  They must stay below the margins the
- * kernels use (3e-4, 2e-6, 2.5e-4 * max(1, sectors / 360), 5e-4).  err has room for 4 floats.
- * Synchronous. */
+ * sectors), err[3] of the azimuth AS A FRACTION of its margin (which grows towards the x axis, where
+ * the reference's own value is ill-conditioned; k_split / k_label).  The first three must stay below
+ * the margins the kernels use (3e-4, 2e-6, 2.5e-4 * max(1, sectors / 360)), the last below 1.  err
+ * has room for 4 floats.  Synchronous. */
 int urf_selftest_fast(urf_ctx* ctx, uint64_t n_samples, float* err);
 /* Test hook: bit 2 (value 4) forces the general (comparison network) path of the star-shaped sort
  * for every sector; 0 in production.  Takes effect with the next classify call. */

@@ -523,10 +523,10 @@ def test_device_arithmetic_selftest(ctx_big):
 def test_fast_path_error_bounds(ctx_big):
     """Ring and sector are decided from float approximations of the angles wherever the
     approximation is clear of every decision boundary by a margin (urf_device.hpp); the margins
-    (3e-4 deg, 2e-6 rad, 2.5e-4, 5e-4 deg) must dominate the error measured on 2^28 pseudo-random points."""
+    (3e-4 deg, 2e-6 rad, 2.5e-4, the azimuth's 5e-4 + 6e-4 / delta deg) must dominate the error measured on 2^28 pseudo-random points."""
     ctx_big.set_params(u.default_params())
     ev, ea, eu, ez = ctx_big.selftest_fast(1 << 28)
-    assert ev < 1.0e-4 and ea < 0.7e-6 and eu < 0.85e-4 and ez < 1.7e-4, (ev, ea, eu, ez)
+    assert ev < 1.0e-4 and ea < 0.7e-6 and eu < 0.85e-4 and ez < 0.5, (ev, ea, eu, ez)   # ez: fraction of the azimuth margin
     # the sector margin scales with the number of sectors (urf_dev_params::sector_margin): at the
     # largest supported count the measured error of the scaled polar angle must stay below a third of it
     p = u.default_params()

@@ -42,6 +42,23 @@ __device__ __forceinline__ unsigned long long urf_match_any_fast(unsigned key, u
     return urf_match_any(key, nbits);
 }
 
+/* The same among the lanes that hold a key (`on`); the mask of a lane without one is unspecified.
+ * The shortcuts look at those lanes only: a region of interest that drops part of a firing, or
+ * points that match no ring, must not push the whole wave onto the bit-by-bit path. */
+__device__ __forceinline__ unsigned long long urf_match_any_on(unsigned key, bool on, unsigned nbits)
+{
+    const unsigned long long vm = __ballot(on);
+    if (vm == 0)
+        return 0ull;
+    const unsigned f = (unsigned)__ffsll((long long)vm) - 1u;
+    const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)key, (int)f);
+    if (__ballot(on && key != first) == 0)
+        return vm;
+    if (__ballot(on && key != first + (urf_lane() - f)) == 0)
+        return 1ull << urf_lane();
+    return urf_match_any(on ? key : (1u << nbits) - 1u, nbits) & vm;   /* the all-ones key is no valid key */
+}
+
 __device__ __forceinline__ unsigned urf_popc_below(unsigned long long m)
 {
     return __popcll(m & ((1ull << urf_lane()) - 1ull));
@@ -295,11 +312,19 @@ __device__ __forceinline__ int urf_fast_sector(float x, float y, float Kfi, unsi
  * approximately: the polar angle (the one the sector comes from: k_split evaluates the arc tangent
  * once per point) turned by a quarter.  The reference takes asin(|x| / d) with |x| / d rounded to
  * float, which is ill-conditioned towards the x axis: its own deviation from the true angle is up
- * to 1.2e-7 * |x|/|y| rad.  Inside |y| >= |x| / 16 (urf_fast_az_ok) that is 1.1e-4 deg, and with the
- * other roundings |approx - reference| <= URF_FAST_AZ_ERR (measured by urf_selftest_fast); closer
- * to the x axis the users take the exact sequence.  Not valid across the 0/360 seam, which the
- * users treat as undecided anyway (the approximation is then within the margin of an integer). */
+ * to 1.2e-7 * |x|/|y| rad = 3.94e-4 / delta deg, delta = the azimuth's distance from the x axis (90 /
+ * 270 deg) in degrees.  The margin follows it (urf_fast_az_eps): |approx - reference| <=
+ * URF_FAST_AZ_ERR + 6e-4 / delta (measured by urf_selftest_fast as a fraction of the margin), down
+ * to |y| = |x| / 1024 (delta = 0.056 deg, margin 0.011 deg); only closer to the axis the users take
+ * the exact sequence (urf_fast_az_ok).  Not valid across the 0/360 seam, which the users treat as
+ * undecided anyway (the approximation is then within the margin of an integer). */
 #define URF_FAST_AZ_ERR 5.0e-4f
+#define URF_FAST_AZ_RATIO 1024.0f
+__device__ __forceinline__ float urf_fast_az_eps(float az)
+{
+    const float delta = __builtin_fminf(__builtin_fabsf(az - 90.0f), __builtin_fabsf(az - 270.0f));
+    return URF_FAST_AZ_ERR + 6.0e-4f * __builtin_amdgcn_rcpf(__builtin_fmaxf(delta, 0.04f));
+}
 __device__ __forceinline__ float urf_fast_azimuth_of(float fi)
 {
     const float az = fi * 57.295779513082323f + 90.0f;
@@ -308,7 +333,7 @@ __device__ __forceinline__ float urf_fast_azimuth_of(float fi)
 __device__ __forceinline__ bool urf_fast_az_ok(float x, float y)
 {
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-    return (ay * 16.0f >= ax) & (ay >= URF_FAST_MIN) & (ax <= URF_FAST_MAX) & (ay <= URF_FAST_MAX);
+    return (ay * URF_FAST_AZ_RATIO >= ax) & (ay >= URF_FAST_MIN) & (ax <= URF_FAST_MAX) & (ay <= URF_FAST_MAX);
 }
 __device__ __forceinline__ bool urf_fast_azimuth(float x, float y, float* out)
 {

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
         }
         {
             const bool on = rkey[q] != URF_RING_NONE;
-            const unsigned long long m = urf_match_any_fast(on ? rkey[q] : C, dp.ring_keybits);
+            const unsigned long long m = urf_match_any_on(rkey[q], on, dp.ring_keybits);
             const unsigned old = my_r[on ? rkey[q] : 0];
             if (on && urf_is_leader(m))
                 my_r[rkey[q]] = (uint16_t)(old + (unsigned)__popcll(m));
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
         srank[q] = 0;
         if (star) {
             const bool on = skey[q] != URF_SEC_NONE;
-            const unsigned long long m = urf_match_any_fast(on ? skey[q] : K, dp.sec_keybits);
+            const unsigned long long m = urf_match_any_on(skey[q], on, dp.sec_keybits);
             const unsigned old = my_s[on ? skey[q] : 0];
             if (on && urf_is_leader(m))
                 my_s[skey[q]] = (uint16_t)(old + (unsigned)__popcll(m));
@@ -1838,7 +1838,9 @@ struct urf_ring_shared {
  * points of the ring in the tiles before t (P[ntiles] = n), radd[t] = scratch index of the first
  * point of the ring's run in tile t, minus P[t]: position j of the ring lives at radd[tile(j)] + j.
  * Both tables sit in LDS.  The tile is guessed from the ring's average run length (exact for an
- * organised sweep: every firing adds one point to every ring) and found by bisection otherwise. */
+ * organised sweep: every firing adds one point to every ring) and found by bisection otherwise.
+ * (A 256-entry inverse table + forward walk instead of the bisection was measured: no gain on a
+ * sweep cut by the default region of interest, 9 % slower on a full one -- registers.) */
 struct urf_ring_map {
     const unsigned* P;
     const unsigned* radd;
@@ -1935,11 +1937,9 @@ __device__ __forceinline__ bool urf_z_zero_angle(float inv_cp, float angleFilter
 
 /* the two instances k_ring uses: operands gathered from the ring-sorted arrays through the ring's
  * map (quad mapping), or read from an LDS window whose element 0 is ring position `origin` */
-__device__ __noinline__ bool urf_z_zero_angle_gather(const float* rx, const float* ry, const unsigned* P, const unsigned* A,
-                                                     unsigned ntiles, float scale, float inv_cp, float angleFilter2, int p, int cp,
-                                                     float px, float py)
+__device__ __noinline__ bool urf_z_zero_angle_gather(const float* rx, const float* ry, const urf_ring_map map, float inv_cp,
+                                                     float angleFilter2, int p, int cp, float px, float py)
 {
-    const urf_ring_map map = { P, A, ntiles, scale };
     auto gxy = [&](int r, float& x, float& y) {
         const unsigned idx = map.at((unsigned)r);
         x = rx[idx];
@@ -2106,10 +2106,10 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
 #pragma unroll
                 for (int e4 = 0; e4 < 4; e4++)
                     if (j + e4 >= 0 && j + e4 < n) {
-                        const unsigned idx = map.at((unsigned)(j + e4));
-                        ex[e4] = a.rx[idx];
-                        ey[e4] = a.ry[idx];
-                        ez[e4] = a.rz[idx];
+                        const unsigned ie = map.at((unsigned)(j + e4));
+                        ex[e4] = a.rx[ie];
+                        ey[e4] = a.ry[ie];
+                        ez[e4] = a.rz[ie];
                     }
                 fx[m] = make_float4(ex[0], ex[1], ex[2], ex[3]);
                 fy[m] = make_float4(ey[0], ey[1], ey[2], ey[3]);
@@ -2152,7 +2152,11 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
              * list, which is worked off densely (all lanes busy instead of the two or three that
              * sit on a curb) when it fills up and at the end of the ring. */
             const int q0 = cs + 4 * (int)tid;
+#ifdef URF_EXP_SKIP_EVAL
+            if (false) {
+#else
             if (q0 < n) {
+#endif
                 const float4* zp = (const float4*)(S.zs + 4 * tid + PAD - 4);   /* slot of q0 - 5 */
                 float w[16];
 #pragma unroll
@@ -2212,7 +2216,11 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                 }
             }
             __syncthreads();
+#ifdef URF_EXP_SKIP_CAND
+            if (false) {
+#else
             if (S.n_cand > URF_RING_CAND - CH || cs + CH >= n) {   /* the next chunk might not fit / last chunk */
+#endif
                 const unsigned nc = S.n_cand;
                 for (unsigned e = tid; e < nc; e += URF_RING_THREADS) {
                     const unsigned v = S.cand[e], t = v >> URF_CAND_SHIFT;
@@ -2227,7 +2235,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                             flag |= 2u;
                     }
                     if ((t & URF_CAND_ZZERO) &&   /* operands come from the ring-sorted arrays (L2) */
-                        urf_z_zero_angle_gather(a.rx, a.ry, mapP, mapA, ntiles, map.scale, dp.inv_cp, dp.p.angleFilter2, p, 5, px, py))
+                        urf_z_zero_angle_gather(a.rx, a.ry, map, dp.inv_cp, dp.p.angleFilter2, p, 5, px, py))
                         flag |= 4u;
                     if (flag || (t & URF_CAND_EXACT)) {
                         const float az = urf_ring_point(a.rd2, S, ip, px, py, flag, want_quad);
@@ -2298,50 +2306,64 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
         __syncthreads();
     }
 
-    atomicMax(&S.maxs, (unsigned long long)__double_as_longlong(maxs));   /* non-negative doubles order like integers */
-    __syncthreads();
+#ifdef URF_EXP_SKIP_EPILOGUE
+    return;
+#endif
+    {   /* the ring's largest squared range: wave maximum first, one LDS atomic per wave
+         * (non-negative doubles order like integers) */
+        unsigned long long m = (unsigned long long)__double_as_longlong(maxs);
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)m, o), hi = (unsigned)__shfl_xor((int)(unsigned)(m >> 32), o);
+            const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+            m = w > m ? w : m;
+        }
+        if ((tid & 63) == 0)
+            atomicMax(&S.maxs, m);
+    }
+    /* sufmin[i] = min curb azimuth >= i ; premax[i] = max curb azimuth <= i ; NaN = none.  Both are
+     * prefix maxima: premax over the cells in order, sufmin over the cells in REVERSE order of the
+     * bit-flipped values (a minimum is the maximum of the complements).  Three consecutive cells per
+     * thread, one DPP scan across the wave, the first wave's total handed to the second. */
+    static_assert(URF_RING_THREADS == 128 && 3 * URF_RING_THREADS >= URF_DEG_CELLS, "three cells per thread, two waves");
+    __shared__ unsigned wtot[2];
+    unsigned up[3], dn[3];
+#pragma unroll
+    for (unsigned e = 0; e < 3; e++) {
+        const unsigned i = 3 * tid + e;                 /* cell of the prefix maximum */
+        up[e] = i < URF_DEG_CELLS ? (unsigned)(cmax[i] + 1) : 0u;                          /* none (-1) -> 0 */
+        dn[e] = i < URF_DEG_CELLS ? ~(unsigned)cmin[URF_DEG_CELLS - 1 - i] : 0u;           /* none (0x7fffffff) -> 0x80000000, below every value */
+        if (e) {
+            up[e] = up[e] > up[e - 1] ? up[e] : up[e - 1];
+            dn[e] = dn[e] > dn[e - 1] ? dn[e] : dn[e - 1];
+        }
+    }
+    const unsigned iu = urf_wave_scan_max(up[2]), id = urf_wave_scan_max(dn[2]);
+    if (tid == 63) {
+        wtot[0] = iu;
+        wtot[1] = id;
+    }
+    unsigned pu = (unsigned)__shfl_up((int)iu, 1), pd = (unsigned)__shfl_up((int)id, 1);
+    if ((tid & 63) == 0)
+        pu = pd = 0;
+    __syncthreads();   /* S.maxs and wtot are complete */
+    if (tid >= 64) {
+        pu = pu > wtot[0] ? pu : wtot[0];
+        pd = pd > wtot[1] ? pd : wtot[1];
+    }
     if (tid == 0)
         a.maxdist[(size_t)s * C + c] = (float)__builtin_sqrt(__longlong_as_double((long long)S.maxs));
     if (want_quad && tid < 4)
         a.quad[(size_t)s * 4 + tid] = __uint_as_float((unsigned)sh_q[tid]);
-
-    /* sufmin[i] = min curb azimuth >= i ; premax[i] = max curb azimuth <= i ; NaN = none.
-     * Six 64-cell segments: suffix-min / prefix-max inside a segment by wave
-     * shuffles, then combined with the totals of the segments behind / in front. */
-    __shared__ int segmin[6], segmax[6];
-    const unsigned wave = tid >> 6, lane = tid & 63;
-    for (unsigned seg = wave; seg < 6; seg += URF_RING_THREADS / 64) {
-        const unsigned cidx = seg * 64 + lane;
-        int mn = cidx < URF_DEG_CELLS ? cmin[cidx] : URF_INT_NONE_MIN;
-        int mx = cidx < URF_DEG_CELLS ? cmax[cidx] : -1;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int wmn = __shfl_down(mn, o), wmx = __shfl_up(mx, o);
-            if ((int)lane + o < 64)
-                mn = wmn < mn ? wmn : mn;
-            if ((int)lane >= o)
-                mx = wmx > mx ? wmx : mx;
-        }
-        if (cidx < URF_DEG_CELLS) {
-            cmin[cidx] = mn;
-            cmax[cidx] = mx;
-        }
-        if (lane == 0)
-            segmin[seg] = mn;
-        if (lane == 63)
-            segmax[seg] = mx;
-    }
-    __syncthreads();
     float* sm = a.sufmin + ((size_t)s * C + c) * URF_DEG_CELLS;
     float* pm = a.premax + ((size_t)s * C + c) * URF_DEG_CELLS;
-    for (unsigned i = tid; i < URF_DEG_CELLS; i += URF_RING_THREADS) {
-        const unsigned seg = i >> 6;
-        int mn = cmin[i], mx = cmax[i];
-        for (unsigned g = seg + 1; g < 6; g++)
-            mn = segmin[g] < mn ? segmin[g] : mn;
-        for (unsigned g = 0; g < seg; g++)
-            mx = segmax[g] > mx ? segmax[g] : mx;
-        sm[i] = mn == URF_INT_NONE_MIN ? __builtin_nanf("") : __uint_as_float((unsigned)mn);
-        pm[i] = mx < 0 ? __builtin_nanf("") : __uint_as_float((unsigned)mx);
+#pragma unroll
+    for (unsigned e = 0; e < 3; e++) {
+        const unsigned i = 3 * tid + e;
+        if (i < URF_DEG_CELLS) {
+            const unsigned u = up[e] > pu ? up[e] : pu, d = dn[e] > pd ? dn[e] : pd;
+            pm[i] = u == 0 ? __builtin_nanf("") : __uint_as_float(u - 1u);
+            sm[URF_DEG_CELLS - 1 - i] = (d == 0x80000000u || d == 0u) ? __builtin_nanf("") : __uint_as_float(~d);
+        }
     }
 }
 
@@ -2646,7 +2668,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
              * the exact azimuth. */
             bool unsure;
             const bool road = urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c], raz[q],
-                                            (flag & URF_RFLAG_AZ_APPROX) ? URF_FAST_AZ_ERR : 0.0f, unsure);
+                                            (flag & URF_RFLAG_AZ_APPROX) ? urf_fast_az_eps(raz[q]) : 0.0f, unsure);
             bool road_final = road;
             if (unsure) {
                 const unsigned e = atomicAdd(&n_unsure, 1u);
@@ -3138,6 +3160,12 @@ __global__ __launch_bounds__(256) void k_selftest_fast(unsigned long long n, flo
                 c[k] = __builtin_ldexpf(c[k], (int)(h % 141u) - 70);
             }
         }
+        /* another eighth close to the x axis (|y| / |x| between 1 / 2048 and 1 / 8), where the azimuth's
+         * margin grows with 1 / delta and its end (urf_fast_az_ok) lies */
+        if ((i & 7) == 2) {
+            h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27;
+            c[1] = c[0] * __builtin_ldexpf(1.0f + (float)(h >> 41) * (1.0f / 8388608.0f), -(int)(4 + (h & 7u))) * ((h & 8u) ? -1.0f : 1.0f);
+        }
         const float x = c[0], y = c[1], z = c[2] * 0.25f;
         float vt;
         if (urf_fast_vertical_angle(x, y, z, &vt)) {
@@ -3147,8 +3175,8 @@ __global__ __launch_bounds__(256) void k_selftest_fast(unsigned long long n, flo
         float azt;
         if (urf_fast_azimuth(x, y, &azt)) {
             float d2;
-            const float d = __builtin_fabsf(azt - urf_azimuth(x, y, &d2));
-            if (d < 180.0f)   /* the 0/360 seam is never decided on the approximation */
+            const float d = __builtin_fabsf(azt - urf_azimuth(x, y, &d2)) / urf_fast_az_eps(azt);   /* as a fraction of the margin */
+            if (d < 1000.0f)   /* the 0/360 seam is never decided on the approximation */
                 ez = d > ez ? d : ez;
         }
         if (x != 0.f || y != 0.f) {
