@@ -392,6 +392,50 @@ def test_ring_table_zero_sentinel(ctx_big):
     assert ig2.n_nan_azimuth == int((st2["ring"][[3, 100, 101, 102]] >= 0).sum())
 
 
+def late_ring_cloud(n=60000, late_at=40000, seed=5):
+    """8 rings from the first firing on, a 9th one that shows up only `late_at` points into the sweep."""
+    rng = np.random.default_rng(seed)
+    i = np.arange(n)
+    elev = np.deg2rad(-22.0 + 2.0 * (i % 8))
+    late = (i >= late_at) & (i % 97 == 0)
+    elev[late] = np.deg2rad(-4.0)
+    az = i * (2 * np.pi / n) + 1e-3
+    t = 1.8 / -np.sin(elev) * (1 + 1e-4 * rng.random(n))
+    x, y, z = t * np.cos(elev) * np.cos(az), t * np.cos(elev) * np.sin(az), t * np.sin(elev)
+    x, y, z = x.astype(np.float32), y.astype(np.float32), z.astype(np.float32)
+    r = np.sqrt(x * x + y * y)
+    _, first = np.unique(r, return_index=True)   # no planar-range ties inside a sector
+    keep = np.zeros(n, bool)
+    keep[first] = True
+    return x[keep], y[keep], z[keep]
+
+
+def test_speculative_ring_table_is_repaired():
+    """k_ring_table stops looking for new rings after 16384 quiet points and lets k_split check the
+    rest; a ring that shows up later than that makes k_split raise the scan's redo flag, the table
+    is rebuilt the long way and the scan split again -- in the same call.  Afterwards the context no
+    longer speculates; results stay the reference's either way."""
+    p = O.cfg_params("cfg2")
+    x, y, z = late_ring_cloud()
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    assert ib["n_rings"] == 9
+    ok = O.cfg_cloud("cfg2", 88)
+    ok = tuple(a[:len(x)].copy() for a in ok)
+    lb_ok, ib_ok, _ = O.run_b(*ok, p)
+    with u.Context(len(x), 3, params=p) as ctx:
+        labels, infos = run_batch(ctx, [ok, (x, y, z), ok], p)          # only the middle scan needs the repair
+        assert np.array_equal(labels[1], lb) and infos[1][2] == 9
+        assert np.array_equal(labels[0], lb_ok) and np.array_equal(labels[2], lb_ok)
+        labels, infos = run_batch(ctx, [(x, y, z), ok, (x, y, z)], p)   # (no speculation any more)
+        assert np.array_equal(labels[0], lb) and np.array_equal(labels[2], lb) and np.array_equal(labels[1], lb_ok)
+    with u.Context(len(x), 1, params=p) as ctx:                         # the callback path: captured graph, then re-captured
+        for rep in range(3):
+            lg, ig = ctx.classify_xyz(x, y, z)
+            assert np.array_equal(lg, lb) and info_equal(ig, ib)
+            lg, ig = ctx.classify_xyz(*ok)
+            assert np.array_equal(lg, lb_ok)
+
+
 def test_storage_order_invariance(ctx_big):
     p = O.cfg_params("cfg2")
     x, y, z = O.cfg_cloud("cfg2", 71)

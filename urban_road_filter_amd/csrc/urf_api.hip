@@ -75,6 +75,11 @@ struct urf_ctx {
     std::vector<std::vector<hipEvent_t>> timing_events;   /* sets of URF_NUM_KERNELS+1 events, created once and reused */
     size_t timing_used = 0;         /* sets recorded since the last urf_kernel_timing() */
     uint32_t* offsets_copy = nullptr;   /* [max_batch + 1] the ragged offsets of the last call (context-owned) */
+    /* k_ring_table speculates (stops when no new ring has shown up for a while, k_split checks);
+     * a scan that proves it wrong is repaired in the same call and raises this host-visible flag,
+     * after which the context builds its tables the long way */
+    uint32_t* h_spec_failed = nullptr;  /* pinned, device-mapped */
+    bool speculate = true;
     /* last call, for the entry points that read its intermediate results (urf_read_stage,
      * urf_ordered_indices, urf_marker_points): the kernel arguments and parameters it ran with */
     uint32_t last_scans = 0;
@@ -210,7 +215,8 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles)
     A(k.angle, S * C) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
-    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 2)
+    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 4)
+    A(k.table_upto, S) A(k.table_redo, S) A(k.redo_list, S)
     A(k.maxdist, S * C) A(k.quad, S * 4)
     A(k.sufmin, S * C * URF_DEG_CELLS) A(k.premax, S * C * URF_DEG_CELLS)
     A(k.stop_f, S * URF_DEG_CELLS) A(k.stop_b, S * URF_DEG_CELLS)
@@ -221,6 +227,17 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
 #undef A
     k.sstride = c->sstride;
+    {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess)
+            return fail(URF_ERR_HIP);
+        c->h_spec_failed = (uint32_t*)hp;
+        *c->h_spec_failed = 0;
+        void* dp_ = nullptr;
+        if (hipHostGetDevicePointer(&dp_, hp, 0) != hipSuccess)
+            return fail(URF_ERR_HIP);
+        k.spec_failed = (uint32_t*)dp_;
+    }
     /* x_zero_method.cpp:24-27: newY[j] = newY[j-1] + 0.0100 (float += double), a
      * data-independent table shared by all rings */
     {
@@ -241,6 +258,8 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
 
 static void free_lazy(urf_ctx* c)
 {
+    if (c->h_spec_failed)
+        (void)hipHostFree(c->h_spec_failed);
     for (auto& sl : c->slots) {
         if (sl.exec)
             (void)hipGraphExecDestroy(sl.exec);
@@ -462,6 +481,11 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     if (a.tiles == 0)
         a.tiles = 1;
     a.sstride = c->sstride;
+    if (c->speculate && *c->h_spec_failed) {   /* an earlier call had to repair a speculative ring table */
+        c->speculate = false;
+        c->epoch++;
+    }
+    a.table_lookahead = c->speculate ? URF_TABLE_LOOKAHEAD : 0u;
     a.capture = (uint32_t)c->capture;
     a.labels = d_labels;
     if (c->capture != 1)
@@ -489,17 +513,21 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     mark();
     hipLaunchKernelGGL(k_ring_table, g_scan, dim3(256), 0, st, a, dp);
     mark();
+    URF_HIP(c, hipMemsetAsync(a.star_count, 0, 4 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_split, g_tiles, dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
+    if (a.table_lookahead) {   /* normally both find nothing to do */
+        hipLaunchKernelGGL(k_table_repair, g_scan, dim3(256), 0, st, a, dp);
+        hipLaunchKernelGGL(k_split_repair, dim3(c->n_cus), dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
+    }
     mark();
-    if (star)
-        URF_HIP(c, hipMemsetAsync(a.star_count, 0, 2 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_index, g_scan, dim3(256), 0, st, a, dp);
     mark();
     if (star) {
         const dim3 g_sec(K, n_scans);
         hipLaunchKernelGGL(k_star_sort_small, g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
         /* persistent workgroups over the (normally empty) work lists of oversized sectors */
-        hipLaunchKernelGGL(k_star_sort_mid, dim3(c->n_cus * 4), dim3(URF_STAR_MID_THREADS), 0, st, a, dp);
+        hipLaunchKernelGGL(k_star_sort_mid, dim3(c->n_cus * (URF_MID_WAVES * 256 / URF_STAR_MID_THREADS)), dim3(URF_STAR_MID_THREADS), 0, st,
+                           a, dp);   /* as many workgroups as are resident */
         hipLaunchKernelGGL(k_star_sort_big, dim3(c->n_cus * 2), dim3(256), 0, st, a, dp);
     }
     mark();   /* "k_star_sort" = the three sort kernels (mid / big run over normally empty work lists) */

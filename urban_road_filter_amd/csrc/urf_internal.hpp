@@ -25,6 +25,7 @@
 #define URF_MAX_TILES       4096    /* tiles per scan (k_ring keeps one table entry per tile in LDS) */
 #define URF_SCAN_PAD        512     /* scratch elements per scan beyond its tiles: rings start at multiples of 4 */
 #define URF_SLOT_NONE       0xFFFFu
+#define URF_TABLE_LOOKAHEAD 16384   /* k_ring_table gives up waiting for a new ring after this many points (speculation) */
 
 #define URF_RFLAG_AZ_APPROX 0x80u   /* rflag: raz holds the float approximation, not the reference value */
 #define URF_RING_NONE       0xFFu
@@ -84,6 +85,7 @@ struct urf_kargs {
     uint32_t max_len;
     uint32_t tiles;             /* tiles per scan = ceil(max_len / URF_TILE): stride of the per-tile tables */
     uint32_t sstride;           /* scratch elements per scan */
+    uint32_t table_lookahead;   /* k_ring_table: stop after this many points without a new leader (0: never), see there */
     uint32_t capture;           /* 0 production; 1 every point takes the exact sequence, values recorded;
                                    2 production decisions, ring / sector keys recorded */
     /* output */
@@ -127,7 +129,11 @@ struct urf_kargs {
     uint32_t* star_first;       /* [S][sectors] last sorted index the walk may visit */
     uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 513..2048 points */
     uint32_t* star_list_big;    /* [S*sectors] ... with more than 2048 points */
-    uint32_t* star_count;       /* [2] lengths of the two lists (zeroed per call) */
+    uint32_t* star_count;       /* [4] lengths of the two lists, [2] = length of redo_list (zeroed per call) */
+    uint32_t* table_upto;       /* [S] first point a speculative k_ring_table did not look at (0xffffffff: none) */
+    uint32_t* table_redo;       /* [S] k_split: the speculative table of the scan is incomplete */
+    uint32_t* redo_list;        /* [S] such scans (k_table_repair) */
+    uint32_t* spec_failed;      /* host-mapped flag: some speculation failed */
     float*    big_r;            /* sector-major copies of the sectors on the "big" list (sorted in place) */
     float*    big_z;
     uint32_t* big_i;

@@ -139,13 +139,30 @@ __device__ __forceinline__ bool urf_leader_match_point(const float* SL, unsigned
 }
 
 #define URF_TABLE_SCAN_PPT 8
-__global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params dp)
+/* Speculation (lookahead > 0): when `lookahead` points in a row brought no new leader the walk stops
+ * and hands the rest of the scan to k_split, which classifies every point against the table anyway:
+ * a region-of-interest point behind the stop that matches no entry of a table that is not full
+ * would have become a leader -- k_split then raises table_redo[s], k_table_repair builds the table
+ * again without the shortcut and k_split_repair splits the scan again (and the context stops
+ * speculating).  A sweep whose region of interest cuts the outer rings off (the reference's default)
+ * otherwise pays a full extra pass over its points just to learn that no further ring shows up.
+ * Not taken once a leader equal to 0 has been seen (matching is order dependent then). */
+struct urf_table_shared {
+    float L[URF_MAX_CHANNELS];    /* leaders in insertion order (the reference's angle[]) */
+    float SL[URF_MAX_CHANNELS];   /* the matchable ones, ascending */
+    unsigned nL, nmatch, zero, fresh;
+    unsigned mins[4];
+};
+__device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp, unsigned s, unsigned lookahead, urf_table_shared& T)
 {
-    __shared__ float L[URF_MAX_CHANNELS];    /* leaders in insertion order (the reference's angle[]) */
-    __shared__ float SL[URF_MAX_CHANNELS];   /* the matchable ones, ascending */
-    __shared__ unsigned sh_nL, sh_nmatch, sh_zero, sh_new;
-    __shared__ unsigned sh_min[4];
-    const unsigned s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* const L = T.L;
+    float* const SL = T.SL;
+    unsigned& sh_nL = T.nL;
+    unsigned& sh_nmatch = T.nmatch;
+    unsigned& sh_zero = T.zero;
+    unsigned& sh_new = T.fresh;
+    unsigned* const sh_min = T.mins;
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned C = (unsigned)dp.p.channels;
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params 
     __syncthreads();
 
     const float interval = dp.p.interval;
-    unsigned pos = 0;
+    unsigned pos = 0, upto = 0xffffffffu;   /* upto: first point the walk did not look at (speculation) */
     while (pos < len && sh_nL < C) {
         /* ---- serial step: wave 0, points [pos, pos + 64) ---- */
         if (wave == 0) {
@@ -225,6 +242,7 @@ __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params 
             continue;
         /* ---- scan mode: first point in [pos, len) that no leader matches ---- */
         const unsigned nmatch = sh_nmatch;
+        unsigned quiet = 0;   /* points looked at since the last new leader */
         while (pos < len) {
             unsigned first = 0xffffffffu;
             float px[URF_TABLE_SCAN_PPT], py[URF_TABLE_SCAN_PPT], pz[URF_TABLE_SCAN_PPT];
@@ -259,9 +277,20 @@ __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params 
                 break;
             }
             pos += 256 * URF_TABLE_SCAN_PPT;
+            quiet += 256 * URF_TABLE_SCAN_PPT;
+            if (lookahead && quiet >= lookahead && !sh_zero && pos < len) {
+                upto = pos;
+                break;
+            }
         }
+        if (upto != 0xffffffffu)
+            break;
     }
     __syncthreads();
+    if (tid == 0) {
+        a.table_upto[s] = upto;
+        a.table_redo[s] = 0;
+    }
 
     /* std::sort(angle, angle + index), lidar_segmentation.cpp:205 (rank sort) */
     const unsigned n = sh_nL;
@@ -297,6 +326,26 @@ __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params 
             }
             lut[cell] = (uint8_t)lo;
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params dp)
+{
+    __shared__ urf_table_shared T;
+    urf_ring_table_scan(a, dp, blockIdx.x, a.table_lookahead, T);
+}
+
+/* the scans whose speculative table k_split found incomplete: the whole walk, listed for k_split_repair */
+__global__ __launch_bounds__(256) void k_table_repair(urf_kargs a, urf_dev_params dp)
+{
+    __shared__ urf_table_shared T;
+    const unsigned s = blockIdx.x;
+    if (!a.table_redo[s])
+        return;
+    urf_ring_table_scan(a, dp, s, 0, T);
+    if (threadIdx.x == 0) {
+        a.redo_list[atomicAdd(&a.star_count[2], 1u)] = s;
+        *a.spec_failed = 1u;   /* host-visible: the context stops speculating */
     }
 }
 
@@ -375,10 +424,9 @@ __device__ __noinline__ urf_exact_key urf_exact_keys(const float* tab, unsigned 
 #ifndef URF_SPLIT_WAVES_PER_EU
 #define URF_SPLIT_WAVES_PER_EU 6   /* 73 VGPRs without spills; A/B on one box: 4 -> 1.39 ms, 6 -> 1.04 ms, 8 (32 B of scratch) -> 1.12 ms */
 #endif
-__global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_SPLIT_WAVES_PER_EU, URF_SPLIT_WAVES_PER_EU))) void k_split(urf_kargs a, urf_dev_params dp)
+__device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev_params& dp, unsigned s, unsigned t, unsigned char* sh_raw)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sh_raw[];
-    const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    const unsigned tid = threadIdx.x;
     const unsigned wave = tid >> 6, lane = tid & 63;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
@@ -412,6 +460,9 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
         pz[q] = valid ? a.z[off + i] : 0.f;
     }
     const unsigned nR = a.info[s].n_rings;
+    /* a speculative ring table (k_ring_table) is checked here: a region-of-interest point at or behind
+     * `upto` that matches none of its entries would have been a new leader */
+    const unsigned upto = nR < C ? a.table_upto[s] : 0xffffffffu;
     for (unsigned k = tid; k < URF_TILE_WAVES * (C + Ks) / 2; k += URF_TILE_THREADS)
         ((unsigned*)wcnt_r)[k] = 0;
     if (tid < URF_MAX_CHANNELS)
@@ -476,6 +527,8 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
         const bool settled = roi & !open;
         rkey[q] = settled ? rk : URF_RING_NONE;
         skey[q] = settled ? sk : URF_SEC_NONE;
+        if (settled & (rk == URF_RING_NONE) & (i >= upto))
+            a.table_redo[s] = 1u;   /* (rare; every writer writes the same value) */
         if (open) {
             pending[atomicAdd(&misc[1], 1u)] = (uint16_t)li;
             openmask |= 1u << q;
@@ -503,6 +556,8 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
             sk = URF_SEC_NONE;
         if (exact_all)
             a.valpha[sb + i] = ek.valpha;   /* stage capture only */
+        if (ek.ring == URF_RING_NONE && i >= upto)
+            a.table_redo[s] = 1u;
         keyr[li] = (uint8_t)ek.ring;
         keys[li] = (uint16_t)sk;
     }
@@ -663,6 +718,24 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
             a.tsoff[row * (K + 1) + k] = (uint16_t)soff[k];
     if (tid == 0)
         a.tile_roi[row] = misc[0];
+}
+
+__global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_SPLIT_WAVES_PER_EU, URF_SPLIT_WAVES_PER_EU))) void k_split(urf_kargs a, urf_dev_params dp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_split[];
+    urf_split_tile(a, dp, blockIdx.y, blockIdx.x, sh_split);
+}
+
+/* the scans k_table_repair listed (normally none): their tiles once more, with the complete table.
+ * Persistent workgroups over list x tiles. */
+__global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_SPLIT_WAVES_PER_EU, URF_SPLIT_WAVES_PER_EU))) void k_split_repair(urf_kargs a, urf_dev_params dp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_split[];
+    const unsigned n = a.star_count[2];
+    for (unsigned w = blockIdx.x; w < n * a.tiles; w += gridDim.x) {
+        urf_split_tile(a, dp, a.redo_list[w / a.tiles], w % a.tiles, sh_split);
+        __syncthreads();   /* the LDS carve is reused by the next tile */
+    }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -930,49 +1003,6 @@ __device__ __forceinline__ unsigned urf_count_less64(const unsigned long long* b
     return pos;
 }
 
-/* Common tail: `fin[0..n)` holds the sorted keys.  Writes slopes / distance terms / ring
- * positions in sorted order (wslp, wg, ssrt) and returns (all threads) the index of the
- * first "static" hit (slope > slope_param), or n.  The walk can never pass that index, so
- * the tail stops after the chunk of NT elements that contains it: on a street most sectors
- * meet the curb within their first third.  The heights are gathered from the unsorted
- * sector-major array (or from an LDS copy `zs`). */
-template <int NT, int EPT>
-__device__ __forceinline__ unsigned urf_star_emit(const urf_kargs& a, const urf_dev_params& dp, unsigned sb, unsigned obase, unsigned n,
-                                                  const unsigned long long* fin, unsigned* sh_first)
-{
-    const unsigned tid = threadIdx.x;
-    const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
-#pragma unroll
-    for (int e = 0; e < EPT; e++) {
-        const unsigned i = tid + (unsigned)e * NT;
-        if ((unsigned)e * NT >= n)
-            break;
-        if (i < n) {
-            const unsigned long long kb = fin[i];
-            const unsigned pb = (unsigned)kb;   /* the point's index in the sector-sorted arrays, relative to the scan */
-            float slp = 0.f, g = 0.f;
-            if (i >= 1) {
-                const unsigned long long ka = fin[i - 1];
-                const float ax = __uint_as_float((unsigned)(ka >> 32)), bx = __uint_as_float((unsigned)(kb >> 32));
-                const float ay = a.sz[sb + (unsigned)ka];
-                const float by = a.sz[sb + pb];
-                slp = (by - ay) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
-                g = (bx - ax) * kdist;
-                if (slp > slope_param)
-                    atomicMin(sh_first, i);
-            }
-            const unsigned sl = a.sslot[sb + pb];
-            a.ssrt[obase + i] = sl == URF_SLOT_NONE ? 0xffffffffu : (pb & ~(URF_TILE - 1u)) + sl;
-            a.wslp[obase + i] = slp;
-            a.wg[obase + i] = g;
-        }
-        __syncthreads();
-        if (*sh_first < ((unsigned)e + 1) * NT)
-            break;
-    }
-    return *sh_first;
-}
-
 /* The runs of sector k: the non-empty pieces (tile, first slot, count) of the sector in tile order
  * (k_index tables).  runP[r] = position inside the sector of the run's first point, runA[r] = index
  * of that point in the sector-sorted arrays (relative to the scan) minus runP[r], so that point i
@@ -1219,8 +1249,8 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
             S[rank[q]] = sreg[q];
         }
     __syncthreads();
-    /* tail (see urf_star_emit): slopes / distance terms / ring positions in sorted order, stop
-     * after the 64-element chunk that holds the first static hit */
+    /* tail: slopes / distance terms / ring positions in sorted order; the walk can never pass the first
+     * "static" hit (slope > slope_param): stop after the 64-element chunk that holds it */
     const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
 #pragma unroll
     for (unsigned q = 0; q < MAXB; q++) {
@@ -1322,9 +1352,10 @@ struct urf_sort_shared {
     unsigned rmin, rmax, maxc;
     unsigned w[8];
 };
+/* rank[e] = number of keys of the workgroup smaller than key[e] (keys are distinct) */
 template <int NT, int EPT, int NB>
-__device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EPT], unsigned n, unsigned long long* A,
-                                                    unsigned* cnt, urf_sort_shared* sh, bool force_general)
+__device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EPT], unsigned n, unsigned long long* A,
+                                                    unsigned* cnt, urf_sort_shared* sh, bool force_general, unsigned (&rank)[EPT])
 {
     static_assert(NB % NT == 0 && NT / 64 <= 8, "bucket scan layout");
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1408,7 +1439,6 @@ __device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EP
     /* in-bucket ranking is quadratic in the bucket size, but up to a few hundred keys per bucket it is
      * still cheaper than the bitonic network below (128 x 4096 sweeps: 2.13 -> 1.74 ms with 256 instead of 64) */
     if (sh->maxc <= 256 && !force_general) {
-        unsigned rank[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; e++)
             if (key[e] != ~0ull)
@@ -1430,11 +1460,6 @@ __device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EP
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int e = 0; e < EPT; e++)
-            if (key[e] != ~0ull)
-                A[rank[e]] = key[e];
-        __syncthreads();
     } else {
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
@@ -1444,14 +1469,46 @@ __device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EP
         }
         __syncthreads();
         urf_bitonic_keys<NT>(A, n);
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {   /* where did the key end up? */
+            unsigned lo = 0, hi = n;
+            while (lo < hi) {
+                const unsigned mid = (lo + hi) >> 1;
+                if (A[mid] < key[e])
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            rank[e] = lo;
+        }
+        __syncthreads();
     }
+}
+
+/* ... and the sorted keys in A[0..n) */
+template <int NT, int EPT, int NB>
+__device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EPT], unsigned n, unsigned long long* A,
+                                                    unsigned* cnt, urf_sort_shared* sh, bool force_general)
+{
+    unsigned rank[EPT];
+    urf_block_rank_keys<NT, EPT, NB>(key, n, A, cnt, sh, force_general, rank);
+#pragma unroll
+    for (int e = 0; e < EPT; e++)
+        if (key[e] != ~0ull)
+            A[rank[e]] = key[e];
+    __syncthreads();
 }
 
 /* sectors with 513..2048 points (e.g. 128 rings x 4096 columns): persistent
  * workgroups of 256 threads walk the work list built by k_index. */
+#ifndef URF_STAR_MID_THREADS
 #define URF_STAR_MID_THREADS 256
+#endif
 #define URF_STAR_MID_CAP 2048
-__global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_kargs a, urf_dev_params dp)
+#ifndef URF_MID_WAVES
+#define URF_MID_WAVES 4
+#endif
+__global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_per_eu(URF_MID_WAVES, URF_MID_WAVES))) void k_star_sort_mid(urf_kargs a, urf_dev_params dp)
 {
     constexpr unsigned NT = URF_STAR_MID_THREADS, NB = 2048, EPT = URF_STAR_MID_CAP / NT;
     __shared__ unsigned long long A[URF_STAR_MID_CAP];
@@ -1481,21 +1538,66 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) void k_star_sort_mid(urf_karg
         __syncthreads();
         const unsigned nruns = sh_nruns;
         unsigned long long key[EPT];
+        float zreg[EPT];      /* height and ring-sorted index travel with the key: the tail then needs */
+        unsigned sreg[EPT];   /* no dependent gathers from memory (as in k_star_sort_small) */
         unsigned r = 0;
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++) {
             const unsigned i = tid + e * NT;
             key[e] = ~0ull;
+            zreg[e] = 0.f;
+            sreg[e] = 0;
             if (i < n) {
                 while (r + 1 < nruns && i >= runP[r + 1])
                     r++;
-                const unsigned adr = runA[r] + i;   /* grows with i: the tie-break, and the way back to z / slot */
+                const unsigned adr = runA[r] + i;   /* grows with i: the tie-break */
                 key[e] = ((unsigned long long)urf_fbits(a.sr[sb + adr]) << 32) | adr;
+                zreg[e] = a.sz[sb + adr];
+                const unsigned sl = a.sslot[sb + adr];
+                sreg[e] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
             }
         }
         __syncthreads();   /* the run list has been read: A is free */
-        urf_block_sort_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, (dp.exp_flags & 4u) != 0);
-        const unsigned first = urf_star_emit<NT, EPT>(a, dp, sb, obase, n, A, &sh_first);
+        unsigned rank[EPT];
+        urf_block_rank_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, (dp.exp_flags & 4u) != 0, rank);
+        /* range bits, height, ring-sorted index in sorted order (A and cnt are free again) */
+        unsigned* R = (unsigned*)A;
+        float* Z = (float*)A + URF_STAR_MID_CAP;
+        unsigned* S = cnt;
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++)
+            if (key[e] != ~0ull) {
+                R[rank[e]] = (unsigned)(key[e] >> 32);
+                Z[rank[e]] = zreg[e];
+                S[rank[e]] = sreg[e];
+            }
+        __syncthreads();
+        /* tail: slopes / distance terms / ring-sorted indices in sorted order; the walk can never pass the
+         * first "static" hit (slope > slope_param), so stop after the chunk of NT elements that holds it */
+        const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++) {
+            const unsigned i = tid + e * NT;
+            if (e * NT >= n)
+                break;
+            if (i < n) {
+                float slp = 0.f, g = 0.f;
+                if (i >= 1) {
+                    const float ax = __uint_as_float(R[i - 1]), bx = __uint_as_float(R[i]);
+                    slp = (Z[i] - Z[i - 1]) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
+                    g = (bx - ax) * kdist;
+                    if (slp > slope_param)
+                        atomicMin(&sh_first, i);
+                }
+                a.ssrt[obase + i] = S[i];
+                a.wslp[obase + i] = slp;
+                a.wg[obase + i] = g;
+            }
+            __syncthreads();
+            if (sh_first < (e + 1) * NT)
+                break;
+        }
+        const unsigned first = sh_first;
         if (tid == 0)
             a.star_first[sk] = first < n - 1 ? first : n - 1;
         __syncthreads();
