@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--parity-scans", type=int, default=4)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("URF_BENCH_BACKEND", "nccl"))
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-outputs", action="store_true")
     args = ap.parse_args()
 
     import torch   # first: the HIP runtime torch bundles is the one the C-ABI library binds to
@@ -299,7 +300,7 @@ def main():
     # the optional outputs of SURVEY.md 8f for the whole batch (not part of `value`): index sets,
     # published order, marker points
     outputs_ms = None
-    if world == 1 and args.workload == "cfg3" and not args.no_e2e:
+    if world == 1 and args.workload == "cfg3" and not args.no_outputs:
         idx = [torch.empty((S, N_PTS), dtype=torch.int32, device=dev) for _ in range(4)]
         cnt = torch.zeros((S, 4), dtype=torch.int32, device=dev)
         mpts = torch.empty((S, 361, 4), dtype=torch.float32, device=dev)

@@ -12,7 +12,9 @@
  * max_distance, and both halves are processed recursively; lines of fewer than 3 points and
  * max_distance < 0 are copied.  Coordinates are float (xy = point_xy<float>,
  * data_structures.hpp:38), comparisons are made on squared distances in float.
- * Parity of this step against the real library is UNPINNED (it cannot be run here).
+ * The real library cannot be run here; the behaviour is pinned by known answers instead
+ * (tests/test_simplify_kat.py): the worked example of Boost.Geometry's documentation of simplify
+ * and hand-derived cases for the documented strategy.
  */
 #ifndef URF_RDP_H
 #define URF_RDP_H

@@ -6,9 +6,9 @@
     profiles/hbm_traffic.json          HBM bytes per launch of the dominant kernel (read by bench.py)
   python tools/make_profiles.py gpurun_out/r1b r1b
 HBM traffic = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE counts 64 B per
-128 B read request (MI355X_MICROARCH.md, HBM section); confirmed here on k_ingest, which must read
-12 B/point = 1.61e9 B per launch and reports FETCH_SIZE x 1024 = 0.81e9.  WRITE_SIZE needs no
-correction (k_scatter writes 28 B/point = 3.76e9 B and reports 3.76e9)."""
+128 B read request (MI355X_MICROARCH.md, HBM section); confirmed here on k_split, which must read
+12 B/point = 1.61e9 B per launch and reports FETCH_SIZE x 1024 = 0.82e9.  WRITE_SIZE needs no
+correction (k_split writes 29.5 B/point = 3.96e9 B and reports it)."""
 import csv
 import glob
 import io
@@ -52,7 +52,9 @@ def main(src, tag):
     def avg(k, c):
         v = vals.get((k, c), [0.0])
         return sum(v) / len(v)
-    kernels = sorted({k for k, _ in vals if k.startswith("k_")})
+    pipeline = ("k_ring_table", "k_split", "k_table_repair", "k_split_repair", "k_index", "k_star_sort_small", "k_star_sort_mid",
+                "k_star_sort_big", "k_star_walk", "k_ring", "k_beams", "k_label")
+    kernels = sorted({k for k, _ in vals if k in pipeline})
     per = {k: int(2 * avg(k, "FETCH_SIZE") * 1024 + avg(k, "WRITE_SIZE") * 1024) for k in kernels}
     # bench.py's timing slot "k_star_sort" spans k_star_sort_small/mid/big (the latter two run over
     # normally empty work lists); every other slot is one kernel

@@ -7,7 +7,8 @@
  * visualization_msgs::Marker / MarkerArray are mirrored with the members the reference sets.
  * boost::geometry::simplify (third party, not in the reference checkout nor in this image) is
  * restated as Douglas-Peucker with the point-to-segment distance, float coordinates, "keep iff
- * strictly farther than the tolerance"; that step cannot be checked against the real library here.
+ * strictly farther than the tolerance"; the real library cannot be run here, the step is pinned by
+ * the worked example of Boost.Geometry's documentation and hand-derived cases (urf_simplify_line).
  */
 #ifndef URF_MARKER_HPP
 #define URF_MARKER_HPP

@@ -1502,11 +1502,11 @@ __device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EP
 /* sectors with 513..2048 points (e.g. 128 rings x 4096 columns): persistent
  * workgroups of 256 threads walk the work list built by k_index. */
 #ifndef URF_STAR_MID_THREADS
-#define URF_STAR_MID_THREADS 256
+#define URF_STAR_MID_THREADS 512   /* A/B on 256 x 128x4096 sweeps: 256 threads x 4 waves/SIMD 1.93 ms, 512 x 6 1.91 ms, 512 x 8 1.72 ms */
 #endif
 #define URF_STAR_MID_CAP 2048
 #ifndef URF_MID_WAVES
-#define URF_MID_WAVES 4
+#define URF_MID_WAVES 8
 #endif
 __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_per_eu(URF_MID_WAVES, URF_MID_WAVES))) void k_star_sort_mid(urf_kargs a, urf_dev_params dp)
 {
