@@ -127,7 +127,7 @@ struct urf_kargs {
     uint32_t* sec_off;          /* [S][sectors+1] */
     int32_t*  star_hit;         /* [S][sectors] ring-major position of the sector's curb point; -1 = none or on no ring */
     uint32_t* star_first;       /* [S][sectors] last sorted index the walk may visit */
-    uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 513..2048 points */
+    uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 385..2048 points */
     uint32_t* star_list_big;    /* [S*sectors] ... with more than 2048 points */
     uint32_t* star_count;       /* [4] lengths of the two lists, [2] = length of redo_list (zeroed per call) */
     uint32_t* table_upto;       /* [S] first point a speculative k_ring_table did not look at (0xffffffff: none) */

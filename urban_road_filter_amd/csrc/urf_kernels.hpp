@@ -46,6 +46,7 @@
 #define URF_INGEST_THREADS 256       /* tile kernels that need no big LDS tile run 8 workgroups per CU */
 #define URF_LABEL_TILE_THREADS 256   /* k_label: one tile per workgroup, 16 slots per thread, 8 workgroups per CU */
 #define URF_STAR_MID_CAP_ 2048
+#define URF_STAR_SMALL_CAP 384       /* k_star_sort_small: sectors of up to 6 x 64 points, one wave each */
 
 /* ------------------------------------------------------------------------- */
 /* PointCloud2 records -> SoA                                                  */
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
     for (unsigned k0 = 0; k0 < K; k0 += 256) {
         const unsigned k = k0 + tid;
         const unsigned c = k < K ? a.sec_cnt[(size_t)s * K + k] : 0;
-        const bool mid = c > 512 && c <= URF_STAR_MID_CAP_, big = c > URF_STAR_MID_CAP_;
+        const bool mid = c > URF_STAR_SMALL_CAP && c <= URF_STAR_MID_CAP_, big = c > URF_STAR_MID_CAP_;
         const unsigned long long bm = __ballot(mid), bb = __ballot(big);
         unsigned pm = 0, pb = 0;
         if (urf_lane() == 0) {
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
  * Sort key = (range bits << 32 | position in the sector-major array); the
  * position grows with the input index (the split is stable), so the order is
  * total where the reference's std::sort leaves ties unspecified (:109).
- * Small sectors (<= 512 points, <= 8 per lane): every 64-element block is
+ * Small sectors (<= 384 points, <= 6 per lane): every 64-element block is
  * sorted in registers by an in-wave bitonic network (shuffles, no LDS traffic),
  * then each element finds its final rank by binary search in the other blocks
  * (multiway merge by ranking).  Larger sectors: bitonic network in LDS
@@ -1048,7 +1049,7 @@ __device__ __forceinline__ unsigned urf_sector_runs(const urf_kargs& a, unsigned
     return nr;
 }
 
-/* sectors with at most 512 points: one wave per (sector, scan).
+/* sectors with at most 384 points: one wave per (sector, scan).
  * Fast path: distribution sort.  The range bits are quantised monotonically
  * into URF_STAR_NB buckets ((bits - min) >> shift), a counting sort by bucket places
  * every key next to the few keys sharing its bucket, and each key then counts
@@ -1282,7 +1283,10 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
 
 /* amdgpu_waves_per_eu(6, 6): 6 KB of LDS allow 26 waves per CU; without the cap the register ranking
  * below takes 98 VGPRs and halves the occupancy (0.75 -> 0.92 ms instead of 0.70) */
-__global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_star_sort_small(urf_kargs a, urf_dev_params dp)
+#ifndef URF_SMALL_WAVES
+#define URF_SMALL_WAVES 6
+#endif
+__global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_eu(URF_SMALL_WAVES, URF_SMALL_WAVES))) void k_star_sort_small(urf_kargs a, urf_dev_params dp)
 {
     constexpr unsigned NB = URF_STAR_NB;            /* buckets */
     __shared__ unsigned long long A[8 * 64];        /* keys by bucket, then range / height of the sorted sector */
@@ -1297,7 +1301,7 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
     if (status != URF_OK)
         return;
     const unsigned n = so1 - so0;
-    if (n > 512)
+    if (n > URF_STAR_SMALL_CAP)
         return;   /* on a work list (k_index) */
     if (n < 2) {
         if (lane == 0)
@@ -1311,11 +1315,10 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
         sh_first = n;
     const unsigned nruns = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, row, (unsigned*)A, (unsigned*)A + 512);
     __syncthreads();
-    /* per-lane element count fixed at compile time: 6 covers a sector of a 64 x 2048 sweep */
-    if (n <= 384)
-        urf_star_sort_sector<6>(a, dp, sb, obase, n, nruns, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
-    else
-        urf_star_sort_sector<8>(a, dp, sb, obase, n, nruns, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
+    /* per-lane element count fixed at compile time: 6 covers a sector of a 64 x 2048 sweep.  (An
+     * 8-per-lane instance for sectors of up to 512 points made the kernel spill 68 bytes per lane at
+     * its 80 registers; such sectors take the workgroup path now.) */
+    urf_star_sort_sector<URF_STAR_SMALL_CAP / 64>(a, dp, sb, obase, n, nruns, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
 }
 
 template <int NT>
@@ -1499,7 +1502,7 @@ __device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EP
     __syncthreads();
 }
 
-/* sectors with 513..2048 points (e.g. 128 rings x 4096 columns): persistent
+/* sectors with 385..2048 points (e.g. 128 rings x 4096 columns): persistent
  * workgroups of 256 threads walk the work list built by k_index. */
 #ifndef URF_STAR_MID_THREADS
 #define URF_STAR_MID_THREADS 512   /* A/B on 256 x 128x4096 sweeps: 256 threads x 4 waves/SIMD 1.93 ms, 512 x 6 1.91 ms, 512 x 8 1.72 ms */
