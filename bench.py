@@ -145,7 +145,7 @@ def e2e_callback_path(u, O, params, n_sweeps=8, reps=40, stream_reps=160):
         recs.append(buf.reshape(-1))
     out = {"bytes_in_per_scan": int(recs[0].nbytes), "bytes_out_per_scan": n,
            "pcie_bound_scans_per_s": round(63e9 / (recs[0].nbytes + n), 1)}
-    with u.Context(n, 1, params=params) as ctx:
+    with u.Context(n, 2, params=params) as ctx:   # two scratch rows: the kernels of two sweeps overlap
         lab = np.empty(n, np.uint8)
         lb, _, _ = O.run_b(*u.synth_cloud(RINGS, COLS, 1, 9000), params)
         lg, _ = ctx.classify_pc2(recs[0], n, 32, 0, 4, 8)

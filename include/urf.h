@@ -198,7 +198,9 @@ int urf_classify_pc2(urf_ctx* ctx, const uint8_t* data, uint32_t n_points,
 /* The same, asynchronously: the message is copied to pinned memory and sent to the device on a
  * copy stream, classified on the context's stream by ONE graph launch (the kernel sequence of a
  * sweep of this shape is captured once and replayed), and the labels come back to pinned memory.
- * Two sweeps may be in flight (the copy of sweep i+1 overlaps the kernels of sweep i):
+ * Two sweeps may be in flight (the copy of sweep i+1 overlaps the kernels of sweep i; with a context
+ * created for max_batch >= 2 each of the two has its own scratch and compute stream, so their
+ * kernels overlap as well):
  *     urf_classify_pc2_async(ctx, msg_a, ..., &ta);
  *     urf_classify_pc2_async(ctx, msg_b, ..., &tb);      // a third one returns URF_ERR_BUSY
  *     urf_classify_pc2_wait(ctx, ta, labels_a, &info_a);  // blocks until sweep a is done

@@ -22,9 +22,11 @@ def records(x, y, z, step=32, ox=0, oy=4, oz=8):
     return buf.reshape(-1)
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    c = u.Context(N, 1, params=O.cfg_params("cfg2"))
+@pytest.fixture(scope="module", params=[1, 2], ids=["one_scratch_row", "two_scratch_rows"])
+def ctx(request):
+    """max_batch 1: both slots share the scratch and the stream (only the copies overlap);
+    max_batch 2: every slot has its own scratch row and compute stream (the kernels overlap too)."""
+    c = u.Context(N, request.param, params=O.cfg_params("cfg2"))
     yield c
     c.close()
 

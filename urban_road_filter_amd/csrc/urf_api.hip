@@ -53,6 +53,7 @@ struct urf_ctx {
         uint32_t n_points = 0, ticket = 0;
     } slots[2];
     hipStream_t copy_stream = nullptr;
+    hipStream_t slot_stream = nullptr;   /* compute stream of slot 1 (slot 0 runs on `stream`) */
     uint32_t next_ticket = 0;
     uint64_t epoch = 1;             /* bumped by everything a captured sequence depends on */
     /* lazily, sized for the largest number of scans asked for so far: scratch of the index-list and
@@ -215,7 +216,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles)
     A(k.angle, S * C) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
-    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 4)
+    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 8)
     A(k.table_upto, S) A(k.table_redo, S) A(k.redo_list, S)
     A(k.maxdist, S * C) A(k.quad, S * 4)
     A(k.sufmin, S * C * URF_DEG_CELLS) A(k.premax, S * C * URF_DEG_CELLS)
@@ -282,6 +283,8 @@ static void free_lazy(urf_ctx* c)
     }
     if (c->copy_stream)
         (void)hipStreamDestroy(c->copy_stream);
+    if (c->slot_stream)
+        (void)hipStreamDestroy(c->slot_stream);
     for (void* p : { (void*)c->mk_d, (void*)c->mk_pos, (void*)c->mk_red, (void*)c->mk_out, (void*)c->ord_keys,
                      (void*)c->ord_pos, (void*)c->ord_lists })
         if (p)
@@ -320,6 +323,8 @@ extern "C" int urf_set_params(urf_ctx* c, const urf_params* p)
     if (rc != URF_OK)
         return rc;
     URF_HIP(c, hipSetDevice(c->device));
+    if (c->slot_stream)
+        URF_HIP(c, hipStreamSynchronize(c->slot_stream));   /* a sweep in flight on the second slot keeps its parameters */
     c->params = *p;
     c->epoch++;
     return upload_params(c);
@@ -449,20 +454,49 @@ extern "C" int urf_kernel_timing(urf_ctx* c, double* ms_sum, uint32_t* n_calls)
 
 extern "C" const char* urf_last_error(const urf_ctx* c) { return c ? c->last_error.c_str() : ""; }
 
+/* The context's scratch with every per-scan array advanced by `row` scans (allocation strides):
+ * what the second slot of the callback path runs on, so that two sweeps' kernels can be in flight
+ * on two streams.  Row 0 = the context's own arguments. */
+static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
+{
+    urf_kargs k = c->k;
+    if (row == 0)
+        return k;
+    const size_t P = (size_t)row * c->sstride, tiles = c->max_tiles, C = URF_MAX_CHANNELS, K = URF_MAX_SECTORS, r = row;
+    k.rx += P; k.ry += P; k.rz += P; k.rsrc += P; k.raz += P; k.rflag += P;
+    k.sr += P; k.sz += P; k.sslot += P; k.ssrt += P; k.wslp += P; k.wg += P;
+    k.big_r += P; k.big_z += P; k.big_i += P;
+    if (k.valpha) {
+        k.valpha += P; k.seckey += P; k.ringkey += P; k.rd2 += P;
+    }
+    k.tile_roi += r * tiles; k.troff += r * tiles * (C + 1); k.tsoff += r * tiles * (K + 1);
+    k.rpre += r * C * (tiles + 1); k.rstart += r * C * tiles;
+    k.angle += r * C; k.ring_lut += r * URF_LUT_CELLS; k.ring_cnt += r * C; k.ring_off += r * (C + 1);
+    k.sec_cnt += r * K; k.sec_off += r * (K + 1); k.star_hit += r * K;
+    k.star_first += r * K; k.star_list_mid += r * K; k.star_list_big += r * K; k.star_count += 4 * r;
+    k.table_upto += r; k.table_redo += r; k.redo_list += r;
+    k.maxdist += r * C; k.quad += r * 4;
+    k.sufmin += r * C * URF_DEG_CELLS; k.premax += r * C * URF_DEG_CELLS;
+    k.stop_f += r * URF_DEG_CELLS; k.stop_b += r * URF_DEG_CELLS;
+    k.act_f += r * C * 6; k.act_b += r * C * 6; k.qk += r * C;
+    k.info += r;
+    return k;
+}
+
 /* ---- the pipeline ---------------------------------------------------------- */
 static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const float* d_z,
                         const uint32_t* d_offsets, uint32_t n_per_scan, uint32_t max_len, uint32_t n_scans,
-                        uint8_t* d_labels, urf_scan_info* d_info)
+                        uint8_t* d_labels, urf_scan_info* d_info, uint32_t row = 0, hipStream_t on_stream = nullptr)
 {
     if (!d_x || !d_y || !d_z || !d_labels)
         return URF_ERR_INVALID_ARG;
     if (n_scans == 0)
         return URF_OK;
-    if (n_scans > c->max_batch || max_len > c->max_points)
+    if (row + n_scans > c->max_batch || max_len > c->max_points)
         return URF_ERR_CAPACITY;
     URF_HIP(c, hipSetDevice(c->device));
-    hipStream_t st = c->stream;
-    urf_kargs a = c->k;
+    hipStream_t st = on_stream ? on_stream : c->stream;
+    urf_kargs a = kargs_row(c, row);
     a.x = d_x;
     a.y = d_y;
     a.z = d_z;
@@ -611,10 +645,19 @@ extern "C" int urf_classify_batch_pc2(urf_ctx* c, const uint8_t* d_data, uint32_
 }
 
 /* ---- the callback path: one sweep, host buffers ------------------------------- */
+/* Slot i of the callback path works on scratch row i and (slot 1) on its own compute stream when the
+ * context was created for at least two scans: the kernels of two sweeps then overlap on the device
+ * (a single sweep's kernels are a few dozen workgroups each).  With max_batch == 1 both slots share
+ * row 0 and the context's stream: only the copies overlap. */
+static uint32_t slot_row(const urf_ctx* c, const urf_ctx::slot_t& sl) { return c->max_batch >= 2 ? (uint32_t)(&sl - c->slots) : 0u; }
+static hipStream_t slot_stream(urf_ctx* c, const urf_ctx::slot_t& sl) { return slot_row(c, sl) ? c->slot_stream : c->stream; }
+
 static int slot_prepare(urf_ctx* c, urf_ctx::slot_t& sl, size_t bytes)
 {
-    if (!c->copy_stream)
+    if (!c->copy_stream) {
         URF_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        URF_HIP(c, hipStreamCreateWithFlags(&c->slot_stream, hipStreamNonBlocking));
+    }
     if (!sl.ev_h2d) {
         URF_HIP(c, hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
         URF_HIP(c, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
@@ -652,13 +695,16 @@ static int slot_prepare(urf_ctx* c, urf_ctx::slot_t& sl, size_t bytes)
 static int slot_launch(urf_ctx* c, urf_ctx::slot_t& sl, uint32_t n_points, uint32_t point_step, uint32_t off_x,
                        uint32_t off_y, uint32_t off_z)
 {
-    hipLaunchKernelGGL(k_pc2_to_soa, dim3((n_points + 255) / 256), dim3(256), 0, c->stream, sl.d_raw, (unsigned long long)n_points,
-                       point_step, off_x, off_y, off_z, c->sx, c->sy, c->sz);
-    const int rc = run_pipeline(c, c->sx, c->sy, c->sz, nullptr, n_points, n_points, 1, sl.d_labels, nullptr);
+    const uint32_t row = slot_row(c, sl);
+    hipStream_t st = slot_stream(c, sl);
+    float *sx = c->sx + (size_t)row * c->max_points, *sy = c->sy + (size_t)row * c->max_points, *sz = c->sz + (size_t)row * c->max_points;
+    hipLaunchKernelGGL(k_pc2_to_soa, dim3((n_points + 255) / 256), dim3(256), 0, st, sl.d_raw, (unsigned long long)n_points,
+                       point_step, off_x, off_y, off_z, sx, sy, sz);
+    const int rc = run_pipeline(c, sx, sy, sz, nullptr, n_points, n_points, 1, sl.d_labels, nullptr, row, st);
     if (rc != URF_OK)
         return rc;
-    URF_HIP(c, hipMemcpyAsync(sl.h_labels, sl.d_labels, n_points, hipMemcpyDeviceToHost, c->stream));
-    URF_HIP(c, hipMemcpyAsync(sl.h_info, c->k.info, sizeof(urf_scan_info), hipMemcpyDeviceToHost, c->stream));
+    URF_HIP(c, hipMemcpyAsync(sl.h_labels, sl.d_labels, n_points, hipMemcpyDeviceToHost, st));
+    URF_HIP(c, hipMemcpyAsync(sl.h_info, kargs_row(c, row).info, sizeof(urf_scan_info), hipMemcpyDeviceToHost, st));
     return URF_OK;
 }
 
@@ -694,11 +740,21 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
         rc = ensure_soa_staging(c);
     if (rc != URF_OK)
         return rc;
-    if (data != sl.h_in)
-        std::memcpy(sl.h_in, data, bytes);   /* urf_pinned_input() lets a producer write there directly */
-    URF_HIP(c, hipMemcpyAsync(sl.d_raw, sl.h_in, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    if (data != sl.h_in) {
+        /* staged in pieces, so that the DMA of a piece runs while the CPU copies the next one
+         * (urf_pinned_input() lets a producer write into the pinned buffer directly: no staging) */
+        const size_t piece = 1u << 20;
+        for (size_t o = 0; o < bytes; o += piece) {
+            const size_t m = bytes - o < piece ? bytes - o : piece;
+            std::memcpy(sl.h_in + o, data + o, m);
+            URF_HIP(c, hipMemcpyAsync(sl.d_raw + o, sl.h_in + o, m, hipMemcpyHostToDevice, c->copy_stream));
+        }
+    } else {
+        URF_HIP(c, hipMemcpyAsync(sl.d_raw, sl.h_in, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    }
     URF_HIP(c, hipEventRecord(sl.ev_h2d, c->copy_stream));
-    URF_HIP(c, hipStreamWaitEvent(c->stream, sl.ev_h2d, 0));
+    hipStream_t st = slot_stream(c, sl);
+    URF_HIP(c, hipStreamWaitEvent(st, sl.ev_h2d, 0));
     /* the launch sequence of a sweep of this shape is captured once and replayed (one graph launch
      * instead of a dozen kernel launches per callback); anything it depends on bumps the epoch */
     const uint64_t key[3] = { c->epoch, ((uint64_t)n_points << 32) | point_step,
@@ -711,10 +767,10 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
             (void)hipGraphDestroy(sl.graph);
         sl.exec = nullptr;
         sl.graph = nullptr;
-        URF_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+        URF_HIP(c, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
         rc = slot_launch(c, sl, n_points, point_step, off_x, off_y, off_z);
         hipGraph_t g = nullptr;
-        const hipError_t e = hipStreamEndCapture(c->stream, &g);
+        const hipError_t e = hipStreamEndCapture(st, &g);
         if (rc != URF_OK || e != hipSuccess) {
             if (g)
                 (void)hipGraphDestroy(g);
@@ -731,7 +787,7 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
         sl.cap_dp = c->last_dp;
     }
     if (use_graph) {
-        URF_HIP(c, hipGraphLaunch(sl.exec, c->stream));
+        URF_HIP(c, hipGraphLaunch(sl.exec, st));
         c->last_scans = 1;      /* what urf_read_stage / urf_marker_points / urf_ordered_indices look at */
         c->last_a = sl.cap_a;
         c->last_dp = sl.cap_dp;
@@ -739,8 +795,10 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
         rc = slot_launch(c, sl, n_points, point_step, off_x, off_y, off_z);
         if (rc != URF_OK)
             return rc;
+        sl.cap_a = c->last_a;
+        sl.cap_dp = c->last_dp;
     }
-    URF_HIP(c, hipEventRecord(sl.ev_done, c->stream));
+    URF_HIP(c, hipEventRecord(sl.ev_done, st));
     sl.pending = true;
     sl.n_points = n_points;
     sl.ticket = c->next_ticket;
@@ -757,6 +815,9 @@ extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* label
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
     URF_HIP(c, hipEventSynchronize(sl.ev_done));
+    c->last_scans = 1;   /* urf_read_stage / urf_marker_points / urf_ordered_indices now look at THIS sweep */
+    c->last_a = sl.cap_a;
+    c->last_dp = sl.cap_dp;
     if (labels_out)
         std::memcpy(labels_out, sl.h_labels, sl.n_points);
     if (info)
