@@ -411,7 +411,7 @@ def late_ring_cloud(n=60000, late_at=40000, seed=5):
 
 
 def test_speculative_ring_table_is_repaired():
-    """k_ring_table stops looking for new rings after 16384 quiet points and lets k_split check the
+    """k_ring_table stops looking for new rings after 8192 quiet points and lets k_split check the
     rest; a ring that shows up later than that makes k_split raise the scan's redo flag, the table
     is rebuilt the long way and the scan split again -- in the same call.  Afterwards the context no
     longer speculates; results stay the reference's either way."""

@@ -25,7 +25,7 @@
 #define URF_MAX_TILES       4096    /* tiles per scan (k_ring keeps one table entry per tile in LDS) */
 #define URF_SCAN_PAD        512     /* scratch elements per scan beyond its tiles: rings start at multiples of 4 */
 #define URF_SLOT_NONE       0xFFFFu
-#define URF_TABLE_LOOKAHEAD 16384   /* k_ring_table gives up waiting for a new ring after this many points (speculation) */
+#define URF_TABLE_LOOKAHEAD 8192    /* k_ring_table gives up waiting for a new ring after this many points (speculation) */
 
 #define URF_RFLAG_AZ_APPROX 0x80u   /* rflag: raz holds the float approximation, not the reference value */
 #define URF_RING_NONE       0xFFu
