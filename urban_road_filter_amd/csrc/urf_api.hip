@@ -221,7 +221,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.maxdist, S * C) A(k.quad, S * 4)
     A(k.sufmin, S * C * URF_DEG_CELLS) A(k.premax, S * C * URF_DEG_CELLS)
     A(k.stop_f, S * URF_DEG_CELLS) A(k.stop_b, S * URF_DEG_CELLS)
-    A(k.act_f, S * C * 6) A(k.act_b, S * C * 6) A(k.qk, S * C)
+    A(k.win, S * C * URF_DEG_CELLS)
     A(k.info, S)
     A(c->offsets_copy, S + 1)
     A(c->compact_cnt, S * tiles * 4)
@@ -478,7 +478,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     k.maxdist += r * C; k.quad += r * 4;
     k.sufmin += r * C * URF_DEG_CELLS; k.premax += r * C * URF_DEG_CELLS;
     k.stop_f += r * URF_DEG_CELLS; k.stop_b += r * URF_DEG_CELLS;
-    k.act_f += r * C * 6; k.act_b += r * C * 6; k.qk += r * C;
+    k.win += r * C * URF_DEG_CELLS;
     k.info += r;
     return k;
 }

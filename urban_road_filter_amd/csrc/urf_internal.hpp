@@ -74,6 +74,9 @@ struct urf_dev_params {
  * a sector's runs are read from tsoff directly (it meets few tiles).  What k_ring produces per point
  * (rflag, exact azimuths) goes into the point's ring-sorted slot; what the star sort produces is
  * contiguous per sector (wslp, wg, ssrt: at s * sstride + sec_off[k] + i). */
+/* k_beams -> k_label, per (ring, integer degree) */
+struct urf_win { float hi, lo; };
+
 struct urf_kargs {
     /* input */
     const float* x;
@@ -143,9 +146,9 @@ struct urf_kargs {
     float*    premax;           /* [S][channels][361] */
     int16_t*  stop_f;           /* [S][361] */
     int16_t*  stop_b;           /* [S][361] */
-    double*   qk;               /* [S][channels] arcDistance / ((maxDistance[k] * pi) / 180), k_beams -> k_label */
-    unsigned long long* act_f;  /* [S][channels][6] bit i: forward beam i reached beyond the ring */
-    unsigned long long* act_b;  /* [S][channels][6] same for backward beams */
+    urf_win*  win;              /* [S][channels][361] k_beams -> k_label.  .x: upper end of the window of the
+                                 * nearest forward beam at or below degree d that reached beyond the ring
+                                 * (-inf: none); .y: lower end for the nearest backward beam at or above d (+inf) */
     /* tables */
     const float*    newY;       /* [max_points] x_zero_method.cpp:24-27 */
     const urf_beam* beams;      /* [sectors] */

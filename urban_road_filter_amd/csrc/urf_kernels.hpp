@@ -2515,6 +2515,8 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
 {
     __shared__ double qk[URF_MAX_CHANNELS];
     __shared__ float q[4];
+    __shared__ unsigned long long mf[URF_MAX_CHANNELS * 6], mb[URF_MAX_CHANNELS * 6];
+    __shared__ int16_t pf[URF_MAX_CHANNELS * 6], nb[URF_MAX_CHANNELS * 6];
     const unsigned s = blockIdx.x, tid = threadIdx.x;
     const urf_scan_info in = a.info[s];
     if (in.status != URF_OK)
@@ -2526,10 +2528,8 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
         /* q1..q4 come from sorted ring 1 (blind_spots.cpp:19) */
         q[tid] = (dp.p.blind_spots && nR > 1) ? a.quad[(size_t)s * 4 + tid] : init[tid];
     }
-    for (unsigned k = tid; k < nR; k += URF_LABEL_THREADS) {
+    for (unsigned k = tid; k < nR; k += URF_LABEL_THREADS)
         qk[k] = urf_arc_ratio(dp, maxd[0], maxd[k]);
-        a.qk[(size_t)s * C + k] = qk[k];   /* k_label's tiles need it too: computed once per scan, here */
-    }
     __syncthreads();
     if (tid < 4 && !(dp.p.blind_spots && nR > 1))
         a.quad[(size_t)s * 4 + tid] = q[tid];
@@ -2568,13 +2568,45 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
         a.stop_f[(size_t)s * URF_DEG_CELLS + i] = (int16_t)sf;
         a.stop_b[(size_t)s * URF_DEG_CELLS + i] = (int16_t)sb;
     }
-    /* per ring: bit i set <=> the beam starting at degree i reached beyond that ring
-     * (six 64-bit words per ring and direction, consumed by k_label) */
+    /* Per ring k: bit i of mf / mb <=> the forward / backward beam that starts at degree i reached
+     * beyond ring k.  From the masks, for every (ring, degree d): the window end of the nearest such
+     * forward beam at or below d and of the nearest backward beam at or above d -- all k_label needs
+     * to decide a point (windows [i, hi_k(i)] and [lo_k(i), i] move monotonically with i). */
     for (unsigned k = 0; k < nR; k++) {
         const unsigned long long bf = __ballot(sf > (int)k), bb = __ballot(sb > (int)k);
         if (urf_lane() == 0) {
-            a.act_f[((size_t)s * C + k) * 6 + (tid >> 6)] = bf;
-            a.act_b[((size_t)s * C + k) * 6 + (tid >> 6)] = bb;
+            mf[k * 6 + (tid >> 6)] = bf;
+            mb[k * 6 + (tid >> 6)] = bb;
+        }
+    }
+    __syncthreads();
+    /* highest set forward bit in the words below word w / lowest set backward bit in the words above */
+    for (unsigned e = tid; e < nR * 6; e += URF_LABEL_THREADS) {
+        const unsigned k = e / 6, w = e % 6;
+        int below = -1, above = -1;
+        for (unsigned v = 0; v < w; v++)
+            if (mf[k * 6 + v])
+                below = (int)(v * 64 + 63 - __clzll((long long)mf[k * 6 + v]));
+        for (unsigned v = 5; v > w; v--)
+            if (mb[k * 6 + v])
+                above = (int)(v * 64 + __ffsll((long long)mb[k * 6 + v]) - 1);
+        pf[e] = (int16_t)below;
+        nb[e] = (int16_t)above;
+    }
+    __syncthreads();
+    if (inrange) {
+        const unsigned w = tid >> 6, b = tid & 63;
+        const unsigned long long le = b == 63 ? ~0ull : ((2ull << b) - 1ull), ge = ~0ull << b;
+        urf_win* win = a.win + (size_t)s * C * URF_DEG_CELLS + i;
+        for (unsigned k = 0; k < nR; k++) {
+            const unsigned long long f = mf[k * 6 + w] & le, g = mb[k * 6 + w] & ge;
+            const int jf = f ? (int)(w * 64 + 63 - __clzll((long long)f)) : (int)pf[k * 6 + w];
+            const int jb = g ? (int)(w * 64 + __ffsll((long long)g) - 1) : (int)nb[k * 6 + w];
+            const double q = qk[k];
+            urf_win o;
+            o.hi = jf >= 0 ? urf_fwd_hi(dp, jf, k, q) : -__builtin_inff();
+            o.lo = jb >= 0 ? urf_bwd_lo(dp, jb, k, q) : __builtin_inff();
+            win[(size_t)k * URF_DEG_CELLS] = o;
         }
     }
 }
@@ -2595,62 +2627,41 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
 /* byte image of the tile's labels; consecutive ring-major slots of an organised sweep lie 64
  * bytes apart in input order, so the row (i >> 6) rotates the column (i & 63) to spread the
  * byte stores over the LDS banks */
-/* Is a non-curb point of ring c with azimuth az road?  af / ab: the ring's words of act_f / act_b.
+/* Is a non-curb point with azimuth az road?  win: the point's ring's row of k_beams' window table.
  * With eps > 0 the azimuth is only known to within eps: `unsure` is set when a decision taken
- * here (floor, ceil, either window comparison) could come out differently for the true value. */
-__device__ __forceinline__ bool urf_road_test(const urf_dev_params& dp, const unsigned long long* af,
-                                              const unsigned long long* ab, unsigned c, double qkc, float az, float eps,
-                                              bool& unsure)
+ * here (floor, ceil, either window comparison) could come out differently for the true value.
+ * A NaN azimuth fails both comparisons (blind_spots.cpp:128,237 compare it the same way). */
+__device__ __forceinline__ bool urf_road_test(const urf_win* __restrict__ win, float az, float eps, bool& unsure)
 {
-    unsure = false;
-    if (!(az == az))
-        return false;
-    bool road = false;
-    const float fl = __builtin_floorf(az);
-    if (eps > 0.0f)
-        unsure = az - fl <= eps || (fl + 1.0f) - az <= eps;
-    int cf = (int)fl;
+    const float fl = __builtin_floorf(az), ce = __builtin_ceilf(az);
+    const bool num = az == az;
+    int cf = num ? (int)fl : 0, cb = num ? (int)ce : 0;
     cf = cf < 0 ? 0 : (cf > 360 ? 360 : cf);
-    {
-        int w = cf >> 6;
-        const int b = cf & 63;
-        unsigned long long mm = af[w] & (b == 63 ? ~0ull : ((2ull << b) - 1ull));
-        while (mm == 0 && w > 0)
-            mm = af[--w];
-        if (mm) {
-            const int i = w * 64 + 63 - __clzll((long long)mm);
-            const float hi = urf_fwd_hi(dp, i, c, qkc);
-            road = az <= hi;
-            unsure = unsure || (eps > 0.0f && __builtin_fabsf(az - hi) <= eps);
-        }
-    }
-    if (!road) {
-        int cb = (int)__builtin_ceilf(az);
-        cb = cb < 0 ? 0 : (cb > 360 ? 360 : cb);
-        int w = cb >> 6;
-        const int b = cb & 63;
-        unsigned long long mm = ab[w] & (~0ull << b);
-        while (mm == 0 && w < 5)
-            mm = ab[++w];
-        if (mm) {
-            const int i = w * 64 + __ffsll((long long)mm) - 1;
-            const float lo = urf_bwd_lo(dp, i, c, qkc);
-            road = az >= lo;
-            unsure = unsure || (eps > 0.0f && __builtin_fabsf(az - lo) <= eps);
-        }
-    }
+    cb = cb < 0 ? 0 : (cb > 360 ? 360 : cb);
+    const float hi = win[cf].hi, lo = win[cb].lo;
+    const bool road = az <= hi || az >= lo;
+    unsure = eps > 0.0f && (az - fl <= eps || (fl + 1.0f) - az <= eps || __builtin_fabsf(az - hi) <= eps ||
+                            __builtin_fabsf(az - lo) <= eps);
     return road;
+}
+
+/* the same decision on the exact azimuth of the point in ring-sorted slot `slot` */
+__device__ __noinline__ bool urf_road_exact(const urf_kargs& a, const urf_win* win, unsigned slot)
+{
+    float d2;
+    bool unsure;
+    return urf_road_test(win, urf_azimuth(a.rx[slot], a.ry[slot], &d2), 0.0f, unsure);
 }
 
 #define URF_LABEL_UNSURE 256   /* capacity of the list of points decided on the exact azimuth */
 #define URF_IMG(i) (((i) & ~63u) | ((((i) & 63u) + ((i) >> 6)) & 63u))
-/* amdgpu_waves_per_eu(7, 7): 20 KB of LDS allow seven workgroups per CU; measured 0.620 -> 0.609 ms */
-__global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_label(urf_kargs a, urf_dev_params dp)
+#ifndef URF_LABEL_WAVES
+#define URF_LABEL_WAVES 8
+#endif
+__global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_LABEL_WAVES, URF_LABEL_WAVES))) void k_label(urf_kargs a, urf_dev_params dp)
 {
-    __shared__ unsigned long long actf[URF_MAX_CHANNELS * 6], actb[URF_MAX_CHANNELS * 6];
-    __shared__ double qk[URF_MAX_CHANNELS];
     __shared__ unsigned koff[URF_MAX_CHANNELS + 1];
-    __shared__ uint8_t img[URF_TILE];
+    __shared__ uint8_t img[URF_TILE + 4];   /* + a spare byte for the slots past the tile's last */
     __shared__ uint8_t ring_of[URF_TILE] __attribute__((aligned(8)));
     __shared__ unsigned wave_max[URF_LABEL_TILE_THREADS / 64];
     __shared__ unsigned cnt_road, cnt_curb, n_unsure;
@@ -2677,16 +2688,9 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
             a.labels[off + i] = 0;
         return;
     }
-    const unsigned nR = in.n_rings;
-    if (tid <= C) {
+    if (tid <= C)
         koff[tid] = v_koff;
-        if (tid < C)
-            qk[tid] = tid < nR ? a.qk[(size_t)s * C + tid] : 0.0;
-    }
-    for (unsigned w = tid; w < nR * 6; w += URF_LABEL_TILE_THREADS) {
-        actf[w] = a.act_f[(size_t)s * C * 6 + w];
-        actb[w] = a.act_b[(size_t)s * C * 6 + w];
-    }
+    const urf_win* win = a.win + (size_t)s * C * URF_DEG_CELLS;
     for (unsigned i = tid; i < URF_TILE / 4; i += URF_LABEL_TILE_THREADS) {
         ((unsigned*)img)[i] = 0xffffffffu;
         ((unsigned*)ring_of)[i] = 0;
@@ -2725,8 +2729,12 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         if ((tid & 63) == 0)
             pre = 0;
         __syncthreads();
-        for (unsigned w = 0; w < (tid >> 6); w++)
-            pre = wave_max[w] > pre ? wave_max[w] : pre;
+        static_assert(URF_LABEL_TILE_THREADS == 256, "four waves");
+#pragma unroll
+        for (unsigned w = 0; w < 3; w++) {
+            const unsigned m = w < (tid >> 6) ? wave_max[w] : 0u;
+            pre = m > pre ? m : pre;
+        }
         unsigned o0 = 0, o1 = 0;
 #pragma unroll
         for (unsigned e = 0; e < 4; e++) {
@@ -2737,63 +2745,57 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         w32[2 * tid + 1] = o1;
     }
     __syncthreads();
-
     unsigned my_road = 0, my_curb = 0;
+    if (npts != 0) {   /* uniform; 0: no point of the tile lies on a ring */
+    /* Straight-line per point: slots past the tile's last one repeat that slot (every address stays
+     * valid) and drop their result into a spare byte of the image. */
     unsigned rc[Q], rpos[Q];
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
         const unsigned j = tid + q * URF_LABEL_TILE_THREADS;
-        rc[q] = j < npts ? (unsigned)ring_of[j] - 1u : 0u;
-        rpos[q] = j < npts ? sb + tbase + j : 0xffffffffu;   /* the point's ring-sorted slot: flag, azimuth, source, x, y */
+        const unsigned jc = j < npts ? j : npts - 1u;
+        rc[q] = (unsigned)ring_of[jc] - 1u;
+        rpos[q] = sb + tbase + jc;   /* the point's ring-sorted slot: flag, azimuth, source, x, y */
     }
     unsigned rfl[Q], rsr[Q];
     float raz[Q];
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {   /* all loads in flight before the tests */
-        const bool on = rpos[q] != 0xffffffffu;
-        rfl[q] = on ? (unsigned)a.rflag[rpos[q]] : 0u;
-        raz[q] = on ? a.raz[rpos[q]] : 0.f;
-        rsr[q] = on ? (unsigned)a.rsrc[rpos[q]] : 0u;   /* index inside the tile */
+        rfl[q] = (unsigned)a.rflag[rpos[q]];
+        raz[q] = a.raz[rpos[q]];
+        rsr[q] = (unsigned)a.rsrc[rpos[q]];   /* index inside the tile */
     }
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        if (rpos[q] == 0xffffffffu)
-            continue;
+        const bool valid = tid + q * URF_LABEL_TILE_THREADS < npts;
         const unsigned c = rc[q];
         const unsigned flag = rfl[q];
         const unsigned src = rsr[q];
-        uint8_t lab = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0);
-        if (flag & 7u) {
-            lab |= URF_LABEL_CURB;
-            my_curb++;
-        } else {
-            /* k_ring stored a float approximation of the azimuth for most points (error <=
-             * URF_FAST_AZ_ERR).  Every decision that the approximation clears by that margin is the
-             * reference's decision; the rare point that does not is listed and decided below on
-             * the exact azimuth. */
-            bool unsure;
-            const bool road = urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c], raz[q],
-                                            (flag & URF_RFLAG_AZ_APPROX) ? urf_fast_az_eps(raz[q]) : 0.0f, unsure);
-            bool road_final = road;
-            if (unsure) {
-                const unsigned e = atomicAdd(&n_unsure, 1u);
-                const unsigned slot = rpos[q];
-                if (e < URF_LABEL_UNSURE) {
-                    un_pos[e] = slot;
-                    un_key[e] = src | (c << 16);
-                    road_final = false;   /* placeholder, corrected after the tile is written */
-                } else {
-                    float d2;   /* list full (pathological input): decide here */
-                    road_final = urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c],
-                                               urf_azimuth(a.rx[slot], a.ry[slot], &d2), 0.0f, unsure);
-                }
-            }
-            if (road_final) {
-                lab |= URF_LABEL_ROAD;
-                my_road++;
+        const bool curb = (flag & 7u) != 0;
+        /* k_ring stored a float approximation of the azimuth for most points (error <=
+         * urf_fast_az_eps).  Every decision that the approximation clears by that margin is the
+         * reference's decision; the rare point that does not is listed and decided below on
+         * the exact azimuth. */
+        bool unsure;
+        bool road = urf_road_test(win + c * URF_DEG_CELLS, raz[q],
+                                  (flag & URF_RFLAG_AZ_APPROX) ? urf_fast_az_eps(raz[q]) : 0.0f, unsure);
+        if (unsure && valid && !curb) {
+            const unsigned e = atomicAdd(&n_unsure, 1u);
+            if (e < URF_LABEL_UNSURE) {
+                un_pos[e] = rpos[q];
+                un_key[e] = src | (c << 16);
+                road = false;   /* placeholder, corrected after the tile is written */
+            } else {
+                road = urf_road_exact(a, win + c * URF_DEG_CELLS, rpos[q]);   /* list full (pathological input) */
             }
         }
-        img[URF_IMG(src)] = lab;
+        road = road && !curb;
+        const unsigned lab = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0) |
+                             (curb ? URF_LABEL_CURB : 0) | (road ? URF_LABEL_ROAD : 0);
+        my_curb += (valid && curb) ? 1u : 0u;
+        my_road += (valid && road) ? 1u : 0u;
+        img[valid ? URF_IMG(src) : URF_TILE] = (uint8_t)lab;
+    }
     }
     __syncthreads();
     static_assert(URF_LABEL_UNSURE <= URF_LABEL_TILE_THREADS, "one listed point per thread");
@@ -2818,7 +2820,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         const unsigned c = tkey >> 16, li = tkey & 0xffffu;
         float d2;
         bool unsure;
-        if (urf_road_test(dp, actf + c * 6, actb + c * 6, c, qk[c], urf_azimuth(tx, ty, &d2), 0.0f, unsure)) {
+        if (urf_road_test(win + c * URF_DEG_CELLS, urf_azimuth(tx, ty, &d2), 0.0f, unsure)) {
             a.labels[off + tbase + li] = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0) | URF_LABEL_ROAD;
             my_road++;
         }
