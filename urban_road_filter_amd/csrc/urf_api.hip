@@ -212,7 +212,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.rx, T) A(k.ry, T) A(k.rz, T) A(k.rsrc, T) A(k.raz, T) A(k.rflag, T)
     A(k.sr, T) A(k.sz, T) A(k.sslot, T) A(k.ssrt, T) A(k.wslp, T) A(k.wg, T)
     A(k.big_r, T) A(k.big_z, T) A(k.big_i, T)
-    A(k.tile_roi, S * tiles) A(k.troff, S * tiles * (C + 1)) A(k.tsoff, S * tiles * (K + 1))
+    A(k.tile_roi, S * tiles) A(k.roi_bits, S * tiles * (URF_TILE / 64)) A(k.troff, S * tiles * (C + 1)) A(k.tsoff, S * tiles * (K + 1))
     A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles)
     A(k.angle, S * C) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
@@ -469,7 +469,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     if (k.valpha) {
         k.valpha += P; k.seckey += P; k.ringkey += P; k.rd2 += P;
     }
-    k.tile_roi += r * tiles; k.troff += r * tiles * (C + 1); k.tsoff += r * tiles * (K + 1);
+    k.tile_roi += r * tiles; k.roi_bits += r * tiles * (URF_TILE / 64); k.troff += r * tiles * (C + 1); k.tsoff += r * tiles * (K + 1);
     k.rpre += r * C * (tiles + 1); k.rstart += r * C * tiles;
     k.angle += r * C; k.ring_lut += r * URF_LUT_CELLS; k.ring_cnt += r * C; k.ring_off += r * (C + 1);
     k.sec_cnt += r * K; k.sec_off += r * (K + 1); k.star_hit += r * K;

@@ -146,6 +146,7 @@ struct urf_kargs {
     float*    premax;           /* [S][channels][361] */
     int16_t*  stop_f;           /* [S][361] */
     int16_t*  stop_b;           /* [S][361] */
+    unsigned long long* roi_bits; /* [S][tiles][32] bit i of a tile: input point i lies in the region of interest (k_split -> k_label) */
     urf_win*  win;              /* [S][channels][361] k_beams -> k_label.  .x: upper end of the window of the
                                  * nearest forward beam at or below degree d that reached beyond the ring
                                  * (-inf: none); .y: lower end for the nearest backward beam at or above d (+inf) */

@@ -534,14 +534,15 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             pending[atomicAdd(&misc[1], 1u)] = (uint16_t)li;
             openmask |= 1u << q;
         }
-        if (valid) {
-            a.labels[off + i] = roi ? URF_FLAG_ROI : 0;
-            if (exact_all && !roi)
-                a.valpha[sb + i] = -1.0f;   /* stage capture only */
-        }
+        if (valid && exact_all && !roi)
+            a.valpha[sb + i] = -1.0f;   /* stage capture only */
+        /* the label bytes are k_label's: it gets the region-of-interest bits of the tile, 64 per word */
         const unsigned long long rb = __ballot(roi);
-        if (lane == 0 && rb)
-            atomicAdd(&misc[0], (unsigned)__popcll(rb));
+        if (lane == 0) {
+            a.roi_bits[((size_t)s * a.tiles + t) * (URF_TILE / 64) + (li >> 6)] = rb;
+            if (rb)
+                atomicAdd(&misc[0], (unsigned)__popcll(rb));
+        }
 #ifdef URF_SPLIT_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);   /* one point at a time: keeps the live ranges of the four unrolled iterations apart */
 #endif
@@ -2654,14 +2655,17 @@ __device__ __noinline__ bool urf_road_exact(const urf_kargs& a, const urf_win* w
 }
 
 #define URF_LABEL_UNSURE 256   /* capacity of the list of points decided on the exact azimuth */
-#define URF_IMG(i) (((i) & ~63u) | ((((i) & 63u) + ((i) >> 6)) & 63u))
+/* byte image of the tile's labels in input order, every 64-byte row followed by four spare bytes:
+ * consecutive ring-major slots of an organised sweep lie 64 bytes apart in input order and so land
+ * in different LDS banks, while four consecutive labels still form one aligned word */
+#define URF_IMG(i) ((i) + 4u * ((i) >> 6))
 #ifndef URF_LABEL_WAVES
 #define URF_LABEL_WAVES 8
 #endif
 __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_LABEL_WAVES, URF_LABEL_WAVES))) void k_label(urf_kargs a, urf_dev_params dp)
 {
     __shared__ unsigned koff[URF_MAX_CHANNELS + 1];
-    __shared__ uint8_t img[URF_TILE + 4];   /* + a spare byte for the slots past the tile's last */
+    __shared__ uint8_t img[URF_TILE + URF_TILE / 16 + 4] __attribute__((aligned(8)));   /* + a spare byte for the slots past the tile's last */
     __shared__ uint8_t ring_of[URF_TILE] __attribute__((aligned(8)));
     __shared__ unsigned wave_max[URF_LABEL_TILE_THREADS / 64];
     __shared__ unsigned cnt_road, cnt_curb, n_unsure;
@@ -2691,9 +2695,16 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     if (tid <= C)
         koff[tid] = v_koff;
     const urf_win* win = a.win + (size_t)s * C * URF_DEG_CELLS;
-    for (unsigned i = tid; i < URF_TILE / 4; i += URF_LABEL_TILE_THREADS) {
-        ((unsigned*)img)[i] = 0xffffffffu;
-        ((unsigned*)ring_of)[i] = 0;
+    {
+        /* the image starts as the labels of points on no ring: the region-of-interest flag or nothing
+         * (k_split left the tile's 2048 bits); this thread's byte covers input points 8 tid .. 8 tid + 7 */
+        static_assert(URF_TILE == 8 * URF_LABEL_TILE_THREADS, "one byte of the bitmap per thread");
+        const unsigned bits = ((const uint8_t*)(a.roi_bits + row * (URF_TILE / 64)))[tid];
+        unsigned* i32 = (unsigned*)img + 2 * tid + (tid >> 3);
+        i32[0] = (((bits & 15u) * 0x00204081u) & 0x01010101u) * URF_FLAG_ROI;
+        i32[1] = (((bits >> 4) * 0x00204081u) & 0x01010101u) * URF_FLAG_ROI;
+        ((unsigned*)ring_of)[tid] = 0;
+        ((unsigned*)ring_of)[tid + URF_LABEL_TILE_THREADS] = 0;
     }
     if (tid == 0) {
         cnt_road = 0;
@@ -2747,28 +2758,23 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     __syncthreads();
     unsigned my_road = 0, my_curb = 0;
     if (npts != 0) {   /* uniform; 0: no point of the tile lies on a ring */
-    /* Straight-line per point: slots past the tile's last one repeat that slot (every address stays
-     * valid) and drop their result into a spare byte of the image. */
-    unsigned rc[Q], rpos[Q];
-#pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const unsigned j = tid + q * URF_LABEL_TILE_THREADS;
-        const unsigned jc = j < npts ? j : npts - 1u;
-        rc[q] = (unsigned)ring_of[jc] - 1u;
-        rpos[q] = sb + tbase + jc;   /* the point's ring-sorted slot: flag, azimuth, source, x, y */
-    }
+    /* Straight-line per point: slots past the tile's last one read whatever the scratch holds there
+     * (the tile's 2048 slots are allocated, every table index is clamped) and drop their result into a
+     * spare byte of the image. */
+    const unsigned slot0 = sb + tbase + tid;   /* ring-sorted slot of point q: slot0 + 256 q (flag, azimuth, source, x, y) */
     unsigned rfl[Q], rsr[Q];
     float raz[Q];
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {   /* all loads in flight before the tests */
-        rfl[q] = (unsigned)a.rflag[rpos[q]];
-        raz[q] = a.raz[rpos[q]];
-        rsr[q] = (unsigned)a.rsrc[rpos[q]];   /* index inside the tile */
+        rfl[q] = (unsigned)a.rflag[slot0 + q * URF_LABEL_TILE_THREADS];
+        raz[q] = a.raz[slot0 + q * URF_LABEL_TILE_THREADS];
+        rsr[q] = (unsigned)a.rsrc[slot0 + q * URF_LABEL_TILE_THREADS];   /* index inside the tile */
     }
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const bool valid = tid + q * URF_LABEL_TILE_THREADS < npts;
-        const unsigned c = rc[q];
+        const unsigned j = tid + q * URF_LABEL_TILE_THREADS;
+        const bool valid = j < npts;
+        const unsigned c = (unsigned)ring_of[j] - 1u;   /* (past the last slot: the last ring, from the prefix maximum) */
         const unsigned flag = rfl[q];
         const unsigned src = rsr[q];
         const bool curb = (flag & 7u) != 0;
@@ -2782,11 +2788,11 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         if (unsure && valid && !curb) {
             const unsigned e = atomicAdd(&n_unsure, 1u);
             if (e < URF_LABEL_UNSURE) {
-                un_pos[e] = rpos[q];
+                un_pos[e] = slot0 + q * URF_LABEL_TILE_THREADS;
                 un_key[e] = src | (c << 16);
                 road = false;   /* placeholder, corrected after the tile is written */
             } else {
-                road = urf_road_exact(a, win + c * URF_DEG_CELLS, rpos[q]);   /* list full (pathological input) */
+                road = urf_road_exact(a, win + c * URF_DEG_CELLS, slot0 + q * URF_LABEL_TILE_THREADS);   /* list full (pathological input) */
             }
         }
         road = road && !curb;
@@ -2794,7 +2800,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
                              (curb ? URF_LABEL_CURB : 0) | (road ? URF_LABEL_ROAD : 0);
         my_curb += (valid && curb) ? 1u : 0u;
         my_road += (valid && road) ? 1u : 0u;
-        img[valid ? URF_IMG(src) : URF_TILE] = (uint8_t)lab;
+        img[valid ? URF_IMG(src & (URF_TILE - 1u)) : URF_TILE + URF_TILE / 16] = (uint8_t)lab;
     }
     }
     __syncthreads();
@@ -2810,10 +2816,18 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         tx = a.rx[un_pos[tid]];
         ty = a.ry[un_pos[tid]];
     }
-    for (unsigned i = tid; i < URF_TILE; i += URF_LABEL_TILE_THREADS) {
-        const uint8_t l = img[URF_IMG(i)];
-        if (l != 0xff && tbase + i < len)
-            a.labels[off + tbase + i] = l;   /* points on no ring keep the label k_split wrote */
+    {
+        uint8_t* out = a.labels + off + tbase;
+        if (tbase + URF_TILE <= len && ((uintptr_t)out & 3u) == 0) {   /* uniform */
+#pragma unroll
+            for (unsigned r = 0; r < URF_TILE / 4 / URF_LABEL_TILE_THREADS; r++) {
+                const unsigned k = tid + r * URF_LABEL_TILE_THREADS;
+                ((unsigned*)out)[k] = ((const unsigned*)img)[k + (k >> 4)];
+            }
+        } else {
+            for (unsigned i = tid; i < URF_TILE && tbase + i < len; i += URF_LABEL_TILE_THREADS)
+                out[i] = img[URF_IMG(i)];
+        }
     }
     __syncthreads();   /* the tile's stores come first, the corrections second */
     if (tail) {
