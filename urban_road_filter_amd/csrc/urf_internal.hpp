@@ -74,6 +74,11 @@ struct urf_dev_params {
  * a sector's runs are read from tsoff directly (it meets few tiles).  What k_ring produces per point
  * (rflag, exact azimuths) goes into the point's ring-sorted slot; what the star sort produces is
  * contiguous per sector (wslp, wg, ssrt: at s * sstride + sec_off[k] + i). */
+/* A sector's points sit in one run per tile (k_split's sector-sorted order).  The first two non-empty
+ * runs: point i of the sector is element a0 + i of the sector-sorted arrays for i < c0, a1 + (i - c0)
+ * beyond (indices relative to the scan's scratch); nruns > 2: the sort walks the per-tile tables. */
+struct urf_sec_run { uint32_t a0, c0, a1, nruns; };
+
 /* k_beams -> k_label, per (ring, integer degree) */
 struct urf_win { float hi, lo; };
 
@@ -127,6 +132,7 @@ struct urf_kargs {
     uint32_t* ring_cnt;         /* [S][channels] */
     uint32_t* ring_off;         /* [S][channels+1] ring points of the scan in front of ring c (exclusive scan of ring_cnt) */
     uint32_t* sec_cnt;          /* [S][sectors] */
+    urf_sec_run* sec_run;       /* [S][sectors] the sector's first two runs (k_index -> k_star_sort_small) */
     uint32_t* sec_off;          /* [S][sectors+1] */
     int32_t*  star_hit;         /* [S][sectors] ring-major position of the sector's curb point; -1 = none or on no ring */
     uint32_t* star_first;       /* [S][sectors] last sorted index the walk may visit */

@@ -884,6 +884,7 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
         const uint16_t* toff = a.tsoff + (size_t)s * a.tiles * (K + 1);
         for (unsigned k = tid; k < K; k += 256) {
             unsigned run = 0;
+            urf_sec_run sr = { 0u, 0u, 0u, 0u };
             for (unsigned t0 = 0; t0 < ntiles; t0 += 16) {
                 unsigned v0[16], v1[16];
 #pragma unroll
@@ -893,10 +894,22 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
                     v1[u] = in ? (unsigned)toff[(size_t)(t0 + u) * (K + 1) + k + 1] : 0u;
                 }
 #pragma unroll
-                for (unsigned u = 0; u < 16; u++)
-                    run += v1[u] - v0[u];
+                for (unsigned u = 0; u < 16; u++) {
+                    const unsigned c = v1[u] - v0[u];
+                    if (c) {
+                        if (sr.nruns == 0) {
+                            sr.a0 = (t0 + u) * URF_TILE + v0[u];
+                            sr.c0 = c;
+                        } else if (sr.nruns == 1) {
+                            sr.a1 = (t0 + u) * URF_TILE + v0[u];
+                        }
+                        sr.nruns++;
+                    }
+                    run += c;
+                }
             }
             a.sec_cnt[(size_t)s * K + k] = run;
+            a.sec_run[(size_t)s * K + k] = sr;
         }
     }
     for (unsigned k0 = 0; k0 < C; k0 += 64)
@@ -1063,8 +1076,8 @@ __device__ __forceinline__ unsigned urf_sector_runs(const urf_kargs& a, unsigned
  * bitonic network and the blocks are merged by ranking. */
 template <unsigned MAXB>
 __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const urf_dev_params& dp, unsigned sb, unsigned obase, unsigned n,
-                                                     unsigned nruns, unsigned long long* A, unsigned* cnt, unsigned* sh_first,
-                                                     uint32_t* star_first_out)
+                                                     unsigned nruns, const urf_sec_run& two, unsigned long long* A, unsigned* cnt,
+                                                     unsigned* sh_first, uint32_t* star_first_out)
 {
     constexpr unsigned NB = URF_STAR_NB, PL = NB / 64;
     const unsigned lane = threadIdx.x;
@@ -1081,6 +1094,8 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
          * exactly as the position would, and it finds the point's companions again. */
         const unsigned* runP = (const unsigned*)A;
         const unsigned* runA = runP + 512;
+        const bool simple = nruns == 0;   /* at most two runs, described by `two` (uniform) */
+        const unsigned a1m = two.a1 - two.c0;
         unsigned r = 0;
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
@@ -1089,9 +1104,12 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
             zreg[q] = 0.f;
             sreg[q] = 0;
             if (q < B && i < n) {
-                while (r + 1 < nruns && i >= runP[r + 1])
-                    r++;
-                const unsigned adr = runA[r] + i;
+                unsigned adr = i + (i < two.c0 ? two.a0 : a1m);
+                if (!simple) {
+                    while (r + 1 < nruns && i >= runP[r + 1])
+                        r++;
+                    adr = runA[r] + i;
+                }
                 const unsigned rb = urf_fbits(a.sr[sb + adr]);
                 zreg[q] = a.sz[sb + adr];
                 const unsigned sl = a.sslot[sb + adr];
@@ -1298,7 +1316,7 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
     /* status, both ends of the sector and its run table in ONE round trip */
     const int status = a.info[s].status;
     const unsigned so0 = a.sec_off[(size_t)s * (K + 1) + k], so1 = a.sec_off[(size_t)s * (K + 1) + k + 1];
-    const urf_run_row row = urf_sector_run_row(a, s, K, k, 0);
+    const urf_sec_run two = a.sec_run[(size_t)s * K + k];
     if (status != URF_OK)
         return;
     const unsigned n = so1 - so0;
@@ -1314,12 +1332,17 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
     const unsigned sb = urf_sbase(a, s), obase = sb + so0;
     if (lane == 0)
         sh_first = n;
-    const unsigned nruns = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, row, (unsigned*)A, (unsigned*)A + 512);
-    __syncthreads();
+    /* a sector of an organised sweep meets one or two tiles: k_index described those runs; only a
+     * sector scattered over more tiles builds the list of its runs from k_split's per-tile tables */
+    unsigned nruns = 0;
+    if (two.nruns > 2) {
+        nruns = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, urf_sector_run_row(a, s, K, k, 0), (unsigned*)A, (unsigned*)A + 512);
+        __syncthreads();
+    }
     /* per-lane element count fixed at compile time: 6 covers a sector of a 64 x 2048 sweep.  (An
      * 8-per-lane instance for sectors of up to 512 points made the kernel spill 68 bytes per lane at
      * its 80 registers; such sectors take the workgroup path now.) */
-    urf_star_sort_sector<URF_STAR_SMALL_CAP / 64>(a, dp, sb, obase, n, nruns, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
+    urf_star_sort_sector<URF_STAR_SMALL_CAP / 64>(a, dp, sb, obase, n, nruns, two, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
 }
 
 template <int NT>
