@@ -1096,28 +1096,37 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
         const unsigned* runA = runP + 512;
         const bool simple = nruns == 0;   /* at most two runs, described by `two` (uniform) */
         const unsigned a1m = two.a1 - two.c0;
-        unsigned r = 0;
+        /* straight-line: elements past the sector's end repeat its last one (valid addresses) and
+         * are dropped afterwards; all loads of the lane are in flight together */
+        unsigned r = 0, adr[MAXB], rbv[MAXB], slv[MAXB];
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
-            const unsigned i = q * 64 + lane;
-            key[q] = ~0ull;
-            zreg[q] = 0.f;
-            sreg[q] = 0;
-            if (q < B && i < n) {
-                unsigned adr = i + (i < two.c0 ? two.a0 : a1m);
-                if (!simple) {
-                    while (r + 1 < nruns && i >= runP[r + 1])
-                        r++;
-                    adr = runA[r] + i;
-                }
-                const unsigned rb = urf_fbits(a.sr[sb + adr]);
-                zreg[q] = a.sz[sb + adr];
-                const unsigned sl = a.sslot[sb + adr];
-                sreg[q] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
-                key[q] = ((unsigned long long)rb << 32) | adr;
-                rmin = rb < rmin ? rb : rmin;
-                rmax = rb > rmax ? rb : rmax;
+            const unsigned i = q * 64 + lane, ic = i < n ? i : n - 1u;
+            adr[q] = ic + (ic < two.c0 ? two.a0 : a1m);
+            if (!simple) {
+                while (r + 1 < nruns && ic >= runP[r + 1])
+                    r++;
+                adr[q] = runA[r] + ic;
             }
+        }
+#pragma unroll
+        for (unsigned q = 0; q < MAXB; q++) {
+            rbv[q] = 0;
+            slv[q] = 0;
+            zreg[q] = 0.f;
+            if (q < B) {   /* uniform */
+                rbv[q] = urf_fbits(a.sr[sb + adr[q]]);
+                zreg[q] = a.sz[sb + adr[q]];
+                slv[q] = a.sslot[sb + adr[q]];
+            }
+        }
+#pragma unroll
+        for (unsigned q = 0; q < MAXB; q++) {
+            const bool valid = q * 64 + lane < n;
+            sreg[q] = slv[q] == URF_SLOT_NONE ? 0xffffffffu : (adr[q] & ~(URF_TILE - 1u)) + slv[q];
+            key[q] = valid ? ((unsigned long long)rbv[q] << 32) | adr[q] : ~0ull;
+            rmin = valid && rbv[q] < rmin ? rbv[q] : rmin;
+            rmax = valid && rbv[q] > rmax ? rbv[q] : rmax;
         }
     }
     for (unsigned c = lane; c <= NB; c += 64)
