@@ -214,7 +214,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.big_r, T) A(k.big_z, T) A(k.big_i, T)
     A(k.tile_roi, S * tiles) A(k.roi_bits, S * tiles * (URF_TILE / 64)) A(k.troff, S * tiles * (C + 1)) A(k.tsoff, S * tiles * (K + 1))
     A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles)
-    A(k.angle, S * C) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
+    A(k.angle, S * C) A(k.ring_thr, S * C * 4) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_run, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
     A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 8)
     A(k.table_upto, S) A(k.table_redo, S) A(k.redo_list, S)
@@ -471,7 +471,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     }
     k.tile_roi += r * tiles; k.roi_bits += r * tiles * (URF_TILE / 64); k.troff += r * tiles * (C + 1); k.tsoff += r * tiles * (K + 1);
     k.rpre += r * C * (tiles + 1); k.rstart += r * C * tiles;
-    k.angle += r * C; k.ring_lut += r * URF_LUT_CELLS; k.ring_cnt += r * C; k.ring_off += r * (C + 1);
+    k.angle += r * C; k.ring_thr += r * C * 4; k.ring_lut += r * URF_LUT_CELLS; k.ring_cnt += r * C; k.ring_off += r * (C + 1);
     k.sec_cnt += r * K; k.sec_run += r * K; k.sec_off += r * (K + 1); k.star_hit += r * K;
     k.star_first += r * K; k.star_list_mid += r * K; k.star_list_big += r * K; k.star_count += 4 * r;
     k.table_upto += r; k.table_redo += r; k.redo_list += r;

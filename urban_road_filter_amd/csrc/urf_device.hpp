@@ -280,6 +280,76 @@ __device__ __forceinline__ bool urf_fast_vertical_angle(float x, float y, float 
     return (rho >= URF_FAST_MIN) & (rho <= URF_FAST_MAX) & (__builtin_fabsf(z) <= 4.0f * rho);
 }
 
+/* The ring of a point is decided without any arc tangent: u = -z / rho = cot(vertical angle) falls
+ * strictly as the angle grows, so "the angle lies in [lo, hi] deg" is "u lies in [cot hi, cot lo]", and
+ * k_ring_table turns every table entry's window into thresholds on u once per scan
+ * (urf_ring_thresholds).  u from one v_rsq_f32 (1 ulp) and one product: relative error <= 3e-7 (three
+ * roundings of x*x + y*y, half of which reaches the root), i.e. <= 3e-7 * |u| / (1 + u*u) <= 1.5e-7
+ * rad = 9e-6 deg of angle; the reference's own value deviates from the true angle by up to
+ * 1.2e-7 * |z| / rho rad (it rounds |z| / d to float before the acos) + half an ulp of the result,
+ * hence the restriction to |u| <= 4 as before.  Together < 5e-5 deg; the margin stays
+ * URF_FAST_VALPHA_ERR = 3e-4 deg (urf_selftest_fast measures |angle(u) - reference|). */
+#define URF_FAST_MIN2 1.0e-30f
+#define URF_FAST_MAX2 1.0e36f
+__device__ __forceinline__ bool urf_fast_cot(float x, float y, float z, float* u_out)
+{
+    const float rho2 = x * x + y * y;
+    const float u = -z * __builtin_amdgcn_rsqf(rho2);
+    *u_out = u;
+    return (rho2 >= URF_FAST_MIN2) & (rho2 <= URF_FAST_MAX2) & (__builtin_fabsf(u) <= URF_LUT_UMAX);   /* NaN: false */
+}
+
+/* cot of an angle given in degrees, clamped to [1, 179] deg (|cot| = 57 there: beyond every u the fast
+ * path accepts, so the clamp changes no decision), in binary64: tan(t), t = pi/2 - angle, from the
+ * Taylor series of sin / cos at t/2 (|t/2| <= 0.78: the first neglected terms are below 1e-19) and
+ * the double-angle formula.  Error ~1e-15 relative; needs 1e-7. */
+__device__ __forceinline__ double urf_cot_deg(double deg)
+{
+    deg = deg < 1.0 ? 1.0 : (deg > 179.0 ? 179.0 : deg);
+    const double h = (90.0 - deg) * (URF_PI_D / 360.0);
+    const double v = h * h;
+    double sn = -1.0 / 121645100408832000.0;             /* 1/19! */
+    sn = __builtin_fma(sn, v, 1.0 / 355687428096000.0);   /* 1/17! */
+    sn = __builtin_fma(sn, v, -1.0 / 1307674368000.0);
+    sn = __builtin_fma(sn, v, 1.0 / 6227020800.0);
+    sn = __builtin_fma(sn, v, -1.0 / 39916800.0);
+    sn = __builtin_fma(sn, v, 1.0 / 362880.0);
+    sn = __builtin_fma(sn, v, -1.0 / 5040.0);
+    sn = __builtin_fma(sn, v, 1.0 / 120.0);
+    sn = __builtin_fma(sn, v, -1.0 / 6.0);
+    sn = __builtin_fma(sn * v, h, h);
+    double cs = 1.0 / 6402373705728000.0;                 /* 1/18! */
+    cs = __builtin_fma(cs, v, -1.0 / 20922789888000.0);
+    cs = __builtin_fma(cs, v, 1.0 / 87178291200.0);
+    cs = __builtin_fma(cs, v, -1.0 / 479001600.0);
+    cs = __builtin_fma(cs, v, 1.0 / 3628800.0);
+    cs = __builtin_fma(cs, v, -1.0 / 40320.0);
+    cs = __builtin_fma(cs, v, 1.0 / 720.0);
+    cs = __builtin_fma(cs, v, -1.0 / 24.0);
+    cs = __builtin_fma(cs, v, 0.5);
+    cs = __builtin_fma(-cs, v, 1.0);
+    const double th = sn / cs;
+    return 2.0 * th / (1.0 - th * th);
+}
+
+/* Thresholds on u for the table entry `angle` (deg) with the margin e (deg) on either side of its
+ * window [angle - interval, angle + interval]:
+ *   u <  .x                the entry lies surely below the point's window: fl(angle - alpha) < -interval
+ *   .y <= u <= .z          the entry surely matches:                       |fl(angle - alpha)| <= interval
+ *   u >  .w                the entry lies surely above the point's window: fl(angle - alpha) > interval
+ * (.x < .y <= .z < .w; with a window narrower than 2 e nothing "surely matches": .y > .z) */
+struct urf_ring_thr { float x, y, z, w; };
+__device__ __forceinline__ urf_ring_thr urf_ring_thresholds(float angle, float interval, float e)
+{
+    const double a = (double)angle, iv = (double)interval, ee = (double)e;
+    urf_ring_thr t;
+    t.x = (float)urf_cot_deg(a + iv + ee);
+    t.y = (float)urf_cot_deg(a + iv - ee);
+    t.z = (float)urf_cot_deg(a - iv + ee);
+    t.w = (float)urf_cot_deg(a - iv - ee);
+    return t;
+}
+
 /* Sector of star_shaped_search.cpp:164-171 when the scaled polar angle u = fi * Kfi is clear of an
  * integer by more than `margin`; -1 = undecided.  Both error sources grow with the number of sectors:
  * the reference's own roundings (two of the angle, one of the product: <= 3 ulp of u, u < sectors) and

@@ -14,8 +14,10 @@
 #define URF_MAX_CHANNELS    128    /* ring keys fit 7 bits + "none" */
 #define URF_MAX_SECTORS     1022   /* sector keys fit 10 bits + "none" */
 #define URF_MAX_CURB_POINTS 30     /* cfg/LidarFilters.cfg:36 */
-#define URF_LUT_SCALE       16.0f  /* cells per degree of the ring lookup table (k_ring_table -> k_ingest) */
-#define URF_LUT_CELLS       2884   /* 180 * 16 + 1 cells, padded to a multiple of 4 */
+/* ring lookup table (k_ring_table -> k_split), over u = -z / rho = cot(vertical angle) in [-4, 4] */
+#define URF_LUT_UMAX        4.0f
+#define URF_LUT_SCALE       512.0f /* cells per unit of u: 1/512 = 0.11 deg at the horizon, less elsewhere */
+#define URF_LUT_CELLS       4100   /* 8 * 512 + 1 cells (u == 4 has its own), padded to a multiple of 4 */
 #define URF_DEG_CELLS       361    /* integer degrees 0..360 (blind_spots.cpp:68,177) */
 
 /* one tile = the unit of the stable multi-split by ring / by sector */
@@ -128,7 +130,11 @@ struct urf_kargs {
     uint16_t* rstart;           /* [S][C][tiles]   = troff[t][c] */
     /* per scan */
     float*    angle;            /* [S][channels] sorted ring-angle table */
-    uint8_t*  ring_lut;         /* [S][URF_LUT_CELLS] first table entry a vertical angle of the cell can match */
+    uint8_t*  ring_lut;         /* [S][URF_LUT_CELLS] number of table entries no point of the cell (of u) can match */
+    float*    ring_thr;         /* [S][channels][4] per table entry, in u = cot(vertical angle), which FALLS as the angle
+                                 * grows: u < .x the entry lies surely below the point's window (skip it), u in
+                                 * [.y, .z] it surely matches, u > .w it surely lies above the window
+                                 * (urf_device.hpp: urf_ring_thresholds) */
     uint32_t* ring_cnt;         /* [S][channels] */
     uint32_t* ring_off;         /* [S][channels+1] ring points of the scan in front of ring c (exclusive scan of ring_cnt) */
     uint32_t* sec_cnt;          /* [S][sectors] */

@@ -308,21 +308,28 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
     if (tid == 0)
         a.info[s].n_rings = n;
     __syncthreads();
-    /* Lookup table for k_ingest's float fast path: cell c covers the vertical angles
-     * [c / 16, (c + 1) / 16) deg; lut[c] = number of table entries that cannot match the cell's
-     * smallest angle (they lie below it by more than interval + the approximation's error).  The
-     * count only grows with the angle, so a point starts its search at lut[cell] and usually ends
-     * it there or one entry later, instead of bisecting the table. */
+    /* k_split decides rings on u = -z / rho = cot(vertical angle) (urf_device.hpp: urf_fast_cot): per
+     * table entry the thresholds on u (urf_ring_thresholds), and a lookup table over u: cell c covers
+     * [c / 512 - 4, (c + 1) / 512 - 4); lut[c] = number of entries that lie surely below the window of
+     * every point of the cell (u < their .x; the .x fall with the entry's index).  A point starts its
+     * search at lut[cell] and usually ends it there or one entry later, instead of bisecting the table.
+     * (A cell index that float rounding pushes up by one only lowers the count: still valid.) */
     {
         const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;
+        if (tid < n) {
+            const urf_ring_thr t = urf_ring_thresholds(SL[tid], interval, e);
+            ((urf_ring_thr*)a.ring_thr)[(size_t)s * C + tid] = t;
+            L[tid] = t.x;   /* the leaders in insertion order are no longer needed */
+        }
+        __syncthreads();
         uint8_t* lut = a.ring_lut + (size_t)s * URF_LUT_CELLS;
         for (unsigned cell = tid; cell < URF_LUT_CELLS; cell += 256) {
-            const float v0 = (float)cell * (1.0f / URF_LUT_SCALE);
+            const float u1 = (float)(cell + 1) * (1.0f / URF_LUT_SCALE) - URF_LUT_UMAX;   /* exact */
             unsigned lo = 0;
 #pragma unroll
             for (unsigned step = URF_MAX_CHANNELS; step > 0; step >>= 1) {
                 const unsigned idx = lo + step - 1;
-                if (idx < n && !(SL[idx & (URF_MAX_CHANNELS - 1)] - v0 >= -(interval + e)))
+                if (idx < n && L[idx & (URF_MAX_CHANNELS - 1)] >= u1)
                     lo += step;
             }
             lut[cell] = (uint8_t)lo;
@@ -376,13 +383,13 @@ __global__ __launch_bounds__(256) void k_table_repair(urf_kargs a, urf_dev_param
 
 __host__ __device__ inline unsigned urf_align16(unsigned v) { return (v + 15u) & ~15u; }
 
-/* LDS carve of k_split: tab | lut | koff[C+1] | soff[Ks+1] | misc[16] |
+/* LDS carve of k_split: tab | ul | thr | lut | koff[C+1] | soff[Ks+1] | misc[16] |
  * union { keyr[T] u8, keys[T] u16, pending[T] u16, wcnt_r[W][C] u16, wcnt_s[W][Ks] u16 ;
  *         staging x y z azimuth src [URF_SLOTS] u32 } */
 __host__ __device__ inline size_t urf_split_lds_bytes(unsigned C, unsigned K, bool star)
 {
     const unsigned Ks = star ? K : 0;
-    const size_t fixed = URF_MAX_CHANNELS * 4 + urf_align16(URF_LUT_CELLS) + urf_align16((C + 1) * 4) +
+    const size_t fixed = URF_MAX_CHANNELS * (4 + 4 + 16) + urf_align16(URF_LUT_CELLS) + urf_align16((C + 1) * 4) +
                          urf_align16((Ks + 1) * 4) + 64;
     const size_t phase_a = 5 * (size_t)URF_TILE + urf_align16(2 * URF_TILE_WAVES * (C + Ks));
     const size_t phase_b = 5 * (size_t)URF_SLOTS * 4;
@@ -437,8 +444,10 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
     const unsigned Ks = star ? K : 0;
-    float* tab = (float*)sh_raw;
-    uint8_t* lut = (uint8_t*)(tab + URF_MAX_CHANNELS);
+    float* tab = (float*)sh_raw;                       /* the sorted ring angles (exact pass) */
+    float* ul = tab + URF_MAX_CHANNELS;                /* urf_ring_thr::x of every entry: the probes */
+    urf_ring_thr* thr = (urf_ring_thr*)(ul + URF_MAX_CHANNELS);
+    uint8_t* lut = (uint8_t*)(thr + URF_MAX_CHANNELS);
     unsigned* koff = (unsigned*)(lut + urf_align16(URF_LUT_CELLS));
     unsigned* soff = koff + urf_align16((C + 1) * 4) / 4;
     unsigned* misc = soff + urf_align16((Ks + 1) * 4) / 4;   /* [0] ROI points, [1] pending, [2..9] wave sums */
@@ -466,8 +475,12 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     const unsigned upto = nR < C ? a.table_upto[s] : 0xffffffffu;
     for (unsigned k = tid; k < URF_TILE_WAVES * (C + Ks) / 2; k += URF_TILE_THREADS)
         ((unsigned*)wcnt_r)[k] = 0;
-    if (tid < URF_MAX_CHANNELS)
+    if (tid < URF_MAX_CHANNELS) {
         tab[tid] = tid < nR ? a.angle[(size_t)s * C + tid] : 0.f;
+        const float4 t = ((const float4*)a.ring_thr)[(size_t)s * C + (tid < nR ? tid : 0u)];   /* entries >= nR are never used */
+        ((float4*)thr)[tid] = t;
+        ul[tid] = t.x;
+    }
     if (tid < 16)
         misc[tid] = 0;
     for (unsigned i = tid; i < URF_LUT_CELLS / 4; i += URF_TILE_THREADS)
@@ -475,9 +488,9 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     __syncthreads();
 
     const float interval = dp.p.interval;
-    /* Ring, float fast path (urf_device.hpp) unless the stage capture wants the exact angle: with
-     * |vt - alpha| <= e, entries below vt - interval - e surely do not match, an entry within
-     * interval - e surely does, one beyond interval + e surely does not.
+    /* Ring, float fast path (urf_device.hpp: urf_fast_cot, urf_ring_thresholds) unless the stage
+     * capture wants the exact angle: u = cot(vertical angle) is compared with the thresholds
+     * k_ring_table derived from every entry's window -- no arc tangent, no square root.
      *
      * Main pass: only what the approximations decide, and without per-lane branches (every test is
      * a select: the wave executes both sides of a divergent branch anyway, and the exec-mask
@@ -486,7 +499,6 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
      * capture wants exact angles) is listed and takes the reference's exact sequence in a second,
      * dense pass: the exact code exists once instead of four times in the unrolled loop, and its
      * f64 chains never run with two lanes of a wave. */
-    const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;   /* + rounding of fl(angle[j] - alpha) */
     const bool exact_all = a.capture == 1;
     unsigned rkey[Q], skey[Q];
     float azf[Q];            /* approximate azimuth [deg] (urf_device.hpp), consumed by k_label */
@@ -497,23 +509,20 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         const bool valid = i < len;
         const float x = px[q], y = py[q], z = pz[q];
         const bool roi = valid & urf_in_roi(dp.p, x, y, z);
-        float vt;
-        const bool fast = urf_fast_vertical_angle(x, y, z, &vt) & roi & !exact_all;
-        vt = fast ? vt : 0.f;
+        float u;
+        const bool fast = urf_fast_cot(x, y, z, &u) & roi & !exact_all;
+        u = fast ? u : 0.f;
         /* lo = number of table entries surely below the point's window: the cell's count from the
-         * lookup table, plus up to two entries between the cell's start and the angle (a third one
-         * is rare and left to the exact pass) */
-        const unsigned cell = (unsigned)(vt * URF_LUT_SCALE);   /* vt in [0, 180] */
-        unsigned lo = lut[cell < URF_LUT_CELLS - 1 ? cell : URF_LUT_CELLS - 1];
-        float tv = tab[lo & (URF_MAX_CHANNELS - 1)];
-        lo += (lo < nR) & !(tv - vt >= -(interval + e));
-        tv = tab[lo & (URF_MAX_CHANNELS - 1)];
-        lo += (lo < nR) & !(tv - vt >= -(interval + e));
-        tv = tab[lo & (URF_MAX_CHANNELS - 1)];
-        const bool unsettled = (lo < nR) & !(tv - vt >= -(interval + e));
-        const float d = tv - vt;
-        const bool none = (lo >= nR) | (d > interval + e);                        /* no entry can match */
-        const bool match = !none & (__builtin_fabsf(d) <= interval - e);         /* the first candidate surely matches */
+         * lookup table, plus up to two entries between the cell's end and u (a third one is rare
+         * and left to the exact pass) */
+        const unsigned cell = (unsigned)((u + URF_LUT_UMAX) * URF_LUT_SCALE);   /* u in [-4, 4]: cell <= 4096 */
+        unsigned lo = lut[cell];
+        lo += (lo < nR) & (u < ul[lo & (URF_MAX_CHANNELS - 1)]);
+        lo += (lo < nR) & (u < ul[lo & (URF_MAX_CHANNELS - 1)]);
+        const urf_ring_thr tv = thr[lo & (URF_MAX_CHANNELS - 1)];
+        const bool unsettled = (lo < nR) & (u < tv.x);
+        const bool none = (lo >= nR) | (u > tv.w);                 /* no entry can match */
+        const bool match = !none & (u >= tv.y) & (u <= tv.z);      /* the first candidate surely matches */
         bool open = roi & (!fast | unsettled | !(none | match));
         unsigned rk = match ? lo : URF_RING_NONE, sk = URF_SEC_NONE;
         const float fi = urf_fast_polar(x, y);   /* one arc tangent: the star sector and the azimuth */
@@ -3321,8 +3330,14 @@ __global__ __launch_bounds__(256) void k_selftest_fast(unsigned long long n, flo
         }
         const float x = c[0], y = c[1], z = c[2] * 0.25f;
         float vt;
-        if (urf_fast_vertical_angle(x, y, z, &vt)) {
+        if (urf_fast_vertical_angle(x, y, z, &vt)) {   /* k_ring_table's look-ahead */
             const float d = __builtin_fabsf(vt - urf_vertical_angle(x, y, z));
+            ev = d > ev ? d : ev;
+        }
+        float uc;
+        if (urf_fast_cot(x, y, z, &uc)) {   /* k_split: the angle whose cotangent uc is (atan2 rounded to float: +-1e-5 deg) */
+            const float au = (float)((double)urf_atan2f(1.0f, uc) * (180.0 / URF_PI_D));
+            const float d = __builtin_fabsf(au - urf_vertical_angle(x, y, z));
             ev = d > ev ? d : ev;
         }
         float azt;
