@@ -429,6 +429,21 @@ __device__ __noinline__ urf_exact_key urf_exact_keys(const float* tab, unsigned 
     return r;
 }
 
+/* timing experiment (tools/ab_noparity.sh): wave 0 of a few workgroups in the middle of the grid prints
+ * the shader-clock cycles between the kernel's barriers */
+#ifdef URF_EXP_PHASE_CLOCK
+#define URF_PHASE_DECL unsigned long long ph_t[16]; unsigned ph_n = 0; ph_t[ph_n++] = __builtin_amdgcn_s_memtime()
+#define URF_PHASE_MARK ph_t[ph_n++] = __builtin_amdgcn_s_memtime()
+#define URF_PHASE_DUMP(name)                                                                                  \
+    if (threadIdx.x == 0 && blockIdx.y == gridDim.y / 2 && blockIdx.x < 4) {                                   \
+        for (unsigned ph_i = 1; ph_i < ph_n; ph_i++)                                                           \
+            printf("%s wg %u phase %u: %llu cycles\n", name, blockIdx.x, ph_i, ph_t[ph_i] - ph_t[ph_i - 1]); \
+    }
+#else
+#define URF_PHASE_DECL
+#define URF_PHASE_MARK
+#define URF_PHASE_DUMP(name)
+#endif
 #ifndef URF_SPLIT_WAVES_PER_EU
 #define URF_SPLIT_WAVES_PER_EU 6   /* 73 VGPRs without spills; A/B on one box: 4 -> 1.39 ms, 6 -> 1.04 ms, 8 (32 B of scratch) -> 1.12 ms */
 #endif
@@ -441,6 +456,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     const unsigned tbase = t * URF_TILE;
     if (tbase >= len)
         return;
+    URF_PHASE_DECL;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
     const unsigned Ks = star ? K : 0;
@@ -459,10 +475,24 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     uint16_t* wcnt_s = wcnt_r + (size_t)URF_TILE_WAVES * C;
     const unsigned sb = urf_sbase(a, s);
 
+    /* Everything the workgroup needs from memory is requested in ONE round trip, none of it depending
+     * on another load's result: the scan's tables (unconditionally -- entries at or beyond n_rings are
+     * never looked at) first, then the tile's points.  (With the table loads depending on n_rings the
+     * workgroup spent a third of its life, 12 000 of 34 000 cycles, in front of its first barrier.) */
     constexpr unsigned Q = URF_TILE / URF_TILE_THREADS;
+    constexpr unsigned LUT_WORDS = URF_LUT_CELLS / 4, LUT_PT = (LUT_WORDS + URF_TILE_THREADS - 1) / URF_TILE_THREADS;
+    const unsigned trow = tid < URF_MAX_CHANNELS ? tid : 0u;
+    const float tab_v = a.angle[(size_t)s * C + trow];
+    const float4 thr_v = ((const float4*)a.ring_thr)[(size_t)s * C + trow];
+    unsigned lut_v[LUT_PT];
+#pragma unroll
+    for (unsigned e = 0; e < LUT_PT; e++) {
+        const unsigned i = tid + e * URF_TILE_THREADS;
+        lut_v[e] = ((const unsigned*)(a.ring_lut + (size_t)s * URF_LUT_CELLS))[i < LUT_WORDS ? i : 0u];
+    }
     float px[Q], py[Q], pz[Q];
 #pragma unroll
-    for (unsigned q = 0; q < Q; q++) {   /* all loads of the tile in flight before anything else */
+    for (unsigned q = 0; q < Q; q++) {
         const unsigned i = tbase + wave * 256 + q * 64 + lane;
         const bool valid = i < len;
         px[q] = valid ? a.x[off + i] : 0.f;
@@ -472,20 +502,29 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     const unsigned nR = a.info[s].n_rings;
     /* a speculative ring table (k_ring_table) is checked here: a region-of-interest point at or behind
      * `upto` that matches none of its entries would have been a new leader */
-    const unsigned upto = nR < C ? a.table_upto[s] : 0xffffffffu;
+    const unsigned upto_v = a.table_upto[s];
+    const unsigned upto = nR < C ? upto_v : 0xffffffffu;
     for (unsigned k = tid; k < URF_TILE_WAVES * (C + Ks) / 2; k += URF_TILE_THREADS)
         ((unsigned*)wcnt_r)[k] = 0;
-    if (tid < URF_MAX_CHANNELS) {
-        tab[tid] = tid < nR ? a.angle[(size_t)s * C + tid] : 0.f;
-        const float4 t = ((const float4*)a.ring_thr)[(size_t)s * C + (tid < nR ? tid : 0u)];   /* entries >= nR are never used */
-        ((float4*)thr)[tid] = t;
-        ul[tid] = t.x;
-    }
     if (tid < 16)
         misc[tid] = 0;
-    for (unsigned i = tid; i < URF_LUT_CELLS / 4; i += URF_TILE_THREADS)
-        ((unsigned*)lut)[i] = ((const unsigned*)(a.ring_lut + (size_t)s * URF_LUT_CELLS))[i];
+    if (tid < URF_MAX_CHANNELS) {
+        tab[tid] = tab_v;
+        ((float4*)thr)[tid] = thr_v;
+        ul[tid] = thr_v.x;
+    }
+#pragma unroll
+    for (unsigned e = 0; e < LUT_PT; e++) {
+        const unsigned i = tid + e * URF_TILE_THREADS;
+        if (i < LUT_WORDS)
+            ((unsigned*)lut)[i] = lut_v[e];
+    }
     __syncthreads();
+    URF_PHASE_MARK;
+#ifdef URF_EXP_PHASE_CLOCK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* x / y / z have arrived */
+    URF_PHASE_MARK;
+#endif
 
     const float interval = dp.p.interval;
     /* Ring, float fast path (urf_device.hpp: urf_fast_cot, urf_ring_thresholds) unless the stage
@@ -503,28 +542,52 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     unsigned rkey[Q], skey[Q];
     float azf[Q];            /* approximate azimuth [deg] (urf_device.hpp), consumed by k_label */
     unsigned openmask = 0;   /* bit q: point q of this thread is on the pending list */
+    /* Written phase by phase over the thread's four points, so that the four dependent LDS reads of
+     * the ring search (lookup cell, two probes, the entry's thresholds) are in flight for all four
+     * points at once: point after point the wave sat through sixteen LDS round trips here. */
+    float uu[Q];
+    unsigned lo[Q], roim = 0, fastm = 0, openm = 0;
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned li = wave * 256 + q * 64 + lane, i = tbase + li;
-        const bool valid = i < len;
+        const unsigned i = tbase + wave * 256 + q * 64 + lane;
         const float x = px[q], y = py[q], z = pz[q];
-        const bool roi = valid & urf_in_roi(dp.p, x, y, z);
+        const bool roi = (i < len) & urf_in_roi(dp.p, x, y, z);
         float u;
         const bool fast = urf_fast_cot(x, y, z, &u) & roi & !exact_all;
-        u = fast ? u : 0.f;
+        uu[q] = fast ? u : 0.f;
+        roim |= (unsigned)roi << q;
+        fastm |= (unsigned)fast << q;
         /* lo = number of table entries surely below the point's window: the cell's count from the
          * lookup table, plus up to two entries between the cell's end and u (a third one is rare
          * and left to the exact pass) */
-        const unsigned cell = (unsigned)((u + URF_LUT_UMAX) * URF_LUT_SCALE);   /* u in [-4, 4]: cell <= 4096 */
-        unsigned lo = lut[cell];
-        lo += (lo < nR) & (u < ul[lo & (URF_MAX_CHANNELS - 1)]);
-        lo += (lo < nR) & (u < ul[lo & (URF_MAX_CHANNELS - 1)]);
-        const urf_ring_thr tv = thr[lo & (URF_MAX_CHANNELS - 1)];
-        const bool unsettled = (lo < nR) & (u < tv.x);
-        const bool none = (lo >= nR) | (u > tv.w);                 /* no entry can match */
+        const unsigned cell = (unsigned)((uu[q] + URF_LUT_UMAX) * URF_LUT_SCALE);   /* u in [-4, 4]: cell <= 4096 */
+        lo[q] = lut[cell];
+    }
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++)
+        lo[q] += (lo[q] < nR) & (uu[q] < ul[lo[q] & (URF_MAX_CHANNELS - 1)]);
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++)
+        lo[q] += (lo[q] < nR) & (uu[q] < ul[lo[q] & (URF_MAX_CHANNELS - 1)]);
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const float u = uu[q];
+        const urf_ring_thr tv = thr[lo[q] & (URF_MAX_CHANNELS - 1)];
+        const bool unsettled = (lo[q] < nR) & (u < tv.x);
+        const bool none = (lo[q] >= nR) | (u > tv.w);              /* no entry can match */
         const bool match = !none & (u >= tv.y) & (u <= tv.z);      /* the first candidate surely matches */
-        bool open = roi & (!fast | unsettled | !(none | match));
-        unsigned rk = match ? lo : URF_RING_NONE, sk = URF_SEC_NONE;
+        const bool roi = (roim >> q) & 1u, fast = (fastm >> q) & 1u;
+        openm |= (unsigned)(roi & (!fast | unsettled | !(none | match))) << q;
+        rkey[q] = match ? lo[q] : URF_RING_NONE;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned li = wave * 256 + q * 64 + lane, i = tbase + li;
+        const float x = px[q], y = py[q];
+        const bool roi = (roim >> q) & 1u;
+        bool open = (openm >> q) & 1u;
+        const unsigned rk = rkey[q];
+        unsigned sk = URF_SEC_NONE;
         const float fi = urf_fast_polar(x, y);   /* one arc tangent: the star sector and the azimuth */
         azf[q] = urf_fast_azimuth_of(fi);
         if (star) {
@@ -543,7 +606,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             pending[atomicAdd(&misc[1], 1u)] = (uint16_t)li;
             openmask |= 1u << q;
         }
-        if (valid && exact_all && !roi)
+        if (i < len && exact_all && !roi)
             a.valpha[sb + i] = -1.0f;   /* stage capture only */
         /* the label bytes are k_label's: it gets the region-of-interest bits of the tile, 64 per word */
         const unsigned long long rb = __ballot(roi);
@@ -552,11 +615,9 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             if (rb)
                 atomicAdd(&misc[0], (unsigned)__popcll(rb));
         }
-#ifdef URF_SPLIT_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);   /* one point at a time: keeps the live ranges of the four unrolled iterations apart */
-#endif
     }
     __syncthreads();
+    URF_PHASE_MARK;
     const unsigned np = misc[1];
     for (unsigned k = tid; k < np; k += URF_TILE_THREADS) {
         const unsigned li = pending[k], i = tbase + li;
@@ -573,6 +634,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         keys[li] = (uint16_t)sk;
     }
     __syncthreads();
+    URF_PHASE_MARK;
 
     /* step 1: ranks inside the wave's own 256 points.  The lanes of a step that share a key read
      * the key's running count (one LDS address: a broadcast), the first of them adds the group's
@@ -610,6 +672,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         }
     }
     __syncthreads();
+    URF_PHASE_MARK;
     /* step 2: exclusive scan over the waves, one thread per key; totals to koff / soff */
     for (unsigned k = tid; k < C; k += URF_TILE_THREADS) {
         unsigned run = 0;
@@ -630,6 +693,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         soff[k] = run;
     }
     __syncthreads();
+    URF_PHASE_MARK;
     /* step 3: first slot of every ring (C <= 128: wave 0) and of every sector (K <= 1022: two keys
      * per thread) inside the tile */
     unsigned sv0 = 0, sv1 = 0, sinc = 0;
@@ -652,6 +716,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             koff[C] = total0 + total1;
     }
     __syncthreads();
+    URF_PHASE_MARK;
     if (star) {
         unsigned wb = 0, total = 0;
 #pragma unroll
@@ -668,6 +733,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             soff[K] = total;
     }
     __syncthreads();
+    URF_PHASE_MARK;
 
     /* step 4: slot in the tile's ring-sorted order (lp) and sector-sorted order (sp) */
     unsigned lp[Q], sp[Q];
@@ -684,6 +750,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         }
     }
     __syncthreads();   /* keys and wcnt are dead: their memory becomes the staging buffers */
+    URF_PHASE_MARK;
     unsigned* stx = (unsigned*)un;
     unsigned* sty = stx + URF_SLOTS;
     unsigned* stz = sty + URF_SLOTS;
@@ -712,6 +779,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         }
     }
     __syncthreads();
+    URF_PHASE_MARK;
     const unsigned tile_ring_pts = koff[C];
     for (unsigned j = tid; j < tile_ring_pts; j += URF_TILE_THREADS) {
         const unsigned sl = URF_SLOT(j);
@@ -729,6 +797,8 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             a.tsoff[row * (K + 1) + k] = (uint16_t)soff[k];
     if (tid == 0)
         a.tile_roi[row] = misc[0];
+    URF_PHASE_MARK;
+    URF_PHASE_DUMP("k_split");
 }
 
 __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_SPLIT_WAVES_PER_EU, URF_SPLIT_WAVES_PER_EU))) void k_split(urf_kargs a, urf_dev_params dp)
