@@ -439,10 +439,24 @@ __device__ __noinline__ urf_exact_key urf_exact_keys(const float* tab, unsigned 
         for (unsigned ph_i = 1; ph_i < ph_n; ph_i++)                                                           \
             printf("%s wg %u phase %u: %llu cycles\n", name, blockIdx.x, ph_i, ph_t[ph_i] - ph_t[ph_i - 1]); \
     }
+#define URF_PHASE_ACC(k) do { const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); ph_t[k] += ph_now - ph_last; ph_last = ph_now; } while (0)
+#define URF_PHASE_ACC_DECL unsigned long long ph_t[12] = { 0 }, ph_last = __builtin_amdgcn_s_memtime()
+#define URF_PH_PARAMS , unsigned long long* ph_t, unsigned long long& ph_last
+#define URF_PH_ARGS , ph_t, ph_last
+#define URF_PHASE_ACC_DUMP(name, n)                                                                           \
+    if (threadIdx.x == 0 && blockIdx.y == gridDim.y / 2 && blockIdx.x < 4) {                                   \
+        for (unsigned ph_i = 0; ph_i < (n); ph_i++)                                                            \
+            printf("%s wg %u phase %u: %llu cycles\n", name, blockIdx.x, ph_i, ph_t[ph_i]);                   \
+    }
 #else
 #define URF_PHASE_DECL
 #define URF_PHASE_MARK
 #define URF_PHASE_DUMP(name)
+#define URF_PHASE_ACC(k)
+#define URF_PHASE_ACC_DECL
+#define URF_PHASE_ACC_DUMP(name, n)
+#define URF_PH_PARAMS
+#define URF_PH_ARGS
 #endif
 #ifndef URF_SPLIT_WAVES_PER_EU
 #define URF_SPLIT_WAVES_PER_EU 6   /* 73 VGPRs without spills; A/B on one box: 4 -> 1.39 ms, 6 -> 1.04 ms, 8 (32 B of scratch) -> 1.12 ms */
@@ -1467,10 +1481,11 @@ struct urf_sort_shared {
     unsigned rmin, rmax, maxc;
     unsigned w[8];
 };
-/* rank[e] = number of keys of the workgroup smaller than key[e] (keys are distinct) */
+/* rank[e] = number of keys of the workgroup smaller than key[e] (keys are distinct).  The keys come
+ * back PERMUTED among the threads (every key exactly once, each with its rank). */
 template <int NT, int EPT, int NB>
 __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EPT], unsigned n, unsigned long long* A,
-                                                    unsigned* cnt, urf_sort_shared* sh, bool force_general, unsigned (&rank)[EPT])
+                                                    unsigned* cnt, urf_sort_shared* sh, bool force_general, unsigned (&rank)[EPT] URF_PH_PARAMS)
 {
     static_assert(NB % NT == 0 && NT / 64 <= 8, "bucket scan layout");
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1482,6 +1497,7 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
     for (unsigned c = tid; c <= NB; c += NT)
         cnt[c] = 0;
     __syncthreads();
+    URF_PHASE_ACC(4);
     unsigned rmin = 0xffffffffu, rmax = 0;
 #pragma unroll
     for (int e = 0; e < EPT; e++)
@@ -1490,16 +1506,14 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
             rmin = rb < rmin ? rb : rmin;
             rmax = rb > rmax ? rb : rmax;
         }
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned lo = __shfl_xor(rmin, o), hi = __shfl_xor(rmax, o);
-        rmin = lo < rmin ? lo : rmin;
-        rmax = hi > rmax ? hi : rmax;
-    }
+    rmin = urf_wave_min(rmin);   /* DPP: no bpermute addresses / lane masks for the compiler to hoist out of */
+    rmax = urf_wave_max(rmax);   /* the persistent loop (they cost the kernel registers it does not have) */
     if (lane == 0) {
         atomicMin(&sh->rmin, rmin);
         atomicMax(&sh->rmax, rmax);
     }
     __syncthreads();
+    URF_PHASE_ACC(5);
     rmin = sh->rmin;
     const unsigned range = sh->rmax - rmin;
     unsigned shf = 0;
@@ -1516,6 +1530,7 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
         }
     }
     __syncthreads();
+    URF_PHASE_ACC(6);
     {   /* exclusive scan of the NB counts: NB/NT consecutive counters per thread */
         unsigned c8[NB / NT], sum = 0, maxc = 0;
 #pragma unroll
@@ -1524,18 +1539,10 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
             sum += c8[e];
             maxc = c8[e] > maxc ? c8[e] : maxc;
         }
-        unsigned inc = sum;
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned v = __shfl_up(inc, o);
-            if ((int)lane >= o)
-                inc += v;
-        }
+        const unsigned inc = urf_wave_scan_add(sum);
         if (lane == 63)
             sh->w[wave] = inc;
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned v = __shfl_xor(maxc, o);
-            maxc = v > maxc ? v : maxc;
-        }
+        maxc = urf_wave_max(maxc);
         if (lane == 0)
             atomicMax(&sh->maxc, maxc);
         __syncthreads();
@@ -1551,6 +1558,7 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
             cnt[NB] = run;
     }
     __syncthreads();
+    URF_PHASE_ACC(7);
     /* in-bucket ranking is quadratic in the bucket size, but up to a few hundred keys per bucket it is
      * still cheaper than the bitonic network below (128 x 4096 sweeps: 2.13 -> 1.74 ms with 256 instead of 64) */
     if (sh->maxc <= 256 && !force_general) {
@@ -1559,11 +1567,23 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
             if (key[e] != ~0ull)
                 A[cnt[bkt[e]] + wq[e]] = key[e];
         __syncthreads();
+        URF_PHASE_ACC(8);
+        /* From here on a thread owns the keys at POSITIONS tid + e * NT of the bucket-ordered array
+         * instead of the ones it loaded: the lanes of a wave then sit in the same few buckets and loop
+         * equally long.  (A wall puts 70 or 100 keys of a 128 x 4096 sweep's sector into one bucket; owned by
+         * 70 threads spread over all eight waves, every wave looped as long as that bucket is large.)
+         * The caller goes on with the (key, rank) pairs it gets back. */
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const unsigned pos = tid + (unsigned)e * NT;
+            key[e] = pos < n ? A[pos] : ~0ull;
+        }
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
             rank[e] = 0;
             if (key[e] != ~0ull) {
-                const unsigned b0 = cnt[bkt[e]], b1 = cnt[bkt[e] + 1];
+                const unsigned b = ((unsigned)(key[e] >> 32) - rmin) >> shf;
+                const unsigned b0 = cnt[b], b1 = cnt[b + 1];
                 unsigned r = b0, t = b0;
                 for (; t + 1 < b1; t += 2) {   /* two bucket-mates per trip */
                     const unsigned long long k0 = A[t], k1 = A[t + 1];
@@ -1575,6 +1595,7 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
             }
         }
         __syncthreads();
+        URF_PHASE_ACC(9);
     } else {
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
@@ -1606,7 +1627,8 @@ __device__ __forceinline__ void urf_block_sort_keys(unsigned long long (&key)[EP
                                                     unsigned* cnt, urf_sort_shared* sh, bool force_general)
 {
     unsigned rank[EPT];
-    urf_block_rank_keys<NT, EPT, NB>(key, n, A, cnt, sh, force_general, rank);
+    URF_PHASE_ACC_DECL;
+    urf_block_rank_keys<NT, EPT, NB>(key, n, A, cnt, sh, force_general, rank URF_PH_ARGS);
 #pragma unroll
     for (int e = 0; e < EPT; e++)
         if (key[e] != ~0ull)
@@ -1633,28 +1655,45 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
     const unsigned K = (unsigned)dp.p.sectors;
     const unsigned count = a.star_count[0];
     const unsigned tid = threadIdx.x;
+    URF_PHASE_ACC_DECL;
+    /* The description of a sector (list entry -> size, place, first two runs: two dependent round
+     * trips) is fetched one iteration ahead, into scalar registers: at the top of an iteration it
+     * has long arrived.  (Fetched on the spot, with the run list built from the per-tile tables by
+     * one wave, this cost 7 000 of the 32 000 cycles a sector took.) */
+    auto list_entry = [&](unsigned w) -> unsigned { return w < count ? a.star_list_mid[w] : 0u; };
+    unsigned sk_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)list_entry(blockIdx.x));
+    unsigned n_cur = a.sec_cnt[sk_cur], so_cur = a.sec_off[(size_t)(sk_cur / K) * (K + 1) + sk_cur % K];
+    urf_sec_run two_cur = a.sec_run[sk_cur];
     for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
-        const unsigned sk = a.star_list_mid[w];
+        const unsigned sk_next = (unsigned)__builtin_amdgcn_readfirstlane((int)list_entry(w + gridDim.x));
+        const unsigned sk = sk_cur;
         const unsigned s = sk / K, k = sk % K;
         unsigned off, len;
         urf_scan_range(a, s, off, len);
-        const unsigned n = a.sec_cnt[(size_t)s * K + k];
-        const unsigned sb = urf_sbase(a, s), obase = sb + a.sec_off[(size_t)s * (K + 1) + k];
-        /* the sector's runs (<= n <= 2048 of them) sit in A's memory until the keys are in registers */
+        const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)n_cur);
+        const unsigned sb = urf_sbase(a, s);
+        const unsigned obase = sb + (unsigned)__builtin_amdgcn_readfirstlane((int)so_cur);
+        const unsigned two_a0 = (unsigned)__builtin_amdgcn_readfirstlane((int)two_cur.a0);
+        const unsigned two_c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)two_cur.c0);
+        const unsigned two_a1 = (unsigned)__builtin_amdgcn_readfirstlane((int)two_cur.a1);
+        const bool simple = (unsigned)__builtin_amdgcn_readfirstlane((int)two_cur.nruns) <= 2u;
+        /* a sector scattered over more than two tiles: its runs (<= n <= 2048 of them) are listed in A's
+         * memory until the keys are in registers */
         unsigned* runP = (unsigned*)A;
         unsigned* runA = runP + URF_STAR_MID_CAP;
-        if (tid < 64) {
+        if (!simple && tid < 64) {
             const unsigned nr = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, urf_sector_run_row(a, s, K, k, 0), runP, runA);
-            if (tid == 0) {
+            if (tid == 0)
                 sh_nruns = nr;
-                sh_first = n;
-            }
         }
+        if (tid == 0)
+            sh_first = n;
         __syncthreads();
-        const unsigned nruns = sh_nruns;
+        URF_PHASE_ACC(0);
+        const unsigned nruns = simple ? 0u : sh_nruns;
         unsigned long long key[EPT];
-        float zreg[EPT];      /* height and ring-sorted index travel with the key: the tail then needs */
-        unsigned sreg[EPT];   /* no dependent gathers from memory (as in k_star_sort_small) */
+        float zreg[EPT];      /* height and ring-sorted index of the keys (fetched after the ranking) */
+        unsigned sreg[EPT];
         unsigned r = 0;
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++) {
@@ -1663,18 +1702,36 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
             zreg[e] = 0.f;
             sreg[e] = 0;
             if (i < n) {
-                while (r + 1 < nruns && i >= runP[r + 1])
-                    r++;
-                const unsigned adr = runA[r] + i;   /* grows with i: the tie-break */
+                unsigned adr = i < two_c0 ? two_a0 + i : two_a1 + (i - two_c0);   /* grows with i: the tie-break */
+                if (!simple) {
+                    while (r + 1 < nruns && i >= runP[r + 1])
+                        r++;
+                    adr = runA[r] + i;
+                }
                 key[e] = ((unsigned long long)urf_fbits(a.sr[sb + adr]) << 32) | adr;
+            }
+        }
+        /* the next sector's description: requested now, used at the top of the next iteration */
+        sk_cur = sk_next;
+        n_cur = a.sec_cnt[sk_next];
+        so_cur = a.sec_off[(size_t)(sk_next / K) * (K + 1) + sk_next % K];
+        two_cur = a.sec_run[sk_next];
+        __syncthreads();   /* the run list has been read: A is free */
+        URF_PHASE_ACC(1);
+        unsigned rank[EPT];
+        urf_block_rank_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, (dp.exp_flags & 4u) != 0, rank URF_PH_ARGS);
+        /* height and ring-sorted index are fetched once the ranks are known (the low half of a key is
+         * the point's place in the sector-sorted arrays): carried along from the start they did not
+         * fit the 64 registers of 8 waves per SIMD and went through scratch memory */
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++)
+            if (key[e] != ~0ull) {
+                const unsigned adr = (unsigned)key[e];
                 zreg[e] = a.sz[sb + adr];
                 const unsigned sl = a.sslot[sb + adr];
                 sreg[e] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
             }
-        }
-        __syncthreads();   /* the run list has been read: A is free */
-        unsigned rank[EPT];
-        urf_block_rank_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, (dp.exp_flags & 4u) != 0, rank);
+        URF_PHASE_ACC(2);
         /* range bits, height, ring-sorted index in sorted order (A and cnt are free again) */
         unsigned* R = (unsigned*)A;
         float* Z = (float*)A + URF_STAR_MID_CAP;
@@ -1716,7 +1773,13 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
         if (tid == 0)
             a.star_first[sk] = first < n - 1 ? first : n - 1;
         __syncthreads();
+        URF_PHASE_ACC(3);
     }
+#ifdef URF_EXP_PHASE_CLOCK
+    if (threadIdx.x == 0 && blockIdx.x < 3)
+        printf("k_star_sort_mid wg %u: runs %llu load %llu rank-rest %llu tail %llu | zero %llu minmax %llu count %llu scan %llu scatter %llu loop %llu cycles, %u sectors\n", blockIdx.x, ph_t[0], ph_t[1], ph_t[2], ph_t[3],
+               ph_t[4], ph_t[5], ph_t[6], ph_t[7], ph_t[8], ph_t[9], (count + gridDim.x - 1 - blockIdx.x) / gridDim.x);
+#endif
 }
 
 /* sectors with more than 2048 points (adversarial clouds): gathered into sector-major
@@ -2224,6 +2287,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
     /* Everything the workgroup needs before it can start is requested at once (scan summary, the
      * ring's size and place, the first 128 entries of its run table, the first 384 star-shaped
      * hits): a chain of dependent round trips cost a fifth of a workgroup's life. */
+    URF_PHASE_ACC_DECL;
     const urf_scan_info in = a.info[s];
     const int n = (int)a.ring_cnt[(size_t)s * C + c];
     const unsigned ro = a.ring_off[(size_t)s * (C + 1) + c];   /* the ring's first position among the scan's ring points (star hits) */
@@ -2274,6 +2338,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
         S.n_cand = 0;
     }
     __syncthreads();
+    URF_PHASE_ACC(0);
     if (star) {   /* lidar_segmentation.cpp:241-242: the star-shaped hits that lie on this ring */
 #pragma unroll
         for (unsigned u = 0; u < 3; u++)   /* ring-major positions (scan-relative) or 0xffffffff */
@@ -2286,6 +2351,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();
+    URF_PHASE_ACC(1);
     const unsigned nh = S.n_hits;
     double maxs = 0.0;
     const bool quads = cp == 5;
@@ -2360,6 +2426,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                 S.hb[buf ^ 1u][tid] = 0;
         }
         __syncthreads();
+        URF_PHASE_ACC(2);
         if (cs + CH < n)
             fetch(cs + CH);
         if (quads) {
@@ -2433,6 +2500,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                 }
             }
             __syncthreads();
+            URF_PHASE_ACC(3);
 #ifdef URF_EXP_SKIP_CAND
             if (false) {
 #else
@@ -2463,6 +2531,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                     }
                 }
                 __syncthreads();
+                URF_PHASE_ACC(4);
                 if (tid == 0)
                     S.n_cand = 0;
             }
@@ -2521,6 +2590,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
             }
         }
         __syncthreads();
+        URF_PHASE_ACC(5);
     }
 
 #ifdef URF_EXP_SKIP_EPILOGUE
@@ -2582,6 +2652,8 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
             sm[URF_DEG_CELLS - 1 - i] = (d == 0x80000000u || d == 0u) ? __builtin_nanf("") : __uint_as_float(~d);
         }
     }
+    URF_PHASE_ACC(6);
+    URF_PHASE_ACC_DUMP("k_ring", 7);
 }
 
 /* ------------------------------------------------------------------------- */
