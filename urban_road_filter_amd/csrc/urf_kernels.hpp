@@ -1175,6 +1175,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
     constexpr unsigned NB = URF_STAR_NB, PL = NB / 64;
     const unsigned lane = threadIdx.x;
     const unsigned B = (n + 63) >> 6;
+    URF_PHASE_ACC_DECL;
     unsigned long long key[MAXB];
     float zreg[MAXB];      /* height and ring-major position travel with the key: the tail */
     unsigned sreg[MAXB];   /* then needs no dependent gathers from memory */
@@ -1229,6 +1230,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
     const unsigned range = rmax - rmin;
     const unsigned sh = range < NB ? 0u : (unsigned)(32 - __clz((int)range)) - URF_STAR_LOG_NB;   /* (range >> sh) < NB */
     __syncthreads();
+    URF_PHASE_ACC(0);
 
     unsigned bkt[MAXB], wq[MAXB];
 #pragma unroll
@@ -1241,6 +1243,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
         }
     }
     __syncthreads();
+    URF_PHASE_ACC(1);
     /* exclusive scan of the counts: NB / 64 consecutive counters per lane */
     unsigned maxc = 0;
     {
@@ -1271,6 +1274,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
         }
     }
     __syncthreads();
+    URF_PHASE_ACC(2);
 
     unsigned rank[MAXB];
     if (maxc <= 64 && !(dp.exp_flags & 4u)) {
@@ -1310,30 +1314,49 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
             rank[q] = (bb[q] & 0xffffu) + (ol[q] >> 8);
         }
         if (__any(need)) {
+            /* The keys of the buckets that mix lanes (a wall, a curb face: a few per cent of the keys) are
+             * ranked by POSITION in the bucket-ordered copy: lane l takes positions 64 q + l, so the lanes
+             * that have work in a step sit in the same one or two buckets and the step takes as many
+             * trips as THAT bucket is large -- ranked by their owners, every one of the six steps had
+             * some lane in the largest bucket (21 trips of four keys per sector on average instead of 5).
+             * The rank travels back through the unused tail of A (n <= 384 of its 512 entries). */
+            static_assert(MAXB * 64 <= 384, "the rank slots live behind the keys in A");
+            uint16_t* RK = (uint16_t*)(A + 384);
 #pragma unroll
             for (unsigned q = 0; q < MAXB; q++)
-                if (q < B && key[q] != ~0ull)
-                    A[(bb[q] & 0xffffu) + wq[q]] = key[q];
+                if (q < B && key[q] != ~0ull) {
+                    const unsigned pos = (bb[q] & 0xffffu) + wq[q];
+                    A[pos] = key[q];
+                    RK[pos] = (bb[q] >> 16) != (ol[q] & 0xffu) ? (uint16_t)0xffffu : (uint16_t)0;
+                }
             __syncthreads();
 #pragma unroll
             for (unsigned q = 0; q < MAXB; q++) {
-                if (q < B && key[q] != ~0ull && (bb[q] >> 16) != (ol[q] & 0xffu)) {
-                    const unsigned b0 = bb[q] & 0xffffu, b1 = b0 + (bb[q] >> 16);
+                const unsigned pos = q * 64 + lane;
+                if (q < B && pos < n && RK[pos] == 0xffffu) {
+                    const unsigned long long kk = A[pos];
+                    const unsigned bk = ((unsigned)(kk >> 32) - rmin) >> sh;
+                    const unsigned b0 = cnt[bk], b1 = cnt[bk + 1];
                     unsigned r = b0, t = b0;
                     for (; t + 3 < b1; t += 4) {   /* four bucket-mates per trip */
                         const unsigned long long k0 = A[t], k1 = A[t + 1], k2 = A[t + 2], k3 = A[t + 3];
-                        r += (k0 < key[q]) + (k1 < key[q]) + (k2 < key[q]) + (k3 < key[q]);
+                        r += (k0 < kk) + (k1 < kk) + (k2 < kk) + (k3 < kk);
                     }
                     if (t + 1 < b1) {
                         const unsigned long long k0 = A[t], k1 = A[t + 1];
-                        r += (k0 < key[q]) + (k1 < key[q]);
+                        r += (k0 < kk) + (k1 < kk);
                         t += 2;
                     }
                     if (t < b1)
-                        r += A[t] < key[q];
-                    rank[q] = r;
+                        r += A[t] < kk;
+                    RK[pos] = (uint16_t)r;
                 }
             }
+            __syncthreads();
+#pragma unroll
+            for (unsigned q = 0; q < MAXB; q++)
+                if (q < B && key[q] != ~0ull && (bb[q] >> 16) != (ol[q] & 0xffu))
+                    rank[q] = RK[(bb[q] & 0xffffu) + wq[q]];
         }
     } else {
         /* general path: in-register block sorts + multiway merge by ranking */
@@ -1360,6 +1383,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
         }
     }
     __syncthreads();   /* every lane has its ranks: A and cnt may be overwritten */
+    URF_PHASE_ACC(3);
     unsigned* R = (unsigned*)A;      /* range bits, height, ring-major position in sorted order */
     float* Z = (float*)A + 512;
     unsigned* S = cnt;
@@ -1371,6 +1395,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
             S[rank[q]] = sreg[q];
         }
     __syncthreads();
+    URF_PHASE_ACC(4);
     /* tail: slopes / distance terms / ring positions in sorted order; the walk can never pass the first
      * "static" hit (slope > slope_param): stop after the 64-element chunk that holds it */
     const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
@@ -1399,6 +1424,11 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
     const unsigned first = *sh_first;
     if (lane == 0)
         *star_first_out = first < n - 1 ? first : n - 1;   /* last index the walk may visit */
+    URF_PHASE_ACC(5);
+#ifdef URF_EXP_PHASE_CLOCK
+    if (threadIdx.x == 0 && blockIdx.y == gridDim.y / 2 && blockIdx.x >= 100 && blockIdx.x < 104)
+        printf("k_star_sort_small sector %u n %u: load %llu count %llu scan %llu rank %llu place %llu tail %llu\n", blockIdx.x, n, ph_t[0], ph_t[1], ph_t[2], ph_t[3], ph_t[4], ph_t[5]);
+#endif
 }
 
 
