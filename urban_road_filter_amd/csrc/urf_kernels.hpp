@@ -2899,6 +2899,17 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
      * loses a resident workgroup.) */
     const urf_scan_info in = a.info[s];
     const unsigned v_koff = tid <= C ? (unsigned)a.troff[row * (C + 1) + tid] : 0;
+    /* ... and so are the records of the thread's eight slots (their addresses depend on nothing but the
+     * thread's index: requested behind the tables they arrive while the rings of the slots are worked out) */
+    const unsigned slot0 = sb + tbase + tid;   /* ring-sorted slot of point q: slot0 + 256 q (flag, azimuth, source, x, y) */
+    unsigned rfl[Q], rsr[Q];
+    float raz[Q];
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        rfl[q] = (unsigned)a.rflag[slot0 + q * URF_LABEL_TILE_THREADS];
+        raz[q] = a.raz[slot0 + q * URF_LABEL_TILE_THREADS];
+        rsr[q] = (unsigned)a.rsrc[slot0 + q * URF_LABEL_TILE_THREADS];   /* index inside the tile */
+    }
     if (in.status != URF_OK) {
         /* nothing is published for this scan (lidar_segmentation.cpp:124-126): all labels 0 */
         for (unsigned i = tbase + tid; i < len && i < tbase + URF_TILE; i += URF_LABEL_TILE_THREADS)
@@ -2974,20 +2985,35 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     /* Straight-line per point: slots past the tile's last one read whatever the scratch holds there
      * (the tile's 2048 slots are allocated, every table index is clamped) and drop their result into a
      * spare byte of the image. */
-    const unsigned slot0 = sb + tbase + tid;   /* ring-sorted slot of point q: slot0 + 256 q (flag, azimuth, source, x, y) */
-    unsigned rfl[Q], rsr[Q];
-    float raz[Q];
+    /* the window ends of all eight points are requested before any of them is looked at (point after
+     * point the workgroup sat through eight dependent round trips to the table here) */
+#ifndef URF_LABEL_QB
+#define URF_LABEL_QB 2   /* A/B: 2 at 8 waves per SIMD 0.382 ms, 4 at 7 waves (72 registers) 0.390, 4 at 8 waves (48 B of scratch) 0.477; point by point 0.425 */
+#endif
+    constexpr unsigned QB = URF_LABEL_QB;   /* points per batch of table requests */
 #pragma unroll
-    for (unsigned q = 0; q < Q; q++) {   /* all loads in flight before the tests */
-        rfl[q] = (unsigned)a.rflag[slot0 + q * URF_LABEL_TILE_THREADS];
-        raz[q] = a.raz[slot0 + q * URF_LABEL_TILE_THREADS];
-        rsr[q] = (unsigned)a.rsrc[slot0 + q * URF_LABEL_TILE_THREADS];   /* index inside the tile */
+    for (unsigned q0 = 0; q0 < Q; q0 += QB) {
+    float whi[QB], wlo[QB];
+    unsigned cc[QB];
+#pragma unroll
+    for (unsigned qq = 0; qq < QB; qq++) {
+        const unsigned q = q0 + qq;
+        const unsigned j = tid + q * URF_LABEL_TILE_THREADS;
+        cc[qq] = (unsigned)ring_of[j] - 1u;   /* (past the last slot: the last ring, from the prefix maximum) */
+        const float az = raz[q];
+        const bool num = az == az;
+        int cf = num ? (int)__builtin_floorf(az) : 0, cb = num ? (int)__builtin_ceilf(az) : 0;
+        cf = cf < 0 ? 0 : (cf > 360 ? 360 : cf);
+        cb = cb < 0 ? 0 : (cb > 360 ? 360 : cb);
+        whi[qq] = win[cc[qq] * URF_DEG_CELLS + cf].hi;
+        wlo[qq] = win[cc[qq] * URF_DEG_CELLS + cb].lo;
     }
 #pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
+    for (unsigned qq = 0; qq < QB; qq++) {
+        const unsigned q = q0 + qq;
         const unsigned j = tid + q * URF_LABEL_TILE_THREADS;
         const bool valid = j < npts;
-        const unsigned c = (unsigned)ring_of[j] - 1u;   /* (past the last slot: the last ring, from the prefix maximum) */
+        const unsigned c = cc[qq];
         const unsigned flag = rfl[q];
         const unsigned src = rsr[q];
         const bool curb = (flag & 7u) != 0;
@@ -2995,9 +3021,11 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
          * urf_fast_az_eps).  Every decision that the approximation clears by that margin is the
          * reference's decision; the rare point that does not is listed and decided below on
          * the exact azimuth. */
-        bool unsure;
-        bool road = urf_road_test(win + c * URF_DEG_CELLS, raz[q],
-                                  (flag & URF_RFLAG_AZ_APPROX) ? urf_fast_az_eps(raz[q]) : 0.0f, unsure);
+        const float az = raz[q], eps = (flag & URF_RFLAG_AZ_APPROX) ? urf_fast_az_eps(az) : 0.0f;
+        const float fl = __builtin_floorf(az);
+        bool road = az <= whi[qq] || az >= wlo[qq];   /* urf_road_test with the window ends at hand */
+        const bool unsure = eps > 0.0f && (az - fl <= eps || (fl + 1.0f) - az <= eps || __builtin_fabsf(az - whi[qq]) <= eps ||
+                                           __builtin_fabsf(az - wlo[qq]) <= eps);
         if (unsure && valid && !curb) {
             const unsigned e = atomicAdd(&n_unsure, 1u);
             if (e < URF_LABEL_UNSURE) {
@@ -3014,6 +3042,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         my_curb += (valid && curb) ? 1u : 0u;
         my_road += (valid && road) ? 1u : 0u;
         img[valid ? URF_IMG(src & (URF_TILE - 1u)) : URF_TILE + URF_TILE / 16] = (uint8_t)lab;
+    }
     }
     }
     __syncthreads();
