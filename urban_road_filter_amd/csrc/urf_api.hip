@@ -60,6 +60,7 @@ struct urf_ctx {
      * marker-point outputs (sstride entries resp. channels x 361 cells per scan) */
     unsigned long long* ord_keys = nullptr;
     uint32_t* ord_pos = nullptr;
+    uint32_t* ord_cls = nullptr;   /* [scans][URF_MAX_CHANNELS][2] road / curb points per ring (k_ring_order -> k_ordered_lists) */
     uint32_t ord_scans = 0;
     uint32_t* ord_lists = nullptr;  /* single-scan entry point: 3 x sstride + 4 */
     float* mk_d = nullptr;
@@ -286,7 +287,7 @@ static void free_lazy(urf_ctx* c)
     if (c->slot_stream)
         (void)hipStreamDestroy(c->slot_stream);
     for (void* p : { (void*)c->mk_d, (void*)c->mk_pos, (void*)c->mk_red, (void*)c->mk_out, (void*)c->ord_keys,
-                     (void*)c->ord_pos, (void*)c->ord_lists })
+                     (void*)c->ord_pos, (void*)c->ord_cls, (void*)c->ord_lists })
         if (p)
             (void)hipFree(p);
     if (c->sx) {
@@ -891,15 +892,19 @@ static int ensure_order_scratch(urf_ctx* c, uint32_t n_scans)
     if (c->ord_keys) {
         (void)hipFree(c->ord_keys);
         (void)hipFree(c->ord_pos);
+        (void)hipFree(c->ord_cls);
         c->ord_keys = nullptr;
         c->ord_pos = nullptr;
+        c->ord_cls = nullptr;
         c->ord_scans = 0;
     }
-    void *p0 = nullptr, *p1 = nullptr;
+    void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
     URF_HIP(c, hipMalloc(&p0, (size_t)n_scans * c->sstride * sizeof(unsigned long long)));
     URF_HIP(c, hipMalloc(&p1, (size_t)n_scans * c->sstride * sizeof(uint32_t)));
+    URF_HIP(c, hipMalloc(&p2, (size_t)n_scans * URF_MAX_CHANNELS * 2 * sizeof(uint32_t)));
     c->ord_keys = (unsigned long long*)p0;
     c->ord_pos = (uint32_t*)p1;
+    c->ord_cls = (uint32_t*)p2;
     c->ord_scans = n_scans;
     return URF_OK;
 }
@@ -913,9 +918,10 @@ static int launch_ordered(urf_ctx* c, uint32_t s0, uint32_t n, uint32_t* d_road,
         return rc;
     const urf_kargs a = c->last_a;   /* the call's own arguments and parameters, whatever was set since */
     const urf_dev_params dp = c->last_dp;
-    hipLaunchKernelGGL(k_ring_order, dim3((unsigned)dp.p.channels, n), dim3(256), 0, c->stream, a, dp, s0, c->ord_keys, c->ord_pos);
-    hipLaunchKernelGGL(k_ordered_lists, dim3(n), dim3(1024), 0, c->stream, a, dp, s0, c->ord_pos, d_road, d_curb, d_r10, stride,
-                       d_counts);
+    hipLaunchKernelGGL(k_ring_order, dim3((unsigned)dp.p.channels, n), dim3(256), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), c->stream, a, dp,
+                       s0, c->ord_keys, c->ord_pos, c->ord_cls);
+    hipLaunchKernelGGL(k_ordered_lists, dim3((unsigned)dp.p.channels, n), dim3(256), 0, c->stream, a, dp, s0, c->ord_pos, c->ord_cls, d_road,
+                       d_curb, d_r10, stride, d_counts);
     URF_HIP(c, hipGetLastError());
     return URF_OK;
 }
@@ -987,7 +993,8 @@ static int launch_markers(urf_ctx* c, uint32_t s0, uint32_t n, float* d_pts, uin
     }
     const urf_kargs a = c->last_a;
     const urf_dev_params dp = c->last_dp;
-    hipLaunchKernelGGL(k_marker_ring, dim3((unsigned)dp.p.channels, n), dim3(256), 0, c->stream, a, dp, s0, c->mk_d, c->mk_pos, c->mk_red);
+    hipLaunchKernelGGL(k_marker_ring, dim3((unsigned)dp.p.channels, n), dim3(256), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), c->stream, a, dp, s0,
+                       c->mk_d, c->mk_pos, c->mk_red);
     hipLaunchKernelGGL(k_marker_bins, dim3(n), dim3(384), 0, c->stream, a, dp, s0, c->mk_d, c->mk_pos, c->mk_red, d_pts, d_counts);
     URF_HIP(c, hipGetLastError());
     return URF_OK;

@@ -3218,18 +3218,24 @@ __global__ __launch_bounds__(URF_COMPACT_THREADS) void k_compact_write(const uin
  * order open -- and writes the ring-major position of the i-th point of the ring in azimuth
  * order.  Rings of up to 2048 points sort in LDS, longer ones in global memory. */
 __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params dp, unsigned s0,
-                                                    unsigned long long* gkeys_all, unsigned* rord_all)
+                                                    unsigned long long* gkeys_all, unsigned* rord_all, unsigned* rcls_all)
 {
     constexpr unsigned NT = 256, NB = 2048, EPT = 8, CAP = NT * EPT;
     __shared__ unsigned long long A[CAP];
     __shared__ unsigned cnt[NB + 1];
     __shared__ urf_sort_shared ssh;
+    __shared__ unsigned ncls[2];
+    extern __shared__ unsigned sh_ord_tab[];   /* P[tiles + 1], radd[tiles] (urf_ring_map) */
     const unsigned c = blockIdx.x, s = s0 + blockIdx.y, tid = threadIdx.x;
     unsigned long long* gkeys = gkeys_all + (size_t)blockIdx.y * a.sstride;   /* per scan of the launch: sstride entries */
     unsigned* rord = rord_all + (size_t)blockIdx.y * a.sstride;
+    unsigned* rcls = rcls_all + ((size_t)blockIdx.y * URF_MAX_CHANNELS + c) * 2;   /* road / curb points of the ring */
     const urf_scan_info in = a.info[s];
-    if (in.status != URF_OK || c >= in.n_rings)
+    if (in.status != URF_OK || c >= in.n_rings) {
+        if (tid < 2)
+            rcls[tid] = 0;
         return;
+    }
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned C = (unsigned)dp.p.channels;
@@ -3237,22 +3243,70 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
     const unsigned rel = a.ring_off[(size_t)s * (C + 1) + c];   /* scan-relative start of the ring */
     const unsigned sb = urf_sbase(a, s);
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
+    /* the ring's run table in LDS (k_ring's map): position in the ring -> ring-sorted slot without a
+     * bisection in global memory */
+    unsigned* const mapP = sh_ord_tab;
+    unsigned* const mapA = sh_ord_tab + a.tiles + 1;
+    {
+        const unsigned* gp = a.rpre + ((size_t)s * C + c) * (a.tiles + 1);
+        const uint16_t* gs = a.rstart + ((size_t)s * C + c) * a.tiles;
+        for (unsigned t = tid; t <= ntiles; t += NT) {
+            const unsigned pt = gp[t];
+            mapP[t] = pt;
+            if (t < ntiles)
+                mapA[t] = t * URF_TILE + gs[t] - pt;   /* relative to the scan's scratch base */
+        }
+    }
+    if (tid < 2)
+        ncls[tid] = 0;
+    __syncthreads();
+    const urf_ring_map map = { mapP, mapA, ntiles, (float)ntiles / (float)(n > 0 ? n : 1) };
+    /* what is published for position i of the ring: the point's input index | its class << 30 */
+    auto entry_of = [&](unsigned i, unsigned& cls) {
+        const unsigned slot = map.at(i);
+        const unsigned src = (slot & ~(URF_TILE - 1u)) + (unsigned)a.rsrc[sb + slot];
+        cls = a.labels[off + src] & URF_LABEL_MASK;
+        return src | (cls << 30);
+    };
+    unsigned my_road = 0, my_curb = 0;
     if (n <= CAP) {
         unsigned long long key[EPT];
+        unsigned slot[EPT], fl[EPT];
+        float az[EPT];
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++) {   /* slot records of the thread's eight points in flight together */
+            const unsigned i = tid + e * NT;
+            slot[e] = i < n ? map.at(i) : 0u;
+            fl[e] = (unsigned)a.rflag[sb + slot[e]];
+            az[e] = a.raz[sb + slot[e]];
+        }
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++) {
             const unsigned i = tid + e * NT;
             key[e] = ~0ull;
-            if (i < n)
-                key[e] = ((unsigned long long)urf_fbits(urf_exact_az(a, sb + urf_ring_slot(a, s, C, c, ntiles, i))) << 32) | i;
+            if (i < n) {
+                if (fl[e] & URF_RFLAG_AZ_APPROX) {   /* raz holds k_split's approximation */
+                    float d2;
+                    az[e] = urf_azimuth(a.rx[sb + slot[e]], a.ry[sb + slot[e]], &d2);
+                }
+                key[e] = ((unsigned long long)urf_fbits(az[e]) << 32) | i;
+            }
         }
         urf_block_sort_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, false);
-        for (unsigned i = tid; i < n; i += NT)
-            rord[rel + i] = rel + (unsigned)A[i];
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++) {
+            const unsigned j = tid + e * NT;
+            if (j < n) {
+                unsigned cls;
+                rord[rel + j] = entry_of((unsigned)A[j], cls);
+                my_road += cls == URF_LABEL_ROAD;
+                my_curb += cls == URF_LABEL_CURB;
+            }
+        }
     } else {
         unsigned long long* G = gkeys + rel;
         for (unsigned i = tid; i < n; i += NT)
-            G[i] = ((unsigned long long)urf_fbits(urf_exact_az(a, sb + urf_ring_slot(a, s, C, c, ntiles, i))) << 32) | i;
+            G[i] = ((unsigned long long)urf_fbits(urf_exact_az(a, sb + map.at(i))) << 32) | i;
         __threadfence_block();
         __syncthreads();
         unsigned P = 1;
@@ -3275,95 +3329,96 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
                 __threadfence_block();
                 __syncthreads();
             }
-        for (unsigned i = tid; i < n; i += NT)
-            rord[rel + i] = rel + (unsigned)G[i];
+        for (unsigned j = tid; j < n; j += NT) {
+            unsigned cls;
+            rord[rel + j] = entry_of((unsigned)G[j], cls);
+            my_road += cls == URF_LABEL_ROAD;
+            my_curb += cls == URF_LABEL_CURB;
+        }
     }
+    if (my_road)
+        atomicAdd(&ncls[0], my_road);
+    if (my_curb)
+        atomicAdd(&ncls[1], my_curb);
+    __syncthreads();
+    if (tid < 2)
+        rcls[tid] = ncls[tid];
 }
 
-/* Walks the rings of one scan in order, every ring in azimuth order (rord), and appends the
- * input index of each point to the list(s) its label puts it in.  Single workgroup; order is
- * kept by ballot + prefix per 1024 points. */
-__global__ __launch_bounds__(1024) void k_ordered_lists(urf_kargs a, urf_dev_params dp, unsigned s0, const unsigned* rord_all,
-                                                        unsigned* road_all, unsigned* curb_all, unsigned* ring10_all,
-                                                        unsigned stride, unsigned* counts_all)
+/* The lists of one scan = its rings in order, every ring in azimuth order (k_ring_order left, per ring
+ * position, the point's input index and class, and per ring the number of road / curb points): workgroup
+ * (ring, scan) finds where its ring starts in each list (the counts of the rings in front of it) and
+ * appends its points in order -- ballot + prefix per 256 entries.  (One workgroup per SCAN walking all
+ * ring points with three barriers per 1024 of them took 1.5 ms per 1024 sweeps.) */
+__global__ __launch_bounds__(256) void k_ordered_lists(urf_kargs a, urf_dev_params dp, unsigned s0, const unsigned* rord_all,
+                                                       const unsigned* rcls_all, unsigned* road_all, unsigned* curb_all,
+                                                       unsigned* ring10_all, unsigned stride, unsigned* counts_all)
 {
-    const unsigned s = s0 + blockIdx.x;
-    const unsigned* rord = rord_all + (size_t)blockIdx.x * a.sstride;
-    unsigned* road = road_all ? road_all + (size_t)blockIdx.x * stride : nullptr;
-    unsigned* curb = curb_all ? curb_all + (size_t)blockIdx.x * stride : nullptr;
-    unsigned* ring10 = ring10_all ? ring10_all + (size_t)blockIdx.x * stride : nullptr;
-    unsigned* counts = counts_all + (size_t)blockIdx.x * 3;
-    __shared__ unsigned wsum[3][16];
-    __shared__ unsigned run[3];
-    __shared__ unsigned sroff[URF_MAX_CHANNELS + 1], srcnt[URF_MAX_CHANNELS];
+    const unsigned c = blockIdx.x, s = s0 + blockIdx.y;
+    const unsigned* rord = rord_all + (size_t)blockIdx.y * a.sstride;
+    const unsigned* rcls = rcls_all + (size_t)blockIdx.y * URF_MAX_CHANNELS * 2;
+    unsigned* road = road_all ? road_all + (size_t)blockIdx.y * stride : nullptr;
+    unsigned* curb = curb_all ? curb_all + (size_t)blockIdx.y * stride : nullptr;
+    unsigned* ring10 = ring10_all ? ring10_all + (size_t)blockIdx.y * stride : nullptr;
+    unsigned* counts = counts_all + (size_t)blockIdx.y * 3;
+    __shared__ unsigned wsum[2][4];
+    __shared__ unsigned base[2];
     const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const urf_scan_info in = a.info[s];
     const unsigned C = (unsigned)dp.p.channels;
-    if (tid < 3)
-        run[tid] = 0;
-    if (in.status == URF_OK && tid <= C) {
-        sroff[tid] = a.ring_off[(size_t)s * (C + 1) + tid];
-        if (tid < C)
-            srcnt[tid] = a.ring_cnt[(size_t)s * C + tid];
+    const unsigned nR = in.status == URF_OK ? in.n_rings : 0;
+    if (c >= nR) {
+        if (c == 0 && tid < 3)
+            counts[tid] = 0;   /* nothing is published for this scan */
+        return;
+    }
+    if (tid < 2)
+        base[tid] = 0;
+    __syncthreads();
+    if (tid < c) {   /* c <= 127 rings in front */
+        atomicAdd(&base[0], rcls[2 * tid]);
+        atomicAdd(&base[1], rcls[2 * tid + 1]);
     }
     __syncthreads();
-    if (in.status == URF_OK) {
-        unsigned off, len;
-        urf_scan_range(a, s, off, len);
-        const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
-        const unsigned sb = urf_sbase(a, s);
-        const unsigned total = sroff[in.n_rings];   /* ring starts are padded to multiples of 4: positions behind a ring's last point are skipped */
-        for (unsigned b0 = 0; b0 < total; b0 += 1024) {
-            const unsigned p = b0 + tid;
-            unsigned src = 0, l = 0, c = 0;
-            bool valid = false;
-            if (p < total) {
-                unsigned lo = 0, hi = in.n_rings;   /* largest ring c with sroff[c] <= p */
-                while (hi - lo > 1) {
-                    const unsigned mid = (lo + hi) >> 1;
-                    if (sroff[mid] <= p)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
-                c = lo;
-                valid = p - sroff[c] < srcnt[c];
-            }
-            if (valid) {
-                const unsigned slot = urf_ring_slot(a, s, C, c, ntiles, rord[p] - sroff[c]);
-                src = (slot & ~(URF_TILE - 1u)) + a.rsrc[sb + slot];
-                l = a.labels[off + src];
-            }
-            const bool f[3] = { valid && (l & URF_LABEL_MASK) == URF_LABEL_ROAD,
-                                valid && (l & URF_LABEL_MASK) == URF_LABEL_CURB, valid && c == 10 };
-            unsigned below[3];
-            for (int k = 0; k < 3; k++) {
-                const unsigned long long m = __ballot(f[k]);
-                below[k] = __popcll(m & ((1ull << lane) - 1ull));
-                if (lane == 0)
-                    wsum[k][wave] = __popcll(m);
-            }
-            __syncthreads();
-            unsigned* outs[3] = { road, curb, ring10 };
-            for (int k = 0; k < 3; k++) {
-                unsigned pre = run[k];
-                for (unsigned w = 0; w < wave; w++)
-                    pre += wsum[k][w];
-                if (f[k] && outs[k])
-                    outs[k][pre + below[k]] = src;
-            }
-            __syncthreads();
-            if (tid < 3) {
-                unsigned t = 0;
-                for (int w = 0; w < 16; w++)
-                    t += wsum[tid][w];
-                run[tid] += t;
-            }
-            __syncthreads();
+    unsigned run0 = base[0], run1 = base[1];
+    const unsigned n = a.ring_cnt[(size_t)s * C + c];
+    const unsigned rel = a.ring_off[(size_t)s * (C + 1) + c];
+    for (unsigned j0 = 0; j0 < n; j0 += 256) {
+        const unsigned j = j0 + tid;
+        const unsigned ent = j < n ? rord[rel + j] : 0u;
+        const unsigned src = ent & 0x3fffffffu, cls = j < n ? ent >> 30 : 0u;
+        const unsigned long long m0 = __ballot(cls == URF_LABEL_ROAD), m1 = __ballot(cls == URF_LABEL_CURB);
+        if (lane == 0) {
+            wsum[0][wave] = (unsigned)__popcll(m0);
+            wsum[1][wave] = (unsigned)__popcll(m1);
         }
+        __syncthreads();
+        unsigned p0 = run0 + urf_popc_below(m0), p1 = run1 + urf_popc_below(m1);
+#pragma unroll
+        for (unsigned w = 0; w < 4; w++) {
+            p0 += w < wave ? wsum[0][w] : 0u;
+            p1 += w < wave ? wsum[1][w] : 0u;
+            run0 += wsum[0][w];
+            run1 += wsum[1][w];
+        }
+        if (cls == URF_LABEL_ROAD && road)
+            road[p0] = src;
+        if (cls == URF_LABEL_CURB && curb)
+            curb[p1] = src;
+        if (c == 10 && j < n && ring10)   /* lidar_segmentation.cpp:605-608: every point of sorted ring 10 */
+            ring10[j] = src;
+        __syncthreads();
     }
-    if (tid < 3)
-        counts[tid] = run[tid];
+    if (tid == 0) {
+        if (c + 1 == nR) {
+            counts[0] = run0;
+            counts[1] = run1;
+            if (nR <= 10)
+                counts[2] = 0;
+        }
+        if (c == 10)
+            counts[2] = n;
+    }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -3401,6 +3456,90 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
         nrmin[i] = URF_INT_NONE_MIN;
         best[i] = 0;
         bestpos[i] = 0xffffffffu;
+    }
+    constexpr unsigned EPT = 8;
+    if (n <= 256 * EPT) {
+        /* The usual ring (at most 2048 points): every point is looked at ONCE -- its slot through the
+         * ring's run table in LDS (k_ring's map) instead of a bisection in global memory, slot records,
+         * then labels, eight points per thread in flight at a time -- and azimuth, label and slot stay
+         * in registers for the three passes.  (Pass by pass, with seven dependent loads per point and
+         * the exact azimuth worked out three times, this kernel took longer than the whole
+         * classification: 3.9 ms per 1024 sweeps.) */
+        extern __shared__ unsigned sh_mark_tab[];   /* P[tiles + 1], radd[tiles] (urf_ring_map) */
+        unsigned* const mapP = sh_mark_tab;
+        unsigned* const mapA = sh_mark_tab + a.tiles + 1;
+        {
+            const unsigned* gp = a.rpre + ((size_t)s * C + c) * (a.tiles + 1);
+            const uint16_t* gs = a.rstart + ((size_t)s * C + c) * a.tiles;
+            for (unsigned t = tid; t <= ntiles; t += 256) {
+                const unsigned pt = gp[t];
+                mapP[t] = pt;
+                if (t < ntiles)
+                    mapA[t] = t * URF_TILE + gs[t] - pt;   /* relative to the scan's scratch base */
+            }
+        }
+        __syncthreads();
+        const urf_ring_map map = { mapP, mapA, ntiles, (float)ntiles / (float)(n > 0 ? n : 1) };
+        unsigned slot[EPT], fl[EPT], sr[EPT];
+        float az[EPT];
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++) {
+            const unsigned p = tid + e * 256;
+            slot[e] = p < n ? map.at(p) : 0u;
+            fl[e] = (unsigned)a.rflag[sb + slot[e]];
+            az[e] = a.raz[sb + slot[e]];
+            sr[e] = (unsigned)a.rsrc[sb + slot[e]];
+        }
+        unsigned labs = 0;   /* two bits per point */
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++) {
+            const unsigned lab = a.labels[off + (slot[e] & ~(URF_TILE - 1u)) + sr[e]] & URF_LABEL_MASK;
+            labs |= lab << (2 * e);
+        }
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++)
+            if (tid + e * 256 < n && (fl[e] & URF_RFLAG_AZ_APPROX)) {   /* raz holds k_split's approximation */
+                float d2;
+                az[e] = urf_azimuth(a.rx[sb + slot[e]], a.ry[sb + slot[e]], &d2);
+            }
+        /* pass 1: where does the scan of this ring stop in each degree (:318) */
+        int bin[EPT];
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++) {
+            const int b = (int)__builtin_floorf(az[e]);
+            bin[e] = b < 0 ? 0 : (b > 360 ? 360 : b);
+            if (tid + e * 256 < n && az[e] == az[e] && ((labs >> (2 * e)) & 3u) != URF_LABEL_ROAD)
+                atomicMin(&nrmin[bin[e]], (int)urf_fbits(az[e]));
+        }
+        __syncthreads();
+        /* pass 2: farthest road point in front of it (:325-335); key = (d, first in azimuth order) */
+        unsigned long long key[EPT];
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++) {
+            key[e] = 0;
+            if (tid + e * 256 < n && az[e] == az[e] && ((labs >> (2 * e)) & 3u) == URF_LABEL_ROAD &&
+                (int)urf_fbits(az[e]) < nrmin[bin[e]]) {
+                const float x = a.rx[sb + slot[e]], y = a.ry[sb + slot[e]];
+                const float d = (float)__builtin_sqrt((double)(0.f - x) * (double)(0.f - x) + (double)(0.f - y) * (double)(0.f - y));
+                if (d > 0.0f) {   /* "d > maxDistanceRoad" with maxDistanceRoad starting at 0 */
+                    key[e] = ((unsigned long long)urf_fbits(d) << 32) | (0xffffffffu - urf_fbits(az[e]));
+                    atomicMax(&best[bin[e]], key[e]);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (unsigned e = 0; e < EPT; e++)
+            if (key[e] != 0 && key[e] == best[bin[e]])
+                atomicMin(&bestpos[bin[e]], tid + e * 256);
+        __syncthreads();
+        for (unsigned i = tid; i < URF_DEG_CELLS; i += 256) {
+            const size_t o = (size_t)c * URF_DEG_CELLS + i;
+            m_d[o] = __uint_as_float((unsigned)(best[i] >> 32));
+            m_pos[o] = bestpos[i] == 0xffffffffu ? 0xffffffffu : sb + map.at(bestpos[i]);
+            m_red[o] = nrmin[i] != URF_INT_NONE_MIN;
+        }
+        return;
     }
     __syncthreads();
     /* pass 1: where does the scan of this ring stop in each degree (:318) */
