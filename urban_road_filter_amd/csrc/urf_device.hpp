@@ -289,14 +289,15 @@ __device__ __forceinline__ bool urf_fast_vertical_angle(float x, float y, float 
  * 1.2e-7 * |z| / rho rad (it rounds |z| / d to float before the acos) + half an ulp of the result,
  * hence the restriction to |u| <= 4 as before.  Together < 5e-5 deg; the margin stays
  * URF_FAST_VALPHA_ERR = 3e-4 deg (urf_selftest_fast measures |angle(u) - reference|). */
-#define URF_FAST_MIN2 1.0e-30f
+#define URF_FAST_MIN2 2.0e-30f   /* max(|x|, |y|) >= 1e-15 = URF_FAST_MIN */
 #define URF_FAST_MAX2 1.0e36f
-__device__ __forceinline__ bool urf_fast_cot(float x, float y, float z, float* u_out)
+__device__ __forceinline__ bool urf_fast_cot(float x, float y, float z, float* u_out, bool* planar_ok)
 {
     const float rho2 = x * x + y * y;
     const float u = -z * __builtin_amdgcn_rsqf(rho2);
     *u_out = u;
-    return (rho2 >= URF_FAST_MIN2) & (rho2 <= URF_FAST_MAX2) & (__builtin_fabsf(u) <= URF_LUT_UMAX);   /* NaN: false */
+    *planar_ok = (rho2 >= URF_FAST_MIN2) & (rho2 <= URF_FAST_MAX2);   /* x, y of a magnitude the fast paths accept (NaN: false) */
+    return *planar_ok & (__builtin_fabsf(u) <= URF_LUT_UMAX);
 }
 
 /* cot of an angle given in degrees, clamped to [1, 179] deg (|cot| = 57 there: beyond every u the fast
@@ -371,6 +372,16 @@ __device__ __forceinline__ int urf_fast_sector_of(float fi, float x, float y, fl
     const float fr = u - f;
     const bool ok = (mx >= URF_FAST_MIN) & (mx <= URF_FAST_MAX) & (fr > margin) & (fr < 1.0f - margin) & (f >= 0.0f) &
                     (f < (float)sectors);
+    return ok ? (int)f : -1;
+}
+/* the same when the caller has already checked the magnitudes: x*x + y*y within [URF_FAST_MIN2,
+ * URF_FAST_MAX2] puts max(|x|, |y|) within [URF_FAST_MIN, URF_FAST_MAX]; fi >= 0 makes the floor non-negative, a NaN fails the comparisons of its fraction */
+__device__ __forceinline__ int urf_fast_sector_ranged(float fi, float Kfi, unsigned sectors, float margin)
+{
+    const float u = fi * Kfi;
+    const float f = __builtin_floorf(u);
+    const float fr = u - f;
+    const bool ok = (fr > margin) & (fr < 1.0f - margin) & (f < (float)sectors);
     return ok ? (int)f : -1;
 }
 __device__ __forceinline__ int urf_fast_sector(float x, float y, float Kfi, unsigned sectors, float margin)

@@ -567,7 +567,8 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         const float x = px[q], y = py[q], z = pz[q];
         const bool roi = (i < len) & urf_in_roi(dp.p, x, y, z);
         float u;
-        const bool fast = urf_fast_cot(x, y, z, &u) & roi & !exact_all;
+        bool planar;
+        const bool fast = urf_fast_cot(x, y, z, &u, &planar) & roi & !exact_all;
         uu[q] = fast ? u : 0.f;
         roim |= (unsigned)roi << q;
         fastm |= (unsigned)fast << q;
@@ -605,7 +606,9 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         const float fi = urf_fast_polar(x, y);   /* one arc tangent: the star sector and the azimuth */
         azf[q] = urf_fast_azimuth_of(fi);
         if (star) {
-            const int fs = urf_fast_sector_of(fi, x, y, dp.Kfi, K, dp.sector_margin);
+            /* (decided on the approximation only where the ring was: magnitudes checked there; the few
+             * points steeper than |z| = 4 rho take the exact sequence for both) */
+            const int fs = ((fastm >> q) & 1u) ? urf_fast_sector_ranged(fi, dp.Kfi, K, dp.sector_margin) : -1;
             open = open | (roi & (fs < 0));
             sk = (unsigned)fs;
             if (dp.p.starbeam_filter && !urf_in_beam(a.beams[fs < 0 ? 0 : fs], x, y))
@@ -3688,7 +3691,8 @@ __global__ __launch_bounds__(256) void k_selftest_fast(unsigned long long n, flo
             ev = d > ev ? d : ev;
         }
         float uc;
-        if (urf_fast_cot(x, y, z, &uc)) {   /* k_split: the angle whose cotangent uc is (atan2 rounded to float: +-1e-5 deg) */
+        bool planar_ok;
+        if (urf_fast_cot(x, y, z, &uc, &planar_ok)) {   /* k_split: the angle whose cotangent uc is (atan2 rounded to float: +-1e-5 deg) */
             const float au = (float)((double)urf_atan2f(1.0f, uc) * (180.0 / URF_PI_D));
             const float d = __builtin_fabsf(au - urf_vertical_angle(x, y, z));
             ev = d > ev ? d : ev;
