@@ -2,7 +2,8 @@
 unorganised clouds / parameter sets (tests/fuzz.py), HIP path in its production configuration
 (float fast paths active) against oracle B: labels, ring, sector and detector stages.
     python tools/fuzz_more.py [first_seed last_seed]   (on the GPU box)
-Last runs: seeds 10000..12499 and 20000..29999, 0 mismatches."""
+Last runs: seeds 10000..12499 and 20000..29999 (round 1), 30000..33999 and 40000..79999 (round 2, after the ring decision on
+cot / position ranking changes): 0 mismatches."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
 import numpy as np, oracles as O, urban_road_filter_amd as u
@@ -13,13 +14,17 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10000, int(sys.argv
     (x, y, z), p = case(seed)
     lb, ib, st = O.run_b(x, y, z, p, debug=True)
     ctx.set_params(p)
-    lg, ig = ctx.classify_xyz(x, y, z)
+    lg, ig = ctx.classify_xyz(x, y, z)   # the production path proper
     n = len(x)
     ok = np.array_equal(lg, lb)
+    ctx.enable_stage_capture(2)          # the same decisions, ring / sector recorded
+    lg2, _ = ctx.classify_xyz(x, y, z)
+    ok = ok and np.array_equal(lg2, lb)
     if ib["status"] == 0:
         ok = ok and np.array_equal(ctx.read_stage(u.STAGE_RING, n), st["ring"]) and np.array_equal(ctx.read_stage(u.STAGE_DETECT, n), st["detect"])
         if p.star_shaped_method:
             ok = ok and np.array_equal(ctx.read_stage(u.STAGE_SECTOR, n), st["sector"])
+    ctx.enable_stage_capture(0)
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, int((lg != lb).sum()), flush=True)
