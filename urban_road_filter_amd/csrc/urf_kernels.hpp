@@ -5,11 +5,13 @@
  * the scan, the other grid dimension the tile / ring / sector inside it.
  * Pipeline (reference lines each kernel replaces; DESIGN.md has the full map):
  *
- *   k_ring_table   first-fit ring-angle table + sort, straight from x/y/z   lidar_segmentation.cpp:145-196,205
- *   k_ingest       ROI test, vertical angle, ring of every point, star sector, per-tile ring and
- *                  sector histograms    lidar_segmentation.cpp:106-166,226-233, star_shaped_search.cpp:162-174
- *   k_offsets      piece < 30 test, exclusive scans of both histograms      lidar_segmentation.cpp:120-126
- *   k_scatter      stable split into ring-major and sector-major order   lidar_segmentation.cpp:238-242,276
+ *   k_ring_table   first-fit ring-angle table + sort, straight from x/y/z; per-entry thresholds on
+ *                  cot(vertical angle) and the lookup table over it            lidar_segmentation.cpp:145-196,205
+ *   k_split        ONE pass over x/y/z per 2048-point tile: ROI test, ring and star sector of every point,
+ *                  stable split of the tile by ring and by sector into its own region of the scratch
+ *                  arrays      lidar_segmentation.cpp:106-166,226-242,276, star_shaped_search.cpp:162-174
+ *   k_index        piece < 30 test, per-ring run tables over the tiles, sector sizes and first runs
+ *                                                                              lidar_segmentation.cpp:120-126
  *   k_star_sort_*  per-sector sort by range, slopes             star_shaped_search.cpp:109-129
  *   k_star_walk    per-sector running-mean slope test           star_shaped_search.cpp:123-149
  *   k_ring         x_zero, z_zero, azimuth, maxDistance, per-degree curb tables,
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void k_pc2_to_soa(const uint8_t* __restrict__ 
  * (lidar_segmentation.cpp:168-196).  Equivalent formulation used here: leader
  * k+1 is the first point after leader k that matches none of the leaders 0..k.
  * It runs first, straight from x/y/z, so that the one pass over the points that
- * follows (k_ingest) can already assign rings.
+ * follows (k_split) can already assign rings.
  *
  * One workgroup per scan, two alternating modes:
  *   serial   one wave takes the next 64 points; a new leader costs one ballot
@@ -1286,8 +1288,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
          * registers of one lane (element q * 64 + lane = firing q, ring lane): every lane first
          * ranks its own keys against each other (15 register comparisons for 6 keys).  A key whose
          * bucket holds nothing but keys of its own lane is done; only the others read the bucket
-         * from LDS.  The kernel is bound by the LDS pipe (PMC: 72 % of its cycles, a third of them
-         * bank conflicts), and this loop was most of its traffic. */
+         * from LDS. */
         unsigned ol[MAXB];   /* keys of this lane in the same bucket (incl. itself) | smaller ones among them << 8 */
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
