@@ -692,46 +692,43 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     }
     __syncthreads();
     URF_PHASE_MARK;
-    /* step 2: exclusive scan over the waves, one thread per key; totals to koff / soff */
-    for (unsigned k = tid; k < C; k += URF_TILE_THREADS) {
+    /* steps 2 + 3: per key the exclusive scan of its counts over the waves (four at a time read before they are
+     * written back), then -- by the same thread, no barrier in between -- the scan across the keys: first
+     * slot of every ring (C <= 128: the last wave, two keys per lane) and of every sector (K <= 1022: two
+     * keys per thread) inside the tile */
+    auto column = [&](uint16_t* col, unsigned stride) -> unsigned {
         unsigned run = 0;
-        for (unsigned w = 0; w < URF_TILE_WAVES; w++) {
-            const unsigned c = wcnt_r[w * C + k];
-            wcnt_r[w * C + k] = (uint16_t)run;
-            run += c;
+#pragma unroll
+        for (unsigned w0 = 0; w0 < URF_TILE_WAVES; w0 += 4) {   /* four at a time: the kernel has no registers to spare */
+            unsigned c[4];
+#pragma unroll
+            for (unsigned w = 0; w < 4; w++)
+                c[w] = col[(w0 + w) * stride];
+#pragma unroll
+            for (unsigned w = 0; w < 4; w++) {
+                col[(w0 + w) * stride] = (uint16_t)run;
+                run += c[w];
+            }
         }
-        koff[k] = run;
-    }
-    for (unsigned k = tid; k < Ks; k += URF_TILE_THREADS) {
-        unsigned run = 0;
-        for (unsigned w = 0; w < URF_TILE_WAVES; w++) {
-            const unsigned c = wcnt_s[w * K + k];
-            wcnt_s[w * K + k] = (uint16_t)run;
-            run += c;
-        }
-        soff[k] = run;
-    }
-    __syncthreads();
-    URF_PHASE_MARK;
-    /* step 3: first slot of every ring (C <= 128: wave 0) and of every sector (K <= 1022: two keys
-     * per thread) inside the tile */
+        return run;
+    };
     unsigned sv0 = 0, sv1 = 0, sinc = 0;
     if (star) {
-        sv0 = 2 * tid < K ? soff[2 * tid] : 0;
-        sv1 = 2 * tid + 1 < K ? soff[2 * tid + 1] : 0;
+        sv0 = 2 * tid < K ? column(wcnt_s + 2 * tid, K) : 0;
+        sv1 = 2 * tid + 1 < K ? column(wcnt_s + 2 * tid + 1, K) : 0;
         sinc = urf_wave_scan_add(sv0 + sv1);
         if (lane == 63)
             misc[2 + wave] = sinc;
     }
-    if (tid < 64) {
-        const unsigned v0 = tid < C ? koff[tid] : 0, v1 = tid + 64 < C ? koff[tid + 64] : 0;
+    if (wave == URF_TILE_WAVES - 1) {
+        const unsigned v0 = lane < C ? column(wcnt_r + lane, C) : 0, v1 = lane + 64 < C ? column(wcnt_r + lane + 64, C) : 0;
         const unsigned i0 = urf_wave_scan_add(v0), i1 = urf_wave_scan_add(v1);
         const unsigned total0 = __shfl(i0, 63), total1 = __shfl(i1, 63);
-        if (tid < C)
-            koff[tid] = i0 - v0;
-        if (tid + 64 < C)
-            koff[tid + 64] = total0 + i1 - v1;
-        if (tid == 0)
+        if (lane < C)
+            koff[lane] = i0 - v0;
+        if (lane + 64 < C)
+            koff[lane + 64] = total0 + i1 - v1;
+        if (lane == 0)
             koff[C] = total0 + total1;
     }
     __syncthreads();
