@@ -190,6 +190,21 @@ def test_uniform_batch_of_distinct_scans():
         check_against_b(labels, infos, scans, p)
 
 
+def test_batch_of_eleven_scans():
+    """k_label maps its workgroups XCD-aware in groups of eight scans; the scans of an incomplete group
+    keep the plain mapping.  Eleven scans: one complete group and three scans outside it, one of them
+    failing the 30-point threshold."""
+    p = O.cfg_params("cfg2")
+    scans = [O.cfg_cloud("cfg2" if s % 3 else "narrow", 40 + s) for s in range(11)]
+    few = tuple(a.copy() for a in scans[9])
+    few[0][29:] = 1.0e6   # all but 29 points far outside the region of interest
+    scans[9] = few
+    with u.Context(64 * 2048, 11) as ctx:
+        labels, infos = run_batch(ctx, scans, p)
+        check_against_b(labels, infos, scans, p)
+        assert infos[9][0] == 1 and not labels[9].any()
+
+
 def test_ragged_batch_with_empty_tiny_and_partial_scans():
     p = O.cfg_params("cfg2")
     full = O.cfg_cloud("cfg2", 21)
@@ -297,6 +312,27 @@ def test_crowded_sectors(ctx_big, n_pts):
     p = O.cfg_params("cfg2")
     p.interval = 1.0
     x, y, z = crowded_cloud(n_pts)
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, len(x)), st["detect"])
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+
+
+def test_mid_size_sector_scattered_over_many_tiles(ctx_big):
+    """A sector of 385..2048 points whose points are spread over ten input tiles: k_star_sort_mid then
+    cannot use the two-run description of k_index and builds the sector's run list from the per-tile
+    tables; the small sectors around it take the run-list path of k_star_sort_small."""
+    p = O.cfg_params("cfg2")
+    p.interval = 1.0
+    xc, yc, zc = crowded_cloud(1400, seed=11)           # ~1400 points in sectors 10 / 11
+    xs, ys, zs = O.cfg_cloud("narrow", 77)
+    keep = np.arange(0, len(xs), 7)                      # a thinned sweep: small sectors everywhere
+    xs, ys, zs = xs[keep], ys[keep], zs[keep]
+    x, y, z = np.concatenate([xc, xs]), np.concatenate([yc, ys]), np.concatenate([zc, zs])
+    perm = np.random.default_rng(12).permutation(len(x))   # unorganised: every sector meets every tile
+    x, y, z = x[perm], y[perm], z[perm]
+    assert len(x) > 8 * 2048
     lb, ib, st = O.run_b(x, y, z, p, debug=True)
     ctx_big.set_params(p)
     lg, ig = ctx_big.classify_xyz(x, y, z)
