@@ -463,9 +463,9 @@ __device__ __noinline__ urf_exact_key urf_exact_keys(const float* tab, unsigned 
 #ifndef URF_SPLIT_WAVES_PER_EU
 #define URF_SPLIT_WAVES_PER_EU 6   /* 73 VGPRs without spills; A/B on one box: 4 -> 1.39 ms, 6 -> 1.04 ms, 8 (32 B of scratch) -> 1.12 ms */
 #endif
-__device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev_params& dp, unsigned s, unsigned t, unsigned char* sh_raw)
+__device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev_params& dp, unsigned s, unsigned t, unsigned char* sh_raw,
+                                               const unsigned tid)
 {
-    const unsigned tid = threadIdx.x;
     const unsigned wave = tid >> 6, lane = tid & 63;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
@@ -820,7 +820,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
 __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_SPLIT_WAVES_PER_EU, URF_SPLIT_WAVES_PER_EU))) void k_split(urf_kargs a, urf_dev_params dp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_split[];
-    urf_split_tile(a, dp, blockIdx.y, blockIdx.x, sh_split);
+    urf_split_tile(a, dp, blockIdx.y, blockIdx.x, sh_split, threadIdx.x);
 }
 
 /* the scans k_table_repair listed (normally none): their tiles once more, with the complete table.
@@ -830,7 +830,9 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_split[];
     const unsigned n = a.star_count[2];
     for (unsigned w = blockIdx.x; w < n * a.tiles; w += gridDim.x) {
-        urf_split_tile(a, dp, a.redo_list[w / a.tiles], w % a.tiles, sh_split);
+        unsigned tid_i = threadIdx.x;   /* opaque per iteration: nothing thread-derived is hoisted out of the loop (and spilled) */
+        asm volatile("" : "+v"(tid_i));
+        urf_split_tile(a, dp, a.redo_list[w / a.tiles], w % a.tiles, sh_split, tid_i);
         __syncthreads();   /* the LDS carve is reused by the next tile */
     }
 }
