@@ -213,7 +213,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.rx, T) A(k.ry, T) A(k.rz, T) A(k.rsrc, T) A(k.raz, T) A(k.rflag, T)
     A(k.sr, T) A(k.sz, T) A(k.sslot, T) A(k.ssrt, T) A(k.wslp, T) A(k.wg, T)
     A(k.big_r, T) A(k.big_z, T) A(k.big_i, T)
-    A(k.tile_roi, S * tiles) A(k.roi_bits, S * tiles * (URF_TILE / 64)) A(k.troff, S * tiles * (C + 1)) A(k.tsoff, S * tiles * (K + 1))
+    A(k.tile_roi, S * tiles) A(k.roi_bits, S * tiles * (URF_TILE / 64)) A(k.troff, S * tiles * (C + 1)) A(k.tsoff, S * tiles * (K + 1)) A(k.tmaxs, S * tiles * C)
     A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles)
     A(k.angle, S * C) A(k.ring_thr, S * C * 4) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_run, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
@@ -470,7 +470,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     if (k.valpha) {
         k.valpha += P; k.seckey += P; k.ringkey += P; k.rd2 += P;
     }
-    k.tile_roi += r * tiles; k.roi_bits += r * tiles * (URF_TILE / 64); k.troff += r * tiles * (C + 1); k.tsoff += r * tiles * (K + 1);
+    k.tile_roi += r * tiles; k.roi_bits += r * tiles * (URF_TILE / 64); k.troff += r * tiles * (C + 1); k.tsoff += r * tiles * (K + 1); k.tmaxs += r * tiles * C;
     k.rpre += r * C * (tiles + 1); k.rstart += r * C * tiles;
     k.angle += r * C; k.ring_thr += r * C * 4; k.ring_lut += r * URF_LUT_CELLS; k.ring_cnt += r * C; k.ring_off += r * (C + 1);
     k.sec_cnt += r * K; k.sec_run += r * K; k.sec_off += r * (K + 1); k.star_hit += r * K;
@@ -570,7 +570,10 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         hipLaunchKernelGGL(k_star_walk, dim3((K + 63) / 64, n_scans), dim3(64), 0, st, a, dp);
     mark();
     const dim3 g_ring(C, n_scans);
-    hipLaunchKernelGGL(k_ring, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
+    if (dp.p.curbPoints == 5)   /* the reference's default: four points per thread, z only */
+        hipLaunchKernelGGL(k_ring, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
+    else
+        hipLaunchKernelGGL(k_ring_general, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
     mark();
     hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_LABEL_THREADS), 0, st, a, dp);
     mark();

@@ -30,6 +30,7 @@
 #define URF_TABLE_LOOKAHEAD 8192    /* k_ring_table gives up waiting for a new ring after this many points (speculation) */
 
 #define URF_RFLAG_AZ_APPROX 0x80u   /* rflag: raz holds the float approximation, not the reference value */
+#define URF_RAZ_UNKNOWN      -1.0f   /* raz of a point too close to the x axis for the approximation (urf_fast_az_ok): exact azimuth on demand */
 #define URF_RING_NONE       0xFFu
 #define URF_SEC_NONE        0x3FFu
 
@@ -125,6 +126,7 @@ struct urf_kargs {
     uint32_t* tile_roi;         /* [S][tiles] ROI points of the tile */
     uint16_t* troff;            /* [S][tiles][C+1] first ring-sorted slot of ring c in the tile; [C] = ring points of the tile */
     uint16_t* tsoff;            /* [S][tiles][K+1] same for star sectors */
+    unsigned long long* tmaxs;  /* [S][tiles][C] largest x*x + y*y (binary64 bits) among the tile's points of ring c (k_split -> k_ring: maxDistance) */
     /* per scan x key x tile (k_index) */
     uint32_t* rpre;             /* [S][C][tiles+1] points of ring c in the tiles before t; [ntiles] = ring_cnt */
     uint16_t* rstart;           /* [S][C][tiles]   = troff[t][c] */

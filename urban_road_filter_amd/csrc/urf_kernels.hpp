@@ -385,14 +385,14 @@ __global__ __launch_bounds__(256) void k_table_repair(urf_kargs a, urf_dev_param
 
 __host__ __device__ inline unsigned urf_align16(unsigned v) { return (v + 15u) & ~15u; }
 
-/* LDS carve of k_split: tab | ul | thr | lut | koff[C+1] | soff[Ks+1] | misc[16] |
+/* LDS carve of k_split: tab | ul | thr | lut | koff[C+1] | soff[Ks+1] | misc[16] | tmax[C] u64 |
  * union { keyr[T] u8, keys[T] u16, pending[T] u16, wcnt_r[W][C] u16, wcnt_s[W][Ks] u16 ;
  *         staging x y z azimuth src [URF_SLOTS] u32 } */
 __host__ __device__ inline size_t urf_split_lds_bytes(unsigned C, unsigned K, bool star)
 {
     const unsigned Ks = star ? K : 0;
     const size_t fixed = URF_MAX_CHANNELS * (4 + 4 + 16) + urf_align16(URF_LUT_CELLS) + urf_align16((C + 1) * 4) +
-                         urf_align16((Ks + 1) * 4) + 64;
+                         urf_align16((Ks + 1) * 4) + 64 + urf_align16(C * 8);
     const size_t phase_a = 5 * (size_t)URF_TILE + urf_align16(2 * URF_TILE_WAVES * (C + Ks));
     const size_t phase_b = 5 * (size_t)URF_SLOTS * 4;
     return fixed + (phase_a > phase_b ? phase_a : phase_b);
@@ -483,7 +483,8 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     unsigned* koff = (unsigned*)(lut + urf_align16(URF_LUT_CELLS));
     unsigned* soff = koff + urf_align16((C + 1) * 4) / 4;
     unsigned* misc = soff + urf_align16((Ks + 1) * 4) / 4;   /* [0] ROI points, [1] pending, [2..9] wave sums */
-    unsigned char* un = (unsigned char*)(misc + 16);
+    unsigned long long* tmax = (unsigned long long*)(misc + 16);   /* largest x*x + y*y per ring (binary64 bits: non-negative doubles order like integers) */
+    unsigned char* un = (unsigned char*)(tmax + urf_align16(C * 8) / 8);
     uint8_t* keyr = un;
     uint16_t* keys = (uint16_t*)(un + URF_TILE);
     uint16_t* pending = keys + URF_TILE;
@@ -524,6 +525,8 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         ((unsigned*)wcnt_r)[k] = 0;
     if (tid < 16)
         misc[tid] = 0;
+    if (tid < C)
+        tmax[tid] = 0;
     if (tid < URF_MAX_CHANNELS) {
         tab[tid] = tab_v;
         ((float4*)thr)[tid] = thr_v;
@@ -606,7 +609,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         const unsigned rk = rkey[q];
         unsigned sk = URF_SEC_NONE;
         const float fi = urf_fast_polar(x, y);   /* one arc tangent: the star sector and the azimuth */
-        azf[q] = urf_fast_azimuth_of(fi);
+        azf[q] = urf_fast_az_ok(x, y) ? urf_fast_azimuth_of(fi) : URF_RAZ_UNKNOWN;   /* (too close to the x axis: exact on demand) */
         if (star) {
             /* (decided on the approximation only where the ring was: magnitudes checked there; the few
              * points steeper than |z| = 4 rho take the exact sequence for both) */
@@ -679,6 +682,13 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             if (on && urf_is_leader(m))
                 my_r[rkey[q]] = (uint16_t)(old + (unsigned)__popcll(m));
             rrank[q] = old + urf_popc_below(m);
+            /* maxDistance (lidar_segmentation.cpp:271-274) is the largest float(sqrt(double s)), s = x^2 + y^2,
+             * of a ring: both roundings are monotone, so the largest s is tracked -- here, where x and y
+             * are at hand, per tile and ring; k_ring takes the maximum over the tiles and streams only z */
+            if (on) {
+                const double s2 = (double)px[q] * (double)px[q] + (double)py[q] * (double)py[q];
+                atomicMax(&tmax[rkey[q]], (unsigned long long)__double_as_longlong(s2));
+            }
         }
         srank[q] = 0;
         if (star) {
@@ -808,6 +818,8 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     const size_t row = (size_t)s * a.tiles + t;
     for (unsigned k = tid; k <= C; k += URF_TILE_THREADS)
         a.troff[row * (C + 1) + k] = (uint16_t)koff[k];
+    for (unsigned k = tid; k < C; k += URF_TILE_THREADS)
+        a.tmaxs[row * C + k] = tmax[k];
     if (star)
         for (unsigned k = tid; k <= K; k += URF_TILE_THREADS)
             a.tsoff[row * (K + 1) + k] = (uint16_t)soff[k];
@@ -2127,9 +2139,12 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
 #define URF_RING_CAND 1024   /* capacity of the candidate list; flushed when a chunk might not fit */
 #define URF_RING_PAD 32   /* LDS slots in front of a chunk, >= URF_MAX_CURB_POINTS, multiple of 4 */
 
-struct urf_ring_shared {
-    float xs[URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
-    float ys[URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
+/* (the instance for curbPoints == 5 keeps no x / y windows and a shorter candidate list: 13 KB instead of
+ * 18, twelve resident workgroups per CU instead of eight) */
+template <bool QUADS>
+struct urf_ring_shared_t {
+    float xs[QUADS ? 4 : URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
+    float ys[QUADS ? 4 : URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
     float zs[URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
     int cmin[URF_DEG_CELLS], cmax[URF_DEG_CELLS];
     int q[4];
@@ -2138,9 +2153,11 @@ struct urf_ring_shared {
     unsigned n_hits;
     unsigned hb[2][URF_RING_CHUNK / 32];   /* star-hit bit per point of the chunk, double buffered */
     /* quad mapping: the ring's points that need one of the expensive evaluations, compacted */
-    unsigned cand[URF_RING_CAND];          /* ring-relative position | URF_CAND_* << URF_CAND_SHIFT */
+    static constexpr unsigned CAND = QUADS ? URF_RING_CAND - 128 : URF_RING_CAND;
+    unsigned cand[CAND];                   /* ring-relative position | URF_CAND_* << URF_CAND_SHIFT */
     unsigned n_cand;
 };
+typedef urf_ring_shared_t<false> urf_ring_shared;
 #define URF_CAND_SHIFT 28   /* position below, URF_CAND_* above */
 #define URF_CAND_XZERO 1u   /* passed the height tests of x_zero: angle test pending */
 #define URF_CAND_ZZERO 2u   /* same for z_zero */
@@ -2274,7 +2291,8 @@ __device__ __noinline__ bool urf_z_zero_angle_window(const float* xs, const floa
  * (lidar_segmentation.cpp:245-269, blind_spots.cpp:19-56); returns the azimuth.
  * maxDistance (:271-274) is the largest float(sqrt(double s)), s = x^2 + y^2: both roundings
  * are monotone, so the callers track the largest s instead. */
-__device__ __noinline__ float urf_ring_point(float* rd2, urf_ring_shared& S, unsigned gpos, float px, float py,
+template <class SHARED>
+__device__ __noinline__ float urf_ring_point(float* rd2, SHARED& S, unsigned gpos, float px, float py,
                                              unsigned flag, bool want_quad)
 {
     float d2;
@@ -2306,10 +2324,14 @@ __device__ __noinline__ float urf_ring_point(float* rd2, urf_ring_shared& S, uns
 
 /* 4 waves per SIMD (<= 128 VGPRs): the kernel hides its barrier and memory latencies with resident
  * workgroups, measured 1.19 -> 1.00 ms against the compiler's own choice of 155 VGPRs */
-__global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ring(urf_kargs a, urf_dev_params dp)
+/* QUADS: curbPoints == 5 (the reference's default), four consecutive points per thread on z alone;
+ * otherwise the general path with x / y / z windows.  Two instances, so that the common one does not
+ * carry the other's registers. */
+template <bool QUADS>
+__device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_params& dp)
 {
     constexpr int CH = URF_RING_CHUNK, PAD = URF_RING_PAD;
-    __shared__ urf_ring_shared S;
+    __shared__ urf_ring_shared_t<QUADS> S;
     extern __shared__ unsigned sh_ring_tab[];   /* P[tiles + 1], radd[tiles] (urf_ring_map) */
     int* const cmin = S.cmin;
     int* const cmax = S.cmax;
@@ -2328,6 +2350,8 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
     const uint16_t* gs = a.rstart + ((size_t)s * C + c) * a.tiles;
     const unsigned pt0 = tid <= a.tiles ? gp[tid] : 0;
     const unsigned st0 = tid < a.tiles ? (unsigned)gs[tid] : 0;
+    /* the largest x*x + y*y of the ring's points per tile (k_split): maxDistance without reading x / y here */
+    const unsigned long long tm0 = a.tmaxs[((size_t)s * a.tiles + (tid < a.tiles ? tid : 0u)) * C + c];
     unsigned h0[3];
 #pragma unroll
     for (unsigned u = 0; u < 3; u++)
@@ -2386,8 +2410,16 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
     __syncthreads();
     URF_PHASE_ACC(1);
     const unsigned nh = S.n_hits;
+    constexpr bool quads = QUADS;
     double maxs = 0.0;
-    const bool quads = cp == 5;
+    {   /* (rows of tiles behind the scan's last one hold whatever an earlier call left there) */
+        unsigned long long tm = tid < ntiles ? tm0 : 0ull;
+        for (unsigned t = tid + URF_RING_THREADS; t < ntiles; t += URF_RING_THREADS) {
+            const unsigned long long v = a.tmaxs[((size_t)s * a.tiles + t) * C + c];
+            tm = v > tm ? v : tm;
+        }
+        maxs = __longlong_as_double((long long)tm);
+    }
     const int cs0 = 0;
     const int zpad = PAD + (cp & 3);   /* z slot of chunk point 0: puts p - cp of a quad on a 16-byte boundary for cp = 5 */
     unsigned buf = 0;
@@ -2412,8 +2444,10 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                 const unsigned idx = mapA[t] + (unsigned)j;
                 if ((unsigned)j + 3 < mapP[t + 1] && (idx & 3u) == 0) {
                     wide = true;
-                    fx[m] = *(const float4*)(a.rx + idx);
-                    fy[m] = *(const float4*)(a.ry + idx);
+                    if (!quads) {   /* (uniform) the four-points-per-thread path works on z alone */
+                        fx[m] = *(const float4*)(a.rx + idx);
+                        fy[m] = *(const float4*)(a.ry + idx);
+                    }
                     fz[m] = *(const float4*)(a.rz + idx);
                 }
             }
@@ -2423,8 +2457,10 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                 for (int e4 = 0; e4 < 4; e4++)
                     if (j + e4 >= 0 && j + e4 < n) {
                         const unsigned ie = map.at((unsigned)(j + e4));
-                        ex[e4] = a.rx[ie];
-                        ey[e4] = a.ry[ie];
+                        if (!quads) {
+                            ex[e4] = a.rx[ie];
+                            ey[e4] = a.ry[ie];
+                        }
                         ez[e4] = a.rz[ie];
                     }
                 fx[m] = make_float4(ex[0], ex[1], ex[2], ex[3]);
@@ -2442,8 +2478,10 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
             for (int m = 0; m < NSQ; m++) {
                 const int li = 4 * ((int)tid + m * URF_RING_THREADS);   /* slot of position cs - PAD + li */
                 if (li < CH + 2 * PAD) {
-                    *(float4*)(S.xs + li) = fx[m];
-                    *(float4*)(S.ys + li) = fy[m];
+                    if (!quads) {
+                        *(float4*)(S.xs + li) = fx[m];
+                        *(float4*)(S.ys + li) = fy[m];
+                    }
                     S.zs[li + zpad - PAD] = fz[m].x;
                     S.zs[li + zpad - PAD + 1] = fz[m].y;
                     S.zs[li + zpad - PAD + 2] = fz[m].z;
@@ -2481,8 +2519,6 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                     const float4 t = zp[v];
                     w[4 * v] = t.x; w[4 * v + 1] = t.y; w[4 * v + 2] = t.z; w[4 * v + 3] = t.w;
                 }
-                const float4 X = *(const float4*)(S.xs + 4 * tid + PAD), Y = *(const float4*)(S.ys + 4 * tid + PAD);
-                const float qx[4] = { X.x, X.y, X.z, X.w }, qy[4] = { Y.x, Y.y, Y.z, Y.w };
                 /* M[j] = max |z| over window slots j..j+5 (z_zero_method.cpp:39-40, :48-49: centre included) */
                 float T[12], M[9];
 #pragma unroll
@@ -2511,10 +2547,11 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
                             (double)__builtin_fabsf(max1 - max2) >= 0.05)                        /* z_zero_method.cpp:67-69 */
                             t |= URF_CAND_ZZERO;
                     }
-                    if (!urf_fast_az_ok(qx[i], qy[i]) || a.rd2)   /* k_split's approximate azimuth is no good here */
+                    /* (a point too close to the x axis for k_split's approximate azimuth carries URF_RAZ_UNKNOWN
+                     * and gets its exact azimuth in k_label; the ring's largest range comes from k_split's
+                     * per-tile maxima: this path reads neither x nor y) */
+                    if (a.rd2)   /* stage capture: exact azimuth and planar range of every point */
                         t |= URF_CAND_EXACT;
-                    const double s2 = (double)qx[i] * (double)qx[i] + (double)qy[i] * (double)qy[i];
-                    maxs = s2 > maxs ? s2 : maxs;
                     if (t)
                         S.cand[atomicAdd(&S.n_cand, 1u)] = (unsigned)p | (t << URF_CAND_SHIFT);
                 }
@@ -2537,7 +2574,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
 #ifdef URF_EXP_SKIP_CAND
             if (false) {
 #else
-            if (S.n_cand > URF_RING_CAND - CH || cs + CH >= n) {   /* the next chunk might not fit / last chunk */
+            if (S.n_cand > urf_ring_shared_t<QUADS>::CAND - CH || cs + CH >= n) {   /* the next chunk might not fit / last chunk */
 #endif
                 const unsigned nc = S.n_cand;
                 for (unsigned e = tid; e < nc; e += URF_RING_THREADS) {
@@ -2687,6 +2724,18 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
     }
     URF_PHASE_ACC(6);
     URF_PHASE_ACC_DUMP("k_ring", 7);
+}
+
+#ifndef URF_RING_WAVES
+#define URF_RING_WAVES 6   /* 77 registers, 13.6 KB of LDS: twelve workgroups per CU (A/B: 4 -> 0.640 ms, 5 -> 0.547, 6 -> 0.51) */
+#endif
+__global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_eu(URF_RING_WAVES, URF_RING_WAVES))) void k_ring(urf_kargs a, urf_dev_params dp)
+{
+    urf_ring_body<true>(a, dp);
+}
+__global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ring_general(urf_kargs a, urf_dev_params dp)
+{
+    urf_ring_body<false>(a, dp);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -2862,12 +2911,14 @@ __device__ __forceinline__ bool urf_road_test(const urf_win* __restrict__ win, f
     return road;
 }
 
-/* the same decision on the exact azimuth of the point in ring-sorted slot `slot` */
-__device__ __noinline__ bool urf_road_exact(const urf_kargs& a, const urf_win* win, unsigned slot)
+/* the same decision on the exact azimuth of the point in ring-sorted slot `slot`: bit 0 = road, bit 1 =
+ * the azimuth is NaN (x == y == 0: deviation D5, counted by the caller) */
+__device__ __noinline__ unsigned urf_road_exact(const urf_kargs& a, const urf_win* win, unsigned slot)
 {
     float d2;
     bool unsure;
-    return urf_road_test(win, urf_azimuth(a.rx[slot], a.ry[slot], &d2), 0.0f, unsure);
+    const float az = urf_azimuth(a.rx[slot], a.ry[slot], &d2);
+    return (urf_road_test(win, az, 0.0f, unsure) ? 1u : 0u) | (az == az ? 0u : 2u);
 }
 
 #define URF_LABEL_UNSURE 256   /* capacity of the list of points decided on the exact azimuth */
@@ -3040,8 +3091,9 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         const float az = raz[q], eps = (flag & URF_RFLAG_AZ_APPROX) ? urf_fast_az_eps(az) : 0.0f;
         const float fl = __builtin_floorf(az);
         bool road = az <= whi[qq] || az >= wlo[qq];   /* urf_road_test with the window ends at hand */
-        const bool unsure = eps > 0.0f && (az - fl <= eps || (fl + 1.0f) - az <= eps || __builtin_fabsf(az - whi[qq]) <= eps ||
-                                           __builtin_fabsf(az - wlo[qq]) <= eps);
+        /* (URF_RAZ_UNKNOWN = -1: k_split had no usable approximation -- the point lies too close to the x axis) */
+        const bool unsure = eps > 0.0f && (az < 0.0f || az - fl <= eps || (fl + 1.0f) - az <= eps ||
+                                           __builtin_fabsf(az - whi[qq]) <= eps || __builtin_fabsf(az - wlo[qq]) <= eps);
         if (unsure && valid && !curb) {
             const unsigned e = atomicAdd(&n_unsure, 1u);
             if (e < URF_LABEL_UNSURE) {
@@ -3049,7 +3101,10 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
                 un_key[e] = src | (c << 16);
                 road = false;   /* placeholder, corrected after the tile is written */
             } else {
-                road = urf_road_exact(a, win + c * URF_DEG_CELLS, slot0 + q * URF_LABEL_TILE_THREADS);   /* list full (pathological input) */
+                const unsigned re = urf_road_exact(a, win + c * URF_DEG_CELLS, slot0 + q * URF_LABEL_TILE_THREADS);   /* list full (pathological input) */
+                road = re & 1u;
+                if (re & 2u)
+                    atomicAdd(&a.info[s].n_nan_azimuth, 1u);
             }
         }
         road = road && !curb;
@@ -3090,12 +3145,15 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     __syncthreads();   /* the tile's stores come first, the corrections second */
     if (tail) {
         const unsigned c = tkey >> 16, li = tkey & 0xffffu;
-        float d2;
         bool unsure;
-        if (urf_road_test(win + c * URF_DEG_CELLS, urf_azimuth(tx, ty, &d2), 0.0f, unsure)) {
+        float d2;
+        const float az = urf_azimuth(tx, ty, &d2);
+        if (urf_road_test(win + c * URF_DEG_CELLS, az, 0.0f, unsure)) {
             a.labels[off + tbase + li] = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0) | URF_LABEL_ROAD;
             my_road++;
         }
+        if (!(az == az))   /* x == y == 0: deviation D5 (include/urf.h), counted per scan */
+            atomicAdd(&a.info[s].n_nan_azimuth, 1u);
     }
     if (my_road)
         atomicAdd(&cnt_road, my_road);
