@@ -319,6 +319,23 @@ def test_crowded_sectors(ctx_big, n_pts):
     assert np.array_equal(lg, lb) and info_equal(ig, ib)
 
 
+def test_many_star_hits_on_one_ring(ctx_big):
+    """With a wide `interval` the sweep's 64 beams merge into a handful of rings, so that one ring collects
+    more star-shaped hits than k_ring keeps in LDS (URF_RING_HITS = 62) and every chunk rescans the scan's
+    hits instead."""
+    p = O.cfg_params("cfg2")
+    p.interval = 4.0
+    x, y, z = O.cfg_cloud("cfg2", 31)
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    assert ib["n_rings"] <= 6
+    ring_of_hit = st["ring"][(st["detect"] & 1) != 0]
+    assert np.bincount(ring_of_hit[ring_of_hit >= 0]).max() > 62
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, len(x)), st["detect"])
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+
+
 def test_mid_size_sector_scattered_over_many_tiles(ctx_big):
     """A sector of 385..2048 points whose points are spread over ten input tiles: k_star_sort_mid then
     cannot use the two-run description of k_index and builds the sector's run list from the per-tile

@@ -2138,6 +2138,7 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
 #define URF_RING_CHUNK (URF_RING_THREADS * URF_RING_PPT)
 #define URF_RING_CAND 1024   /* capacity of the candidate list; flushed when a chunk might not fit */
 #define URF_RING_PAD 32   /* LDS slots in front of a chunk, >= URF_MAX_CURB_POINTS, multiple of 4 */
+#define URF_RING_HITS 62  /* star-shaped hits of one ring kept in LDS (more: rescanned per chunk) */
 
 /* (the instance for curbPoints == 5 keeps no x / y windows and a shorter candidate list: 13 KB instead of
  * 18, twelve resident workgroups per CU instead of eight) */
@@ -2149,7 +2150,7 @@ struct urf_ring_shared_t {
     int cmin[URF_DEG_CELLS], cmax[URF_DEG_CELLS];
     int q[4];
     unsigned long long maxs;
-    unsigned hits[URF_MAX_SECTORS + 2];
+    unsigned hits[URF_RING_HITS];
     unsigned n_hits;
     unsigned hb[2][URF_RING_CHUNK / 32];   /* star-hit bit per point of the chunk, double buffered */
     /* quad mapping: the ring's points that need one of the expensive evaluations, compacted */
@@ -2391,20 +2392,29 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
         sh_q[2] = (int)urf_fbits(180.f);
         sh_q[3] = (int)urf_fbits(360.f);
         S.maxs = 0;
-        S.n_hits = 0;
         S.n_cand = 0;
+        S.n_hits = 0;
     }
     __syncthreads();
     URF_PHASE_ACC(0);
-    if (star) {   /* lidar_segmentation.cpp:241-242: the star-shaped hits that lie on this ring */
+    /* lidar_segmentation.cpp:241-242: the star-shaped hits that lie on this ring, as ring positions.  A short
+     * list (a ring rarely holds more than a handful of the scan's <= 1022 hits; a list for all of them cost
+     * 4 KB of LDS, i.e. resident workgroups); if it overflows, every chunk scans the scan's hits again. */
+    if (star) {
 #pragma unroll
-        for (unsigned u = 0; u < 3; u++)   /* ring-major positions (scan-relative) or 0xffffffff */
-            if (h0[u] >= ro && h0[u] < ro + (unsigned)n)
-                S.hits[atomicAdd(&S.n_hits, 1u)] = h0[u] - ro;
+        for (unsigned u = 0; u < 3; u++)
+            if (h0[u] >= ro && h0[u] < ro + (unsigned)n) {
+                const unsigned e = atomicAdd(&S.n_hits, 1u);
+                if (e < URF_RING_HITS)
+                    S.hits[e] = h0[u] - ro;
+            }
         for (unsigned k = tid + 3 * URF_RING_THREADS; k < K; k += URF_RING_THREADS) {
             const unsigned h = (unsigned)a.star_hit[(size_t)s * K + k];
-            if (h >= ro && h < ro + (unsigned)n)
-                S.hits[atomicAdd(&S.n_hits, 1u)] = h - ro;
+            if (h >= ro && h < ro + (unsigned)n) {
+                const unsigned e = atomicAdd(&S.n_hits, 1u);
+                if (e < URF_RING_HITS)
+                    S.hits[e] = h - ro;
+            }
         }
     }
     __syncthreads();
@@ -2488,10 +2498,18 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                     S.zs[li + zpad - PAD + 3] = fz[m].w;
                 }
             }
-            for (unsigned i = tid; i < nh; i += URF_RING_THREADS) {
-                const int h = (int)S.hits[i] - cs;
-                if (h >= 0 && h < CH)
-                    atomicOr(&S.hb[buf][h >> 5], 1u << (h & 31));
+            if (nh <= URF_RING_HITS) {
+                for (unsigned i = tid; i < nh; i += URF_RING_THREADS) {
+                    const unsigned h = S.hits[i] - (unsigned)cs;
+                    if (h < (unsigned)CH)
+                        atomicOr(&S.hb[buf][h >> 5], 1u << (h & 31));
+                }
+            } else {   /* (a ring that collects more hits than the list holds: pathological input) */
+                for (unsigned k = tid; k < K; k += URF_RING_THREADS) {
+                    const unsigned h = (unsigned)a.star_hit[(size_t)s * K + k] - ro - (unsigned)cs;
+                    if (h < (unsigned)CH && h + (unsigned)cs < (unsigned)n)
+                        atomicOr(&S.hb[buf][h >> 5], 1u << (h & 31));
+                }
             }
             if (tid < CH / 32)
                 S.hb[buf ^ 1u][tid] = 0;
