@@ -360,13 +360,18 @@ int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
  * floats in [0, 600]).  *n_mismatches must come back 0.  Synchronous. */
 int urf_selftest(urf_ctx* ctx, uint64_t* n_mismatches);
 /* Measured error of the float fast paths that settle ring and sector decisions (k_split) over
- * n_samples pseudo-random points: err[0] = max |approx - exact| of the vertical angle [deg],
+ * n_samples pseudo-random points: err[0] = max |approx - exact| of the vertical angle [deg] (k_split: the
+ * angle whose cotangent its u = -z / rho is; k_ring_table's look-ahead: a float arc tangent),
  * err[1] of the polar angle [rad], err[2] of the scaled polar angle (at the configured number of
  * sectors), err[3] of the azimuth AS A FRACTION of its margin (which grows towards the x axis, where
  * the reference's own value is ill-conditioned; k_split / k_label).  The first three must stay below
  * the margins the kernels use (3e-4, 2e-6, 2.5e-4 * max(1, sectors / 360)), the last below 1.  err
  * has room for 4 floats.  Synchronous. */
 int urf_selftest_fast(urf_ctx* ctx, uint64_t n_samples, float* err);
+/* The cotangent (of an angle in degrees, clamped to [1, 179]) from which k_ring_table derives the
+ * thresholds on u = -z / rho that decide a point's ring: the same source evaluated on the host, so that
+ * its accuracy (1e-15; needed: 1e-7) can be checked without a GPU. */
+double urf_ring_threshold_cot(double angle_deg);
 /* Test hook: bit 2 (value 4) forces the general (comparison network) path of the star-shaped sort
  * for every sector; 0 in production.  Takes effect with the next classify call. */
 int urf_set_debug_flags(urf_ctx* ctx, uint32_t flags);

@@ -67,3 +67,27 @@ def test_special_values():
     assert np.float32(L.urf_oracle_atan2f(-0.0, -1.0)) == -pi
     assert L.urf_oracle_atan2f(0.0, 0.0) == 0.0
     assert np.float32(L.urf_oracle_atan2f(1.0, 0.0)) == np.float32(np.pi / 2)
+
+
+def test_ring_threshold_cotangent():
+    """k_ring_table turns every ring-table entry's window into thresholds on u = cot(vertical angle) with a
+    binary64 cotangent built from Taylor series (urf_device.hpp: urf_cot_deg); the library exports the host
+    evaluation of the same source.  Needed: 1e-7 relative; measured here against numpy."""
+    import ctypes as C
+    import urban_road_filter_amd as u
+    lib = u.api.lib()
+    lib.urf_ring_threshold_cot.restype = C.c_double
+    lib.urf_ring_threshold_cot.argtypes = [C.c_double]
+    deg = np.concatenate([np.linspace(1.0, 179.0, 20001), 90.0 + np.array([-1e-9, 0.0, 1e-9]), [14.0362, 165.9638]])
+    got = np.array([lib.urf_ring_threshold_cot(float(d)) for d in deg])
+    want = 1.0 / np.tan(np.deg2rad(deg))
+    # (near 90 degrees, where the cotangent passes through zero, the comparison is absolute: numpy's own
+    # deg2rad rounds the argument there)
+    excess = np.abs(got - want) - (1e-13 * np.abs(want) + 1e-15)
+    assert excess.max() <= 0.0, (excess.max(), deg[np.argmax(excess)])
+    # clamped outside [1, 179] degrees: beyond every u the fast path accepts (|u| <= 4)
+    assert lib.urf_ring_threshold_cot(0.2) == lib.urf_ring_threshold_cot(1.0) > 57.0
+    assert lib.urf_ring_threshold_cot(179.9) == lib.urf_ring_threshold_cot(179.0) < -57.0
+    # strictly decreasing: what turns "the angle lies in a window" into "u lies between two thresholds"
+    assert np.all(np.diff(got[:20001]) < 0)
+

@@ -382,6 +382,11 @@ extern "C" int urf_set_debug_flags(urf_ctx* c, uint32_t flags)
     return URF_OK;
 }
 
+extern "C" double urf_ring_threshold_cot(double angle_deg)
+{
+    return urf_cot_deg(angle_deg);
+}
+
 extern "C" int urf_selftest(urf_ctx* c, uint64_t* n_mismatches)
 {
     if (!c || !n_mismatches)

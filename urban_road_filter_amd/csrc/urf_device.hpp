@@ -304,7 +304,7 @@ __device__ __forceinline__ bool urf_fast_cot(float x, float y, float z, float* u
  * path accepts, so the clamp changes no decision), in binary64: tan(t), t = pi/2 - angle, from the
  * Taylor series of sin / cos at t/2 (|t/2| <= 0.78: the first neglected terms are below 1e-19) and
  * the double-angle formula.  Error ~1e-15 relative; needs 1e-7. */
-__device__ __forceinline__ double urf_cot_deg(double deg)
+__host__ __device__ __forceinline__ double urf_cot_deg(double deg)
 {
     deg = deg < 1.0 ? 1.0 : (deg > 179.0 ? 179.0 : deg);
     const double h = (90.0 - deg) * (URF_PI_D / 360.0);
