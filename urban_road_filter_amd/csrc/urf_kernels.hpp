@@ -2146,13 +2146,16 @@ template <bool QUADS>
 struct urf_ring_shared_t {
     float xs[QUADS ? 4 : URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
     float ys[QUADS ? 4 : URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
-    float zs[URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
+    /* z window of a chunk; the four-points-per-thread instance has two and alternates, so that the next chunk
+     * can be parked while the slower wave still evaluates the current one (one barrier per chunk less) */
+    float zsb[QUADS ? 2 : 1][URF_RING_CHUNK + 2 * URF_RING_PAD + 4] __attribute__((aligned(16)));
     int cmin[URF_DEG_CELLS], cmax[URF_DEG_CELLS];
     int q[4];
     unsigned long long maxs;
     unsigned hits[URF_RING_HITS];
     unsigned n_hits;
-    unsigned hb[2][URF_RING_CHUNK / 32];   /* star-hit bit per point of the chunk, double buffered */
+    unsigned hb[3][URF_RING_CHUNK / 32];   /* star-hit bit per point of the chunk; three in rotation: the one of chunk c + 1
+                                            * is cleared while chunk c is parked and c - 1 may still be read */
     /* quad mapping: the ring's points that need one of the expensive evaluations, compacted */
     static constexpr unsigned CAND = QUADS ? URF_RING_CAND - 128 : URF_RING_CAND;
     unsigned cand[CAND];                   /* ring-relative position | URF_CAND_* << URF_CAND_SHIFT */
@@ -2432,7 +2435,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
     }
     const int cs0 = 0;
     const int zpad = PAD + (cp & 3);   /* z slot of chunk point 0: puts p - cp of a quad on a 16-byte boundary for cp = 5 */
-    unsigned buf = 0;
+    unsigned buf = 0, hbi = 0;   /* z window / hit bitmap of the chunk at hand */
 
     /* The next chunk's points are requested from memory before the current chunk is evaluated and
      * parked in LDS after it: the evaluation hides the latency.  A thread fetches quads of
@@ -2480,7 +2483,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
         }
     };
     fetch(cs0);
-    for (int cs = cs0; cs < n; cs += CH, buf ^= 1u) {
+    for (int cs = cs0; cs < n; cs += CH, buf ^= 1u, hbi = hbi == 2u ? 0u : hbi + 1u) {
         /* park [cs - PAD, cs + CH + PAD) (positions outside the ring hold zeros nobody reads), mark
          * the star hits of the chunk, clear the other bitmap */
         {
@@ -2492,27 +2495,28 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                         *(float4*)(S.xs + li) = fx[m];
                         *(float4*)(S.ys + li) = fy[m];
                     }
-                    S.zs[li + zpad - PAD] = fz[m].x;
-                    S.zs[li + zpad - PAD + 1] = fz[m].y;
-                    S.zs[li + zpad - PAD + 2] = fz[m].z;
-                    S.zs[li + zpad - PAD + 3] = fz[m].w;
+                    float* const zw = S.zsb[QUADS ? buf : 0u];
+                    zw[li + zpad - PAD] = fz[m].x;
+                    zw[li + zpad - PAD + 1] = fz[m].y;
+                    zw[li + zpad - PAD + 2] = fz[m].z;
+                    zw[li + zpad - PAD + 3] = fz[m].w;
                 }
             }
             if (nh <= URF_RING_HITS) {
                 for (unsigned i = tid; i < nh; i += URF_RING_THREADS) {
                     const unsigned h = S.hits[i] - (unsigned)cs;
                     if (h < (unsigned)CH)
-                        atomicOr(&S.hb[buf][h >> 5], 1u << (h & 31));
+                        atomicOr(&S.hb[hbi][h >> 5], 1u << (h & 31));
                 }
             } else {   /* (a ring that collects more hits than the list holds: pathological input) */
                 for (unsigned k = tid; k < K; k += URF_RING_THREADS) {
                     const unsigned h = (unsigned)a.star_hit[(size_t)s * K + k] - ro - (unsigned)cs;
                     if (h < (unsigned)CH && h + (unsigned)cs < (unsigned)n)
-                        atomicOr(&S.hb[buf][h >> 5], 1u << (h & 31));
+                        atomicOr(&S.hb[hbi][h >> 5], 1u << (h & 31));
                 }
             }
             if (tid < CH / 32)
-                S.hb[buf ^ 1u][tid] = 0;
+                S.hb[hbi == 2u ? 0u : hbi + 1u][tid] = 0;
         }
         __syncthreads();
         URF_PHASE_ACC(2);
@@ -2530,7 +2534,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
 #else
             if (q0 < n) {
 #endif
-                const float4* zp = (const float4*)(S.zs + 4 * tid + PAD - 4);   /* slot of q0 - 5 */
+                const float4* zp = (const float4*)(S.zsb[QUADS ? buf : 0u] + 4 * tid + PAD - 4);   /* slot of q0 - 5 */
                 float w[16];
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
@@ -2545,7 +2549,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
 #pragma unroll
                 for (int j = 0; j < 9; j++)
                     M[j] = __builtin_fmaxf(T[j], T[j + 3]);
-                const unsigned hbits = (S.hb[buf][tid >> 3] >> ((tid & 7u) * 4u)) & 15u;
+                const unsigned hbits = (S.hb[hbi][tid >> 3] >> ((tid & 7u) * 4u)) & 15u;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int p = q0 + i;
@@ -2631,8 +2635,8 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                 if (p >= n)
                     continue;
                 const int lp = lc + PAD, lz = lc + zpad;
-                const float px = S.xs[lp], py = S.ys[lp], pz = S.zs[lz];
-                unsigned flag = (S.hb[buf][lc >> 5] >> (lc & 31)) & 1u;
+                const float px = S.xs[lp], py = S.ys[lp], pz = S.zsb[0][lz];
+                unsigned flag = (S.hb[hbi][lc >> 5] >> (lc & 31)) & 1u;
 
                 /* Both detectors are an && of an angle test (f64 sqrt/div, acos) and cheap float
                  * height tests.  The height tests run first: on road surface they fail for
@@ -2641,7 +2645,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                 if (dp.p.x_zero_method) {   /* x_zero_method.cpp:30-68, evaluated for the point it marks */
                     const int j = p - cp / 2;
                     if (j >= cp && j <= (n - 1) - cp) {
-                        const float zj = S.zs[lz - cp / 2], z3 = S.zs[lz - cp / 2 + cp];
+                        const float zj = S.zsb[0][lz - cp / 2], z3 = S.zsb[0][lz - cp / 2 + cp];
                         const bool heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight ||
                                               __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
                                              (double)__builtin_fabsf(zj - z3) >= 0.05;          /* :62-64 */
@@ -2655,7 +2659,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                         const float az = __builtin_fabsf(pz);
                         float max1 = az, max2 = az;
                         for (int k = 1; k <= cp; k++) {                                         /* :39-40, :48-49 */
-                            const float za = __builtin_fabsf(S.zs[lz - k]), zb = __builtin_fabsf(S.zs[lz + k]);
+                            const float za = __builtin_fabsf(S.zsb[0][lz - k]), zb = __builtin_fabsf(S.zsb[0][lz + k]);
                             if (za > max1)
                                 max1 = za;
                             if (zb > max2)
@@ -2677,7 +2681,8 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                     atomicAdd(&a.info[s].n_nan_azimuth, 1u);
             }
         }
-        __syncthreads();
+        if (!QUADS)   /* (two z windows: the next chunk is parked into the other one; n_cand / the hit bitmaps are ordered by the barrier after the parking) */
+            __syncthreads();
         URF_PHASE_ACC(5);
     }
 
