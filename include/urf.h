@@ -49,7 +49,10 @@
 extern "C" {
 #endif
 
-#define URF_ABI_VERSION 1
+/* 2 (round 3): URF_MAX_IN_FLIGHT sweeps on the asynchronous path (tickets map to slots modulo it),
+ * urf_result_labels() validates its ticket, URF_NUM_KERNELS / kernel names as listed below,
+ * urf_enable_stage_capture() takes a mode 0..2, urf_scan_info::n_nan_azimuth is written. */
+#define URF_ABI_VERSION 2
 
 /* ---- label byte --------------------------------------------------------- */
 #define URF_LABEL_MASK   0x03u
@@ -74,7 +77,8 @@ typedef enum urf_status {
     URF_ERR_CAPACITY = -4,       /* scan or batch larger than urf_create() sizes */
     URF_ERR_OOM = -5,
     URF_ERR_PARAMS = -6,         /* parameter outside the supported range */
-    URF_ERR_BUSY = -7            /* both slots of the asynchronous single-scan path are in flight */
+    URF_ERR_BUSY = -7            /* every slot of the asynchronous single-scan path is in flight (or the asked-for
+                                    result is still being written) */
 } urf_status;
 
 /* ---- parameters ----------------------------------------------------------
@@ -196,20 +200,30 @@ int urf_classify_pc2(urf_ctx* ctx, const uint8_t* data, uint32_t n_points,
                      uint8_t* labels_out, urf_scan_info* info);
 
 /* The same, asynchronously: the message is copied to pinned memory and sent to the device on a
- * copy stream, classified on the context's stream by ONE graph launch (the kernel sequence of a
- * sweep of this shape is captured once and replayed), and the labels come back to pinned memory.
- * Two sweeps may be in flight (the copy of sweep i+1 overlaps the kernels of sweep i; with a context
- * created for max_batch >= 2 each of the two has its own scratch and compute stream, so their
- * kernels overlap as well):
+ * copy stream, classified by ONE graph launch (the kernel sequence of a sweep of this shape is
+ * captured once and replayed), and the labels come back to pinned memory.
+ * URF_MAX_IN_FLIGHT sweeps may be in flight (the copy of sweep i+1 overlaps the kernels of sweep i;
+ * with a context created for max_batch >= 2 the sweeps in flight are spread over min(max_batch,
+ * URF_MAX_IN_FLIGHT) scratch rows, each with its own compute stream, so their kernels overlap as well):
  *     urf_classify_pc2_async(ctx, msg_a, ..., &ta);
- *     urf_classify_pc2_async(ctx, msg_b, ..., &tb);      // a third one returns URF_ERR_BUSY
+ *     urf_classify_pc2_async(ctx, msg_b, ..., &tb);      // ... the fifth in a row returns URF_ERR_BUSY
  *     urf_classify_pc2_wait(ctx, ta, labels_a, &info_a);  // blocks until sweep a is done
- * labels_out may be NULL: urf_result_labels() then gives read access to the pinned result buffer,
- * valid until the ticket's slot is used again (two submissions later).  A producer that can fill a
+ * Sweeps must be waited for in the order they were submitted if the results are to be looked at with
+ * urf_read_stage / urf_ordered_indices / urf_marker_points (those see the sweep waited for last).
+ * Every other entry point of the context that touches its scratch memory (the batch calls, the three
+ * just named, urf_compact_indices*) is ordered behind the sweeps still in flight; urf_synchronize()
+ * waits for them as well.
+ * labels_out may be NULL: urf_result_labels() then gives read access to the pinned result buffer of a
+ * ticket that has been waited for, valid until the ticket's slot is used again (URF_MAX_IN_FLIGHT
+ * submissions later); a ticket never issued or overtaken is refused with URF_ERR_INVALID_ARG, one
+ * still in flight with URF_ERR_BUSY.  A producer that can fill a
  * buffer of the library's choosing (a driver, a deserialiser) saves the staging copy: it asks for
  * the pinned input buffer of the NEXT submission with urf_pinned_input() (URF_ERR_BUSY while that
- * slot is still in flight), writes the message there and passes that very pointer as `data`.  Reference: the subscriber callback, lidar_segmentation.cpp:53,95-100, and
+ * slot is still in flight), writes the message there and passes that very pointer as `data` (a message
+ * that starts inside that buffer but is not exactly it, or is longer than the size asked for, is
+ * refused with URF_ERR_INVALID_ARG).  Reference: the subscriber callback, lidar_segmentation.cpp:53,95-100, and
  * the publishers, :612-621. */
+#define URF_MAX_IN_FLIGHT 4
 int urf_classify_pc2_async(urf_ctx* ctx, const uint8_t* data, uint32_t n_points,
                            uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
                            uint32_t* ticket);
@@ -261,7 +275,13 @@ int urf_compact_indices_batch(urf_ctx* ctx, const uint8_t* d_labels, uint32_t n_
  * in exactly that order (points of equal azimuth stay in input order; the
  * reference's unstable sort leaves their order open).  Host buffers with room
  * for n_points entries each (any may be NULL); counts[3] = {road, curb,
- * road_probably}.  Synchronous; costs one extra per-ring sort. */
+ * road_probably}.  Synchronous; costs one extra per-ring sort.
+ * LIFETIME: urf_ordered_indices*, urf_marker_points* and urf_read_stage run kernels over the LAST
+ * classify call's results, which include the caller's own buffers of that call: d_labels (all three)
+ * and, for calls with ragged offsets, nothing else -- the x / y / z these kernels need were copied
+ * into the context's scratch by the call itself.  d_labels of the last classify call must therefore
+ * stay allocated and unmodified until the last of these calls on it has completed (for a sweep of the
+ * callback path the library owns that buffer: nothing to keep alive). */
 int urf_ordered_indices(urf_ctx* ctx, uint32_t scan, uint32_t* road, uint32_t* curb, uint32_t* ring10,
                         uint32_t* counts);
 /* Every scan of the last classify call at once, results on the DEVICE (asynchronous on the
@@ -331,7 +351,7 @@ int urf_read_stage(urf_ctx* ctx, urf_stage what, uint32_t scan, void* host_dst, 
  *      (URF_STAGE_RING, URF_STAGE_SECTOR; mode 0 keeps them only in sorted order).
  * The other stages can be read in every mode.  urf_read_stage, urf_ordered_indices and
  * urf_marker_points look at the LAST classify call of the context with the parameters that call
- * ran with; the label buffer handed to that call must still be alive. */
+ * ran with; the label buffer handed to that call must still be alive (see LIFETIME above). */
 int urf_enable_stage_capture(urf_ctx* ctx, int mode);
 
 /* ---- per-kernel timing (benchmark) ------------------------------------------

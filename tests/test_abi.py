@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_abi_version_and_struct_size():
-    assert u.lib().urf_abi_version() == 1
+    assert u.lib().urf_abi_version() == 2   # include/urf.h: URF_ABI_VERSION
     p = u.default_params()
     assert p.size == ctypes.sizeof(u.Params) == 104
     assert ctypes.sizeof(u.ScanInfo) == 32

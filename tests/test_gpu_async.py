@@ -1,5 +1,5 @@
 """The callback path (SURVEY.md 8b "wire in" / "callback"): one sweep arrives as PointCloud2 bytes in
-host memory, the labels go back to host memory.  urf_classify_pc2_async / _wait keep two sweeps in
+host memory, the labels go back to host memory.  urf_classify_pc2_async / _wait keep up to four sweeps in
 flight (pinned staging, H2D on a copy stream, the kernel sequence replayed from a captured graph);
 urf_classify_pc2 is the same path, waited for at once.  Results must not depend on how a sweep was
 submitted."""
@@ -22,10 +22,14 @@ def records(x, y, z, step=32, ox=0, oy=4, oz=8):
     return buf.reshape(-1)
 
 
-@pytest.fixture(scope="module", params=[1, 2], ids=["one_scratch_row", "two_scratch_rows"])
+IN_FLIGHT = 4   # URF_MAX_IN_FLIGHT
+
+
+@pytest.fixture(scope="module", params=[1, 2, 4], ids=["one_scratch_row", "two_scratch_rows", "four_scratch_rows"])
 def ctx(request):
-    """max_batch 1: both slots share the scratch and the stream (only the copies overlap);
-    max_batch 2: every slot has its own scratch row and compute stream (the kernels overlap too)."""
+    """max_batch 1: all slots share the scratch and the stream (only the copies overlap);
+    max_batch 2 / 4: the slots are spread over that many scratch rows, each with its own compute stream
+    (the kernels overlap too)."""
     c = u.Context(N, request.param, params=O.cfg_params("cfg2"))
     yield c
     c.close()
@@ -35,19 +39,19 @@ def ctx(request):
 def sweeps():
     p = O.cfg_params("cfg2")
     out = []
-    for seed in range(40, 46):
+    for seed in range(40, 50):
         x, y, z = O.cfg_cloud("cfg2" if seed % 2 else "narrow", seed)
         lb, ib, _ = O.run_b(x, y, z, p)
         out.append((records(x, y, z), lb, ib))
     return out
 
 
-def test_two_in_flight_equal_the_oracle(ctx, sweeps):
+def test_sweeps_in_flight_equal_the_oracle(ctx, sweeps):
     ctx.set_params(O.cfg_params("cfg2"))
     got = [None] * len(sweeps)
     tickets = []
     for k, (rec, _, _) in enumerate(sweeps):
-        if len(tickets) == 2:   # both slots busy: a third submission is refused, nothing is lost
+        if len(tickets) == IN_FLIGHT:   # every slot busy: one more submission is refused, nothing is lost
             with pytest.raises(u.UrfError) as e:
                 ctx.classify_pc2_async(rec, N, 32, 0, 4, 8)
             assert e.value.code == -7
@@ -77,14 +81,85 @@ def test_producer_writes_into_the_pinned_buffer(ctx, sweeps):
     ctx.set_params(O.cfg_params("cfg2"))
     rec, lb, _ = sweeps[1]
     seen = set()
-    for rep in range(3):   # both slots get used
+    for rep in range(IN_FLIGHT + 1):   # every slot gets used
         buf = ctx.pinned_input(len(rec))
         seen.add(buf.ctypes.data)
         buf[:] = rec
         t = ctx.classify_pc2_async(buf.ctypes.data, N, 32, 0, 4, 8)
         info = ctx.classify_pc2_wait(t)
         assert info.status == 0 and np.array_equal(ctx.result_labels(t, N), lb)
-    assert len(seen) == 2
+    assert len(seen) == IN_FLIGHT
+
+
+def test_tickets_and_pinned_pointers_are_validated(ctx, sweeps):
+    """urf_result_labels refuses a ticket that was never issued, is still in flight or has been overtaken;
+    a message that lies inside the slot's pinned buffer must be exactly that buffer."""
+    ctx.set_params(O.cfg_params("cfg2"))
+    rec, lb, _ = sweeps[0]
+    t = ctx.classify_pc2_async(rec, N, 32, 0, 4, 8)
+    with pytest.raises(u.UrfError) as e:
+        ctx.result_labels(t, N)
+    assert e.value.code == -7            # in flight
+    with pytest.raises(u.UrfError) as e:
+        ctx.result_labels(t + 1000, N)
+    assert e.value.code == -1            # never issued
+    ctx.classify_pc2_wait(t)
+    assert np.array_equal(ctx.result_labels(t, N), lb)
+    for _ in range(IN_FLIGHT):           # the slot is used again: the old ticket is stale
+        ctx.classify_pc2(rec, N, 32, 0, 4, 8)
+    with pytest.raises(u.UrfError) as e:
+        ctx.result_labels(t, N)
+    assert e.value.code == -1
+    buf = ctx.pinned_input(len(rec))
+    with pytest.raises(u.UrfError) as e:   # starts inside the pinned buffer, but is not the buffer
+        ctx.classify_pc2_async(buf.ctypes.data + 32, N - 1, 32, 0, 4, 8)
+    assert e.value.code == -1
+    small = u.Context(N, 1, params=O.cfg_params("cfg2"))
+    try:
+        b2 = small.pinned_input(32 * 1000)
+        with pytest.raises(u.UrfError) as e:   # longer than the size asked for
+            small.classify_pc2_async(b2.ctypes.data, N, 32, 0, 4, 8)
+        assert e.value.code == -1
+    finally:
+        small.close()
+
+
+def test_batch_calls_and_readbacks_are_ordered_behind_sweeps_in_flight(sweeps):
+    """a batch call overwrites the scratch rows (and the SoA staging) that sweeps of the callback path
+    still in flight on their own streams work on; the read-back entry points read them.  All of them must
+    wait."""
+    p = O.cfg_params("cfg2")
+    import hipmem as H
+    with u.Context(N, 4, params=p) as c:
+        xs = [O.cfg_cloud("cfg2", 60 + k) for k in range(4)]
+        X = np.concatenate([v[0] for v in xs]); Y = np.concatenate([v[1] for v in xs]); Z = np.concatenate([v[2] for v in xs])
+        want = [O.run_b(*v, p)[0] for v in xs]
+        dx, dy, dz = H.DevBuf.from_numpy(X), H.DevBuf.from_numpy(Y), H.DevBuf.from_numpy(Z)
+        dl = H.DevBuf(4 * N)
+        for rep in range(3):
+            ts = [c.classify_pc2_async(sweeps[k][0], N, 32, 0, 4, 8) for k in range(IN_FLIGHT)]
+            c.classify_batch_soa(dx, dy, dz, N, 4, dl, None)   # rows 0..3 while four sweeps are in flight
+            got = []
+            for t in ts:
+                lab = np.empty(N, np.uint8)
+                c.classify_pc2_wait(t, lab)
+                got.append(lab)
+            c.synchronize()
+            L = dl.to_numpy(np.uint8)
+            for k in range(4):
+                assert np.array_equal(got[k], sweeps[k][1]), (rep, k)
+                assert np.array_equal(L[k * N:(k + 1) * N], want[k]), (rep, k)
+        # read-back right after a submission on a row with its own stream
+        t0 = c.classify_pc2_async(sweeps[0][0], N, 32, 0, 4, 8)
+        t1 = c.classify_pc2_async(sweeps[1][0], N, 32, 0, 4, 8)
+        c.classify_pc2_wait(t0)
+        c.classify_pc2_wait(t1)
+        det = c.read_stage(u.STAGE_DETECT, N)
+        assert det.shape == (N,)
+        road, curb, r10 = c.ordered_indices(N)
+        assert set(curb.tolist()) == set(np.nonzero((sweeps[1][1] & 3) == 2)[0].tolist())
+        for b in (dx, dy, dz, dl):
+            b.free()
 
 
 def test_graph_replay_equals_kernel_by_kernel_launches(ctx, sweeps):

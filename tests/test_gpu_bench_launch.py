@@ -38,6 +38,26 @@ def test_two_ranks_over_gloo_on_one_device():
 def test_single_rank_line_has_the_contract_keys():
     d = run_bench("--scans", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "other_configs"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert d["backend"] is None
+    # the other BASELINE configurations, each behind its own parity gate (bench.py: other_configs)
+    oc = d["other_configs"]
+    assert set(oc) == {"cfg2", "cfg5", "default_roi"}
+    for name, e in oc.items():
+        assert e["scans_per_s"] > 0 and 0 < e["frac"] < 1 and e["parity_checked_scans"], name
+    assert oc["cfg5"]["points_per_scan"] == 128 * 4096 and oc["cfg2"]["scans_per_step"] == 1
+
+
+def test_rccl_with_one_rank():
+    """RCCL on the one GPU a test box has: the process group is initialised with backend nccl (= RCCL on ROCm)
+    and world size 1, the barrier and both all-reduces run on device tensors, the group is destroyed.  What stays
+    unproven without a multi-GPU node: RCCL between ranks."""
+    S, K = 32, 2
+    d = run_bench("--force-dist", "--scans", str(S), "--steps", str(K), "--warmup", "1", "--no-cpu-baseline", "--no-e2e",
+                  "--no-other-configs", "--no-outputs")
+    assert d["backend"] == "nccl" and d["n_gpus"] == 1
+    c = d["counters"]   # unchanged by the reduction over one rank
+    assert c["scans"] == S * K and c["points_in"] == S * K * 64 * 2048 and c["ok_scans"] == S * K
+    assert 0 < c["curb"] < c["road"] < c["roi_points"] <= c["points_in"]

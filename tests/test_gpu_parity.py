@@ -178,8 +178,10 @@ def check_against_b(labels, infos, scans, p):
     for k, (x, y, z) in enumerate(scans):
         lb, ib, _ = O.run_b(x, y, z, p)
         assert np.array_equal(labels[k], lb), "scan %d" % k
-        got = dict(zip(("status", "n_roi", "n_rings", "n_ring_pts", "n_road", "n_curb", "n_ring10"), infos[k][:7]))
-        assert got == ib, "scan %d" % k
+        keys = ("status", "n_roi", "n_rings", "n_ring_pts", "n_road", "n_curb", "n_ring10")
+        got = dict(zip(keys, infos[k][:7]))
+        assert got == {f: ib[f] for f in keys}, "scan %d" % k
+        assert infos[k][7] == 0, "scan %d: NaN azimuths counted on a sweep without x == y == 0 points" % k
 
 
 def test_uniform_batch_of_distinct_scans():

@@ -60,7 +60,7 @@ class ScanInfo(C.Structure):
                 ("n_ring10", C.c_uint32), ("n_nan_azimuth", C.c_uint32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "n_nan_azimuth"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class MarkerParams(C.Structure):

@@ -16,6 +16,9 @@
 #include "urf_internal.hpp"
 #include "urf_kernels.hpp"
 
+#define URF_ASYNC_SLOTS 4
+static_assert(URF_ASYNC_SLOTS == URF_MAX_IN_FLIGHT, "include/urf.h documents the number of sweeps in flight");
+
 struct urf_ctx {
     int device = 0;
     uint32_t max_points = 0, max_batch = 0;
@@ -32,9 +35,11 @@ struct urf_ctx {
     /* owned device memory */
     std::vector<void*> allocs;
     float *sx = nullptr, *sy = nullptr, *sz = nullptr;   /* SoA staging for PointCloud2 input */
-    /* The single-scan (callback) path: two slots, so that the H2D copy of sweep i+1 runs on the copy
-     * stream while sweep i is being classified.  Per slot: pinned host staging for the message
-     * bytes and for the results, device copies of both, the captured launch sequence. */
+    /* The single-scan (callback) path: URF_ASYNC_SLOTS sweeps in flight, so that the H2D copy of sweep
+     * i+1 runs on the copy stream while sweep i is being classified and -- with a context created for
+     * several scans -- the kernels of several sweeps overlap on the device (a single sweep's kernels are
+     * a few dozen workgroups each).  Per slot: pinned host staging for the message bytes and for the
+     * results, device copies of both, the captured launch sequence. */
     struct slot_t {
         uint8_t* h_in = nullptr;        /* pinned, h_in_cap bytes */
         size_t h_in_cap = 0;
@@ -49,11 +54,18 @@ struct urf_ctx {
         uint64_t key[3] = { 0, 0, 0 };  /* what the captured sequence was built for */
         urf_kargs cap_a;                /* ... and the kernel arguments / parameters it runs with */
         urf_dev_params cap_dp;
-        bool pending = false;
+        bool pending = false, used = false;
         uint32_t n_points = 0, ticket = 0;
-    } slots[2];
+    } slots[URF_ASYNC_SLOTS];
     hipStream_t copy_stream = nullptr;
-    hipStream_t slot_stream = nullptr;   /* compute stream of slot 1 (slot 0 runs on `stream`) */
+    /* Slot i works on scratch row i % rows, rows = min(max_batch, URF_ASYNC_SLOTS); row 0 runs on the
+     * context's stream, every other row on a stream of its own (slots that share a row share its
+     * stream: they are serialised).  Everything else the context launches runs on `stream`; the two
+     * kinds of work are ordered against each other by events (order_after_slots / order_row_after_main). */
+    hipStream_t row_stream[URF_ASYNC_SLOTS] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev_main = nullptr;          /* recorded on `stream` for a row stream to wait on */
+    uint64_t main_seq = 1;                 /* bumped by every launch on `stream` that touches scratch rows >= 1 or the staging */
+    uint64_t row_seen[URF_ASYNC_SLOTS] = { 0, 0, 0, 0 };
     uint32_t next_ticket = 0;
     uint64_t epoch = 1;             /* bumped by everything a captured sequence depends on */
     /* lazily, sized for the largest number of scans asked for so far: scratch of the index-list and
@@ -162,7 +174,8 @@ static int ensure_capture_arrays(urf_ctx* c)
         return URF_OK;
     int rc;
     if ((rc = dev_alloc(c, &c->k.valpha, c->total)) != URF_OK || (rc = dev_alloc(c, &c->k.seckey, c->total)) != URF_OK ||
-        (rc = dev_alloc(c, &c->k.ringkey, c->total)) != URF_OK || (rc = dev_alloc(c, &c->k.rd2, c->total)) != URF_OK)
+        (rc = dev_alloc(c, &c->k.ringkey, c->total)) != URF_OK || (rc = dev_alloc(c, &c->k.rd2, c->total)) != URF_OK ||
+        (rc = dev_alloc(c, &c->k.caz, c->total)) != URF_OK)
         return rc;
     return URF_OK;
 }
@@ -210,14 +223,14 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
 #define A(ptr, count)                                     \
     if ((rc = dev_alloc(c, &(ptr), (count))) != URF_OK)   \
         return fail(rc);
-    A(k.rx, T) A(k.ry, T) A(k.rz, T) A(k.rsrc, T) A(k.raz, T) A(k.rflag, T)
-    A(k.sr, T) A(k.sz, T) A(k.sslot, T) A(k.ssrt, T) A(k.wslp, T) A(k.wg, T)
+    A(k.rx, T) A(k.ry, T) A(k.rz, T) A(k.rec, T)
+    A(k.sr, T) A(k.sz, T) A(k.sslot, T) A(k.ssrt16, T) A(k.ssrt, T) A(k.wslp, T) A(k.wg, T)
     A(k.big_r, T) A(k.big_z, T) A(k.big_i, T)
     A(k.tile_roi, S * tiles) A(k.roi_bits, S * tiles * (URF_TILE / 64)) A(k.troff, S * tiles * (C + 1)) A(k.tsoff, S * tiles * (K + 1)) A(k.tmaxs, S * tiles * C)
     A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles)
     A(k.angle, S * C) A(k.ring_thr, S * C * 4) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_run, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
-    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 8)
+    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 4 * URF_ASYNC_SLOTS)   /* four counters per scratch row in use at once */
     A(k.table_upto, S) A(k.table_redo, S) A(k.redo_list, S)
     A(k.maxdist, S * C) A(k.quad, S * 4)
     A(k.sufmin, S * C * URF_DEG_CELLS) A(k.premax, S * C * URF_DEG_CELLS)
@@ -284,8 +297,11 @@ static void free_lazy(urf_ctx* c)
     }
     if (c->copy_stream)
         (void)hipStreamDestroy(c->copy_stream);
-    if (c->slot_stream)
-        (void)hipStreamDestroy(c->slot_stream);
+    for (hipStream_t st : c->row_stream)
+        if (st)
+            (void)hipStreamDestroy(st);
+    if (c->ev_main)
+        (void)hipEventDestroy(c->ev_main);
     for (void* p : { (void*)c->mk_d, (void*)c->mk_pos, (void*)c->mk_red, (void*)c->mk_out, (void*)c->ord_keys,
                      (void*)c->ord_pos, (void*)c->ord_cls, (void*)c->ord_lists })
         if (p)
@@ -304,6 +320,9 @@ extern "C" int urf_destroy(urf_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->own_stream)
         (void)hipStreamSynchronize(c->own_stream);
+    for (hipStream_t st : c->row_stream)
+        if (st)
+            (void)hipStreamSynchronize(st);
     for (auto& set : c->timing_events)
         for (hipEvent_t e : set)
             (void)hipEventDestroy(e);
@@ -324,8 +343,9 @@ extern "C" int urf_set_params(urf_ctx* c, const urf_params* p)
     if (rc != URF_OK)
         return rc;
     URF_HIP(c, hipSetDevice(c->device));
-    if (c->slot_stream)
-        URF_HIP(c, hipStreamSynchronize(c->slot_stream));   /* a sweep in flight on the second slot keeps its parameters */
+    for (hipStream_t st : c->row_stream)
+        if (st)
+            URF_HIP(c, hipStreamSynchronize(st));   /* a sweep in flight on another row keeps its parameters */
     c->params = *p;
     c->epoch++;
     return upload_params(c);
@@ -354,6 +374,9 @@ extern "C" int urf_synchronize(urf_ctx* c)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
     URF_HIP(c, hipStreamSynchronize(c->stream));
+    for (hipStream_t st : c->row_stream)   /* sweeps of the callback path in flight on other scratch rows */
+        if (st)
+            URF_HIP(c, hipStreamSynchronize(st));
     return URF_OK;
 }
 
@@ -445,6 +468,9 @@ extern "C" int urf_kernel_timing(urf_ctx* c, double* ms_sum, uint32_t* n_calls)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
     URF_HIP(c, hipStreamSynchronize(c->stream));
+    for (hipStream_t st : c->row_stream)   /* (with timing on, a sweep of the callback path records its events on its row's stream) */
+        if (st)
+            URF_HIP(c, hipStreamSynchronize(st));
     for (size_t i = 0; i < c->timing_used; i++) {
         auto& set = c->timing_events[i];
         for (int k = 0; k < URF_NUM_KERNELS; k++) {
@@ -469,11 +495,11 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     if (row == 0)
         return k;
     const size_t P = (size_t)row * c->sstride, tiles = c->max_tiles, C = URF_MAX_CHANNELS, K = URF_MAX_SECTORS, r = row;
-    k.rx += P; k.ry += P; k.rz += P; k.rsrc += P; k.raz += P; k.rflag += P;
-    k.sr += P; k.sz += P; k.sslot += P; k.ssrt += P; k.wslp += P; k.wg += P;
+    k.rx += P; k.ry += P; k.rz += P; k.rec += P;
+    k.sr += P; k.sz += P; k.sslot += P; k.ssrt16 += P; k.ssrt += P; k.wslp += P; k.wg += P;
     k.big_r += P; k.big_z += P; k.big_i += P;
     if (k.valpha) {
-        k.valpha += P; k.seckey += P; k.ringkey += P; k.rd2 += P;
+        k.valpha += P; k.seckey += P; k.ringkey += P; k.rd2 += P; k.caz += P;
     }
     k.tile_roi += r * tiles; k.roi_bits += r * tiles * (URF_TILE / 64); k.troff += r * tiles * (C + 1); k.tsoff += r * tiles * (K + 1); k.tmaxs += r * tiles * C;
     k.rpre += r * C * (tiles + 1); k.rstart += r * C * tiles;
@@ -489,10 +515,40 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     return k;
 }
 
+/* Work on the context's stream that reads or writes scratch (any row), the SoA staging or the results of
+ * the last call must come after the sweeps of the callback path that are still in flight on OTHER
+ * streams (a batch call overwrites their rows; urf_read_stage / urf_ordered_indices /
+ * urf_marker_points read them) ... */
+static int order_after_slots(urf_ctx* c)
+{
+    for (auto& sl : c->slots)
+        if (sl.pending && sl.ev_done)
+            URF_HIP(c, hipStreamWaitEvent(c->stream, sl.ev_done, 0));   /* (a no-op for a slot that ran on `stream` itself) */
+    c->main_seq++;
+    return URF_OK;
+}
+/* ... and a sweep launched on a row's own stream must come after whatever the context's stream still
+ * has to do with that row or the staging arrays. */
+static int order_row_after_main(urf_ctx* c, uint32_t row, hipStream_t st)
+{
+    if (st == c->stream || c->row_seen[row] == c->main_seq)
+        return URF_OK;
+    if (!c->ev_main)
+        URF_HIP(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+    URF_HIP(c, hipEventRecord(c->ev_main, c->stream));
+    URF_HIP(c, hipStreamWaitEvent(st, c->ev_main, 0));
+    c->row_seen[row] = c->main_seq;
+    return URF_OK;
+}
+
 /* ---- the pipeline ---------------------------------------------------------- */
+/* on_stream == nullptr: a call of the public batch entry points (row 0 onwards, the context's stream,
+ * published as "the last call"); otherwise one sweep of the callback path on its row and stream (the
+ * caller publishes it when it is waited for). */
 static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const float* d_z,
                         const uint32_t* d_offsets, uint32_t n_per_scan, uint32_t max_len, uint32_t n_scans,
-                        uint8_t* d_labels, urf_scan_info* d_info, uint32_t row = 0, hipStream_t on_stream = nullptr)
+                        uint8_t* d_labels, urf_scan_info* d_info, uint32_t row = 0, hipStream_t on_stream = nullptr,
+                        urf_kargs* a_out = nullptr, urf_dev_params* dp_out = nullptr)
 {
     if (!d_x || !d_y || !d_z || !d_labels)
         return URF_ERR_INVALID_ARG;
@@ -502,6 +558,11 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         return URF_ERR_CAPACITY;
     URF_HIP(c, hipSetDevice(c->device));
     hipStream_t st = on_stream ? on_stream : c->stream;
+    if (!on_stream) {
+        const int orc = order_after_slots(c);
+        if (orc != URF_OK)
+            return orc;
+    }
     urf_kargs a = kargs_row(c, row);
     a.x = d_x;
     a.y = d_y;
@@ -528,8 +589,10 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     a.table_lookahead = c->speculate ? URF_TABLE_LOOKAHEAD : 0u;
     a.capture = (uint32_t)c->capture;
     a.labels = d_labels;
-    if (c->capture != 1)
+    if (c->capture != 1) {
         a.rd2 = nullptr;
+        a.caz = nullptr;
+    }
     const urf_dev_params dp = c->dp;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
@@ -587,9 +650,14 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     URF_HIP(c, hipGetLastError());
     if (d_info)
         URF_HIP(c, hipMemcpyAsync(d_info, a.info, (size_t)n_scans * sizeof(urf_scan_info), hipMemcpyDeviceToDevice, st));
-    c->last_scans = n_scans;
-    c->last_a = a;
-    c->last_dp = dp;
+    if (on_stream) {
+        *a_out = a;
+        *dp_out = dp;
+    } else {
+        c->last_scans = n_scans;
+        c->last_a = a;
+        c->last_dp = dp;
+    }
     return URF_OK;
 }
 
@@ -647,6 +715,9 @@ extern "C" int urf_classify_batch_pc2(urf_ctx* c, const uint8_t* d_data, uint32_
     int rc = ensure_soa_staging(c);
     if (rc != URF_OK)
         return rc;
+    rc = order_after_slots(c);   /* the staging arrays are shared with the callback path */
+    if (rc != URF_OK)
+        return rc;
     const unsigned long long total = (unsigned long long)n_per_scan * n_scans;
     hipLaunchKernelGGL(k_pc2_to_soa, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_data, total,
                        point_step, off_x, off_y, off_z, c->sx, c->sy, c->sz);
@@ -654,18 +725,27 @@ extern "C" int urf_classify_batch_pc2(urf_ctx* c, const uint8_t* d_data, uint32_
 }
 
 /* ---- the callback path: one sweep, host buffers ------------------------------- */
-/* Slot i of the callback path works on scratch row i and (slot 1) on its own compute stream when the
- * context was created for at least two scans: the kernels of two sweeps then overlap on the device
- * (a single sweep's kernels are a few dozen workgroups each).  With max_batch == 1 both slots share
- * row 0 and the context's stream: only the copies overlap. */
-static uint32_t slot_row(const urf_ctx* c, const urf_ctx::slot_t& sl) { return c->max_batch >= 2 ? (uint32_t)(&sl - c->slots) : 0u; }
-static hipStream_t slot_stream(urf_ctx* c, const urf_ctx::slot_t& sl) { return slot_row(c, sl) ? c->slot_stream : c->stream; }
+/* Slot i of the callback path works on scratch row i % rows, rows = min(max_batch, URF_ASYNC_SLOTS), and on
+ * that row's compute stream (row 0: the context's stream): with a context created for several scans the
+ * kernels of as many sweeps overlap on the device (a single sweep's kernels are a few dozen workgroups
+ * each).  With max_batch == 1 all slots share row 0 and the context's stream: only the copies overlap. */
+static uint32_t slot_row(const urf_ctx* c, const urf_ctx::slot_t& sl)
+{
+    const uint32_t rows = c->max_batch < URF_ASYNC_SLOTS ? c->max_batch : URF_ASYNC_SLOTS;
+    return (uint32_t)(&sl - c->slots) % rows;
+}
+static hipStream_t slot_stream(urf_ctx* c, const urf_ctx::slot_t& sl)
+{
+    const uint32_t row = slot_row(c, sl);
+    return row ? c->row_stream[row] : c->stream;
+}
 
 static int slot_prepare(urf_ctx* c, urf_ctx::slot_t& sl, size_t bytes)
 {
     if (!c->copy_stream) {
         URF_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        URF_HIP(c, hipStreamCreateWithFlags(&c->slot_stream, hipStreamNonBlocking));
+        for (uint32_t r = 1; r < URF_ASYNC_SLOTS && r < c->max_batch; r++)
+            URF_HIP(c, hipStreamCreateWithFlags(&c->row_stream[r], hipStreamNonBlocking));
     }
     if (!sl.ev_h2d) {
         URF_HIP(c, hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
@@ -680,6 +760,7 @@ static int slot_prepare(urf_ctx* c, urf_ctx::slot_t& sl, size_t bytes)
     }
     if (bytes > sl.h_in_cap) {   /* grows to the largest message seen (a new buffer invalidates the captured sequence) */
         URF_HIP(c, hipStreamSynchronize(c->copy_stream));
+        URF_HIP(c, hipStreamSynchronize(slot_stream(c, sl)));   /* the slot's last sweep may still read d_raw */
         if (sl.h_in)
             (void)hipHostFree(sl.h_in);
         if (sl.d_raw)
@@ -709,7 +790,7 @@ static int slot_launch(urf_ctx* c, urf_ctx::slot_t& sl, uint32_t n_points, uint3
     float *sx = c->sx + (size_t)row * c->max_points, *sy = c->sy + (size_t)row * c->max_points, *sz = c->sz + (size_t)row * c->max_points;
     hipLaunchKernelGGL(k_pc2_to_soa, dim3((n_points + 255) / 256), dim3(256), 0, st, sl.d_raw, (unsigned long long)n_points,
                        point_step, off_x, off_y, off_z, sx, sy, sz);
-    const int rc = run_pipeline(c, sx, sy, sz, nullptr, n_points, n_points, 1, sl.d_labels, nullptr, row, st);
+    const int rc = run_pipeline(c, sx, sy, sz, nullptr, n_points, n_points, 1, sl.d_labels, nullptr, row, st, &sl.cap_a, &sl.cap_dp);
     if (rc != URF_OK)
         return rc;
     URF_HIP(c, hipMemcpyAsync(sl.h_labels, sl.d_labels, n_points, hipMemcpyDeviceToHost, st));
@@ -721,7 +802,7 @@ extern "C" int urf_pinned_input(urf_ctx* c, size_t bytes, uint8_t** ptr)
 {
     if (!c || !ptr || bytes == 0)
         return URF_ERR_INVALID_ARG;
-    urf_ctx::slot_t& sl = c->slots[c->next_ticket & 1u];   /* the slot the next submission uses */
+    urf_ctx::slot_t& sl = c->slots[c->next_ticket % URF_ASYNC_SLOTS];   /* the slot the next submission uses */
     if (sl.pending)
         return URF_ERR_BUSY;
     URF_HIP(c, hipSetDevice(c->device));
@@ -739,11 +820,15 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
         return URF_ERR_INVALID_ARG;   /* before any byte of the message is copied */
     if (n_points > c->max_points)
         return URF_ERR_CAPACITY;
-    urf_ctx::slot_t& sl = c->slots[c->next_ticket & 1u];
+    urf_ctx::slot_t& sl = c->slots[c->next_ticket % URF_ASYNC_SLOTS];
     if (sl.pending)
-        return URF_ERR_BUSY;          /* both slots in flight: urf_classify_pc2_wait() the older one first */
+        return URF_ERR_BUSY;          /* every slot in flight: urf_classify_pc2_wait() the oldest one first */
     URF_HIP(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)n_points * point_step;
+    /* a message inside the slot's pinned buffer must be the buffer urf_pinned_input() handed out, and
+     * fit it: a larger one would make slot_prepare() free the very memory it is about to read */
+    if (sl.h_in && data >= sl.h_in && data < sl.h_in + sl.h_in_cap && (data != sl.h_in || bytes > sl.h_in_cap))
+        return URF_ERR_INVALID_ARG;
     int rc = slot_prepare(c, sl, bytes);
     if (rc == URF_OK)
         rc = ensure_soa_staging(c);
@@ -763,7 +848,16 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
     }
     URF_HIP(c, hipEventRecord(sl.ev_h2d, c->copy_stream));
     hipStream_t st = slot_stream(c, sl);
+    rc = order_row_after_main(c, slot_row(c, sl), st);
+    if (rc != URF_OK)
+        return rc;
     URF_HIP(c, hipStreamWaitEvent(st, sl.ev_h2d, 0));
+    /* a sweep that defeated the speculative ring table (k_table_repair raised the host-visible flag) ends
+     * the speculation for replayed sequences as well: the captured ones are rebuilt without it */
+    if (c->speculate && *c->h_spec_failed) {
+        c->speculate = false;
+        c->epoch++;
+    }
     /* the launch sequence of a sweep of this shape is captured once and replayed (one graph launch
      * instead of a dozen kernel launches per callback); anything it depends on bumps the epoch */
     const uint64_t key[3] = { c->epoch, ((uint64_t)n_points << 32) | point_step,
@@ -792,23 +886,17 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
         sl.key[0] = key[0];
         sl.key[1] = key[1];
         sl.key[2] = key[2];
-        sl.cap_a = c->last_a;   /* (run_pipeline recorded them while capturing) */
-        sl.cap_dp = c->last_dp;
     }
     if (use_graph) {
         URF_HIP(c, hipGraphLaunch(sl.exec, st));
-        c->last_scans = 1;      /* what urf_read_stage / urf_marker_points / urf_ordered_indices look at */
-        c->last_a = sl.cap_a;
-        c->last_dp = sl.cap_dp;
     } else {
         rc = slot_launch(c, sl, n_points, point_step, off_x, off_y, off_z);
         if (rc != URF_OK)
             return rc;
-        sl.cap_a = c->last_a;
-        sl.cap_dp = c->last_dp;
     }
     URF_HIP(c, hipEventRecord(sl.ev_done, st));
     sl.pending = true;
+    sl.used = true;
     sl.n_points = n_points;
     sl.ticket = c->next_ticket;
     *ticket = c->next_ticket++;
@@ -819,12 +907,14 @@ extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* label
 {
     if (!c)
         return URF_ERR_INVALID_ARG;
-    urf_ctx::slot_t& sl = c->slots[ticket & 1u];
+    urf_ctx::slot_t& sl = c->slots[ticket % URF_ASYNC_SLOTS];
     if (!sl.pending || sl.ticket != ticket)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
     URF_HIP(c, hipEventSynchronize(sl.ev_done));
-    c->last_scans = 1;   /* urf_read_stage / urf_marker_points / urf_ordered_indices now look at THIS sweep */
+    /* only now is the sweep "the last call": urf_read_stage / urf_marker_points / urf_ordered_indices look at
+     * its scratch row, which stays untouched until the slot (or a batch call) is used again */
+    c->last_scans = 1;
     c->last_a = sl.cap_a;
     c->last_dp = sl.cap_dp;
     if (labels_out)
@@ -839,7 +929,13 @@ extern "C" int urf_result_labels(urf_ctx* c, uint32_t ticket, const uint8_t** la
 {
     if (!c || !labels)
         return URF_ERR_INVALID_ARG;
-    *labels = c->slots[ticket & 1u].h_labels;
+    *labels = nullptr;
+    const urf_ctx::slot_t& sl = c->slots[ticket % URF_ASYNC_SLOTS];
+    if (!sl.used || sl.ticket != ticket || !sl.h_labels)
+        return URF_ERR_INVALID_ARG;   /* never issued, or its slot has been used again since */
+    if (sl.pending)
+        return URF_ERR_BUSY;          /* not waited for yet: the buffer is still being written */
+    *labels = sl.h_labels;
     return URF_OK;
 }
 
@@ -876,6 +972,11 @@ extern "C" int urf_compact_indices_batch(urf_ctx* c, const uint8_t* d_labels, ui
     if (n_scans == 0 || n_per_scan == 0)
         return URF_OK;
     URF_HIP(c, hipSetDevice(c->device));
+    {
+        const int orc = order_after_slots(c);   /* compact_cnt is shared scratch */
+        if (orc != URF_OK)
+            return orc;
+    }
     const unsigned tiles = (n_per_scan + URF_TILE - 1) / URF_TILE;
     const dim3 grid(tiles, n_scans);
     hipLaunchKernelGGL(k_compact_count, grid, dim3(URF_COMPACT_THREADS), 0, c->stream, d_labels, n_per_scan, tiles, c->compact_cnt);
@@ -921,7 +1022,9 @@ static int ensure_order_scratch(urf_ctx* c, uint32_t n_scans)
 static int launch_ordered(urf_ctx* c, uint32_t s0, uint32_t n, uint32_t* d_road, uint32_t* d_curb, uint32_t* d_r10,
                           uint32_t stride, uint32_t* d_counts)
 {
-    const int rc = ensure_order_scratch(c, n);
+    int rc = order_after_slots(c);
+    if (rc == URF_OK)
+        rc = ensure_order_scratch(c, n);
     if (rc != URF_OK)
         return rc;
     const urf_kargs a = c->last_a;   /* the call's own arguments and parameters, whatever was set since */
@@ -980,6 +1083,11 @@ extern "C" int urf_ordered_indices(urf_ctx* c, uint32_t scan, uint32_t* road, ui
 
 static int launch_markers(urf_ctx* c, uint32_t s0, uint32_t n, float* d_pts, uint32_t* d_counts)
 {
+    {
+        const int orc = order_after_slots(c);
+        if (orc != URF_OK)
+            return orc;
+    }
     const size_t cells = (size_t)URF_MAX_CHANNELS * URF_DEG_CELLS;
     if (n > c->mk_scans) {
         URF_HIP(c, hipStreamSynchronize(c->stream));
@@ -1061,16 +1169,17 @@ static int ring_slot_sources(urf_ctx* c, uint32_t scan, uint32_t len, std::vecto
     const urf_kargs& k = c->last_a;
     const unsigned C = (unsigned)c->last_dp.p.channels;
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
-    std::vector<uint16_t> troff, rsrc;
+    std::vector<uint16_t> troff;
+    std::vector<uint32_t> rec;
     int rc;
     if ((rc = fetch(c, troff, k.troff + (size_t)scan * k.tiles * (C + 1), (size_t)ntiles * (C + 1))) != URF_OK) return rc;
-    if ((rc = fetch(c, rsrc, k.rsrc + (size_t)scan * k.sstride, (size_t)ntiles * URF_TILE)) != URF_OK) return rc;
+    if ((rc = fetch(c, rec, k.rec + (size_t)scan * k.sstride, (size_t)ntiles * URF_TILE)) != URF_OK) return rc;
     slot.clear();
     src.clear();
     for (unsigned t = 0; t < ntiles; t++)
         for (unsigned j = 0; j < troff[(size_t)t * (C + 1) + C]; j++) {
             slot.push_back(t * URF_TILE + j);
-            src.push_back(t * URF_TILE + rsrc[(size_t)t * URF_TILE + j]);
+            src.push_back(t * URF_TILE + (rec[(size_t)t * URF_TILE + j] & URF_REC_SRC_MASK));
         }
     return URF_OK;
 }
@@ -1080,6 +1189,11 @@ extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* h
     if (!c || !host_dst || scan >= c->last_scans)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
+    {
+        const int orc = order_after_slots(c);   /* (sweeps still in flight on other rows' streams) */
+        if (orc != URF_OK)
+            return orc;
+    }
     URF_HIP(c, hipStreamSynchronize(c->stream));
     const urf_kargs& k = c->last_a;   /* the arguments and parameters of the call whose results are read */
     uint32_t len;
@@ -1135,14 +1249,14 @@ extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* h
         if ((rc = ring_slot_sources(c, scan, len, slot, src)) != URF_OK) return rc;
         const size_t span = (size_t)((len + URF_TILE - 1) / URF_TILE) * URF_TILE;
         if (what == URF_STAGE_DETECT) {
-            std::vector<uint8_t> fl;
-            if ((rc = fetch(c, fl, k.rflag + sb, span)) != URF_OK) return rc;
+            std::vector<uint32_t> rec;   /* the detector hits of a slot's record */
+            if ((rc = fetch(c, rec, k.rec + sb, span)) != URF_OK) return rc;
             uint8_t* o = (uint8_t*)host_dst;
             for (size_t p = 0; p < slot.size(); p++)
-                o[src[p]] = fl[slot[p]] & 7u;
+                o[src[p]] = (uint8_t)((rec[slot[p]] >> URF_REC_FLAG_SHIFT) & 7u);
         } else {
             std::vector<float> v;
-            if ((rc = fetch(c, v, (what == URF_STAGE_AZIMUTH ? k.raz : k.rd2) + sb, span)) != URF_OK) return rc;
+            if ((rc = fetch(c, v, (what == URF_STAGE_AZIMUTH ? k.caz : k.rd2) + sb, span)) != URF_OK) return rc;
             float* o = (float*)host_dst;
             for (size_t p = 0; p < slot.size(); p++)
                 o[src[p]] = v[slot[p]];

@@ -411,6 +411,18 @@ __device__ __forceinline__ float urf_fast_azimuth_of(float fi)
     const float az = fi * 57.295779513082323f + 90.0f;
     return az >= 360.0f ? az - 360.0f : az;
 }
+/* the azimuth field of a slot record (urf_internal.hpp: URF_REC_*): az in [0, 360) -> 18-bit code and back
+ * (the code's centre); the all-ones code is "unknown" */
+static_assert(URF_TILE == URF_REC_SRC_MASK + 1u, "the record's source field holds an index inside a tile");
+__device__ __forceinline__ unsigned urf_az_code(float az)
+{
+    const unsigned c = (unsigned)(az * URF_REC_AZ_SCALE);
+    return c < URF_REC_AZ_UNKNOWN - 1u ? c : URF_REC_AZ_UNKNOWN - 1u;
+}
+__device__ __forceinline__ float urf_az_decode(unsigned code)
+{
+    return code == URF_REC_AZ_UNKNOWN ? URF_AZ_UNKNOWN : ((float)code + 0.5f) * URF_REC_AZ_STEP;
+}
 __device__ __forceinline__ bool urf_fast_az_ok(float x, float y)
 {
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);

@@ -29,8 +29,25 @@
 #define URF_SLOT_NONE       0xFFFFu
 #define URF_TABLE_LOOKAHEAD 8192    /* k_ring_table gives up waiting for a new ring after this many points (speculation) */
 
-#define URF_RFLAG_AZ_APPROX 0x80u   /* rflag: raz holds the float approximation, not the reference value */
-#define URF_RAZ_UNKNOWN      -1.0f   /* raz of a point too close to the x axis for the approximation (urf_fast_az_ok): exact azimuth on demand */
+/* The record of a ring-sorted slot (k_split -> k_ring -> k_label), ONE word per point:
+ *   bits  0-10  index of the point inside its input tile (where its label byte goes)
+ *   bits 11-13  detector hits, OR-ed in by k_ring: 1 star-shaped, 2 x_zero, 4 z_zero
+ *   bits 14-31  k_split's float approximation of the azimuth in steps of 360 / 262143 deg
+ *               (URF_REC_AZ_UNKNOWN: the point lies too close to the x axis for the approximation,
+ *               urf_fast_az_ok -- exact azimuth on demand)
+ * The exact azimuth of lidar_segmentation.cpp:245-269 is only ever needed for curb points (beam tables,
+ * k_ring) and for the few points whose road decision the approximation leaves open (k_label); both
+ * compute it from the slot's x / y.  (r2 kept a float azimuth, a source index and a flag byte per
+ * slot: 7 bytes written and 7 read per point instead of 4 and 4.) */
+#define URF_REC_SRC_MASK    0x7FFu
+#define URF_REC_FLAG_SHIFT  11
+#define URF_REC_AZ_SHIFT    14
+#define URF_REC_AZ_UNKNOWN  0x3FFFFu
+#define URF_REC_AZ_SCALE    (262143.0f / 360.0f)
+#define URF_REC_AZ_STEP     (360.0f / 262143.0f)
+#define URF_REC_AZ_QERR     9.0e-4f   /* |decoded - encoded azimuth| <= 0.52 steps = 7.2e-4 deg, plus what the decoded value's
+                                         distance from the x axis adds to urf_fast_az_eps (1.5e-4) */
+#define URF_AZ_UNKNOWN      -1.0f     /* decoded value of URF_REC_AZ_UNKNOWN */
 #define URF_RING_NONE       0xFFu
 #define URF_SEC_NONE        0x3FFu
 
@@ -66,8 +83,8 @@ struct urf_dev_params {
  * [s * sstride, (s + 1) * sstride), sstride = tiles * URF_TILE + URF_SCAN_PAD, independent of where
  * the caller keeps the scan (offsets[]).  Tile t of the scan (input points [t * URF_TILE, ...)) owns
  * [s * sstride + t * URF_TILE, ... + URF_TILE) of every per-point array:
- *   ring-sorted   rx ry rz rsrc   slot j = the tile's points that lie on a ring, ordered by ring,
- *                 raz rflag       input order inside a ring (stable); rsrc = index inside the tile
+ *   ring-sorted   rx ry rz rec    slot j = the tile's points that lie on a ring, ordered by ring,
+ *                                 input order inside a ring (stable); rec = URF_REC_* word
  *   sector-sorted sr sz sslot     the tile's points that take part in the star-shaped search,
  *                                 ordered by sector, input order inside; sslot = the point's
  *                                 ring-sorted slot (URF_SLOT_NONE if it lies on no ring)
@@ -75,8 +92,8 @@ struct urf_dev_params {
  * scan = the concatenation over the tiles of run [troff[t][c], troff[t][c+1]); k_index turns the
  * rings' per-tile run tables into per-ring tables (prefix over the tiles, start inside the tile);
  * a sector's runs are read from tsoff directly (it meets few tiles).  What k_ring produces per point
- * (rflag, exact azimuths) goes into the point's ring-sorted slot; what the star sort produces is
- * contiguous per sector (wslp, wg, ssrt: at s * sstride + sec_off[k] + i). */
+ * (detector hits) goes into the point's ring-sorted record; what the star sort produces is
+ * contiguous per sector (wslp, wg, ssrt16 / ssrt: at s * sstride + sec_off[k] + i). */
 /* A sector's points sit in one run per tile (k_split's sector-sorted order).  The first two non-empty
  * runs: point i of the sector is element a0 + i of the sector-sorted arrays for i < c0, a1 + (i - c0)
  * beyond (indices relative to the scan's scratch); nruns > 2: the sort walks the per-tile tables. */
@@ -106,20 +123,23 @@ struct urf_kargs {
     float*    valpha;
     uint16_t* seckey;
     uint8_t*  ringkey;
+    float*    caz;              /* capture mode 1: exact azimuth per ring-sorted slot (k_ring) */
     /* per point, ring-sorted inside the tile */
     float*    rx;
     float*    ry;
     float*    rz;
-    uint16_t* rsrc;
-    float*    raz;              /* azimuth: k_split's approximation, k_ring's exact value where rflag says so */
+    uint32_t* rec;              /* URF_REC_*: source index | detector hits | approximate azimuth */
     float*    rd2;              /* planar range, stage capture only (may be NULL) */
-    uint8_t*  rflag;            /* k_ring: detector hits (bits 0-2) | URF_RFLAG_AZ_APPROX */
     /* per point, sector-sorted inside the tile */
     float*    sr;
     float*    sz;
     uint16_t* sslot;
     /* per point, sector-major */
-    uint32_t* ssrt;             /* tile-local ring-sorted index (t * URF_TILE + slot) of the i-th point of the sector in sorted order */
+    uint16_t* ssrt16;           /* sectors of at most two runs and at most URF_STAR_MID_CAP points (every sector of an
+                                 * organised sweep): position inside the sector (input order) of the i-th point in sorted order;
+                                 * the walk turns the one it needs into a slot through sec_run and sslot */
+    uint32_t* ssrt;             /* all other sectors: tile-local ring-sorted index (t * URF_TILE + slot) of the i-th point in
+                                 * sorted order, 0xffffffff = on no ring */
     float*    wslp;             /* slope between the (i-1)-th and i-th point of the sector in sorted order */
     float*    wg;               /* (r_i - r_{i-1}) * kdist */
     /* per scan x tile (k_split) */

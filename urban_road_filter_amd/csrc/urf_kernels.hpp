@@ -387,14 +387,14 @@ __host__ __device__ inline unsigned urf_align16(unsigned v) { return (v + 15u) &
 
 /* LDS carve of k_split: tab | ul | thr | lut | koff[C+1] | soff[Ks+1] | misc[16] | tmax[C] u64 |
  * union { keyr[T] u8, keys[T] u16, pending[T] u16, wcnt_r[W][C] u16, wcnt_s[W][Ks] u16 ;
- *         staging x y z azimuth src [URF_SLOTS] u32 } */
+ *         staging x y z record [URF_SLOTS] u32 } */
 __host__ __device__ inline size_t urf_split_lds_bytes(unsigned C, unsigned K, bool star)
 {
     const unsigned Ks = star ? K : 0;
     const size_t fixed = URF_MAX_CHANNELS * (4 + 4 + 16) + urf_align16(URF_LUT_CELLS) + urf_align16((C + 1) * 4) +
                          urf_align16((Ks + 1) * 4) + 64 + urf_align16(C * 8);
     const size_t phase_a = 5 * (size_t)URF_TILE + urf_align16(2 * URF_TILE_WAVES * (C + Ks));
-    const size_t phase_b = 5 * (size_t)URF_SLOTS * 4;
+    const size_t phase_b = 4 * (size_t)URF_SLOTS * 4;
     return fixed + (phase_a > phase_b ? phase_a : phase_b);
 }
 
@@ -559,7 +559,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
      * f64 chains never run with two lanes of a wave. */
     const bool exact_all = a.capture == 1;
     unsigned rkey[Q], skey[Q];
-    float azf[Q];            /* approximate azimuth [deg] (urf_device.hpp), consumed by k_label */
+    unsigned azc[Q];         /* approximate azimuth (urf_device.hpp) as the code of the slot record (URF_REC_*), consumed by k_label */
     unsigned openmask = 0;   /* bit q: point q of this thread is on the pending list */
     /* Written phase by phase over the thread's four points, so that the four dependent LDS reads of
      * the ring search (lookup cell, two probes, the entry's thresholds) are in flight for all four
@@ -569,13 +569,27 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
         const unsigned i = tbase + wave * 256 + q * 64 + lane;
+        roim |= (unsigned)((i < len) & urf_in_roi(dp.p, px[q], py[q], pz[q])) << q;
+    }
+    /* A wave none of whose 256 points lies in the region of interest has nothing to classify (uniform
+     * branch): the reference's default region drops whole azimuth ranges of a sweep, i.e. whole tiles in
+     * firing order (cfg/LidarFilters.cfg:42-51, lidar_segmentation.cpp:100-117). */
+    const bool wave_on = __ballot(roim != 0u) != 0ull;
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        rkey[q] = URF_RING_NONE;
+        skey[q] = URF_SEC_NONE;
+        azc[q] = URF_REC_AZ_UNKNOWN;
+    }
+    if (wave_on) {
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
         const float x = px[q], y = py[q], z = pz[q];
-        const bool roi = (i < len) & urf_in_roi(dp.p, x, y, z);
+        const bool roi = (roim >> q) & 1u;
         float u;
         bool planar;
         const bool fast = urf_fast_cot(x, y, z, &u, &planar) & roi & !exact_all;
         uu[q] = fast ? u : 0.f;
-        roim |= (unsigned)roi << q;
         fastm |= (unsigned)fast << q;
         /* lo = number of table entries surely below the point's window: the cell's count from the
          * lookup table, plus up to two entries between the cell's end and u (a third one is rare
@@ -609,7 +623,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         const unsigned rk = rkey[q];
         unsigned sk = URF_SEC_NONE;
         const float fi = urf_fast_polar(x, y);   /* one arc tangent: the star sector and the azimuth */
-        azf[q] = urf_fast_az_ok(x, y) ? urf_fast_azimuth_of(fi) : URF_RAZ_UNKNOWN;   /* (too close to the x axis: exact on demand) */
+        azc[q] = urf_fast_az_ok(x, y) ? urf_az_code(urf_fast_azimuth_of(fi)) : URF_REC_AZ_UNKNOWN;   /* (too close to the x axis: exact on demand) */
         if (star) {
             /* (decided on the approximation only where the ring was: magnitudes checked there; the few
              * points steeper than |z| = 4 rho take the exact sequence for both) */
@@ -628,6 +642,12 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             pending[atomicAdd(&misc[1], 1u)] = (uint16_t)li;
             openmask |= 1u << q;
         }
+    }
+    }
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned li = wave * 256 + q * 64 + lane, i = tbase + li;
+        const bool roi = (roim >> q) & 1u;
         if (i < len && exact_all && !roi)
             a.valpha[sb + i] = -1.0f;   /* stage capture only */
         /* the label bytes are k_label's: it gets the region-of-interest bits of the tile, 64 per word */
@@ -640,6 +660,30 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     }
     __syncthreads();
     URF_PHASE_MARK;
+    if (misc[0] == 0) {
+        /* no point of the tile lies in the region of interest (uniform): empty run tables, and the
+         * remaining six phases (exact pass, ranks, scans, transposes) have nothing to do */
+        const size_t row0 = (size_t)s * a.tiles + t;
+        for (unsigned k = tid; k <= C; k += URF_TILE_THREADS)
+            a.troff[row0 * (C + 1) + k] = 0;
+        for (unsigned k = tid; k < C; k += URF_TILE_THREADS)
+            a.tmaxs[row0 * C + k] = 0ull;
+        if (star)
+            for (unsigned k = tid; k <= K; k += URF_TILE_THREADS)
+                a.tsoff[row0 * (K + 1) + k] = 0;
+        if (tid == 0)
+            a.tile_roi[row0] = 0;
+        if (a.capture)   /* stage capture only */
+#pragma unroll
+            for (unsigned q = 0; q < Q; q++) {
+                const unsigned i = tbase + wave * 256 + q * 64 + lane;
+                if (i < len) {
+                    a.ringkey[sb + i] = (uint8_t)URF_RING_NONE;
+                    a.seckey[sb + i] = (uint16_t)URF_SEC_NONE;
+                }
+            }
+        return;
+    }
     const unsigned np = misc[1];
     for (unsigned k = tid; k < np; k += URF_TILE_THREADS) {
         const unsigned li = pending[k], i = tbase + li;
@@ -780,8 +824,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     unsigned* stx = (unsigned*)un;
     unsigned* sty = stx + URF_SLOTS;
     unsigned* stz = sty + URF_SLOTS;
-    unsigned* sta = stz + URF_SLOTS;
-    unsigned* sts = sta + URF_SLOTS;
+    unsigned* str = stz + URF_SLOTS;
     const unsigned tb = sb + tbase;
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
@@ -792,8 +835,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             stx[sl] = __float_as_uint(x);
             sty[sl] = __float_as_uint(y);
             stz[sl] = __float_as_uint(z);
-            sta[sl] = __float_as_uint(azf[q]);
-            sts[sl] = li;
+            str[sl] = (azc[q] << URF_REC_AZ_SHIFT) | li;   /* the slot's record: no detector hit so far */
         }
         if (sp[q] != 0xffffffffu) {
             __builtin_nontemporal_store(__builtin_sqrtf(x * x + y * y), &a.sr[tb + sp[q]]);   /* star_shaped_search.cpp:164 */
@@ -812,8 +854,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         __builtin_nontemporal_store(__uint_as_float(stx[sl]), &a.rx[tb + j]);
         __builtin_nontemporal_store(__uint_as_float(sty[sl]), &a.ry[tb + j]);
         __builtin_nontemporal_store(__uint_as_float(stz[sl]), &a.rz[tb + j]);
-        __builtin_nontemporal_store(__uint_as_float(sta[sl]), &a.raz[tb + j]);
-        __builtin_nontemporal_store((uint16_t)sts[sl], &a.rsrc[tb + j]);
+        __builtin_nontemporal_store(str[sl], &a.rec[tb + j]);
     }
     const size_t row = (size_t)s * a.tiles + t;
     for (unsigned k = tid; k <= C; k += URF_TILE_THREADS)
@@ -1193,8 +1234,13 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
     const unsigned B = (n + 63) >> 6;
     URF_PHASE_ACC_DECL;
     unsigned long long key[MAXB];
-    float zreg[MAXB];      /* height and ring-major position travel with the key: the tail */
-    unsigned sreg[MAXB];   /* then needs no dependent gathers from memory */
+    float zreg[MAXB];      /* the height travels with the key: the tail then needs no dependent gathers from memory */
+    /* What the walk finally needs of the sorted sector is ONE point: its curb point.  A sector of at most two
+     * runs (every sector of an organised sweep) therefore publishes, per sorted index, only the point's position
+     * inside the sector (2 bytes; the walk turns the one it wants into a ring-sorted slot through sec_run and
+     * sslot) and never reads the slots.  Sectors scattered over more tiles carry the slot with the key and
+     * publish tile-local ring-sorted indices (4 bytes), as r2 did for all. */
+    unsigned sreg[MAXB];
     unsigned rmin = 0xffffffffu, rmax = 0;
     {
         /* the sector's points are gathered run by run (urf_sector_runs; the list sits in A's memory
@@ -1227,13 +1273,14 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
             if (q < B) {   /* uniform */
                 rbv[q] = urf_fbits(a.sr[sb + adr[q]]);
                 zreg[q] = a.sz[sb + adr[q]];
-                slv[q] = a.sslot[sb + adr[q]];
+                if (!simple)
+                    slv[q] = a.sslot[sb + adr[q]];
             }
         }
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
             const bool valid = q * 64 + lane < n;
-            sreg[q] = slv[q] == URF_SLOT_NONE ? 0xffffffffu : (adr[q] & ~(URF_TILE - 1u)) + slv[q];
+            sreg[q] = simple ? q * 64 + lane : (slv[q] == URF_SLOT_NONE ? 0xffffffffu : (adr[q] & ~(URF_TILE - 1u)) + slv[q]);
             key[q] = valid ? ((unsigned long long)rbv[q] << 32) | adr[q] : ~0ull;
             rmin = valid && rbv[q] < rmin ? rbv[q] : rmin;
             rmax = valid && rbv[q] > rmax ? rbv[q] : rmax;
@@ -1383,8 +1430,12 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
                 if (key[q] != ~0ull) {   /* the key moved to another lane: fetch its companions again */
                     const unsigned adr = (unsigned)key[q];
                     zreg[q] = a.sz[sb + adr];
-                    const unsigned sl = a.sslot[sb + adr];
-                    sreg[q] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+                    if (nruns == 0) {   /* (uniform) at most two runs: the position inside the sector from the address */
+                        sreg[q] = (two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0;
+                    } else {
+                        const unsigned sl = a.sslot[sb + adr];
+                        sreg[q] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+                    }
                 }
             }
         __syncthreads();
@@ -1399,9 +1450,10 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
     }
     __syncthreads();   /* every lane has its ranks: A and cnt may be overwritten */
     URF_PHASE_ACC(3);
-    unsigned* R = (unsigned*)A;      /* range bits, height, ring-major position in sorted order */
+    unsigned* R = (unsigned*)A;      /* range bits, height, position / ring-sorted index in sorted order */
     float* Z = (float*)A + 512;
     unsigned* S = cnt;
+    static_assert(URF_STAR_NB + 1 >= MAXB * 64, "S reuses the bucket counters: one word per point of the sector");
 #pragma unroll
     for (unsigned q = 0; q < MAXB; q++)
         if (q < B && key[q] != ~0ull) {
@@ -1428,7 +1480,10 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
                 if (slp > slope_param)
                     atomicMin(sh_first, i);
             }
-            a.ssrt[obase + i] = S[i];
+            if (nruns == 0)
+                a.ssrt16[obase + i] = (uint16_t)S[i];
+            else
+                a.ssrt[obase + i] = S[i];
             a.wslp[obase + i] = slp;
             a.wg[obase + i] = g;
         }
@@ -1768,13 +1823,18 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
         /* height and ring-sorted index are fetched once the ranks are known (the low half of a key is
          * the point's place in the sector-sorted arrays): carried along from the start they did not
          * fit the 64 registers of 8 waves per SIMD and went through scratch memory */
+        /* (at most two runs: the point's position inside the sector instead of its slot, see urf_star_sort_sector) */
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++)
             if (key[e] != ~0ull) {
                 const unsigned adr = (unsigned)key[e];
                 zreg[e] = a.sz[sb + adr];
-                const unsigned sl = a.sslot[sb + adr];
-                sreg[e] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+                if (simple) {
+                    sreg[e] = adr >= two_a1 && two_a1 > two_a0 ? two_c0 + (adr - two_a1) : adr - two_a0;
+                } else {
+                    const unsigned sl = a.sslot[sb + adr];
+                    sreg[e] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+                }
             }
         URF_PHASE_ACC(2);
         /* range bits, height, ring-sorted index in sorted order (A and cnt are free again) */
@@ -1806,7 +1866,10 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
                     if (slp > slope_param)
                         atomicMin(&sh_first, i);
                 }
-                a.ssrt[obase + i] = S[i];
+                if (simple)
+                    a.ssrt16[obase + i] = (uint16_t)S[i];
+                else
+                    a.ssrt[obase + i] = S[i];
                 a.wslp[obase + i] = slp;
                 a.wg[obase + i] = g;
             }
@@ -2091,10 +2154,24 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
         __syncthreads();
     }
     /* the curb point of the sector, reported where k_ring looks for it: as a position in the
-     * ring-major arrays.  ssrt holds its tile-local ring-sorted index t * URF_TILE + slot; the ring
-     * is the run of tile t that contains the slot (bisection in the tile's run table). */
+     * ring-major arrays.  Its tile-local ring-sorted index t * URF_TILE + slot: for a sector of at
+     * most two runs the sort left the point's position inside the sector (ssrt16), which sec_run turns
+     * into its place in the sector-sorted arrays, where its slot stands; other sectors hold the index
+     * itself (ssrt).  The ring is the run of tile t that contains the slot (bisection in the tile's
+     * run table). */
     int hit = -1;
-    const unsigned v = hit_i ? a.ssrt[base + hit_i] : 0xffffffffu;
+    unsigned v = 0xffffffffu;
+    if (hit_i) {
+        const urf_sec_run two = a.sec_run[(size_t)s * K + k];
+        if (two.nruns <= 2 && n <= URF_STAR_MID_CAP_) {
+            const unsigned i0 = a.ssrt16[base + hit_i];
+            const unsigned adr = i0 < two.c0 ? two.a0 + i0 : two.a1 + (i0 - two.c0);
+            const unsigned sl = a.sslot[urf_sbase(a, s) + adr];
+            v = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+        } else {
+            v = a.ssrt[base + hit_i];
+        }
+    }
     if (v != 0xffffffffu) {
         const unsigned t = v / URF_TILE, j = v % URF_TILE;
         const uint16_t* row = a.troff + ((size_t)s * a.tiles + t) * (C + 1);
@@ -2153,7 +2230,7 @@ struct urf_ring_shared_t {
     int q[4];
     unsigned long long maxs;
     unsigned hits[URF_RING_HITS];
-    unsigned n_hits;
+    unsigned n_hits, n_runs;
     unsigned hb[3][URF_RING_CHUNK / 32];   /* star-hit bit per point of the chunk; three in rotation: the one of chunk c + 1
                                             * is cleared while chunk c is parked and c - 1 may still be read */
     /* quad mapping: the ring's points that need one of the expensive evaluations, compacted */
@@ -2178,7 +2255,7 @@ typedef urf_ring_shared_t<false> urf_ring_shared;
 struct urf_ring_map {
     const unsigned* P;
     const unsigned* radd;
-    unsigned ntiles;
+    unsigned ntiles;   /* entries (k_ring lists the ring's non-empty runs only: then "tile" = index of the run) */
     float scale;   /* ntiles / n */
     __device__ __forceinline__ unsigned tile(unsigned j) const
     {
@@ -2186,6 +2263,10 @@ struct urf_ring_map {
         t = t < ntiles ? t : ntiles - 1;
         if (P[t] <= j && j < P[t + 1])
             return t;
+        /* one entry off (runs of unequal length: a region of interest that cuts firings apart) */
+        const unsigned t1 = j < P[t] ? (t ? t - 1 : 0u) : (t + 1 < ntiles ? t + 1 : t);
+        if (P[t1] <= j && j < P[t1 + 1])
+            return t1;
         unsigned lo = 0, hi = ntiles;   /* largest t with P[t] <= j */
         while (hi - lo > 1) {
             const unsigned mid = (lo + hi) >> 1;
@@ -2296,13 +2377,15 @@ __device__ __noinline__ bool urf_z_zero_angle_window(const float* xs, const floa
  * maxDistance (:271-274) is the largest float(sqrt(double s)), s = x^2 + y^2: both roundings
  * are monotone, so the callers track the largest s instead. */
 template <class SHARED>
-__device__ __noinline__ float urf_ring_point(float* rd2, SHARED& S, unsigned gpos, float px, float py,
+__device__ __noinline__ float urf_ring_point(float* rd2, float* caz, SHARED& S, unsigned gpos, float px, float py,
                                              unsigned flag, bool want_quad)
 {
     float d2;
     const float az = urf_azimuth(px, py, &d2);
-    if (rd2)
+    if (rd2) {   /* stage capture */
         rd2[gpos] = d2;
+        caz[gpos] = az;
+    }
     if (flag && az == az) {
         /* curb point: per-degree tables for the beam march.  The azimuth lies in [0,360];
          * cell_lo = largest integer <= az, cell_hi = smallest integer >= az. */
@@ -2381,8 +2464,6 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
         if (t < ntiles)
             mapA[t] = sb + t * URF_TILE + gs[t] - pt;
     }
-    const urf_ring_map map = { mapP, mapA, ntiles, (float)ntiles / (float)(n > 0 ? n : 1) };
-
     for (unsigned i = tid; i < URF_DEG_CELLS; i += URF_RING_THREADS) {
         cmin[i] = URF_INT_NONE_MIN;
         cmax[i] = -1;
@@ -2400,6 +2481,30 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
     }
     __syncthreads();
     URF_PHASE_ACC(0);
+    /* The ring's map lists its NON-EMPTY runs only: the guess "run = position / average run length" is then
+     * exact for an organised sweep whatever azimuth ranges the region of interest removes (with the empty
+     * tiles of the reference's default region in the table almost every lookup fell through to the bisection:
+     * k_ring took longer on 40 % of the points than on all of them).  One wave compacts the table in place,
+     * 64 entries at a time in ascending order (an entry never moves up), before the barrier below. */
+    if (tid < 64) {
+        unsigned m = 0;
+        for (unsigned t0 = 0; t0 < ntiles; t0 += 64) {
+            const unsigned t = t0 + tid;
+            const unsigned p0 = t < ntiles ? mapP[t] : 0u, p1 = t < ntiles ? mapP[t + 1] : 0u;
+            const unsigned ad = t < ntiles ? mapA[t] : 0u;
+            const unsigned long long bm = __ballot(p1 > p0);
+            if (p1 > p0) {
+                const unsigned e = m + urf_popc_below(bm);
+                mapP[e] = p0;
+                mapA[e] = ad;
+            }
+            m += (unsigned)__popcll(bm);
+        }
+        if (tid == 0) {
+            mapP[m] = (unsigned)n;
+            S.n_runs = m;
+        }
+    }
     /* lidar_segmentation.cpp:241-242: the star-shaped hits that lie on this ring, as ring positions.  A short
      * list (a ring rarely holds more than a handful of the scan's <= 1022 hits; a list for all of them cost
      * 4 KB of LDS, i.e. resident workgroups); if it overflows, every chunk scans the scan's hits again. */
@@ -2423,6 +2528,8 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
     __syncthreads();
     URF_PHASE_ACC(1);
     const unsigned nh = S.n_hits;
+    const unsigned nruns = S.n_runs;
+    const urf_ring_map map = { mapP, mapA, nruns, (float)nruns / (float)(n > 0 ? n : 1) };
     constexpr bool quads = QUADS;
     double maxs = 0.0;
     {   /* (rows of tiles behind the scan's last one hold whatever an earlier call left there) */
@@ -2569,7 +2676,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                             (double)__builtin_fabsf(max1 - max2) >= 0.05)                        /* z_zero_method.cpp:67-69 */
                             t |= URF_CAND_ZZERO;
                     }
-                    /* (a point too close to the x axis for k_split's approximate azimuth carries URF_RAZ_UNKNOWN
+                    /* (a point too close to the x axis for k_split's approximate azimuth carries URF_REC_AZ_UNKNOWN
                      * and gets its exact azimuth in k_label; the ring's largest range comes from k_split's
                      * per-tile maxima: this path reads neither x nor y) */
                     if (a.rd2)   /* stage capture: exact azimuth and planar range of every point */
@@ -2577,19 +2684,8 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                     if (t)
                         S.cand[atomicAdd(&S.n_cand, 1u)] = (unsigned)p | (t << URF_CAND_SHIFT);
                 }
-                /* every point leaves as "no curb, azimuth approximate" (the approximation is the
-                 * one k_split stored next to the point); the candidate pass rewrites the ones for
-                 * which that is not the whole truth.  Flags live in the point's ring-sorted slot. */
-                const unsigned t0 = map.tile((unsigned)q0);
-                const unsigned idx0 = mapA[t0] + (unsigned)q0;
-                if (q0 + 3 < n && (unsigned)q0 + 3 < mapP[t0 + 1] && (idx0 & 3u) == 0) {
-                    *(unsigned*)(a.rflag + idx0) = URF_RFLAG_AZ_APPROX * 0x01010101u;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (q0 + i < n)
-                            a.rflag[map.at((unsigned)(q0 + i))] = (uint8_t)URF_RFLAG_AZ_APPROX;
-                }
+                /* (nothing is stored per point here: k_split left every slot's record as "no detector hit,
+                 * approximate azimuth"; the candidate pass ORs the hits of the few curb points into theirs) */
             }
             __syncthreads();
             URF_PHASE_ACC(3);
@@ -2615,11 +2711,12 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                         urf_z_zero_angle_gather(a.rx, a.ry, map, dp.inv_cp, dp.p.angleFilter2, p, 5, px, py))
                         flag |= 4u;
                     if (flag || (t & URF_CAND_EXACT)) {
-                        const float az = urf_ring_point(a.rd2, S, ip, px, py, flag, want_quad);
-                        a.raz[ip] = az;
-                        a.rflag[ip] = (uint8_t)flag;
-                        if (!(az == az))   /* x == y == 0: deviation D5 (include/urf.h), counted per scan */
-                            atomicAdd(&a.info[s].n_nan_azimuth, 1u);
+                        const float az = urf_ring_point(a.rd2, a.caz, S, ip, px, py, flag, want_quad);
+                        if (flag) {
+                            atomicOr(&a.rec[ip], flag << URF_REC_FLAG_SHIFT);
+                            if (!(az == az))   /* x == y == 0: deviation D5 (include/urf.h), counted per scan (the others: k_label) */
+                                atomicAdd(&a.info[s].n_nan_azimuth, 1u);
+                        }
                     }
                 }
                 __syncthreads();
@@ -2671,14 +2768,17 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                             flag |= 4u;
                     }
                 }
-                const unsigned ip = map.at((unsigned)p);
-                const float az = urf_ring_point(a.rd2, S, ip, px, py, flag, want_quad);
                 const double s2 = (double)px * (double)px + (double)py * (double)py;
                 maxs = s2 > maxs ? s2 : maxs;
-                a.raz[ip] = az;
-                a.rflag[ip] = (uint8_t)flag;
-                if (!(az == az))
-                    atomicAdd(&a.info[s].n_nan_azimuth, 1u);
+                if (flag || a.rd2) {   /* the exact azimuth: curb points (beam tables) and the stage capture */
+                    const unsigned ip = map.at((unsigned)p);
+                    const float az = urf_ring_point(a.rd2, a.caz, S, ip, px, py, flag, want_quad);
+                    if (flag) {
+                        atomicOr(&a.rec[ip], flag << URF_REC_FLAG_SHIFT);
+                        if (!(az == az))
+                            atomicAdd(&a.info[s].n_nan_azimuth, 1u);
+                    }
+                }
             }
         }
         if (!QUADS)   /* (two z windows: the next chunk is parked into the other one; n_cand / the hit bitmaps are ordered by the barrier after the parking) */
@@ -2988,22 +3088,26 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
      * the slots' input indices up front was measured: no gain, and beyond 72 registers the kernel
      * loses a resident workgroup.) */
     const urf_scan_info in = a.info[s];
+    const unsigned troi = a.tile_roi[row];
     const unsigned v_koff = tid <= C ? (unsigned)a.troff[row * (C + 1) + tid] : 0;
     /* ... and so are the records of the thread's eight slots (their addresses depend on nothing but the
      * thread's index: requested behind the tables they arrive while the rings of the slots are worked out) */
-    const unsigned slot0 = sb + tbase + tid;   /* ring-sorted slot of point q: slot0 + 256 q (flag, azimuth, source, x, y) */
-    unsigned rfl[Q], rsr[Q];
-    float raz[Q];
+    const unsigned slot0 = sb + tbase + tid;   /* ring-sorted slot of point q: slot0 + 256 q (record, x, y) */
+    unsigned rec[Q];   /* URF_REC_*: index inside the tile | detector hits | approximate azimuth */
 #pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        rfl[q] = (unsigned)a.rflag[slot0 + q * URF_LABEL_TILE_THREADS];
-        raz[q] = a.raz[slot0 + q * URF_LABEL_TILE_THREADS];
-        rsr[q] = (unsigned)a.rsrc[slot0 + q * URF_LABEL_TILE_THREADS];   /* index inside the tile */
-    }
-    if (in.status != URF_OK) {
-        /* nothing is published for this scan (lidar_segmentation.cpp:124-126): all labels 0 */
-        for (unsigned i = tbase + tid; i < len && i < tbase + URF_TILE; i += URF_LABEL_TILE_THREADS)
-            a.labels[off + i] = 0;
+    for (unsigned q = 0; q < Q; q++)
+        rec[q] = a.rec[slot0 + q * URF_LABEL_TILE_THREADS];
+    if (in.status != URF_OK || troi == 0) {
+        /* nothing is published for this scan (lidar_segmentation.cpp:124-126), or no point of the tile
+         * lies in the region of interest (k_split; the reference's default region drops whole azimuth
+         * ranges of a sweep): all labels 0 */
+        uint8_t* out0 = a.labels + off + tbase;
+        if (tbase + URF_TILE <= len && ((uintptr_t)out0 & 7u) == 0) {   /* uniform */
+            ((uint2*)out0)[tid] = make_uint2(0u, 0u);
+        } else {
+            for (unsigned i = tbase + tid; i < len && i < tbase + URF_TILE; i += URF_LABEL_TILE_THREADS)
+                a.labels[off + i] = 0;
+        }
         return;
     }
     if (tid <= C)
@@ -3090,7 +3194,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         const unsigned q = q0 + qq;
         const unsigned j = tid + q * URF_LABEL_TILE_THREADS;
         cc[qq] = (unsigned)ring_of[j] - 1u;   /* (past the last slot: the last ring, from the prefix maximum) */
-        const float az = raz[q];
+        const float az = urf_az_decode(rec[q] >> URF_REC_AZ_SHIFT);
         const bool num = az == az;
         int cf = num ? (int)__builtin_floorf(az) : 0, cb = num ? (int)__builtin_ceilf(az) : 0;
         cf = cf < 0 ? 0 : (cf > 360 ? 360 : cf);
@@ -3104,19 +3208,18 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         const unsigned j = tid + q * URF_LABEL_TILE_THREADS;
         const bool valid = j < npts;
         const unsigned c = cc[qq];
-        const unsigned flag = rfl[q];
-        const unsigned src = rsr[q];
-        const bool curb = (flag & 7u) != 0;
-        /* k_ring stored a float approximation of the azimuth for most points (error <=
-         * urf_fast_az_eps).  Every decision that the approximation clears by that margin is the
-         * reference's decision; the rare point that does not is listed and decided below on
-         * the exact azimuth. */
-        const float az = raz[q], eps = (flag & URF_RFLAG_AZ_APPROX) ? urf_fast_az_eps(az) : 0.0f;
+        const unsigned src = rec[q] & URF_REC_SRC_MASK;
+        const bool curb = ((rec[q] >> URF_REC_FLAG_SHIFT) & 7u) != 0;
+        /* The record holds k_split's float approximation of the azimuth, quantised (error <=
+         * urf_fast_az_eps + URF_REC_AZ_QERR).  Every decision that the approximation clears by that
+         * margin is the reference's decision; the rare point that does not is listed and decided
+         * below on the exact azimuth. */
+        const float az = urf_az_decode(rec[q] >> URF_REC_AZ_SHIFT), eps = urf_fast_az_eps(az) + URF_REC_AZ_QERR;
         const float fl = __builtin_floorf(az);
         bool road = az <= whi[qq] || az >= wlo[qq];   /* urf_road_test with the window ends at hand */
-        /* (URF_RAZ_UNKNOWN = -1: k_split had no usable approximation -- the point lies too close to the x axis) */
-        const bool unsure = eps > 0.0f && (az < 0.0f || az - fl <= eps || (fl + 1.0f) - az <= eps ||
-                                           __builtin_fabsf(az - whi[qq]) <= eps || __builtin_fabsf(az - wlo[qq]) <= eps);
+        /* (URF_AZ_UNKNOWN = -1: k_split had no usable approximation -- the point lies too close to the x axis) */
+        const bool unsure = az < 0.0f || az - fl <= eps || (fl + 1.0f) - az <= eps ||
+                            __builtin_fabsf(az - whi[qq]) <= eps || __builtin_fabsf(az - wlo[qq]) <= eps;
         if (unsure && valid && !curb) {
             const unsigned e = atomicAdd(&n_unsure, 1u);
             if (e < URF_LABEL_UNSURE) {
@@ -3192,11 +3295,9 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     }
 }
 
-/* exact azimuth of the point in ring-sorted slot `slot` (raz may hold the approximation) */
+/* exact azimuth of the point in ring-sorted slot `slot` (its record holds an approximation) */
 __device__ __forceinline__ float urf_exact_az(const urf_kargs& a, unsigned slot)
 {
-    if (!(a.rflag[slot] & URF_RFLAG_AZ_APPROX))
-        return a.raz[slot];
     float d2;
     return urf_azimuth(a.rx[slot], a.ry[slot], &d2);
 }
@@ -3348,32 +3449,29 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
     /* what is published for position i of the ring: the point's input index | its class << 30 */
     auto entry_of = [&](unsigned i, unsigned& cls) {
         const unsigned slot = map.at(i);
-        const unsigned src = (slot & ~(URF_TILE - 1u)) + (unsigned)a.rsrc[sb + slot];
+        const unsigned src = (slot & ~(URF_TILE - 1u)) + (a.rec[sb + slot] & URF_REC_SRC_MASK);
         cls = a.labels[off + src] & URF_LABEL_MASK;
         return src | (cls << 30);
     };
     unsigned my_road = 0, my_curb = 0;
     if (n <= CAP) {
         unsigned long long key[EPT];
-        unsigned slot[EPT], fl[EPT];
-        float az[EPT];
+        unsigned slot[EPT];
+        float px[EPT], py[EPT];
 #pragma unroll
-        for (unsigned e = 0; e < EPT; e++) {   /* slot records of the thread's eight points in flight together */
+        for (unsigned e = 0; e < EPT; e++) {   /* coordinates of the thread's eight points in flight together */
             const unsigned i = tid + e * NT;
             slot[e] = i < n ? map.at(i) : 0u;
-            fl[e] = (unsigned)a.rflag[sb + slot[e]];
-            az[e] = a.raz[sb + slot[e]];
+            px[e] = a.rx[sb + slot[e]];
+            py[e] = a.ry[sb + slot[e]];
         }
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++) {
             const unsigned i = tid + e * NT;
             key[e] = ~0ull;
             if (i < n) {
-                if (fl[e] & URF_RFLAG_AZ_APPROX) {   /* raz holds k_split's approximation */
-                    float d2;
-                    az[e] = urf_azimuth(a.rx[sb + slot[e]], a.ry[sb + slot[e]], &d2);
-                }
-                key[e] = ((unsigned long long)urf_fbits(az[e]) << 32) | i;
+                float d2;   /* the slot's record holds an approximation: the published order is that of the exact azimuth */
+                key[e] = ((unsigned long long)urf_fbits(urf_azimuth(px[e], py[e], &d2)) << 32) | i;
             }
         }
         urf_block_sort_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, false);
@@ -3535,7 +3633,7 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
     const unsigned sb = urf_sbase(a, s);
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     /* input index of the point in ring-sorted slot `slot` (relative to the scan) */
-    auto src_of = [&](unsigned slot) { return (slot & ~(URF_TILE - 1u)) + (unsigned)a.rsrc[sb + slot]; };
+    auto src_of = [&](unsigned slot) { return (slot & ~(URF_TILE - 1u)) + (a.rec[sb + slot] & URF_REC_SRC_MASK); };
     for (unsigned i = tid; i < URF_DEG_CELLS; i += 256) {
         nrmin[i] = URF_INT_NONE_MIN;
         best[i] = 0;
@@ -3564,15 +3662,15 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
         }
         __syncthreads();
         const urf_ring_map map = { mapP, mapA, ntiles, (float)ntiles / (float)(n > 0 ? n : 1) };
-        unsigned slot[EPT], fl[EPT], sr[EPT];
-        float az[EPT];
+        unsigned slot[EPT], sr[EPT];
+        float az[EPT], px[EPT], py[EPT];
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++) {
             const unsigned p = tid + e * 256;
             slot[e] = p < n ? map.at(p) : 0u;
-            fl[e] = (unsigned)a.rflag[sb + slot[e]];
-            az[e] = a.raz[sb + slot[e]];
-            sr[e] = (unsigned)a.rsrc[sb + slot[e]];
+            sr[e] = a.rec[sb + slot[e]] & URF_REC_SRC_MASK;
+            px[e] = a.rx[sb + slot[e]];
+            py[e] = a.ry[sb + slot[e]];
         }
         unsigned labs = 0;   /* two bits per point */
 #pragma unroll
@@ -3581,11 +3679,10 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
             labs |= lab << (2 * e);
         }
 #pragma unroll
-        for (unsigned e = 0; e < EPT; e++)
-            if (tid + e * 256 < n && (fl[e] & URF_RFLAG_AZ_APPROX)) {   /* raz holds k_split's approximation */
-                float d2;
-                az[e] = urf_azimuth(a.rx[sb + slot[e]], a.ry[sb + slot[e]], &d2);
-            }
+        for (unsigned e = 0; e < EPT; e++) {   /* (the slot's record holds an approximation of the azimuth) */
+            float d2;
+            az[e] = urf_azimuth(px[e], py[e], &d2);
+        }
         /* pass 1: where does the scan of this ring stop in each degree (:318) */
         int bin[EPT];
 #pragma unroll
@@ -3603,7 +3700,7 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
             key[e] = 0;
             if (tid + e * 256 < n && az[e] == az[e] && ((labs >> (2 * e)) & 3u) == URF_LABEL_ROAD &&
                 (int)urf_fbits(az[e]) < nrmin[bin[e]]) {
-                const float x = a.rx[sb + slot[e]], y = a.ry[sb + slot[e]];
+                const float x = px[e], y = py[e];
                 const float d = (float)__builtin_sqrt((double)(0.f - x) * (double)(0.f - x) + (double)(0.f - y) * (double)(0.f - y));
                 if (d > 0.0f) {   /* "d > maxDistanceRoad" with maxDistanceRoad starting at 0 */
                     key[e] = ((unsigned long long)urf_fbits(d) << 32) | (0xffffffffu - urf_fbits(az[e]));

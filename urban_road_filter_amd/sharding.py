@@ -43,7 +43,7 @@ def reduce_run(counters, elapsed_s, device=None):
     import torch.distributed as dist
     c = torch.as_tensor(np.asarray(counters, dtype=np.int64), device=device)
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():   # (also with one rank: bench.py --force-dist runs the collectives on one GPU)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return c.cpu().numpy(), float(t.item())
