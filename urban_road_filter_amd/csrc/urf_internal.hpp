@@ -22,7 +22,9 @@
 
 /* one tile = the unit of the stable multi-split by ring / by sector */
 #define URF_TILE            2048
+#ifndef URF_TILE_THREADS
 #define URF_TILE_THREADS    512     /* k_split: one wave per 256 points of the tile */
+#endif
 #define URF_TILE_GROUPS     (URF_TILE / 64)   /* wave-sized groups per tile */
 #define URF_MAX_TILES       4096    /* tiles per scan (k_ring keeps one table entry per tile in LDS) */
 #define URF_SCAN_PAD        512     /* scratch elements per scan beyond its tiles: rings start at multiples of 4 */

@@ -382,6 +382,7 @@ __global__ __launch_bounds__(256) void k_table_repair(urf_kargs a, urf_dev_param
 #define URF_SLOT(lp) ((lp) + ((lp) >> 6))
 #define URF_SLOTS (URF_TILE + URF_TILE / 64)
 #define URF_TILE_WAVES (URF_TILE_THREADS / 64)
+#define URF_WAVE_PTS (URF_TILE / URF_TILE_WAVES)   /* consecutive points of the tile a wave owns */
 
 __host__ __device__ inline unsigned urf_align16(unsigned v) { return (v + 15u) & ~15u; }
 
@@ -392,7 +393,7 @@ __host__ __device__ inline size_t urf_split_lds_bytes(unsigned C, unsigned K, bo
 {
     const unsigned Ks = star ? K : 0;
     const size_t fixed = URF_MAX_CHANNELS * (4 + 4 + 16) + urf_align16(URF_LUT_CELLS) + urf_align16((C + 1) * 4) +
-                         urf_align16((Ks + 1) * 4) + 64 + urf_align16(C * 8);
+                         urf_align16((Ks + 1) * 4) + 128 + urf_align16(C * 8);
     const size_t phase_a = 5 * (size_t)URF_TILE + urf_align16(2 * URF_TILE_WAVES * (C + Ks));
     const size_t phase_b = 4 * (size_t)URF_SLOTS * 4;
     return fixed + (phase_a > phase_b ? phase_a : phase_b);
@@ -466,13 +467,21 @@ __device__ __noinline__ urf_exact_key urf_exact_keys(const float* tab, unsigned 
 __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev_params& dp, unsigned s, unsigned t, unsigned char* sh_raw,
                                                const unsigned tid)
 {
+#ifdef URF_EXP_WAVE_RFL
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63;
+#else
     const unsigned wave = tid >> 6, lane = tid & 63;
+#endif
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned tbase = t * URF_TILE;
     if (tbase >= len)
         return;
     URF_PHASE_DECL;
+    /* (uniform 64-bit bases + small per-lane offsets: per-lane 64-bit addresses cost register pairs) */
+    const float* __restrict__ const gx = a.x + ((size_t)off + tbase);
+    const float* __restrict__ const gy = a.y + ((size_t)off + tbase);
+    const float* __restrict__ const gz = a.z + ((size_t)off + tbase);
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
     const unsigned Ks = star ? K : 0;
@@ -482,8 +491,9 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     uint8_t* lut = (uint8_t*)(thr + URF_MAX_CHANNELS);
     unsigned* koff = (unsigned*)(lut + urf_align16(URF_LUT_CELLS));
     unsigned* soff = koff + urf_align16((C + 1) * 4) / 4;
-    unsigned* misc = soff + urf_align16((Ks + 1) * 4) / 4;   /* [0] ROI points, [1] pending, [2..9] wave sums */
-    unsigned long long* tmax = (unsigned long long*)(misc + 16);   /* largest x*x + y*y per ring (binary64 bits: non-negative doubles order like integers) */
+    unsigned* misc = soff + urf_align16((Ks + 1) * 4) / 4;   /* [0] ROI points, [1] pending, [2 + wave] wave sums */
+    static_assert(2 + URF_TILE_WAVES <= 32, "misc[2 + wave]");
+    unsigned long long* tmax = (unsigned long long*)(misc + 32);   /* largest x*x + y*y per ring (binary64 bits: non-negative doubles order like integers) */
     unsigned char* un = (unsigned char*)(tmax + urf_align16(C * 8) / 8);
     uint8_t* keyr = un;
     uint16_t* keys = (uint16_t*)(un + URF_TILE);
@@ -510,11 +520,11 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     float px[Q], py[Q], pz[Q];
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned i = tbase + wave * 256 + q * 64 + lane;
-        const bool valid = i < len;
-        px[q] = valid ? a.x[off + i] : 0.f;
-        py[q] = valid ? a.y[off + i] : 0.f;
-        pz[q] = valid ? a.z[off + i] : 0.f;
+        const unsigned li = wave * URF_WAVE_PTS + q * 64 + lane;
+        const bool valid = tbase + li < len;
+        px[q] = valid ? gx[li] : 0.f;
+        py[q] = valid ? gy[li] : 0.f;
+        pz[q] = valid ? gz[li] : 0.f;
     }
     const unsigned nR = a.info[s].n_rings;
     /* a speculative ring table (k_ring_table) is checked here: a region-of-interest point at or behind
@@ -523,7 +533,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     const unsigned upto = nR < C ? upto_v : 0xffffffffu;
     for (unsigned k = tid; k < URF_TILE_WAVES * (C + Ks) / 2; k += URF_TILE_THREADS)
         ((unsigned*)wcnt_r)[k] = 0;
-    if (tid < 16)
+    if (tid < 32)
         misc[tid] = 0;
     if (tid < C)
         tmax[tid] = 0;
@@ -568,7 +578,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     unsigned lo[Q], roim = 0, fastm = 0, openm = 0;
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned i = tbase + wave * 256 + q * 64 + lane;
+        const unsigned i = tbase + wave * URF_WAVE_PTS + q * 64 + lane;
         roim |= (unsigned)((i < len) & urf_in_roi(dp.p, px[q], py[q], pz[q])) << q;
     }
     /* A wave none of whose 256 points lies in the region of interest has nothing to classify (uniform
@@ -616,7 +626,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     }
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned li = wave * 256 + q * 64 + lane, i = tbase + li;
+        const unsigned li = wave * URF_WAVE_PTS + q * 64 + lane, i = tbase + li;
         const float x = px[q], y = py[q];
         const bool roi = (roim >> q) & 1u;
         bool open = (openm >> q) & 1u;
@@ -646,7 +656,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     }
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned li = wave * 256 + q * 64 + lane, i = tbase + li;
+        const unsigned li = wave * URF_WAVE_PTS + q * 64 + lane, i = tbase + li;
         const bool roi = (roim >> q) & 1u;
         if (i < len && exact_all && !roi)
             a.valpha[sb + i] = -1.0f;   /* stage capture only */
@@ -676,7 +686,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         if (a.capture)   /* stage capture only */
 #pragma unroll
             for (unsigned q = 0; q < Q; q++) {
-                const unsigned i = tbase + wave * 256 + q * 64 + lane;
+                const unsigned i = tbase + wave * URF_WAVE_PTS + q * 64 + lane;
                 if (i < len) {
                     a.ringkey[sb + i] = (uint8_t)URF_RING_NONE;
                     a.seckey[sb + i] = (uint16_t)URF_SEC_NONE;
@@ -687,7 +697,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     const unsigned np = misc[1];
     for (unsigned k = tid; k < np; k += URF_TILE_THREADS) {
         const unsigned li = pending[k], i = tbase + li;
-        const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
+        const float x = gx[li], y = gy[li], z = gz[li];
         const urf_exact_key ek = urf_exact_keys(tab, nR, interval, x, y, z, star ? K : 0u, dp.Kfi);
         unsigned sk = ek.sector;
         if (star && dp.p.starbeam_filter && !urf_in_beam(a.beams[sk], x, y))
@@ -710,7 +720,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     uint16_t* my_s = wcnt_s + wave * K;
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned li = wave * 256 + q * 64 + lane, i = tbase + li;
+        const unsigned li = wave * URF_WAVE_PTS + q * 64 + lane, i = tbase + li;
         if (openmask & (1u << q)) {   /* decided by the exact pass */
             rkey[q] = (unsigned)keyr[li];
             skey[q] = star ? (unsigned)keys[li] : URF_SEC_NONE;
@@ -788,12 +798,12 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     __syncthreads();
     URF_PHASE_MARK;
     if (star) {
-        unsigned wb = 0, total = 0;
-#pragma unroll
-        for (unsigned w = 0; w < URF_TILE_WAVES; w++) {
-            wb += w < wave ? misc[2 + w] : 0;
-            total += misc[2 + w];
-        }
+        /* the waves' totals: lane l reads wave l's, one scan, two broadcasts (every thread summing all of them took
+         * as many registers as there are waves) */
+        const unsigned mine = lane < URF_TILE_WAVES ? misc[2 + lane] : 0u;
+        const unsigned minc = urf_wave_scan_add(mine);
+        const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)minc, URF_TILE_WAVES - 1);
+        const unsigned wb = (unsigned)__shfl((int)(minc - mine), (int)wave);
         const unsigned run = wb + sinc - (sv0 + sv1);
         if (2 * tid < K)
             soff[2 * tid] = run;
@@ -826,9 +836,12 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     unsigned* stz = sty + URF_SLOTS;
     unsigned* str = stz + URF_SLOTS;
     const unsigned tb = sb + tbase;
+    float* __restrict__ const o_sr = a.sr + tb;
+    float* __restrict__ const o_sz = a.sz + tb;
+    uint16_t* __restrict__ const o_ss = a.sslot + tb;
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned li = wave * 256 + q * 64 + lane;
+        const unsigned li = wave * URF_WAVE_PTS + q * 64 + lane;
         const float x = px[q], y = py[q], z = pz[q];
         if (lp[q] != 0xffffffffu) {
             const unsigned sl = URF_SLOT(lp[q]);
@@ -838,23 +851,30 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             str[sl] = (azc[q] << URF_REC_AZ_SHIFT) | li;   /* the slot's record: no detector hit so far */
         }
         if (sp[q] != 0xffffffffu) {
-            __builtin_nontemporal_store(__builtin_sqrtf(x * x + y * y), &a.sr[tb + sp[q]]);   /* star_shaped_search.cpp:164 */
-            __builtin_nontemporal_store(z, &a.sz[tb + sp[q]]);
+            const unsigned so = sp[q] & (URF_TILE - 1u);   /* (a slot inside the tile) */
+            __builtin_nontemporal_store(__builtin_sqrtf(x * x + y * y), &o_sr[so]);   /* star_shaped_search.cpp:164 */
+            __builtin_nontemporal_store(z, &o_sz[so]);
             /* where a star-shaped hit on this point has to be reported: its ring-sorted slot (none
              * if the point lies on no ring: such a hit ends the walk but marks nothing that
              * reaches the output, lidar_segmentation.cpp:235-242) */
-            __builtin_nontemporal_store((uint16_t)(lp[q] != 0xffffffffu ? lp[q] : URF_SLOT_NONE), &a.sslot[tb + sp[q]]);
+            __builtin_nontemporal_store((uint16_t)(lp[q] != 0xffffffffu ? lp[q] : URF_SLOT_NONE), &o_ss[so]);
         }
     }
     __syncthreads();
     URF_PHASE_MARK;
     const unsigned tile_ring_pts = koff[C];
-    for (unsigned j = tid; j < tile_ring_pts; j += URF_TILE_THREADS) {
-        const unsigned sl = URF_SLOT(j);
-        __builtin_nontemporal_store(__uint_as_float(stx[sl]), &a.rx[tb + j]);
-        __builtin_nontemporal_store(__uint_as_float(sty[sl]), &a.ry[tb + j]);
-        __builtin_nontemporal_store(__uint_as_float(stz[sl]), &a.rz[tb + j]);
-        __builtin_nontemporal_store(str[sl], &a.rec[tb + j]);
+    {
+        float* __restrict__ const o_rx = a.rx + tb;
+        float* __restrict__ const o_ry = a.ry + tb;
+        float* __restrict__ const o_rz = a.rz + tb;
+        uint32_t* __restrict__ const o_rec = a.rec + tb;
+        for (unsigned j = tid; j < tile_ring_pts; j += URF_TILE_THREADS) {
+            const unsigned sl = URF_SLOT(j);
+            __builtin_nontemporal_store(__uint_as_float(stx[sl]), &o_rx[j]);
+            __builtin_nontemporal_store(__uint_as_float(sty[sl]), &o_ry[j]);
+            __builtin_nontemporal_store(__uint_as_float(stz[sl]), &o_rz[j]);
+            __builtin_nontemporal_store(str[sl], &o_rec[j]);
+        }
     }
     const size_t row = (size_t)s * a.tiles + t;
     for (unsigned k = tid; k <= C; k += URF_TILE_THREADS)
@@ -3182,7 +3202,8 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     /* the window ends of all eight points are requested before any of them is looked at (point after
      * point the workgroup sat through eight dependent round trips to the table here) */
 #ifndef URF_LABEL_QB
-#define URF_LABEL_QB 2   /* A/B: 2 at 8 waves per SIMD 0.382 ms, 4 at 7 waves (72 registers) 0.390, 4 at 8 waves (48 B of scratch) 0.477; point by point 0.425 */
+#define URF_LABEL_QB 4   /* r2 (three arrays per slot): 2 at 8 waves per SIMD 0.382 ms, 4 at 7 waves (72 registers) 0.390, 4 at 8 waves (48 B of
+                          * scratch) 0.477, point by point 0.425; r3 (one record per slot, 63 registers at 4): 2 -> 0.373, 4 -> 0.359 */
 #endif
     constexpr unsigned QB = URF_LABEL_QB;   /* points per batch of table requests */
 #pragma unroll
