@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 case "$OUT" in /*) ;; *) OUT="$REPO/$OUT";; esac
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-outputs --parity-scans 0 $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-outputs --no-other-configs --parity-scans 0 $*"
 pass() {
   name=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- python "$REPO/bench.py" $ARGS > "$OUT/$name.log" 2>&1

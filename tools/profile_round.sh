@@ -13,6 +13,6 @@ cd "$REPO"
 timeout 600 python bench.py --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench rc=$?"; tail -c 400 "$OUT/bench.json"
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-e2e > "$OUT/trace.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-other-configs > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 bash "$REPO/tools/pmc_profile.sh" "$OUT/pmc" | grep pass

@@ -224,7 +224,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     if ((rc = dev_alloc(c, &(ptr), (count))) != URF_OK)   \
         return fail(rc);
     A(k.rx, T) A(k.ry, T) A(k.rz, T) A(k.rec, T)
-    A(k.sr, T) A(k.sz, T) A(k.sslot, T) A(k.ssrt16, T) A(k.ssrt, T) A(k.wslp, T) A(k.wg, T)
+    A(k.sr, T) A(k.sz, T) A(k.sslot, T) A(k.ssrt16, T) A(k.ssrt, T) A(k.wsg, T)
     A(k.big_r, T) A(k.big_z, T) A(k.big_i, T)
     A(k.tile_roi, S * tiles) A(k.roi_bits, S * tiles * (URF_TILE / 64)) A(k.troff, S * tiles * (C + 1)) A(k.tsoff, S * tiles * (K + 1)) A(k.tmaxs, S * tiles * C)
     A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles)
@@ -496,7 +496,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
         return k;
     const size_t P = (size_t)row * c->sstride, tiles = c->max_tiles, C = URF_MAX_CHANNELS, K = URF_MAX_SECTORS, r = row;
     k.rx += P; k.ry += P; k.rz += P; k.rec += P;
-    k.sr += P; k.sz += P; k.sslot += P; k.ssrt16 += P; k.ssrt += P; k.wslp += P; k.wg += P;
+    k.sr += P; k.sz += P; k.sslot += P; k.ssrt16 += P; k.ssrt += P; k.wsg += P;
     k.big_r += P; k.big_z += P; k.big_i += P;
     if (k.valpha) {
         k.valpha += P; k.seckey += P; k.ringkey += P; k.rd2 += P; k.caz += P;

@@ -351,6 +351,14 @@ __device__ __forceinline__ urf_ring_thr urf_ring_thresholds(float angle, float i
     return t;
 }
 
+/* one of the four (which = 0..3: .x .y .z .w) */
+__device__ __forceinline__ float urf_ring_threshold(float angle, float interval, float e, unsigned which)
+{
+    const double a = (double)angle, iv = (double)interval, ee = (double)e;
+    const double arg = which == 0 ? a + iv + ee : (which == 1 ? a + iv - ee : (which == 2 ? a - iv + ee : a - iv - ee));
+    return (float)urf_cot_deg(arg);
+}
+
 /* Sector of star_shaped_search.cpp:164-171 when the scaled polar angle u = fi * Kfi is clear of an
  * integer by more than `margin`; -1 = undecided.  Both error sources grow with the number of sectors:
  * the reference's own roundings (two of the angle, one of the product: <= 3 ulp of u, u < sectors) and

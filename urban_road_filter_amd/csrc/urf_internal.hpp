@@ -95,11 +95,14 @@ struct urf_dev_params {
  * rings' per-tile run tables into per-ring tables (prefix over the tiles, start inside the tile);
  * a sector's runs are read from tsoff directly (it meets few tiles).  What k_ring produces per point
  * (detector hits) goes into the point's ring-sorted record; what the star sort produces is
- * contiguous per sector (wslp, wg, ssrt16 / ssrt: at s * sstride + sec_off[k] + i). */
+ * contiguous per sector (wsg, ssrt16 / ssrt: at s * sstride + sec_off[k] + i). */
 /* A sector's points sit in one run per tile (k_split's sector-sorted order).  The first two non-empty
  * runs: point i of the sector is element a0 + i of the sector-sorted arrays for i < c0, a1 + (i - c0)
  * beyond (indices relative to the scan's scratch); nruns > 2: the sort walks the per-tile tables. */
 struct urf_sec_run { uint32_t a0, c0, a1, nruns; };
+
+/* k_star_sort_* -> k_star_walk, per point of a sector in sorted order */
+struct alignas(8) urf_sg { float slp, g; };
 
 /* k_beams -> k_label, per (ring, integer degree) */
 struct urf_win { float hi, lo; };
@@ -142,8 +145,8 @@ struct urf_kargs {
                                  * the walk turns the one it needs into a slot through sec_run and sslot */
     uint32_t* ssrt;             /* all other sectors: tile-local ring-sorted index (t * URF_TILE + slot) of the i-th point in
                                  * sorted order, 0xffffffff = on no ring */
-    float*    wslp;             /* slope between the (i-1)-th and i-th point of the sector in sorted order */
-    float*    wg;               /* (r_i - r_{i-1}) * kdist */
+    urf_sg*   wsg;              /* .x slope between the (i-1)-th and i-th point of the sector in sorted order, .y (r_i - r_{i-1}) * kdist:
+                                 * side by side, so that the walk fetches both with one 8-byte load (16 steps of a sector = one 128-byte line) */
     /* per scan x tile (k_split) */
     uint32_t* tile_roi;         /* [S][tiles] ROI points of the tile */
     uint16_t* troff;            /* [S][tiles][C+1] first ring-sorted slot of ring c in the tile; [C] = ring points of the tile */

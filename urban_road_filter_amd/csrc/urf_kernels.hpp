@@ -203,6 +203,30 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
             const unsigned nL0 = nL;
             bool un = v >= 0.0f && !urf_leader_match(SL, nmatch, v, interval);
             unsigned long long m;
+            /* One firing of an organised sweep = one point of every ring, steepest beam first: the unmatched points
+             * ascend by more than `interval` from one to the next, so none of them matches another (fl(a - b) is
+             * monotone in a) and ALL of them become leaders, in lane order -- in one step instead of one ballot,
+             * shuffle and insertion per leader (64 dependent rounds: a quarter of this kernel's time on the first
+             * firing).  Anything else (a zero angle, an angle below the largest entry, too many) takes the loop. */
+            m = __ballot(un);
+            if (m != 0 && !zero_seen) {
+                const unsigned long long below = m & ((1ull << lane) - 1ull);
+                const unsigned rank = (unsigned)__popcll(below);
+                const int prev = below ? 63 - __clzll((long long)below) : (int)lane;
+                const float pv = __shfl(v, prev);
+                const float floor_v = nmatch ? SL[nmatch - 1] : -1.0f;   /* (angles are >= 0) */
+                const bool ok = !un || (v != 0.0f && (below ? (v > pv && v - pv > interval) : v > floor_v));
+                const unsigned cnt = (unsigned)__popcll(m);
+                if (__ballot(!ok) == 0 && nL + cnt <= C) {
+                    if (un) {
+                        L[nL + rank] = v;
+                        SL[nmatch + rank] = v;
+                    }
+                    nL += cnt;
+                    nmatch += cnt;
+                    un = false;
+                }
+            }
             while ((m = __ballot(un)) != 0 && nL < C) {
                 const unsigned f = (unsigned)__ffsll((long long)m) - 1u;
                 const float lv = __shfl(v, (int)f);
@@ -318,23 +342,39 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
      * (A cell index that float rounding pushes up by one only lowers the count: still valid.) */
     {
         const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;
-        if (tid < n) {
-            const urf_ring_thr t = urf_ring_thresholds(SL[tid], interval, e);
-            ((urf_ring_thr*)a.ring_thr)[(size_t)s * C + tid] = t;
-            L[tid] = t.x;   /* the leaders in insertion order are no longer needed */
+        /* one cotangent (a binary64 polynomial and two divisions) per thread: entry tid / 4, threshold tid % 4 */
+        for (unsigned k = tid; k < 4 * n; k += 256) {
+            const float t = urf_ring_threshold(SL[k >> 2], interval, e, k & 3u);
+            a.ring_thr[((size_t)s * C) * 4 + k] = t;
+            if ((k & 3u) == 0)
+                L[k >> 2] = t;   /* .x; the leaders in insertion order are no longer needed */
         }
         __syncthreads();
         uint8_t* lut = a.ring_lut + (size_t)s * URF_LUT_CELLS;
-        for (unsigned cell = tid; cell < URF_LUT_CELLS; cell += 256) {
-            const float u1 = (float)(cell + 1) * (1.0f / URF_LUT_SCALE) - URF_LUT_UMAX;   /* exact */
-            unsigned lo = 0;
+        /* four cells per thread at a time, their bisections step by step together (the dependent LDS reads of
+         * one cell after the other were the longest chain of this kernel) */
+        for (unsigned c0 = tid; c0 < URF_LUT_CELLS; c0 += 4 * 256) {
+            float u1[4];
+            unsigned lo[4];
+#pragma unroll
+            for (unsigned q = 0; q < 4; q++) {
+                u1[q] = (float)(c0 + q * 256 + 1) * (1.0f / URF_LUT_SCALE) - URF_LUT_UMAX;   /* exact */
+                lo[q] = 0;
+            }
 #pragma unroll
             for (unsigned step = URF_MAX_CHANNELS; step > 0; step >>= 1) {
-                const unsigned idx = lo + step - 1;
-                if (idx < n && L[idx & (URF_MAX_CHANNELS - 1)] >= u1)
-                    lo += step;
+                float lv[4];
+#pragma unroll
+                for (unsigned q = 0; q < 4; q++)
+                    lv[q] = L[(lo[q] + step - 1) & (URF_MAX_CHANNELS - 1)];
+#pragma unroll
+                for (unsigned q = 0; q < 4; q++)
+                    lo[q] += (lo[q] + step - 1 < n && lv[q] >= u1[q]) ? step : 0u;
             }
-            lut[cell] = (uint8_t)lo;
+#pragma unroll
+            for (unsigned q = 0; q < 4; q++)
+                if (c0 + q * 256 < URF_LUT_CELLS)
+                    lut[c0 + q * 256] = (uint8_t)lo[q];
         }
     }
 }
@@ -410,7 +450,12 @@ struct urf_exact_key {
     unsigned ring, sector;
     float valpha;
 };
-__device__ __noinline__ urf_exact_key urf_exact_keys(const float* tab, unsigned nR, float interval, float x, float y, float z,
+#ifdef URF_EXP_INLINE_EXACT   /* (the r2 build whose parity gate failed at 8 waves per SIMD: kept buildable for the race screen) */
+#define URF_EXACT_INLINE __forceinline__
+#else
+#define URF_EXACT_INLINE __noinline__
+#endif
+__device__ URF_EXACT_INLINE urf_exact_key urf_exact_keys(const float* tab, unsigned nR, float interval, float x, float y, float z,
                                                      unsigned sectors, float Kfi)
 {
     urf_exact_key r;
@@ -1504,8 +1549,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
                 a.ssrt16[obase + i] = (uint16_t)S[i];
             else
                 a.ssrt[obase + i] = S[i];
-            a.wslp[obase + i] = slp;
-            a.wg[obase + i] = g;
+            a.wsg[obase + i] = urf_sg{ slp, g };
         }
         __syncthreads();
         if (*sh_first < (q + 1) * 64)
@@ -1890,8 +1934,7 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
                     a.ssrt16[obase + i] = (uint16_t)S[i];
                 else
                     a.ssrt[obase + i] = S[i];
-                a.wslp[obase + i] = slp;
-                a.wg[obase + i] = g;
+                a.wsg[obase + i] = urf_sg{ slp, g };
             }
             __syncthreads();
             if (sh_first < (e + 1) * NT)
@@ -2003,8 +2046,7 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
                 if (slp > slope_param && i < first)
                     first = i;
             }
-            a.wslp[base + i] = slp;
-            a.wg[base + i] = g;
+            a.wsg[base + i] = urf_sg{ slp, g };
         }
         __syncthreads();   /* every Pq (= ssrt) has been read for the last time */
         for (unsigned i = threadIdx.x; i < n; i += 256)
@@ -2064,8 +2106,9 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
 #pragma unroll
         for (unsigned r = 0; r < 16; r++) {
             const bool on = e >= 1 && e <= rlast[r];
-            vs[r] = on ? a.wslp[rbase[r] + e] : 0.f;
-            vg[r] = on ? a.wg[rbase[r] + e] : 0.f;
+            const urf_sg sg = on ? a.wsg[rbase[r] + e] : urf_sg{ 0.f, 0.f };   /* slope and distance term: one 8-byte load */
+            vs[r] = sg.slp;
+            vg[r] = sg.g;
         }
     };
     auto park = [&]() {
@@ -2946,31 +2989,28 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     const bool inrange = i <= 360;
     const float fi = (float)i;
     const bool blind = !inrange || urf_blind(dp.p, q, i);
-    int sf = -1, sb = -1;
-    if (fi <= dp.fwd_limit && !blind) {   /* blind_spots.cpp:68 */
-        sf = (int)nR;
-        for (unsigned k0 = 0; k0 < nR && sf == (int)nR; k0 += 8) {   /* 8 rings' table entries in flight */
-            float m[8];
+    /* both marches of the degree, ring group by ring group, with the table entries of BOTH directions of a group
+     * requested together (one after the other the two marches cost up to sixteen dependent round trips) */
+    const bool cast_f = fi <= dp.fwd_limit && !blind;   /* blind_spots.cpp:68 */
+    const bool cast_b = fi >= dp.bwd_limit && !blind;   /* blind_spots.cpp:177 */
+    int sf = cast_f ? (int)nR : -1, sb = cast_b ? (int)nR : -1;
+    for (unsigned k0 = 0; k0 < nR; k0 += 8) {   /* 8 rings' entries per direction in flight */
+        const bool go_f = cast_f && sf == (int)nR, go_b = cast_b && sb == (int)nR;
+        if (!__any(go_f || go_b))
+            break;
+        float mfw[8], mbw[8];
 #pragma unroll
-            for (unsigned u = 0; u < 8; u++)
-                m[u] = k0 + u < nR ? a.sufmin[((size_t)s * C + k0 + u) * URF_DEG_CELLS + i] : __builtin_nanf("");
-#pragma unroll
-            for (unsigned u = 0; u < 8; u++)
-                if (sf == (int)nR && k0 + u < nR && m[u] <= urf_fwd_hi(dp, i, k0 + u, qk[k0 + u]))
-                    sf = (int)(k0 + u);
+        for (unsigned u = 0; u < 8; u++) {
+            const bool in = k0 + u < nR;
+            mfw[u] = go_f && in ? a.sufmin[((size_t)s * C + k0 + u) * URF_DEG_CELLS + i] : __builtin_nanf("");
+            mbw[u] = go_b && in ? a.premax[((size_t)s * C + k0 + u) * URF_DEG_CELLS + i] : __builtin_nanf("");
         }
-    }
-    if (fi >= dp.bwd_limit && !blind) {   /* blind_spots.cpp:177 */
-        sb = (int)nR;
-        for (unsigned k0 = 0; k0 < nR && sb == (int)nR; k0 += 8) {
-            float m[8];
 #pragma unroll
-            for (unsigned u = 0; u < 8; u++)
-                m[u] = k0 + u < nR ? a.premax[((size_t)s * C + k0 + u) * URF_DEG_CELLS + i] : __builtin_nanf("");
-#pragma unroll
-            for (unsigned u = 0; u < 8; u++)
-                if (sb == (int)nR && k0 + u < nR && m[u] >= urf_bwd_lo(dp, i, k0 + u, qk[k0 + u]))
-                    sb = (int)(k0 + u);
+        for (unsigned u = 0; u < 8; u++) {
+            if (sf == (int)nR && go_f && k0 + u < nR && mfw[u] <= urf_fwd_hi(dp, i, k0 + u, qk[k0 + u]))
+                sf = (int)(k0 + u);
+            if (sb == (int)nR && go_b && k0 + u < nR && mbw[u] >= urf_bwd_lo(dp, i, k0 + u, qk[k0 + u]))
+                sb = (int)(k0 + u);
         }
     }
     if (inrange) {
