@@ -233,6 +233,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 4 * URF_ASYNC_SLOTS)   /* four counters per scratch row in use at once */
     A(k.table_upto, S) A(k.table_redo, S) A(k.redo_list, S)
     A(k.maxdist, S * C) A(k.quad, S * 4)
+    A(k.curb_cnt, S * C) A(k.curb_az, S * C * URF_CURB_LIST)
     A(k.sufmin, S * C * URF_DEG_CELLS) A(k.premax, S * C * URF_DEG_CELLS)
     A(k.stop_f, S * URF_DEG_CELLS) A(k.stop_b, S * URF_DEG_CELLS)
     A(k.win, S * C * URF_DEG_CELLS)
@@ -508,6 +509,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     k.star_first += r * K; k.star_list_mid += r * K; k.star_list_big += r * K; k.star_count += 4 * r;
     k.table_upto += r; k.table_redo += r; k.redo_list += r;
     k.maxdist += r * C; k.quad += r * 4;
+    k.curb_cnt += r * C; k.curb_az += r * C * URF_CURB_LIST;
     k.sufmin += r * C * URF_DEG_CELLS; k.premax += r * C * URF_DEG_CELLS;
     k.stop_f += r * URF_DEG_CELLS; k.stop_b += r * URF_DEG_CELLS;
     k.win += r * C * URF_DEG_CELLS;
@@ -643,7 +645,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     else
         hipLaunchKernelGGL(k_ring_general, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
     mark();
-    hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_LABEL_THREADS), 0, st, a, dp);
+    hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_LABEL_THREADS), (size_t)C * (24 * sizeof(unsigned) + URF_CURB_LIST * sizeof(float)), st, a, dp);
     mark();
     hipLaunchKernelGGL(k_label, g_tiles, dim3(URF_LABEL_TILE_THREADS), 0, st, a, dp);
     mark();

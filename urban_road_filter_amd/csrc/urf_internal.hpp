@@ -181,7 +181,9 @@ struct urf_kargs {
     uint32_t* big_i;
     float*    maxdist;          /* [S][channels] */
     float*    quad;             /* [S][4] */
-    float*    sufmin;           /* [S][channels][361] */
+    uint32_t* curb_cnt;         /* [S][channels] curb points of the ring with a valid azimuth; 0xffffffff: more than k_ring's list holds, see sufmin / premax */
+    float*    curb_az;          /* [S][channels][URF_CURB_LIST] their exact azimuths (k_ring -> k_beams) */
+    float*    sufmin;           /* [S][channels][361] only for rings whose list overflowed */
     float*    premax;           /* [S][channels][361] */
     int16_t*  stop_f;           /* [S][361] */
     int16_t*  stop_b;           /* [S][361] */

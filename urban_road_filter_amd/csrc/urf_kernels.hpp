@@ -2279,6 +2279,8 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
 #define URF_RING_CAND 1024   /* capacity of the candidate list; flushed when a chunk might not fit */
 #define URF_RING_PAD 32   /* LDS slots in front of a chunk, >= URF_MAX_CURB_POINTS, multiple of 4 */
 #define URF_RING_HITS 62  /* star-shaped hits of one ring kept in LDS (more: rescanned per chunk) */
+#define URF_CURB_LIST 48  /* curb points of one ring handed to k_beams as a list of azimuths (64 x 2048 street sweeps: <= 30); more: per-degree tables */
+#define URF_CURB_DENSE 0xffffffffu
 
 /* (the instance for curbPoints == 5 keeps no x / y windows and a shorter candidate list: 13 KB instead of
  * 18, twelve resident workgroups per CU instead of eight) */
@@ -2294,6 +2296,8 @@ struct urf_ring_shared_t {
     unsigned long long maxs;
     unsigned hits[URF_RING_HITS];
     unsigned n_hits, n_runs;
+    float curb[URF_CURB_LIST];   /* exact azimuths of the ring's curb points (the first URF_CURB_LIST of them) */
+    unsigned n_curb;
     unsigned hb[3][URF_RING_CHUNK / 32];   /* star-hit bit per point of the chunk; three in rotation: the one of chunk c + 1
                                             * is cleared while chunk c is parked and c - 1 may still be read */
     /* quad mapping: the ring's points that need one of the expensive evaluations, compacted */
@@ -2450,8 +2454,12 @@ __device__ __noinline__ float urf_ring_point(float* rd2, float* caz, SHARED& S, 
         caz[gpos] = az;
     }
     if (flag && az == az) {
-        /* curb point: per-degree tables for the beam march.  The azimuth lies in [0,360];
-         * cell_lo = largest integer <= az, cell_hi = smallest integer >= az. */
+        /* curb point: listed for the beam march (k_beams) ... */
+        const unsigned e = atomicAdd(&S.n_curb, 1u);
+        if (e < URF_CURB_LIST)
+            S.curb[e] = az;
+        /* ... and entered in the per-degree tables, which stand in for the list when it overflows.  The
+         * azimuth lies in [0,360]; cell_lo = largest integer <= az, cell_hi = smallest integer >= az. */
         int cl = (int)__builtin_floorf(az), ch = (int)__builtin_ceilf(az);
         cl = cl < 0 ? 0 : (cl > 360 ? 360 : cl);
         ch = ch < 0 ? 0 : (ch > 360 ? 360 : ch);
@@ -2470,6 +2478,26 @@ __device__ __noinline__ float urf_ring_point(float* rd2, float* caz, SHARED& S, 
         }
     }
     return az;
+}
+
+/* upper / lower end of beam i's window on ring k (blind_spots.cpp:107,136-143 / :216,245-252) */
+__device__ __forceinline__ float urf_fwd_hi(const urf_dev_params& dp, int i, unsigned k, double qk)
+{
+    const float fi = (float)i;
+    const float far = fi == dp.fwd_limit ? 360.0f : (float)((double)i + qk);   /* selects, not branches */
+    return k == 0 ? fi + dp.p.beamZone : far;
+}
+__device__ __forceinline__ float urf_bwd_lo(const urf_dev_params& dp, int i, unsigned k, double qk)
+{
+    const float fi = (float)i;
+    const float far = fi == dp.bwd_limit ? 0.0f : (float)((double)i - qk);
+    return k == 0 ? fi - dp.p.beamZone : far;
+}
+/* arcDistance / ((maxDistance[k] * M_PI) / 180), blind_spots.cpp:65,142 */
+__device__ __forceinline__ double urf_arc_ratio(const urf_dev_params& dp, float maxd0, float maxdk)
+{
+    const float arc = (float)((((double)maxd0 * URF_PI_D) / 180.0) * (double)dp.p.beamZone);
+    return (double)arc / (((double)maxdk * URF_PI_D) / 180.0);
 }
 
 /* 4 waves per SIMD (<= 128 VGPRs): the kernel hides its barrier and memory latencies with resident
@@ -2541,6 +2569,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
         S.maxs = 0;
         S.n_cand = 0;
         S.n_hits = 0;
+        S.n_curb = 0;
     }
     __syncthreads();
     URF_PHASE_ACC(0);
@@ -2863,11 +2892,32 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
         if ((tid & 63) == 0)
             atomicMax(&S.maxs, m);
     }
+    __syncthreads();   /* S.maxs is complete (and so is the ring's list of curb points: every candidate pass ended with a barrier) */
+    if (tid == 0)
+        a.maxdist[(size_t)s * C + c] = (float)__builtin_sqrt(__longlong_as_double((long long)S.maxs));
+    if (want_quad && tid < 4)
+        a.quad[(size_t)s * 4 + tid] = __uint_as_float((unsigned)sh_q[tid]);
+    /* What the beam march asks of a ring is "is there a curb point with azimuth in [lo, hi]" (blind_spots.cpp:
+     * 112-116, 151-155).  A ring holds a few dozen curb points at most on real ground, so it hands k_beams their
+     * exact azimuths (<= URF_CURB_LIST floats) instead of two per-degree tables of 361 floats each: 185 KB per
+     * 64-ring scan written here and read there, which made k_beams a bandwidth-bound kernel.  Only a ring with more
+     * curb points than the list holds (rough ground) builds the tables. */
+    const unsigned ncurb = S.n_curb;
+    if (tid == 0)
+        a.curb_cnt[(size_t)s * C + c] = ncurb <= URF_CURB_LIST ? ncurb : URF_CURB_DENSE;
+    if (ncurb <= URF_CURB_LIST) {   /* (uniform) */
+        if (tid < ncurb)
+            a.curb_az[((size_t)s * C + c) * URF_CURB_LIST + tid] = S.curb[tid];
+        URF_PHASE_ACC(6);
+        URF_PHASE_ACC_DUMP("k_ring", 7);
+        return;
+    }
     /* sufmin[i] = min curb azimuth >= i ; premax[i] = max curb azimuth <= i ; NaN = none.  Both are
      * prefix maxima: premax over the cells in order, sufmin over the cells in REVERSE order of the
      * bit-flipped values (a minimum is the maximum of the complements).  Three consecutive cells per
      * thread, one DPP scan across the wave, the first wave's total handed to the second. */
     static_assert(URF_RING_THREADS == 128 && 3 * URF_RING_THREADS >= URF_DEG_CELLS, "three cells per thread, two waves");
+    static_assert(URF_CURB_LIST <= URF_RING_THREADS, "one listed azimuth per thread");
     __shared__ unsigned wtot[2];
     unsigned up[3], dn[3];
 #pragma unroll
@@ -2888,15 +2938,11 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
     unsigned pu = (unsigned)__shfl_up((int)iu, 1), pd = (unsigned)__shfl_up((int)id, 1);
     if ((tid & 63) == 0)
         pu = pd = 0;
-    __syncthreads();   /* S.maxs and wtot are complete */
+    __syncthreads();   /* wtot is complete */
     if (tid >= 64) {
         pu = pu > wtot[0] ? pu : wtot[0];
         pd = pd > wtot[1] ? pd : wtot[1];
     }
-    if (tid == 0)
-        a.maxdist[(size_t)s * C + c] = (float)__builtin_sqrt(__longlong_as_double((long long)S.maxs));
-    if (want_quad && tid < 4)
-        a.quad[(size_t)s * 4 + tid] = __uint_as_float((unsigned)sh_q[tid]);
     float* sm = a.sufmin + ((size_t)s * C + c) * URF_DEG_CELLS;
     float* pm = a.premax + ((size_t)s * C + c) * URF_DEG_CELLS;
 #pragma unroll
@@ -2941,26 +2987,6 @@ __device__ __forceinline__ bool urf_blind(const urf_params& p, const float* q, i
     return (q[3] != 360.f && (fi >= q[3] || i <= 90)) || (q[2] != 180.f && fi <= q[2] && i >= 90);
 }
 
-/* upper / lower end of beam i's window on ring k (blind_spots.cpp:107,136-143 / :216,245-252) */
-__device__ __forceinline__ float urf_fwd_hi(const urf_dev_params& dp, int i, unsigned k, double qk)
-{
-    const float fi = (float)i;
-    const float far = fi == dp.fwd_limit ? 360.0f : (float)((double)i + qk);   /* selects, not branches */
-    return k == 0 ? fi + dp.p.beamZone : far;
-}
-__device__ __forceinline__ float urf_bwd_lo(const urf_dev_params& dp, int i, unsigned k, double qk)
-{
-    const float fi = (float)i;
-    const float far = fi == dp.bwd_limit ? 0.0f : (float)((double)i - qk);
-    return k == 0 ? fi - dp.p.beamZone : far;
-}
-/* arcDistance / ((maxDistance[k] * M_PI) / 180), blind_spots.cpp:65,142 */
-__device__ __forceinline__ double urf_arc_ratio(const urf_dev_params& dp, float maxd0, float maxdk)
-{
-    const float arc = (float)((((double)maxd0 * URF_PI_D) / 180.0) * (double)dp.p.beamZone);
-    return (double)arc / (((double)maxdk * URF_PI_D) / 180.0);
-}
-
 /* One thread per integer degree casts the forward and the backward beam that
  * start there and finds the first ring whose window holds a curb point. */
 __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_dev_params dp)
@@ -2969,11 +2995,27 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     __shared__ float q[4];
     __shared__ unsigned long long mf[URF_MAX_CHANNELS * 6], mb[URF_MAX_CHANNELS * 6];
     __shared__ int16_t pf[URF_MAX_CHANNELS * 6], nb[URF_MAX_CHANNELS * 6];
+    __shared__ unsigned lcnt[URF_MAX_CHANNELS];   /* curb points of ring k (URF_CURB_DENSE: see its per-degree tables) */
+    __shared__ unsigned lpre[URF_MAX_CHANNELS + 1];   /* listed curb points on the rings in front of ring k */
+    extern __shared__ unsigned sh_beams[];            /* sfm[channels][12] | sbm[channels][12] | lst[channels][URF_CURB_LIST] */
     const unsigned s = blockIdx.x, tid = threadIdx.x;
+    const unsigned C = (unsigned)dp.p.channels;
+    unsigned* const sfm = sh_beams;                   /* per ring: the degrees whose forward / backward beam it stops (bit d) */
+    unsigned* const sbm = sfm + C * 12;
+    float* const lst = (float*)(sbm + C * 12);        /* the rings' lists of curb azimuths (k_ring) */
+    /* the scan's summary, the rings' curb counts and their lists are requested together */
     const urf_scan_info in = a.info[s];
+    const unsigned v_cnt = tid < C ? a.curb_cnt[(size_t)s * C + tid] : 0u;
+    constexpr unsigned LPT = (URF_MAX_CHANNELS * URF_CURB_LIST + URF_LABEL_THREADS - 1) / URF_LABEL_THREADS;
+    float v_lst[LPT];
+#pragma unroll
+    for (unsigned e = 0; e < LPT; e++) {
+        const unsigned idx = tid + e * URF_LABEL_THREADS;
+        v_lst[e] = idx < C * URF_CURB_LIST ? a.curb_az[(size_t)s * C * URF_CURB_LIST + idx] : 0.f;   /* (entries behind a ring's count: never looked at) */
+    }
     if (in.status != URF_OK)
         return;
-    const unsigned C = (unsigned)dp.p.channels, nR = in.n_rings;
+    const unsigned nR = in.n_rings;
     const float* maxd = a.maxdist + (size_t)s * C;
     if (tid < 4) {
         const float init[4] = { 0.f, 180.f, 180.f, 360.f };
@@ -2982,35 +3024,139 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     }
     for (unsigned k = tid; k < nR; k += URF_LABEL_THREADS)
         qk[k] = urf_arc_ratio(dp, maxd[0], maxd[k]);
+    if (tid < C)
+        lcnt[tid] = v_cnt;
+#pragma unroll
+    for (unsigned e = 0; e < LPT; e++) {
+        const unsigned idx = tid + e * URF_LABEL_THREADS;
+        if (idx < C * URF_CURB_LIST)
+            lst[idx] = v_lst[e];
+    }
+    for (unsigned e = tid; e < nR * 12; e += URF_LABEL_THREADS) {
+        sfm[e] = 0u;
+        sbm[e] = 0u;
+    }
+    /* where each ring's listed points start in the scan's flat numbering: one wave, two rings per lane */
+    if (tid < 64) {
+        static_assert(URF_MAX_CHANNELS <= 128, "two rings per lane");
+        const unsigned c0 = tid < nR && tid < C && v_cnt != URF_CURB_DENSE ? v_cnt : 0u;
+        const unsigned v1 = tid + 64 < C ? a.curb_cnt[(size_t)s * C + tid + 64] : 0u;
+        const unsigned c1 = tid + 64 < nR && v1 != URF_CURB_DENSE ? v1 : 0u;
+        const unsigned i0 = urf_wave_scan_add(c0), i1 = urf_wave_scan_add(c1);
+        const unsigned t0 = (unsigned)__shfl((int)i0, 63), t1 = (unsigned)__shfl((int)i1, 63);   /* (every lane takes part in the shuffles) */
+        lpre[tid] = i0 - c0;
+        lpre[tid + 64] = t0 + i1 - c1;
+        if (tid == 0)
+            lpre[URF_MAX_CHANNELS] = t0 + t1;
+    }
     __syncthreads();
     if (tid < 4 && !(dp.p.blind_spots && nR > 1))
         a.quad[(size_t)s * 4 + tid] = q[tid];
+    /* The forward beam of degree i stops at the first ring k that holds a curb point with azimuth in [i, hi_k(i)]
+     * (blind_spots.cpp:107-155: the sorted scan from the first point >= i finds one <= hi), the backward beam at
+     * the first with one in [lo_k(i), i] (:216-273).  Turned round: hi_k and lo_k do not fall as the degree grows,
+     * so a curb point (k, az) stops exactly the forward beams of the degrees [dmin, floor(az)], dmin = the smallest
+     * degree with hi_k(dmin) >= az, and the backward beams of [ceil(az), dmax] -- plus the one beam whose window is
+     * stretched to the end of the circle (fi == limit, rings k >= 1).  One thread per listed curb point finds dmin /
+     * dmax (an estimate from the window's width, corrected with the reference's own predicate) and sets the bits of
+     * the interval in the ring's mask: ~700 points per 64 x 2048 sweep, a few predicate tests and two or three
+     * LDS atomics each.  (r2: two per-degree tables of 361 floats per ring, 185 KB per sweep through memory, this
+     * kernel bandwidth-bound; a march through per-ring lists degree by degree compares every degree with every
+     * curb point: 490 000 tests, 0.07 -> 0.16 ms.) */
+    {
+        const bool fl_int = dp.fwd_limit >= 0.0f && dp.fwd_limit <= 360.0f && (float)(int)dp.fwd_limit == dp.fwd_limit;
+        const bool bl_int = dp.bwd_limit >= 0.0f && dp.bwd_limit <= 360.0f && (float)(int)dp.bwd_limit == dp.bwd_limit;
+        auto set_bits = [&](unsigned* m12, int d0, int d1) {   /* degrees d0..d1 (inclusive), 0 <= d0 <= d1 <= 360 */
+            for (int w = d0 >> 5; w <= (d1 >> 5); w++) {
+                const int lo_b = d0 > w * 32 ? d0 - w * 32 : 0, hi_b = d1 < w * 32 + 31 ? d1 - w * 32 : 31;
+                atomicOr(&m12[w], (0xffffffffu >> (31 - hi_b)) & (0xffffffffu << lo_b));
+            }
+        };
+        const unsigned n_ent = lpre[URF_MAX_CHANNELS];
+        for (unsigned idx = tid; idx < n_ent; idx += URF_LABEL_THREADS) {
+            /* the ring of flat entry idx: the last ring whose start is <= idx and that lists something (bisection
+             * over the starts; rings without entries share their successor's start and are stepped over) */
+            unsigned lo_k = 0, hi_k = URF_MAX_CHANNELS;
+#pragma unroll
+            for (unsigned step = 0; step < 7; step++) {
+                const unsigned mid = (lo_k + hi_k) >> 1;
+                if (lpre[mid] <= idx)
+                    lo_k = mid;
+                else
+                    hi_k = mid;
+            }
+            const unsigned k = lo_k;                       /* lpre[k] <= idx < lpre[k + 1] */
+            const float az = lst[k * URF_CURB_LIST + (idx - lpre[k])];   /* in [0, 360] */
+            const double qq = qk[k];
+            const float wd = k == 0 ? dp.p.beamZone : (float)qq;   /* width of the window on this ring */
+            if (!(wd == wd))
+                continue;   /* (NaN: no comparison with such a window end holds) */
+            const int a0 = (int)__builtin_floorf(az), a1 = (int)__builtin_ceilf(az);
+            /* the window ends away from the limit beams (which are added below): monotone in the degree */
+            auto hi_of = [&](int d) { return k == 0 ? (float)d + dp.p.beamZone : (float)((double)d + qq); };
+            auto lo_of = [&](int d) { return k == 0 ? (float)d - dp.p.beamZone : (float)((double)d - qq); };
+            {   /* forward: [dmin, a0] */
+                const float est = __builtin_ceilf(az - wd);
+                int d = !(est >= 0.0f) ? 0 : (est > (float)(a0 + 1) ? a0 + 1 : (int)est);
+                int guard = 0;
+                while (d > 0 && az <= hi_of(d - 1) && guard++ < 400)
+                    d--;
+                while (d <= a0 && !(az <= hi_of(d)) && guard++ < 800)
+                    d++;
+                if (d <= a0)
+                    set_bits(&sfm[k * 12], d, a0);
+                if (k != 0 && fl_int && (int)dp.fwd_limit <= a0)   /* fi == limit: the window reaches 360 >= az */
+                    set_bits(&sfm[k * 12], (int)dp.fwd_limit, (int)dp.fwd_limit);
+            }
+            {   /* backward: [a1, dmax] */
+                const float est = __builtin_floorf(az + wd);
+                int d = !(est <= 360.0f) ? 360 : (est < (float)(a1 - 1) ? a1 - 1 : (int)est);
+                int guard = 0;
+                while (d < 360 && az >= lo_of(d + 1) && guard++ < 400)
+                    d++;
+                while (d >= a1 && !(az >= lo_of(d)) && guard++ < 800)
+                    d--;
+                if (d >= a1)
+                    set_bits(&sbm[k * 12], a1, d);
+                if (k != 0 && bl_int && (int)dp.bwd_limit >= a1)   /* fi == limit: the window reaches 0 <= az */
+                    set_bits(&sbm[k * 12], (int)dp.bwd_limit, (int)dp.bwd_limit);
+            }
+        }
+    }
+    __syncthreads();
     const int i = (int)tid;
     const bool inrange = i <= 360;
     const float fi = (float)i;
     const bool blind = !inrange || urf_blind(dp.p, q, i);
-    /* both marches of the degree, ring group by ring group, with the table entries of BOTH directions of a group
-     * requested together (one after the other the two marches cost up to sixteen dependent round trips) */
     const bool cast_f = fi <= dp.fwd_limit && !blind;   /* blind_spots.cpp:68 */
     const bool cast_b = fi >= dp.bwd_limit && !blind;   /* blind_spots.cpp:177 */
     int sf = cast_f ? (int)nR : -1, sb = cast_b ? (int)nR : -1;
-    for (unsigned k0 = 0; k0 < nR; k0 += 8) {   /* 8 rings' entries per direction in flight */
-        const bool go_f = cast_f && sf == (int)nR, go_b = cast_b && sb == (int)nR;
-        if (!__any(go_f || go_b))
-            break;
-        float mfw[8], mbw[8];
+    {
+        const unsigned w = inrange ? tid >> 5 : 11u;
+        const unsigned bit = 1u << (tid & 31);
+        for (unsigned k0 = 0; k0 < nR; k0 += 8) {   /* (the words of eight rings in flight) */
+            unsigned wf[8], wb[8];
 #pragma unroll
-        for (unsigned u = 0; u < 8; u++) {
-            const bool in = k0 + u < nR;
-            mfw[u] = go_f && in ? a.sufmin[((size_t)s * C + k0 + u) * URF_DEG_CELLS + i] : __builtin_nanf("");
-            mbw[u] = go_b && in ? a.premax[((size_t)s * C + k0 + u) * URF_DEG_CELLS + i] : __builtin_nanf("");
-        }
+            for (unsigned u = 0; u < 8; u++) {
+                const unsigned k = k0 + u < nR ? k0 + u : nR - 1;
+                wf[u] = sfm[k * 12 + w];
+                wb[u] = sbm[k * 12 + w];
+            }
 #pragma unroll
-        for (unsigned u = 0; u < 8; u++) {
-            if (sf == (int)nR && go_f && k0 + u < nR && mfw[u] <= urf_fwd_hi(dp, i, k0 + u, qk[k0 + u]))
-                sf = (int)(k0 + u);
-            if (sb == (int)nR && go_b && k0 + u < nR && mbw[u] >= urf_bwd_lo(dp, i, k0 + u, qk[k0 + u]))
-                sb = (int)(k0 + u);
+            for (unsigned u = 0; u < 8; u++) {
+                const unsigned k = k0 + u;
+                if (k >= nR)
+                    continue;
+                bool hf = (wf[u] & bit) != 0, hb = (wb[u] & bit) != 0;
+                if (lcnt[k] == URF_CURB_DENSE) {   /* (uniform) the ring's list overflowed: its per-degree tables */
+                    hf = cast_f && sf == (int)nR && a.sufmin[((size_t)s * C + k) * URF_DEG_CELLS + i] <= urf_fwd_hi(dp, i, k, qk[k]);
+                    hb = cast_b && sb == (int)nR && a.premax[((size_t)s * C + k) * URF_DEG_CELLS + i] >= urf_bwd_lo(dp, i, k, qk[k]);
+                }
+                if (sf == (int)nR && hf)
+                    sf = (int)k;
+                if (sb == (int)nR && hb)
+                    sb = (int)k;
+            }
         }
     }
     if (inrange) {
