@@ -2997,6 +2997,7 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     __shared__ int16_t pf[URF_MAX_CHANNELS * 6], nb[URF_MAX_CHANNELS * 6];
     __shared__ unsigned lcnt[URF_MAX_CHANNELS];   /* curb points of ring k (URF_CURB_DENSE: see its per-degree tables) */
     __shared__ unsigned lpre[URF_MAX_CHANNELS + 1];   /* listed curb points on the rings in front of ring k */
+    __shared__ unsigned n_dense;                       /* rings whose list overflowed */
     extern __shared__ unsigned sh_beams[];            /* sfm[channels][12] | sbm[channels][12] | lst[channels][URF_CURB_LIST] */
     const unsigned s = blockIdx.x, tid = threadIdx.x;
     const unsigned C = (unsigned)dp.p.channels;
@@ -3004,6 +3005,7 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     unsigned* const sbm = sfm + C * 12;
     float* const lst = (float*)(sbm + C * 12);        /* the rings' lists of curb azimuths (k_ring) */
     /* the scan's summary, the rings' curb counts and their lists are requested together */
+    URF_PHASE_DECL;
     const urf_scan_info in = a.info[s];
     const unsigned v_cnt = tid < C ? a.curb_cnt[(size_t)s * C + tid] : 0u;
     constexpr unsigned LPT = (URF_MAX_CHANNELS * URF_CURB_LIST + URF_LABEL_THREADS - 1) / URF_LABEL_THREADS;
@@ -3046,10 +3048,14 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
         const unsigned t0 = (unsigned)__shfl((int)i0, 63), t1 = (unsigned)__shfl((int)i1, 63);   /* (every lane takes part in the shuffles) */
         lpre[tid] = i0 - c0;
         lpre[tid + 64] = t0 + i1 - c1;
-        if (tid == 0)
+        const unsigned long long dm0 = __ballot(tid < nR && tid < C && v_cnt == URF_CURB_DENSE), dm1 = __ballot(tid + 64 < nR && v1 == URF_CURB_DENSE);
+        if (tid == 0) {
             lpre[URF_MAX_CHANNELS] = t0 + t1;
+            n_dense = (unsigned)__popcll(dm0) + (unsigned)__popcll(dm1);
+        }
     }
     __syncthreads();
+    URF_PHASE_MARK;
     if (tid < 4 && !(dp.p.blind_spots && nR > 1))
         a.quad[(size_t)s * 4 + tid] = q[tid];
     /* The forward beam of degree i stops at the first ring k that holds a curb point with azimuth in [i, hi_k(i)]
@@ -3124,6 +3130,7 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
         }
     }
     __syncthreads();
+    URF_PHASE_MARK;
     const int i = (int)tid;
     const bool inrange = i <= 360;
     const float fi = (float)i;
@@ -3134,6 +3141,7 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     {
         const unsigned w = inrange ? tid >> 5 : 11u;
         const unsigned bit = 1u << (tid & 31);
+        const bool dense_rings = n_dense != 0;   /* (uniform; normally none) */
         for (unsigned k0 = 0; k0 < nR; k0 += 8) {   /* (the words of eight rings in flight) */
             unsigned wf[8], wb[8];
 #pragma unroll
@@ -3145,17 +3153,13 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
 #pragma unroll
             for (unsigned u = 0; u < 8; u++) {
                 const unsigned k = k0 + u;
-                if (k >= nR)
-                    continue;
-                bool hf = (wf[u] & bit) != 0, hb = (wb[u] & bit) != 0;
-                if (lcnt[k] == URF_CURB_DENSE) {   /* (uniform) the ring's list overflowed: its per-degree tables */
+                bool hf = k < nR && (wf[u] & bit) != 0, hb = k < nR && (wb[u] & bit) != 0;
+                if (dense_rings && k < nR && lcnt[k] == URF_CURB_DENSE) {   /* (uniform) the ring's list overflowed: its per-degree tables */
                     hf = cast_f && sf == (int)nR && a.sufmin[((size_t)s * C + k) * URF_DEG_CELLS + i] <= urf_fwd_hi(dp, i, k, qk[k]);
                     hb = cast_b && sb == (int)nR && a.premax[((size_t)s * C + k) * URF_DEG_CELLS + i] >= urf_bwd_lo(dp, i, k, qk[k]);
                 }
-                if (sf == (int)nR && hf)
-                    sf = (int)k;
-                if (sb == (int)nR && hb)
-                    sb = (int)k;
+                sf = (sf == (int)nR && hf) ? (int)k : sf;
+                sb = (sb == (int)nR && hb) ? (int)k : sb;
             }
         }
     }
@@ -3167,14 +3171,22 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
      * beyond ring k.  From the masks, for every (ring, degree d): the window end of the nearest such
      * forward beam at or below d and of the nearest backward beam at or above d -- all k_label needs
      * to decide a point (windows [i, hi_k(i)] and [lo_k(i), i] move monotonically with i). */
-    for (unsigned k = 0; k < nR; k++) {
-        const unsigned long long bf = __ballot(sf > (int)k), bb = __ballot(sb > (int)k);
-        if (urf_lane() == 0) {
-            mf[k * 6 + (tid >> 6)] = bf;
-            mb[k * 6 + (tid >> 6)] = bb;
+    /* (lane u of a wave stores the words of ring k0 + u: 64 rings per round instead of one) */
+    for (unsigned k0 = 0; k0 < nR; k0 += 64) {
+        unsigned long long myf = 0ull, myb = 0ull;
+        const unsigned kn = nR - k0 < 64u ? nR - k0 : 64u;
+        for (unsigned u = 0; u < kn; u++) {
+            const unsigned long long bf = __ballot(sf > (int)(k0 + u)), bb = __ballot(sb > (int)(k0 + u));
+            myf = urf_lane() == u ? bf : myf;
+            myb = urf_lane() == u ? bb : myb;
+        }
+        if (urf_lane() < kn) {
+            mf[(k0 + urf_lane()) * 6 + (tid >> 6)] = myf;
+            mb[(k0 + urf_lane()) * 6 + (tid >> 6)] = myb;
         }
     }
     __syncthreads();
+    URF_PHASE_MARK;
     /* highest set forward bit in the words below word w / lowest set backward bit in the words above */
     for (unsigned e = tid; e < nR * 6; e += URF_LABEL_THREADS) {
         const unsigned k = e / 6, w = e % 6;
@@ -3189,21 +3201,40 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
         nb[e] = (int16_t)above;
     }
     __syncthreads();
+    URF_PHASE_MARK;
     if (inrange) {
         const unsigned w = tid >> 6, b = tid & 63;
         const unsigned long long le = b == 63 ? ~0ull : ((2ull << b) - 1ull), ge = ~0ull << b;
         urf_win* win = a.win + (size_t)s * C * URF_DEG_CELLS + i;
-        for (unsigned k = 0; k < nR; k++) {
-            const unsigned long long f = mf[k * 6 + w] & le, g = mb[k * 6 + w] & ge;
-            const int jf = f ? (int)(w * 64 + 63 - __clzll((long long)f)) : (int)pf[k * 6 + w];
-            const int jb = g ? (int)(w * 64 + __ffsll((long long)g) - 1) : (int)nb[k * 6 + w];
-            const double q = qk[k];
-            urf_win o;
-            o.hi = jf >= 0 ? urf_fwd_hi(dp, jf, k, q) : -__builtin_inff();
-            o.lo = jb >= 0 ? urf_bwd_lo(dp, jb, k, q) : __builtin_inff();
-            win[(size_t)k * URF_DEG_CELLS] = o;
+        for (unsigned k0 = 0; k0 < nR; k0 += 4) {   /* four rings at a time: their masks and ratios read before any is used */
+            unsigned long long f4[4], g4[4];
+            int p4[4], n4[4];
+            double q4[4];
+#pragma unroll
+            for (unsigned u = 0; u < 4; u++) {
+                const unsigned k = k0 + u < nR ? k0 + u : nR - 1;
+                f4[u] = mf[k * 6 + w] & le;
+                g4[u] = mb[k * 6 + w] & ge;
+                p4[u] = (int)pf[k * 6 + w];
+                n4[u] = (int)nb[k * 6 + w];
+                q4[u] = qk[k];
+            }
+#pragma unroll
+            for (unsigned u = 0; u < 4; u++) {
+                const unsigned k = k0 + u;
+                if (k >= nR)
+                    break;
+                const int jf = f4[u] ? (int)(w * 64 + 63 - __clzll((long long)f4[u])) : p4[u];
+                const int jb = g4[u] ? (int)(w * 64 + __ffsll((long long)g4[u]) - 1) : n4[u];
+                urf_win o;
+                o.hi = jf >= 0 ? urf_fwd_hi(dp, jf, k, q4[u]) : -__builtin_inff();
+                o.lo = jb >= 0 ? urf_bwd_lo(dp, jb, k, q4[u]) : __builtin_inff();
+                win[(size_t)k * URF_DEG_CELLS] = o;
+            }
         }
     }
+    URF_PHASE_MARK;
+    URF_PHASE_DUMP("k_beams");
 }
 
 /* ------------------------------------------------------------------------- */
