@@ -281,12 +281,56 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
                 py[q] = on ? a.y[off + i] : 0.f;
                 pz[q] = on ? a.z[off + i] : 0.f;
             }
+            {
+                /* urf_leader_match_point for the thread's eight points together: the bisections in the sorted
+                 * leaders step by step side by side (their LDS reads in flight together; point after point, each
+                 * behind a short-circuit, the look-ahead cost 9 us per 2048 points) */
+                const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;
+                float vt[URF_TABLE_SCAN_PPT];
+                unsigned lb[URF_TABLE_SCAN_PPT], okm = 0, roim = 0;
 #pragma unroll
-            for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++) {
-                const unsigned i = pos + q * 256 + tid;
-                if (i < len && first == 0xffffffffu && urf_in_roi(dp.p, px[q], py[q], pz[q]) &&
-                    !urf_leader_match_point(SL, nmatch, px[q], py[q], pz[q], interval))
-                    first = i;
+                for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++) {
+                    const unsigned i = pos + q * 256 + tid;
+                    roim |= (unsigned)((i < len) & urf_in_roi(dp.p, px[q], py[q], pz[q])) << q;
+                    okm |= (unsigned)urf_fast_vertical_angle(px[q], py[q], pz[q], &vt[q]) << q;
+                    lb[q] = 0;
+                }
+#pragma unroll
+                for (unsigned step = URF_MAX_CHANNELS / 2; step > 0; step >>= 1) {   /* first entry with SL - vt >= -(interval + e) */
+                    float sv[URF_TABLE_SCAN_PPT];
+#pragma unroll
+                    for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++)
+                        sv[q] = SL[(lb[q] + step - 1) & (URF_MAX_CHANNELS - 1)];
+#pragma unroll
+                    for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++)
+                        lb[q] += (lb[q] + step - 1 < nmatch && !(sv[q] - vt[q] >= -(interval + e))) ? step : 0u;
+                }
+                float cv[URF_TABLE_SCAN_PPT];
+#pragma unroll
+                for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++)
+                    cv[q] = SL[lb[q] & (URF_MAX_CHANNELS - 1)];
+#pragma unroll
+                for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++)   /* (the steps add up to 127: a full table of 128 entries all below) */
+                    lb[q] += (lb[q] == URF_MAX_CHANNELS - 1 && lb[q] < nmatch && !(cv[q] - vt[q] >= -(interval + e))) ? 1u : 0u;
+#pragma unroll
+                for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++) {
+                    const unsigned i = pos + q * 256 + tid;
+                    if (!((roim >> q) & 1u))
+                        continue;
+                    /* (lb can reach nmatch only through entries < nmatch, so lb <= nmatch <= 128; an index of 128
+                     * wraps to entry 0 and is not looked at: lb == nmatch) */
+                    const float d = cv[q] - vt[q];
+                    const bool fast = (okm >> q) & 1u;
+                    const bool none = lb[q] >= nmatch || d > interval + e;
+                    const bool sure = !none && __builtin_fabsf(d) <= interval - e;
+                    bool matched;
+                    if (fast && (none || sure))
+                        matched = sure;
+                    else
+                        matched = urf_leader_match(SL, nmatch, urf_vertical_angle(px[q], py[q], pz[q]), interval);
+                    if (!matched && i < first)
+                        first = i;
+                }
             }
             for (int o = 32; o > 0; o >>= 1) {
                 const unsigned w = __shfl_xor(first, o);
