@@ -1559,15 +1559,13 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
     }
     __syncthreads();   /* every lane has its ranks: A and cnt may be overwritten */
     URF_PHASE_ACC(3);
-    unsigned* R = (unsigned*)A;      /* range bits, height, position / ring-sorted index in sorted order */
-    float* Z = (float*)A + 512;
+    uint2* RZ = (uint2*)A;           /* (range bits, height) side by side, position / ring-sorted index, in sorted order */
     unsigned* S = cnt;
     static_assert(URF_STAR_NB + 1 >= MAXB * 64, "S reuses the bucket counters: one word per point of the sector");
 #pragma unroll
     for (unsigned q = 0; q < MAXB; q++)
         if (q < B && key[q] != ~0ull) {
-            R[rank[q]] = (unsigned)(key[q] >> 32);
-            Z[rank[q]] = zreg[q];
+            RZ[rank[q]] = make_uint2((unsigned)(key[q] >> 32), __float_as_uint(zreg[q]));   /* one 8-byte scatter instead of two 4-byte ones */
             S[rank[q]] = sreg[q];
         }
     __syncthreads();
@@ -1583,8 +1581,9 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
         if (i < n) {
             float slp = 0.f, g = 0.f;
             if (i >= 1) {
-                const float ax = __uint_as_float(R[i - 1]), bx = __uint_as_float(R[i]);
-                slp = (Z[i] - Z[i - 1]) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
+                const uint2 pa = RZ[i - 1], pb = RZ[i];
+                const float ax = __uint_as_float(pa.x), bx = __uint_as_float(pb.x);
+                slp = (__uint_as_float(pb.y) - __uint_as_float(pa.y)) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
                 g = (bx - ax) * kdist;
                 if (slp > slope_param)
                     atomicMin(sh_first, i);
