@@ -618,7 +618,6 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     mark();
     hipLaunchKernelGGL(k_ring_table, g_scan, dim3(256), 0, st, a, dp);
     mark();
-    URF_HIP(c, hipMemsetAsync(a.star_count, 0, 4 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_split, g_tiles, dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
     if (a.table_lookahead) {   /* normally both find nothing to do */
         hipLaunchKernelGGL(k_table_repair, g_scan, dim3(256), 0, st, a, dp);

@@ -426,6 +426,8 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
 __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params dp)
 {
     __shared__ urf_table_shared T;
+    if (blockIdx.x == 0 && threadIdx.x < 4)
+        a.star_count[threadIdx.x] = 0;   /* the call's work-list lengths (k_table_repair, k_index): first kernel of the sequence */
     urf_ring_table_scan(a, dp, blockIdx.x, a.table_lookahead, T);
 }
 
