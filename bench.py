@@ -200,8 +200,20 @@ def e2e_callback_path(u, O, params, n_sweeps=8, reps=40, stream_reps=160):
             return stream_reps / (time.perf_counter() - t0)
 
         stream(False)
-        out["e2e_overlapped_scans_per_s"] = round(stream(False), 1)
-        out["e2e_overlapped_scans_per_s_pinned_producer"] = round(stream(True), 1)
+        out["e2e_overlapped_scans_per_s_python_client"] = round(stream(False), 1)
+        out["e2e_overlapped_scans_per_s_pinned_producer_python_client"] = round(stream(True), 1)
+        # the same loops inside the library (urf_bench_callback_stream): what a C / C++ client -- the reference is a
+        # C++ node -- gets, without a Python interpreter between the calls; the labels of the last sweep are checked
+        ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 16, IN_FLIGHT)
+        sec, labn = ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT)
+        lbn, _, _ = O.run_b(*u.synth_cloud(RINGS, COLS, 1, 9000 + (stream_reps - 1) % n_sweeps), params)
+        if not np.array_equal(labn, lbn):
+            raise SystemExit("parity failure on the callback path (native loop)")
+        out["e2e_overlapped_scans_per_s"] = round(stream_reps / sec, 1)
+        sec, _ = ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT, producer_pinned=True)
+        out["e2e_overlapped_scans_per_s_pinned_producer"] = round(stream_reps / sec, 1)
+        sec, _ = ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, reps, 1)
+        out["e2e_latency_ms_native_mean"] = round(1e3 * sec / reps, 4)
     return out
 
 

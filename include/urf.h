@@ -374,6 +374,17 @@ const char* urf_kernel_name(int index);
 int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
                     float* x, float* y, float* z);
 
+/* Benchmark helper: the submit / collect loop of a C / C++ client of the asynchronous path (what a node's
+ * subscriber callback and publisher do, lidar_segmentation.cpp:53,95,612-621), timed inside the library:
+ * n_sweeps messages taken round robin from msgs[0..n_msgs) (host buffers of n_points records each), at most
+ * in_flight (1..URF_MAX_IN_FLIGHT) submitted before the oldest is collected into labels_out (may be NULL).
+ * producer_pinned != 0: the messages are produced in the library's pinned buffers (urf_pinned_input; each
+ * buffer is filled once, outside the producer's cost).  *seconds = wall time of the whole loop. */
+int urf_bench_callback_stream(urf_ctx* ctx, const uint8_t* const* msgs, uint32_t n_msgs, uint32_t n_points,
+                              uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                              uint32_t n_sweeps, uint32_t in_flight, int producer_pinned, uint8_t* labels_out,
+                              double* seconds);
+
 /* ---- diagnostics --------------------------------------------------------- */
 /* Device self test of the arithmetic shortcuts the kernels take (currently: the
  * 3-operation division by pi against the IEEE division, exhaustively over all

@@ -131,6 +131,8 @@ def lib():
         "urf_selftest_fast": [vp, C.c_uint64, C.c_void_p],
         "urf_kernel_timing": [vp, C.c_void_p, C.c_void_p],
         "urf_synth_cloud": [C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, fp, fp, fp],
+        "urf_bench_callback_stream": [vp, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.c_uint32, C.c_uint32, C.c_int, u8p, C.POINTER(C.c_double)],
         "urf_abi_version": [],
     }
     for name, args in sig.items():
@@ -317,6 +319,16 @@ class Context:
         self._check(self._lib.urf_classify_pc2_wait(self._h, ticket, labels.ctypes.data if labels is not None else None,
                                                     C.byref(info)), "urf_classify_pc2_wait")
         return info
+
+    def bench_callback_stream(self, msgs, n_points, point_step, off_x, off_y, off_z, n_sweeps, in_flight, producer_pinned=False):
+        """Seconds the library's own submit / collect loop takes for n_sweeps messages (uint8 arrays), in_flight at a time."""
+        arr = (C.c_void_p * len(msgs))(*[m.ctypes.data for m in msgs])
+        lab = np.empty(n_points, np.uint8)
+        sec = C.c_double(0.0)
+        self._check(self._lib.urf_bench_callback_stream(self._h, arr, len(msgs), n_points, point_step, off_x, off_y, off_z,
+                                                        n_sweeps, in_flight, 1 if producer_pinned else 0, lab.ctypes.data,
+                                                        C.byref(sec)), "urf_bench_callback_stream")
+        return sec.value, lab
 
     def pinned_input(self, nbytes):
         """uint8 numpy view (nbytes long) of the pinned input buffer the NEXT submission will use."""

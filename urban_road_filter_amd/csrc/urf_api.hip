@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -959,6 +960,62 @@ extern "C" int urf_classify_pc2(urf_ctx* c, const uint8_t* data, uint32_t n_poin
     if (rc != URF_OK)
         return rc;
     return urf_classify_pc2_wait(c, ticket, labels_out, info);
+}
+
+/* Benchmark helper: the submit / collect loop of a C or C++ client of the callback path (a ROS node's
+ * subscriber callback and publisher), timed natively -- `n_sweeps` messages (taken round robin from
+ * `msgs`), at most `in_flight` of them submitted before the oldest is collected. */
+extern "C" int urf_bench_callback_stream(urf_ctx* c, const uint8_t* const* msgs, uint32_t n_msgs, uint32_t n_points,
+                                         uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                                         uint32_t n_sweeps, uint32_t in_flight, int producer_pinned, uint8_t* labels_out,
+                                         double* seconds)
+{
+    if (!c || !msgs || n_msgs == 0 || !seconds || in_flight == 0 || in_flight > URF_ASYNC_SLOTS)
+        return URF_ERR_INVALID_ARG;
+    for (uint32_t k = 0; k < n_msgs; k++)
+        if (!msgs[k])
+            return URF_ERR_INVALID_ARG;
+    const size_t bytes = (size_t)n_points * point_step;
+    uint32_t tickets[URF_ASYNC_SLOTS];
+    uint32_t head = 0, count = 0;   /* ring of tickets in flight */
+    urf_scan_info info;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t k = 0; k < n_sweeps; k++) {
+        if (count == in_flight) {
+            const int rc = urf_classify_pc2_wait(c, tickets[head], labels_out, &info);
+            if (rc != URF_OK)
+                return rc;
+            head = (head + 1) % URF_ASYNC_SLOTS;
+            count--;
+        }
+        const uint8_t* data = msgs[k % n_msgs];
+        if (producer_pinned) {   /* the producer fills the library's pinned buffer itself (each slot's once: producing the data is not what is timed) */
+            uint8_t* pin = nullptr;
+            const int rc = urf_pinned_input(c, bytes, &pin);
+            if (rc != URF_OK)
+                return rc;
+            if (k < URF_ASYNC_SLOTS)
+                std::memcpy(pin, data, bytes);
+            data = pin;
+        }
+        uint32_t t = 0;
+        const int rc = urf_classify_pc2_async(c, data, n_points, point_step, off_x, off_y, off_z, &t);
+        if (rc != URF_OK)
+            return rc;
+        tickets[(head + count) % URF_ASYNC_SLOTS] = t;
+        count++;
+    }
+    while (count) {
+        const int rc = urf_classify_pc2_wait(c, tickets[head], labels_out, &info);
+        if (rc != URF_OK)
+            return rc;
+        head = (head + 1) % URF_ASYNC_SLOTS;
+        count--;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    return URF_OK;
 }
 
 /* ---- index-set and marker outputs: every scan of a batch in one launch sequence ------------- */
