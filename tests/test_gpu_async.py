@@ -204,3 +204,23 @@ def test_malformed_layouts_are_refused_before_any_copy(ctx):
         with pytest.raises(u.UrfError) as e:
             ctx.classify_pc2(rec, 100, step, ox, oy, oz)
         assert e.value.code == -1
+
+
+@pytest.mark.parametrize("pinned", [False, True], ids=["staged", "pinned_producer"])
+def test_native_submit_collect_loop(ctx, sweeps, pinned):
+    """urf_bench_callback_stream: the loop a C / C++ client runs (submit until IN_FLIGHT sweeps are in flight, collect
+    the oldest), inside the library.  The labels it hands back are those of the last message."""
+    ctx.set_params(O.cfg_params("cfg2"))
+    msgs = [rec for rec, _, _ in sweeps[:5]]
+    for in_flight in (1, 2, IN_FLIGHT):
+        n_sweeps = 11
+        sec, lab = ctx.bench_callback_stream(msgs, N, 32, 0, 4, 8, n_sweeps, in_flight, producer_pinned=pinned)
+        assert sec > 0
+        if pinned:   # each slot's pinned buffer was filled once, with message k for the k-th submission (k < IN_FLIGHT)
+            want = sweeps[(n_sweeps - 1) % IN_FLIGHT][1]
+        else:
+            want = sweeps[(n_sweeps - 1) % len(msgs)][1]
+        assert np.array_equal(lab, want), (in_flight, pinned)
+    with pytest.raises(u.UrfError) as e:
+        ctx.bench_callback_stream(msgs, N, 32, 0, 4, 8, 4, IN_FLIGHT + 1)
+    assert e.value.code == -1
