@@ -319,7 +319,7 @@ def main():
     ap.add_argument("--scans", type=int, default=0, help="sweeps per GPU per step (default: the workload's, cfg3: 1024)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parity-scans", type=int, default=4)
+    ap.add_argument("--parity-scans", type=int, default=8)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("URF_BENCH_BACKEND", "nccl"))
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-outputs", action="store_true")
