@@ -2112,6 +2112,117 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
  * per sector) into LDS and every lane then reads its own row. */
 #define URF_WALK_CHUNK 16
 #define URF_WALK_INV 512
+/* the running state of one sector's walk (star_shaped_search.cpp:123-149) */
+struct urf_walk_state {
+    float avg, dev, nan;
+    unsigned hit_i;   /* sorted index of the sector's curb point, 0 = none */
+    unsigned lim;     /* last index this lane still walks; 0 = done */
+};
+/* One chunk of URF_WALK_CHUNK steps from index c0 (wave-uniform) of every lane's sector: slopes sl[], distance
+ * terms gg[], the wave-uniform 1 / i in uu[].  All lanes step through the chunk in lockstep; a lane that is past
+ * its sector's end or has found its curb point just stops updating its state (lim = 0). */
+__device__ __forceinline__ void urf_walk_chunk(urf_walk_state& w_, unsigned c0, const float (&sl)[URF_WALK_CHUNK], const float (&gg)[URF_WALK_CHUNK],
+                                               const float (&uu)[URF_WALK_CHUNK], bool anynan, float kdev, float slope_param, int dmin)
+{
+    float avg = w_.avg, dev = w_.dev, nan = w_.nan;
+    unsigned hit_i = w_.hit_i, lim = w_.lim;
+    if (!__any(anynan)) {
+        /* straight-line version: no NaN slope so far in any sector of the wave */
+#pragma unroll
+        for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
+            const unsigned i = c0 + j;
+            if (i == 0)
+                continue;   /* the walk starts at 1 (compile-time j, uniform c0) */
+            const float slp = sl[j];
+            const float w = (float)(int)(i - 1);               /* == (float)i - 0 - 1, exact */
+            float na = avg * w;                                /* star_shaped_search.cpp:135-140 */
+            na = na + slp;
+            na = na * uu[j];
+            float nd = dev * w;
+            nd = nd + __builtin_fabsf(slp - na);
+            nd = nd * uu[j];
+            const bool active = i <= lim;
+            avg = active ? na : avg;
+            dev = active ? nd : dev;
+            const bool h = (slp > slope_param) |               /* :142-143 */
+                           (((int)i > dmin) & ((slp * slp - avg * avg) * kdev * gg[j] > dev));
+            const bool hit_now = active & h;
+            hit_i = hit_now ? i : hit_i;                       /* :146 */
+            lim = hit_now ? 0u : lim;
+        }
+    } else {
+#pragma unroll 1
+        for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
+            const unsigned i = c0 + j;
+            const bool active = i >= 1 && i <= lim;
+            const float slp = sl[j];
+            if (active) {
+                if (slp != slp) {
+                    nan += 1.0f;                               /* :131-132 */
+                } else {
+                    const float w = (float)(int)i - nan - 1.0f;
+                    const float u = 1.0f / ((float)(int)i - nan);
+                    avg *= w;
+                    avg += slp;
+                    avg *= u;
+                    dev *= w;
+                    dev += __builtin_fabsf(slp - avg);
+                    dev *= u;
+                }
+            }
+            const bool h = slp > slope_param ||
+                           ((int)i > dmin && (slp * slp - avg * avg) * kdev * gg[j] > dev);
+            if (active && h) {
+                hit_i = i;
+                lim = 0;
+            }
+        }
+    }
+    w_.avg = avg;
+    w_.dev = dev;
+    w_.nan = nan;
+    w_.hit_i = hit_i;
+    w_.lim = lim;
+}
+
+/* The curb point of sector k (sorted index hit_i, 0 = none), reported where k_ring looks for it: as a position
+ * in the ring-major arrays (-1: none, or on no ring).  Its tile-local ring-sorted index t * URF_TILE + slot: for a
+ * sector of at most two runs the sort left the point's position inside the sector (ssrt16), which sec_run turns
+ * into its place in the sector-sorted arrays, where its slot stands; other sectors hold the index itself (ssrt).
+ * The ring is the run of tile t that contains the slot (bisection in the tile's run table). */
+__device__ __forceinline__ int urf_walk_report(const urf_kargs& a, unsigned s, unsigned K, unsigned C, unsigned k, unsigned n, unsigned base,
+                                               unsigned hit_i)
+{
+    int hit = -1;
+    unsigned v = 0xffffffffu;
+    if (hit_i) {
+        const urf_sec_run two = a.sec_run[(size_t)s * K + k];
+        if (two.nruns <= 2 && n <= URF_STAR_MID_CAP_) {
+            const unsigned i0 = a.ssrt16[base + hit_i];
+            const unsigned adr = i0 < two.c0 ? two.a0 + i0 : two.a1 + (i0 - two.c0);
+            const unsigned sl = a.sslot[urf_sbase(a, s) + adr];
+            v = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+        } else {
+            v = a.ssrt[base + hit_i];
+        }
+    }
+    if (v != 0xffffffffu) {
+        const unsigned t = v / URF_TILE, j = v % URF_TILE;
+        const uint16_t* row = a.troff + ((size_t)s * a.tiles + t) * (C + 1);
+        unsigned lo = 0, hi = C;   /* largest c with row[c] <= j (its run is not empty) */
+        while (hi - lo > 1) {
+            const unsigned mid = (lo + hi) >> 1;
+            if ((unsigned)row[mid] <= j)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const unsigned p = a.rpre[((size_t)s * C + lo) * (a.tiles + 1) + t] + (j - (unsigned)row[lo]);
+        hit = (int)(a.ring_off[(size_t)s * (C + 1) + lo] + p);   /* relative to the scan's scratch base */
+    }
+    return hit;
+}
+
 __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp)
 {
     __shared__ float tS[64][URF_WALK_CHUNK + 1], tG[64][URF_WALK_CHUNK + 1];
@@ -2167,16 +2278,14 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
 
     const float kdev = dp.p.kdev_param, slope_param = dp.slope_param;
     const int dmin = dp.p.dmin_param;
-    float avg = 0.f, dev = 0.f, nan = 0.f;
-    unsigned hit_i = 0;              /* sorted index of the sector's curb point, 0 = none */
-    unsigned lim = last;             /* last index this lane still walks; 0 = done */
+    urf_walk_state W = { 0.f, 0.f, 0.f, 0u, last };
     for (unsigned t = lane; t < URF_WALK_INV; t += 64)
         sinv[t] = 1.0f / (float)(int)t;   /* [0] is never used */
     fetch(0);
     park();
     __syncthreads();
     for (unsigned c0 = 0; c0 <= maxlast; c0 += URF_WALK_CHUNK) {
-        if (!__any(lim != 0))
+        if (!__any(W.lim != 0))
             break;
         const bool more = c0 + URF_WALK_CHUNK <= maxlast;
         if (more)
@@ -2184,7 +2293,7 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
         /* the chunk's operands first: slopes, distance terms and the wave-uniform 1 / i (LDS
          * table; anything fetched inside the dependent chain below would cost more than the step) */
         float sl[URF_WALK_CHUNK], gg[URF_WALK_CHUNK], uu[URF_WALK_CHUNK];
-        bool anynan = nan != 0.0f;
+        bool anynan = W.nan != 0.0f;
 #pragma unroll
         for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
             sl[j] = tS[lane][j];
@@ -2201,99 +2310,14 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
                 uu[j] = 1.0f / (float)(int)(c0 + j);
         }
         __syncthreads();   /* the tile has been read: it may take the next chunk */
-        /* All lanes step through the chunk in lockstep (i is wave-uniform); a lane that is past its
-         * sector's end or has found its curb point just stops updating its state (lim = 0). */
-        if (!__any(anynan)) {
-            /* straight-line version: no NaN slope so far in any sector of the wave */
-#pragma unroll
-            for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
-                const unsigned i = c0 + j;
-                if (i == 0)
-                    continue;   /* the walk starts at 1 (compile-time j, uniform c0) */
-                const float slp = sl[j];
-                const float w = (float)(int)(i - 1);               /* == (float)i - 0 - 1, exact */
-                float na = avg * w;                                /* star_shaped_search.cpp:135-140 */
-                na = na + slp;
-                na = na * uu[j];
-                float nd = dev * w;
-                nd = nd + __builtin_fabsf(slp - na);
-                nd = nd * uu[j];
-                const bool active = i <= lim;
-                avg = active ? na : avg;
-                dev = active ? nd : dev;
-                const bool h = (slp > slope_param) |               /* :142-143 */
-                               (((int)i > dmin) & ((slp * slp - avg * avg) * kdev * gg[j] > dev));
-                const bool hit_now = active & h;
-                hit_i = hit_now ? i : hit_i;                       /* :146 */
-                lim = hit_now ? 0u : lim;
-            }
-        } else {
-#pragma unroll 1
-            for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
-                const unsigned i = c0 + j;
-                const bool active = i >= 1 && i <= lim;
-                const float slp = sl[j];
-                if (active) {
-                    if (slp != slp) {
-                        nan += 1.0f;                               /* :131-132 */
-                    } else {
-                        const float w = (float)(int)i - nan - 1.0f;
-                        const float u = 1.0f / ((float)(int)i - nan);
-                        avg *= w;
-                        avg += slp;
-                        avg *= u;
-                        dev *= w;
-                        dev += __builtin_fabsf(slp - avg);
-                        dev *= u;
-                    }
-                }
-                const bool h = slp > slope_param ||
-                               ((int)i > dmin && (slp * slp - avg * avg) * kdev * gg[j] > dev);
-                if (active && h) {
-                    hit_i = i;
-                    lim = 0;
-                }
-            }
-        }
+        urf_walk_chunk(W, c0, sl, gg, uu, anynan, kdev, slope_param, dmin);
         if (c0 + URF_WALK_CHUNK > last)
-            lim = 0;
+            W.lim = 0;
         if (more)
             park();
         __syncthreads();
     }
-    /* the curb point of the sector, reported where k_ring looks for it: as a position in the
-     * ring-major arrays.  Its tile-local ring-sorted index t * URF_TILE + slot: for a sector of at
-     * most two runs the sort left the point's position inside the sector (ssrt16), which sec_run turns
-     * into its place in the sector-sorted arrays, where its slot stands; other sectors hold the index
-     * itself (ssrt).  The ring is the run of tile t that contains the slot (bisection in the tile's
-     * run table). */
-    int hit = -1;
-    unsigned v = 0xffffffffu;
-    if (hit_i) {
-        const urf_sec_run two = a.sec_run[(size_t)s * K + k];
-        if (two.nruns <= 2 && n <= URF_STAR_MID_CAP_) {
-            const unsigned i0 = a.ssrt16[base + hit_i];
-            const unsigned adr = i0 < two.c0 ? two.a0 + i0 : two.a1 + (i0 - two.c0);
-            const unsigned sl = a.sslot[urf_sbase(a, s) + adr];
-            v = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
-        } else {
-            v = a.ssrt[base + hit_i];
-        }
-    }
-    if (v != 0xffffffffu) {
-        const unsigned t = v / URF_TILE, j = v % URF_TILE;
-        const uint16_t* row = a.troff + ((size_t)s * a.tiles + t) * (C + 1);
-        unsigned lo = 0, hi = C;   /* largest c with row[c] <= j (its run is not empty) */
-        while (hi - lo > 1) {
-            const unsigned mid = (lo + hi) >> 1;
-            if ((unsigned)row[mid] <= j)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const unsigned p = a.rpre[((size_t)s * C + lo) * (a.tiles + 1) + t] + (j - (unsigned)row[lo]);
-        hit = (int)(a.ring_off[(size_t)s * (C + 1) + lo] + p);   /* relative to the scan's scratch base */
-    }
+    const int hit = urf_walk_report(a, s, K, C, k, n, base, W.hit_i);
     if (have)
         a.star_hit[(size_t)s * K + k] = hit;
 }
