@@ -1200,7 +1200,10 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
     for (unsigned k0 = 0; k0 < K; k0 += 256) {
         const unsigned k = k0 + tid;
         const unsigned c = k < K ? a.sec_cnt[(size_t)s * K + k] : 0;
-        const bool mid = c > URF_STAR_SMALL_CAP && c <= URF_STAR_MID_CAP_, big = c > URF_STAR_MID_CAP_;
+        /* (the wave-per-sector kernel takes sectors of at most two runs: one scattered over more tiles -- an
+         * unorganised cloud -- goes the workgroup path whatever its size) */
+        const unsigned nr = k < K ? a.sec_run[(size_t)s * K + k].nruns : 0;   /* (this thread's own store above) */
+        const bool mid = (c > URF_STAR_SMALL_CAP || (nr > 2 && c >= 2)) && c <= URF_STAR_MID_CAP_, big = c > URF_STAR_MID_CAP_;
         const unsigned long long bm = __ballot(mid), bb = __ballot(big);
         unsigned pm = 0, pb = 0;
         if (urf_lane() == 0) {
@@ -1337,7 +1340,7 @@ __device__ __forceinline__ unsigned urf_sector_runs(const urf_kargs& a, unsigned
  * bitonic network and the blocks are merged by ranking. */
 template <unsigned MAXB>
 __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const urf_dev_params& dp, unsigned sb, unsigned obase, unsigned n,
-                                                     unsigned nruns, const urf_sec_run& two, unsigned long long* A, unsigned* cnt,
+                                                     const urf_sec_run& two, unsigned long long* A, unsigned* cnt,
                                                      unsigned* sh_first, uint32_t* star_first_out)
 {
     constexpr unsigned NB = URF_STAR_NB, PL = NB / 64;
@@ -1347,51 +1350,38 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
     unsigned long long key[MAXB];
     float zreg[MAXB];      /* the height travels with the key: the tail then needs no dependent gathers from memory */
     /* What the walk finally needs of the sorted sector is ONE point: its curb point.  A sector of at most two
-     * runs (every sector of an organised sweep) therefore publishes, per sorted index, only the point's position
-     * inside the sector (2 bytes; the walk turns the one it wants into a ring-sorted slot through sec_run and
-     * sslot) and never reads the slots.  Sectors scattered over more tiles carry the slot with the key and
-     * publish tile-local ring-sorted indices (4 bytes), as r2 did for all. */
+     * runs (every sector of an organised sweep, and the only kind this kernel sees) therefore publishes, per
+     * sorted index, only the point's position inside the sector (2 bytes; the walk turns the one it wants into a
+     * ring-sorted slot through sec_run and sslot) and never reads the slots.  Sectors scattered over more tiles take
+     * the workgroup path, which carries the slot with the key and publishes tile-local ring-sorted indices. */
     unsigned sreg[MAXB];
     unsigned rmin = 0xffffffffu, rmax = 0;
     {
-        /* the sector's points are gathered run by run (urf_sector_runs; the list sits in A's memory
-         * until the keys are in registers); a lane's positions grow with q, so does its run.  The
-         * low half of a key is the point's index in the sector-sorted arrays: it grows with the
+        /* The low half of a key is the point's index in the sector-sorted arrays: it grows with the
          * position inside the sector (tiles in order, input order inside), i.e. it breaks ties
          * exactly as the position would, and it finds the point's companions again. */
-        const unsigned* runP = (const unsigned*)A;
-        const unsigned* runA = runP + 512;
-        const bool simple = nruns == 0;   /* at most two runs, described by `two` (uniform) */
         const unsigned a1m = two.a1 - two.c0;
         /* straight-line: elements past the sector's end repeat its last one (valid addresses) and
          * are dropped afterwards; all loads of the lane are in flight together */
-        unsigned r = 0, adr[MAXB], rbv[MAXB], slv[MAXB];
+        unsigned adr[MAXB], rbv[MAXB];
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
             const unsigned i = q * 64 + lane, ic = i < n ? i : n - 1u;
             adr[q] = ic + (ic < two.c0 ? two.a0 : a1m);
-            if (!simple) {
-                while (r + 1 < nruns && ic >= runP[r + 1])
-                    r++;
-                adr[q] = runA[r] + ic;
-            }
         }
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
             rbv[q] = 0;
-            slv[q] = 0;
             zreg[q] = 0.f;
             if (q < B) {   /* uniform */
                 rbv[q] = urf_fbits(a.sr[sb + adr[q]]);
                 zreg[q] = a.sz[sb + adr[q]];
-                if (!simple)
-                    slv[q] = a.sslot[sb + adr[q]];
             }
         }
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
             const bool valid = q * 64 + lane < n;
-            sreg[q] = simple ? q * 64 + lane : (slv[q] == URF_SLOT_NONE ? 0xffffffffu : (adr[q] & ~(URF_TILE - 1u)) + slv[q]);
+            sreg[q] = q * 64 + lane;
             key[q] = valid ? ((unsigned long long)rbv[q] << 32) | adr[q] : ~0ull;
             rmin = valid && rbv[q] < rmin ? rbv[q] : rmin;
             rmax = valid && rbv[q] > rmax ? rbv[q] : rmax;
@@ -1492,7 +1482,9 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
              * that have work in a step sit in the same one or two buckets and the step takes as many
              * trips as THAT bucket is large -- ranked by their owners, every one of the six steps had
              * some lane in the largest bucket (21 trips of four keys per sector on average instead of 5).
-             * The rank travels back through the unused tail of A (n <= 384 of its 512 entries). */
+             * The rank travels back through the unused tail of A (n <= 384 of its 512 entries).  (Keeping it in the
+             * upper halves of the bucket offsets instead makes room for a 7th wave per SIMD, which then spills 12
+             * bytes at its 72 registers: 0.557 ms instead of 0.519.) */
             static_assert(MAXB * 64 <= 384, "the rank slots live behind the keys in A");
             uint16_t* RK = (uint16_t*)(A + 384);
 #pragma unroll
@@ -1541,12 +1533,8 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
                 if (key[q] != ~0ull) {   /* the key moved to another lane: fetch its companions again */
                     const unsigned adr = (unsigned)key[q];
                     zreg[q] = a.sz[sb + adr];
-                    if (nruns == 0) {   /* (uniform) at most two runs: the position inside the sector from the address */
-                        sreg[q] = (two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0;
-                    } else {
-                        const unsigned sl = a.sslot[sb + adr];
-                        sreg[q] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
-                    }
+                    /* at most two runs: the position inside the sector from the address */
+                    sreg[q] = (two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0;
                 }
             }
         __syncthreads();
@@ -1590,10 +1578,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
                 if (slp > slope_param)
                     atomicMin(sh_first, i);
             }
-            if (nruns == 0)
-                a.ssrt16[obase + i] = (uint16_t)S[i];
-            else
-                a.ssrt[obase + i] = S[i];
+            a.ssrt16[obase + i] = (uint16_t)S[i];
             a.wsg[obase + i] = urf_sg{ slp, g };
         }
         __syncthreads();
@@ -1631,29 +1616,23 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
     if (status != URF_OK)
         return;
     const unsigned n = so1 - so0;
-    if (n > URF_STAR_SMALL_CAP)
-        return;   /* on a work list (k_index) */
+    /* a sector of an organised sweep meets one or two tiles, and k_index described those runs: that is the only case
+     * this kernel handles.  One scattered over more tiles (an unorganised cloud) or of more than 384 points is on a
+     * work list of the workgroup kernels (k_index). */
+    if (n > URF_STAR_SMALL_CAP || (two.nruns > 2 && n >= 2))
+        return;
     if (n < 2) {
         if (lane == 0)
             a.star_first[(size_t)s * K + k] = 0;   /* nothing to walk */
         return;
     }
-    unsigned off, len;
-    urf_scan_range(a, s, off, len);
     const unsigned sb = urf_sbase(a, s), obase = sb + so0;
     if (lane == 0)
         sh_first = n;
-    /* a sector of an organised sweep meets one or two tiles: k_index described those runs; only a
-     * sector scattered over more tiles builds the list of its runs from k_split's per-tile tables */
-    unsigned nruns = 0;
-    if (two.nruns > 2) {
-        nruns = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, urf_sector_run_row(a, s, K, k, 0), (unsigned*)A, (unsigned*)A + 512);
-        __syncthreads();
-    }
     /* per-lane element count fixed at compile time: 6 covers a sector of a 64 x 2048 sweep.  (An
      * 8-per-lane instance for sectors of up to 512 points made the kernel spill 68 bytes per lane at
      * its 80 registers; such sectors take the workgroup path now.) */
-    urf_star_sort_sector<URF_STAR_SMALL_CAP / 64>(a, dp, sb, obase, n, nruns, two, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
+    urf_star_sort_sector<URF_STAR_SMALL_CAP / 64>(a, dp, sb, obase, n, two, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
 }
 
 template <int NT>
