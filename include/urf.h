@@ -199,12 +199,13 @@ int urf_classify_pc2(urf_ctx* ctx, const uint8_t* data, uint32_t n_points,
                      uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
                      uint8_t* labels_out, urf_scan_info* info);
 
-/* The same, asynchronously: the message is copied to pinned memory and sent to the device on a
- * copy stream, classified by ONE graph launch (the kernel sequence of a sweep of this shape is
- * captured once and replayed), and the labels come back to pinned memory.
- * URF_MAX_IN_FLIGHT sweeps may be in flight (the copy of sweep i+1 overlaps the kernels of sweep i;
- * with a context created for max_batch >= 2 the sweeps in flight are spread over min(max_batch,
- * URF_MAX_IN_FLIGHT) scratch rows, each with its own compute stream, so their kernels overlap as well):
+/* The same, asynchronously: the message's x / y / z are gathered into pinned memory (three planes: 12 bytes
+ * per point cross PCIe whatever the point_step) and sent to the device, classified by ONE graph launch (the
+ * kernel sequence of a sweep of this shape is captured once and replayed), and the labels come back to pinned
+ * memory.  URF_MAX_IN_FLIGHT sweeps may be in flight; with a context created for max_batch >= 2 they are spread
+ * over min(max_batch, URF_MAX_IN_FLIGHT) scratch rows, each with its own stream (copy in, kernels, copy out), so
+ * that the copies and kernels of different sweeps overlap -- create the context with max_batch >= 4 for the
+ * callback path:
  *     urf_classify_pc2_async(ctx, msg_a, ..., &ta);
  *     urf_classify_pc2_async(ctx, msg_b, ..., &tb);      // ... the fifth in a row returns URF_ERR_BUSY
  *     urf_classify_pc2_wait(ctx, ta, labels_a, &info_a);  // blocks until sweep a is done
@@ -403,6 +404,12 @@ int urf_selftest_fast(urf_ctx* ctx, uint64_t n_samples, float* err);
  * thresholds on u = -z / rho that decide a point's ring: the same source evaluated on the host, so that
  * its accuracy (1e-15; needed: 1e-7) can be checked without a GPU. */
 double urf_ring_threshold_cot(double angle_deg);
+/* Diagnostics of the callback path.  It launches a short kernel sequence first (no repair kernels behind the
+ * speculative ring table, none for the work lists of star sectors of more than 384 points); a sweep that needed what
+ * was left out is run again inside urf_classify_pc2_wait() with the full sequence, and so is every later one.
+ * n_rerun: sweeps run again so far (per cause the first one and those in flight beside it); sequence: bit 0 the ring table is still speculative,
+ * bit 1 the work-list kernels are part of the sequence.  Either pointer may be NULL. */
+int urf_callback_path_state(const urf_ctx* ctx, uint32_t* n_rerun, uint32_t* sequence);
 /* Test hook: bit 2 (value 4) forces the general (comparison network) path of the star-shaped sort
  * for every sector; 0 in production.  Takes effect with the next classify call. */
 int urf_set_debug_flags(urf_ctx* ctx, uint32_t flags);

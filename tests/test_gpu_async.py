@@ -1,6 +1,6 @@
 """The callback path (SURVEY.md 8b "wire in" / "callback"): one sweep arrives as PointCloud2 bytes in
 host memory, the labels go back to host memory.  urf_classify_pc2_async / _wait keep up to four sweeps in
-flight (pinned staging, H2D on a copy stream, the kernel sequence replayed from a captured graph);
+flight (pinned staging, H2D and the kernel sequence -- replayed from a captured graph -- on the slot's stream);
 urf_classify_pc2 is the same path, waited for at once.  Results must not depend on how a sweep was
 submitted."""
 import numpy as np
@@ -224,3 +224,94 @@ def test_native_submit_collect_loop(ctx, sweeps, pinned):
     with pytest.raises(u.UrfError) as e:
         ctx.bench_callback_stream(msgs, N, 32, 0, 4, 8, 4, IN_FLIGHT + 1)
     assert e.value.code == -1
+
+
+def _in_flight(ctx, msgs, n):
+    """Submit all messages, at most IN_FLIGHT at a time; labels and summaries in submission order."""
+    got, tickets = [None] * len(msgs), []
+    for k, rec in enumerate(msgs):
+        if len(tickets) == IN_FLIGHT:
+            j, t = tickets.pop(0)
+            lab = np.empty(n[j], np.uint8)
+            got[j] = (lab, ctx.classify_pc2_wait(t, lab))
+        tickets.append((k, ctx.classify_pc2_async(rec, n[k], 32, 0, 4, 8)))
+    for j, t in tickets:
+        lab = np.empty(n[j], np.uint8)
+        got[j] = (lab, ctx.classify_pc2_wait(t, lab))
+    return got
+
+
+@pytest.mark.parametrize("rows", [1, 4])
+def test_a_sweep_the_short_sequence_cannot_handle_is_run_again(rows):
+    """The callback path launches without the repair kernels of the speculative ring table and without the kernels
+    for oversized star sectors; k_index voids a sweep that needed them (internal status) and urf_classify_pc2_wait runs
+    it again with the full sequence -- as every later sweep.  Here: (i) a sweep with 6 000 extra points in two sectors
+    (mid and big work lists) among ordinary ones, several in flight when the first one comes back void; (ii) in a fresh
+    context a default-ROI sweep stored from the rear (no region-of-interest point among its first 8192: the speculative
+    table is empty).  Nobody ever sees the internal status, all labels equal oracle B."""
+    from test_gpu_parity import crowded_cloud
+    p = O.cfg_params("cfg2")
+    plain = [O.cfg_cloud("cfg2", 60 + k) for k in range(3)]
+    xc, yc, zc = crowded_cloud(6000, seed=61)
+    crowd = tuple(np.concatenate([a, b]) for a, b in zip(O.cfg_cloud("cfg2", 62), (xc, yc, zc)))
+    order = [plain[0], crowd, plain[1], crowd, plain[2], plain[0]]
+    with u.Context(N + 6000, rows, params=p) as ctx:
+        got = _in_flight(ctx, [records(*c) for c in order], [len(c[0]) for c in order])
+        for c, (lab, info) in zip(order, got):
+            lb, ib, _ = O.run_b(*c, p)
+            assert info.status == 0 and np.array_equal(lab, lb)
+            assert (info.n_road, info.n_curb, info.n_roi) == (ib["n_road"], ib["n_curb"], ib["n_roi"])
+        # both crowded sweeps had been launched with the short sequence when the first one came back void; the ring
+        # table is still speculative
+        assert ctx.callback_path_state() == (2, 1 | 2)
+    q = O.cfg_params("default_roi")
+    front = O.cfg_cloud("default_roi", 63)
+    rear = tuple(np.roll(a.reshape(-1, 64), 1024, axis=0).reshape(-1).copy() for a in O.cfg_cloud("default_roi", 64))
+    order = [front, rear, front, rear, front]
+    with u.Context(N, rows, params=q) as ctx:
+        for rep in range(2):
+            got = _in_flight(ctx, [records(*c) for c in order], [N] * len(order))
+            for c, (lab, info) in zip(order, got):
+                lb, ib, _ = O.run_b(*c, q)
+                assert info.status == 0 and np.array_equal(lab, lb)
+                assert (info.n_road, info.n_curb, info.n_rings) == (ib["n_road"], ib["n_curb"], ib["n_rings"])
+        n_rerun, seq = ctx.callback_path_state()
+        # four rows: the second rear sweep was in flight when the first came back void, and is run again as well
+        assert seq == 0 and 1 <= n_rerun <= 2
+
+
+def test_sweeps_of_oversized_sectors_through_the_callback_path():
+    """128 x 4096 sweeps (every star sector on the mid work list): the first one comes back void and is run again,
+    the others take the full sequence at once."""
+    p = O.cfg_params("cfg5")
+    clouds = [O.cfg_cloud("cfg5", 70 + k) for k in range(3)]
+    n = len(clouds[0][0])
+    with u.Context(n, 2, params=p) as ctx:
+        lab, info = ctx.classify_pc2(records(*clouds[0]), n, 32, 0, 4, 8)
+        lb, _, _ = O.run_b(*clouds[0], p)
+        assert info.status == 0 and np.array_equal(lab, lb) and ctx.callback_path_state() == (1, 1 | 2)
+        got = _in_flight(ctx, [records(*c) for c in clouds], [n] * 3)
+        for c, (lab, info) in zip(clouds, got):
+            lb, ib, _ = O.run_b(*c, p)
+            assert info.status == 0 and np.array_equal(lab, lb)
+        assert ctx.callback_path_state() == (1, 1 | 2)
+
+
+@pytest.mark.parametrize("step,ox,oy,oz", [(32, 0, 4, 8), (12, 0, 4, 8), (16, 4, 8, 12), (20, 4, 8, 12), (48, 20, 4, 36), (16, 8, 4, 0)])
+def test_staged_messages_of_any_layout(ctx, step, ox, oy, oz):
+    """A staged message crosses PCIe as three planes (the host gathers x / y / z: four records at a time where they
+    lie side by side with a fourth word behind them, one by one otherwise); a producer that fills the pinned buffer
+    sends the records and the device gathers.  Same labels either way, for sweep lengths that are no multiple of 4."""
+    p = O.cfg_params("cfg2")
+    ctx.set_params(p)
+    x, y, z = O.cfg_cloud("cfg2", 81)
+    for m in (N, 50001, 50002, 50003):
+        lb, _, _ = O.run_b(x[:m], y[:m], z[:m], p)
+        rec = records(x[:m], y[:m], z[:m], step=step, ox=ox, oy=oy, oz=oz)
+        lab, info = ctx.classify_pc2(rec, m, step, ox, oy, oz)
+        assert info.status == 0 and np.array_equal(lab, lb), m
+        pin = ctx.pinned_input(rec.size)
+        pin[:] = rec
+        lab2 = np.empty(m, np.uint8)
+        ctx.classify_pc2_wait(ctx.classify_pc2_async(pin, m, step, ox, oy, oz), lab2)
+        assert np.array_equal(lab2, lb), m

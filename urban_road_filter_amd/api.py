@@ -126,6 +126,7 @@ def lib():
         "urf_marker_points": [vp, C.c_uint32, vp, vp],
         "urf_enable_stage_capture": [vp, C.c_int],
         "urf_set_debug_flags": [vp, C.c_uint32],
+        "urf_callback_path_state": [vp, C.c_void_p, C.c_void_p],
         "urf_enable_kernel_timing": [vp, C.c_int],
         "urf_selftest": [vp, C.c_void_p],
         "urf_selftest_fast": [vp, C.c_uint64, C.c_void_p],
@@ -276,6 +277,12 @@ class Context:
         """0 off; 1 exact arithmetic for every point, all stages readable; 2 production decisions with
         the ring / sector of every input point recorded (STAGE_RING, STAGE_SECTOR)."""
         self._check(self._lib.urf_enable_stage_capture(self._h, int(mode)), "urf_enable_stage_capture")
+
+    def callback_path_state(self):
+        """(sweeps run again so far, sequence bits: 1 speculative ring table, 2 work-list kernels launched)."""
+        n, q = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._lib.urf_callback_path_state(self._h, C.addressof(n), C.addressof(q)), "urf_callback_path_state")
+        return n.value, q.value
 
     def set_debug_flags(self, flags):
         self._check(self._lib.urf_set_debug_flags(self._h, int(flags)), "urf_set_debug_flags")

@@ -12,6 +12,10 @@
 #include <ctime>
 #include <string>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#include <xmmintrin.h>
+#endif
 
 #include "urf.h"
 #include "urf_internal.hpp"
@@ -36,10 +40,9 @@ struct urf_ctx {
     /* owned device memory */
     std::vector<void*> allocs;
     float *sx = nullptr, *sy = nullptr, *sz = nullptr;   /* SoA staging for PointCloud2 input */
-    /* The single-scan (callback) path: URF_ASYNC_SLOTS sweeps in flight, so that the H2D copy of sweep
-     * i+1 runs on the copy stream while sweep i is being classified and -- with a context created for
-     * several scans -- the kernels of several sweeps overlap on the device (a single sweep's kernels are
-     * a few dozen workgroups each).  Per slot: pinned host staging for the message bytes and for the
+    /* The single-scan (callback) path: URF_ASYNC_SLOTS sweeps in flight, so that -- with a context created
+     * for several scans -- the copies and kernels of several sweeps overlap on the device (a single sweep's
+     * kernels are a few dozen workgroups each).  Per slot: pinned host staging for the message bytes and for the
      * results, device copies of both, the captured launch sequence. */
     struct slot_t {
         uint8_t* h_in = nullptr;        /* pinned, h_in_cap bytes */
@@ -49,7 +52,7 @@ struct urf_ctx {
         uint8_t* h_labels = nullptr;    /* pinned, max_points */
         uint8_t* d_labels = nullptr;    /* device, max_points */
         urf_scan_info* h_info = nullptr;   /* pinned */
-        hipEvent_t ev_h2d = nullptr, ev_done = nullptr;
+        hipEvent_t ev_done = nullptr;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         uint64_t key[3] = { 0, 0, 0 };  /* what the captured sequence was built for */
@@ -57,8 +60,15 @@ struct urf_ctx {
         urf_dev_params cap_dp;
         bool pending = false, used = false;
         uint32_t n_points = 0, ticket = 0;
+        uint32_t point_step = 0, off_x = 0, off_y = 0, off_z = 0;   /* layout of the message in d_raw */
+        bool planes = false;            /* d_raw holds x[n] y[n] z[n] (a staged message) instead of the records */
     } slots[URF_ASYNC_SLOTS];
-    hipStream_t copy_stream = nullptr;
+    bool streams_made = false;
+    /* the callback path launches a short sequence first: no repair kernels behind the speculative ring table, no
+     * kernels for the work lists of oversized star sectors (run_pipeline); a sweep that needed one of them comes back
+     * with an internal status and is run again with it, as are all later ones (urf_classify_pc2_wait) */
+    bool slot_lists = false;
+    uint32_t n_rerun = 0;           /* sweeps urf_classify_pc2_wait had to run again */
     /* Slot i works on scratch row i % rows, rows = min(max_batch, URF_ASYNC_SLOTS); row 0 runs on the
      * context's stream, every other row on a stream of its own (slots that share a row share its
      * stream: they are serialised).  Everything else the context launches runs on `stream`; the two
@@ -282,8 +292,6 @@ static void free_lazy(urf_ctx* c)
             (void)hipGraphExecDestroy(sl.exec);
         if (sl.graph)
             (void)hipGraphDestroy(sl.graph);
-        if (sl.ev_h2d)
-            (void)hipEventDestroy(sl.ev_h2d);
         if (sl.ev_done)
             (void)hipEventDestroy(sl.ev_done);
         if (sl.h_in)
@@ -297,8 +305,6 @@ static void free_lazy(urf_ctx* c)
         if (sl.d_labels)
             (void)hipFree(sl.d_labels);
     }
-    if (c->copy_stream)
-        (void)hipStreamDestroy(c->copy_stream);
     for (hipStream_t st : c->row_stream)
         if (st)
             (void)hipStreamDestroy(st);
@@ -394,6 +400,17 @@ extern "C" int urf_enable_stage_capture(urf_ctx* c, int mode)
     }
     c->capture = mode;
     c->epoch++;
+    return URF_OK;
+}
+
+extern "C" int urf_callback_path_state(const urf_ctx* c, uint32_t* n_rerun, uint32_t* sequence)
+{
+    if (!c)
+        return URF_ERR_INVALID_ARG;
+    if (n_rerun)
+        *n_rerun = c->n_rerun;
+    if (sequence)
+        *sequence = (c->speculate ? 1u : 0u) | (c->slot_lists ? 2u : 0u);
     return URF_OK;
 }
 
@@ -590,6 +607,11 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         c->epoch++;
     }
     a.table_lookahead = c->speculate ? URF_TABLE_LOOKAHEAD : 0u;
+    /* A sweep of the callback path is waited for by the host before anybody sees its result: the kernels that
+     * normally find nothing to do -- the two repair kernels behind the speculative ring table, the two for the work
+     * lists of oversized star sectors, 20 of a sweep's 200 microseconds -- are left out, k_index voids a sweep that
+     * needed them, and urf_classify_pc2_wait() runs it again with them. */
+    a.optimistic = on_stream ? ((c->speculate ? URF_OPT_NO_REPAIR : 0u) | (c->slot_lists ? 0u : URF_OPT_NO_LISTS)) : 0u;
     a.capture = (uint32_t)c->capture;
     a.labels = d_labels;
     if (c->capture != 1) {
@@ -620,7 +642,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     hipLaunchKernelGGL(k_ring_table, g_scan, dim3(256), 0, st, a, dp);
     mark();
     hipLaunchKernelGGL(k_split, g_tiles, dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
-    if (a.table_lookahead) {   /* normally both find nothing to do */
+    if (a.table_lookahead && !(a.optimistic & URF_OPT_NO_REPAIR)) {   /* normally both find nothing to do */
         hipLaunchKernelGGL(k_table_repair, g_scan, dim3(256), 0, st, a, dp);
         hipLaunchKernelGGL(k_split_repair, dim3(c->n_cus), dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
     }
@@ -631,9 +653,11 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         const dim3 g_sec(K, n_scans);
         hipLaunchKernelGGL(k_star_sort_small, g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
         /* persistent workgroups over the (normally empty) work lists of oversized sectors */
-        hipLaunchKernelGGL(k_star_sort_mid, dim3(c->n_cus * (URF_MID_WAVES * 256 / URF_STAR_MID_THREADS)), dim3(URF_STAR_MID_THREADS), 0, st,
-                           a, dp);   /* as many workgroups as are resident */
-        hipLaunchKernelGGL(k_star_sort_big, dim3(c->n_cus * 2), dim3(256), 0, st, a, dp);
+        if (!(a.optimistic & URF_OPT_NO_LISTS)) {
+            hipLaunchKernelGGL(k_star_sort_mid, dim3(c->n_cus * (URF_MID_WAVES * 256 / URF_STAR_MID_THREADS)), dim3(URF_STAR_MID_THREADS), 0, st,
+                               a, dp);   /* as many workgroups as are resident */
+            hipLaunchKernelGGL(k_star_sort_big, dim3(c->n_cus * 2), dim3(256), 0, st, a, dp);
+        }
     }
     mark();   /* "k_star_sort" = the three sort kernels (mid / big run over normally empty work lists) */
     if (star)
@@ -744,13 +768,12 @@ static hipStream_t slot_stream(urf_ctx* c, const urf_ctx::slot_t& sl)
 
 static int slot_prepare(urf_ctx* c, urf_ctx::slot_t& sl, size_t bytes)
 {
-    if (!c->copy_stream) {
-        URF_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->streams_made) {
         for (uint32_t r = 1; r < URF_ASYNC_SLOTS && r < c->max_batch; r++)
             URF_HIP(c, hipStreamCreateWithFlags(&c->row_stream[r], hipStreamNonBlocking));
+        c->streams_made = true;
     }
-    if (!sl.ev_h2d) {
-        URF_HIP(c, hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
+    if (!sl.ev_done) {
         URF_HIP(c, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
         void *hl = nullptr, *hi = nullptr, *dl = nullptr;
         URF_HIP(c, hipHostMalloc(&hl, c->max_points, hipHostMallocDefault));
@@ -761,7 +784,6 @@ static int slot_prepare(urf_ctx* c, urf_ctx::slot_t& sl, size_t bytes)
         sl.d_labels = (uint8_t*)dl;
     }
     if (bytes > sl.h_in_cap) {   /* grows to the largest message seen (a new buffer invalidates the captured sequence) */
-        URF_HIP(c, hipStreamSynchronize(c->copy_stream));
         URF_HIP(c, hipStreamSynchronize(slot_stream(c, sl)));   /* the slot's last sweep may still read d_raw */
         if (sl.h_in)
             (void)hipHostFree(sl.h_in);
@@ -782,16 +804,66 @@ static int slot_prepare(urf_ctx* c, urf_ctx::slot_t& sl, size_t bytes)
     return URF_OK;
 }
 
-/* what one sweep of the callback path launches on the compute stream: records -> SoA, the
- * pipeline, results to the pinned host buffers */
+/* host-side cost of the callback path, phase by phase (URF_HOST_TIMES=1: printed by urf_bench_callback_stream) */
+static double g_ht[8];
+static bool g_ht_on = false;
+static inline double ht_now()
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+#define HT(k, t0) do { if (g_ht_on) { const double ht_t = ht_now(); g_ht[k] += ht_t - (t0); (t0) = ht_t; } } while (0)
+
+/* A message that has to be staged anyway is staged as three planes x[n4] y[n4] z[n4], n4 = n rounded up to 4: 12 of
+ * its (typically) 32 bytes per point cross PCIe (84 -> 35 us for a 64 x 2048 sweep), and the device needs no
+ * records -> SoA kernel.  Records whose x, y, z lie side by side with a fourth word behind them inside the record
+ * (pcl::PointXYZI and every PointCloud2 layout of the lidar drivers) go four at a time through a 4 x 4 transpose and
+ * leave with non-temporal stores (the planes are 16-byte aligned; on the test box's EPYC 9575F: memcpy of the 4 MiB
+ * message 108 us, the transpose with ordinary stores 105, with streaming stores 67). */
+static void pc2_to_planes(const uint8_t* data, uint32_t n, uint32_t step, uint32_t ox, uint32_t oy, uint32_t oz, float* X, float* Y,
+                          float* Z)
+{
+    uint32_t i = 0;
+#if defined(__SSE2__)
+    if (oy == ox + 4 && oz == ox + 8 && (uint64_t)ox + 16 <= step) {
+        const uint8_t* p = data + ox;
+        for (; i + 4 <= n; i += 4, p += 4 * (size_t)step) {
+            __m128 r0 = _mm_loadu_ps((const float*)p), r1 = _mm_loadu_ps((const float*)(p + step));
+            __m128 r2 = _mm_loadu_ps((const float*)(p + 2 * (size_t)step)), r3 = _mm_loadu_ps((const float*)(p + 3 * (size_t)step));
+            _MM_TRANSPOSE4_PS(r0, r1, r2, r3);
+            _mm_stream_ps(X + i, r0);
+            _mm_stream_ps(Y + i, r1);
+            _mm_stream_ps(Z + i, r2);
+        }
+        _mm_sfence();   /* before the DMA engine is told to read them */
+    }
+#endif
+    for (; i < n; i++) {
+        const uint8_t* p = data + (size_t)i * step;
+        std::memcpy(X + i, p + ox, 4);
+        std::memcpy(Y + i, p + oy, 4);
+        std::memcpy(Z + i, p + oz, 4);
+    }
+}
+
+/* what one sweep of the callback path launches on the compute stream: records -> SoA (unless the message was
+ * staged as planes), the pipeline, results to the pinned host buffers */
 static int slot_launch(urf_ctx* c, urf_ctx::slot_t& sl, uint32_t n_points, uint32_t point_step, uint32_t off_x,
                        uint32_t off_y, uint32_t off_z)
 {
     const uint32_t row = slot_row(c, sl);
     hipStream_t st = slot_stream(c, sl);
     float *sx = c->sx + (size_t)row * c->max_points, *sy = c->sy + (size_t)row * c->max_points, *sz = c->sz + (size_t)row * c->max_points;
-    hipLaunchKernelGGL(k_pc2_to_soa, dim3((n_points + 255) / 256), dim3(256), 0, st, sl.d_raw, (unsigned long long)n_points,
-                       point_step, off_x, off_y, off_z, sx, sy, sz);
+    if (sl.planes) {
+        const size_t n4 = ((size_t)n_points + 3) & ~(size_t)3;
+        sx = (float*)sl.d_raw;
+        sy = sx + n4;
+        sz = sy + n4;
+    } else {
+        hipLaunchKernelGGL(k_pc2_to_soa, dim3((n_points + 255) / 256), dim3(256), 0, st, sl.d_raw, (unsigned long long)n_points,
+                           point_step, off_x, off_y, off_z, sx, sy, sz);
+    }
     const int rc = run_pipeline(c, sx, sy, sz, nullptr, n_points, n_points, 1, sl.d_labels, nullptr, row, st, &sl.cap_a, &sl.cap_dp);
     if (rc != URF_OK)
         return rc;
@@ -827,33 +899,39 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
         return URF_ERR_BUSY;          /* every slot in flight: urf_classify_pc2_wait() the oldest one first */
     URF_HIP(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)n_points * point_step;
+    double ht0 = g_ht_on ? ht_now() : 0.0;
     /* a message inside the slot's pinned buffer must be the buffer urf_pinned_input() handed out, and
      * fit it: a larger one would make slot_prepare() free the very memory it is about to read */
     if (sl.h_in && data >= sl.h_in && data < sl.h_in + sl.h_in_cap && (data != sl.h_in || bytes > sl.h_in_cap))
         return URF_ERR_INVALID_ARG;
-    int rc = slot_prepare(c, sl, bytes);
+    const bool planes = data != sl.h_in;   /* (a producer that filled the pinned buffer itself wrote records) */
+    const size_t n4 = ((size_t)n_points + 3) & ~(size_t)3;
+    const size_t plane_bytes = 3 * sizeof(float) * n4;
+    int rc = slot_prepare(c, sl, planes && plane_bytes > bytes ? plane_bytes : bytes);
     if (rc == URF_OK)
         rc = ensure_soa_staging(c);
     if (rc != URF_OK)
         return rc;
-    if (data != sl.h_in) {
-        /* staged in pieces, so that the DMA of a piece runs while the CPU copies the next one
-         * (urf_pinned_input() lets a producer write into the pinned buffer directly: no staging) */
-        const size_t piece = 1u << 20;
-        for (size_t o = 0; o < bytes; o += piece) {
-            const size_t m = bytes - o < piece ? bytes - o : piece;
-            std::memcpy(sl.h_in + o, data + o, m);
-            URF_HIP(c, hipMemcpyAsync(sl.d_raw + o, sl.h_in + o, m, hipMemcpyHostToDevice, c->copy_stream));
-        }
-    } else {
-        URF_HIP(c, hipMemcpyAsync(sl.d_raw, sl.h_in, bytes, hipMemcpyHostToDevice, c->copy_stream));
-    }
-    URF_HIP(c, hipEventRecord(sl.ev_h2d, c->copy_stream));
     hipStream_t st = slot_stream(c, sl);
     rc = order_row_after_main(c, slot_row(c, sl), st);
     if (rc != URF_OK)
         return rc;
-    URF_HIP(c, hipStreamWaitEvent(st, sl.ev_h2d, 0));
+    /* The message goes to the device on the slot's own stream, in front of the sweep's kernels.  (r2 / r3 used a copy
+     * stream of its own and an event: one stream more than the process has hardware queues -- four -- so that two of the
+     * four slots shared a queue and ran one after the other: 7 870 -> 8 670 sweeps/s with a pinned producer, 6 460 ->
+     * 7 540 staged.)  Sweeps of other slots run beside the copy as before. */
+    if (planes) {
+        /* (urf_pinned_input() lets a producer write into the pinned buffer directly: no staging) */
+        float* X = (float*)sl.h_in;
+        pc2_to_planes(data, n_points, point_step, off_x, off_y, off_z, X, X + n4, X + 2 * n4);
+        URF_HIP(c, hipMemcpyAsync(sl.d_raw, sl.h_in, plane_bytes, hipMemcpyHostToDevice, st));
+    } else {
+        URF_HIP(c, hipMemcpyAsync(sl.d_raw, sl.h_in, bytes, hipMemcpyHostToDevice, st));
+    }
+    if (planes != sl.planes)
+        sl.key[0] = 0;   /* the captured sequence reads the other format */
+    sl.planes = planes;
+    HT(0, ht0);   /* staging + H2D enqueue */
     /* a sweep that defeated the speculative ring table (k_table_repair raised the host-visible flag) ends
      * the speculation for replayed sequences as well: the captured ones are rebuilt without it */
     if (c->speculate && *c->h_spec_failed) {
@@ -865,6 +943,7 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
     const uint64_t key[3] = { c->epoch, ((uint64_t)n_points << 32) | point_step,
                               ((uint64_t)off_x << 42) ^ ((uint64_t)off_y << 21) ^ off_z };
     const bool use_graph = !c->timing && !(c->debug_flags & 8u);
+    HT(1, ht0);   /* event record, ordering, stream wait */
     if (use_graph && (sl.key[0] != key[0] || sl.key[1] != key[1] || sl.key[2] != key[2] || !sl.exec)) {
         if (sl.exec)
             (void)hipGraphExecDestroy(sl.exec);
@@ -896,10 +975,16 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
         if (rc != URF_OK)
             return rc;
     }
+    HT(2, ht0);   /* graph launch (or the launches themselves) */
     URF_HIP(c, hipEventRecord(sl.ev_done, st));
+    HT(3, ht0);
     sl.pending = true;
     sl.used = true;
     sl.n_points = n_points;
+    sl.point_step = point_step;
+    sl.off_x = off_x;
+    sl.off_y = off_y;
+    sl.off_z = off_z;
     sl.ticket = c->next_ticket;
     *ticket = c->next_ticket++;
     return URF_OK;
@@ -913,7 +998,25 @@ extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* label
     if (!sl.pending || sl.ticket != ticket)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
+    double ht0 = g_ht_on ? ht_now() : 0.0;
     URF_HIP(c, hipEventSynchronize(sl.ev_done));
+    HT(4, ht0);
+    /* the short launch sequence left out something this sweep needed (run_pipeline): once more, with it --
+     * the message is still in the slot's device buffer -- and from now on for every sweep */
+    for (int tries = 0; tries < 3 && (sl.h_info->status == URF_STATUS_REDO_TABLE || sl.h_info->status == URF_STATUS_REDO_LISTS); tries++) {
+        if (sl.h_info->status == URF_STATUS_REDO_TABLE)
+            c->speculate = false;
+        else
+            c->slot_lists = true;
+        c->epoch++;   /* the captured sequences are rebuilt */
+        c->n_rerun++;
+        const int rc = slot_launch(c, sl, sl.n_points, sl.point_step, sl.off_x, sl.off_y, sl.off_z);
+        if (rc != URF_OK)
+            return rc;
+        URF_HIP(c, hipStreamSynchronize(slot_stream(c, sl)));
+    }
+    if (sl.h_info->status == URF_STATUS_REDO_TABLE || sl.h_info->status == URF_STATUS_REDO_LISTS)
+        return URF_ERR_HIP;   /* (cannot happen: the full sequence raises neither) */
     /* only now is the sweep "the last call": urf_read_stage / urf_marker_points / urf_ordered_indices look at
      * its scratch row, which stays untouched until the slot (or a batch call) is used again */
     c->last_scans = 1;
@@ -924,6 +1027,7 @@ extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* label
     if (info)
         *info = *sl.h_info;
     sl.pending = false;
+    HT(5, ht0);
     return URF_OK;
 }
 
@@ -980,6 +1084,9 @@ extern "C" int urf_bench_callback_stream(urf_ctx* c, const uint8_t* const* msgs,
     uint32_t head = 0, count = 0;   /* ring of tickets in flight */
     urf_scan_info info;
     struct timespec t0, t1;
+    g_ht_on = getenv("URF_HOST_TIMES") != nullptr;
+    for (double& v : g_ht)
+        v = 0.0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (uint32_t k = 0; k < n_sweeps; k++) {
         if (count == in_flight) {
@@ -1015,6 +1122,12 @@ extern "C" int urf_bench_callback_stream(urf_ctx* c, const uint8_t* const* msgs,
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    if (g_ht_on) {
+        fprintf(stderr, "host us per sweep (pinned %d, in flight %u): total %.1f | stage+h2d %.1f order %.1f launch %.1f record %.1f wait %.1f rest-of-wait %.1f\n",
+                producer_pinned, in_flight, 1e6 * *seconds / n_sweeps, 1e6 * g_ht[0] / n_sweeps, 1e6 * g_ht[1] / n_sweeps, 1e6 * g_ht[2] / n_sweeps,
+                1e6 * g_ht[3] / n_sweeps, 1e6 * g_ht[4] / n_sweeps, 1e6 * g_ht[5] / n_sweeps);
+        g_ht_on = false;
+    }
     return URF_OK;
 }
 

@@ -49,6 +49,12 @@
 #define URF_REC_AZ_STEP     (360.0f / 262143.0f)
 #define URF_REC_AZ_QERR     9.0e-4f   /* |decoded - encoded azimuth| <= 0.52 steps = 7.2e-4 deg, plus what the decoded value's
                                          distance from the x axis adds to urf_fast_az_eps (1.5e-4) */
+/* (urf_kargs::optimistic) */
+#define URF_OPT_NO_REPAIR 1u   /* k_table_repair / k_split_repair do not follow k_split */
+#define URF_OPT_NO_LISTS 2u    /* k_star_sort_mid / k_star_sort_big do not follow k_star_sort_small */
+/* internal values of urf_scan_info::status: never seen by a caller */
+#define URF_STATUS_REDO_TABLE 0x7f000001
+#define URF_STATUS_REDO_LISTS 0x7f000002
 #define URF_AZ_UNKNOWN      -1.0f     /* decoded value of URF_REC_AZ_UNKNOWN */
 #define URF_RING_NONE       0xFFu
 #define URF_SEC_NONE        0x3FFu
@@ -119,6 +125,8 @@ struct urf_kargs {
     uint32_t tiles;             /* tiles per scan = ceil(max_len / URF_TILE): stride of the per-tile tables */
     uint32_t sstride;           /* scratch elements per scan */
     uint32_t table_lookahead;   /* k_ring_table: stop after this many points without a new leader (0: never), see there */
+    uint32_t optimistic;        /* the callback path's short launch sequence: URF_OPT_* of what it leaves out; k_index turns a scan that
+                                   needed it into URF_STATUS_REDO_*, which urf_classify_pc2_wait() answers with the full sequence */
     uint32_t capture;           /* 0 production; 1 every point takes the exact sequence, values recorded;
                                    2 production decisions, ring / sector keys recorded */
     /* output */

@@ -1127,6 +1127,13 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
     urf_scan_range(a, s, off, len);
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
+    if ((a.optimistic & URF_OPT_NO_REPAIR) && a.table_redo[s]) {
+        /* the speculative ring table was incomplete and nothing has repaired it (callback path): the scan is void,
+         * every later kernel skips it, the host runs it again without the speculation */
+        if (tid == 0)
+            a.info[s].status = URF_STATUS_REDO_TABLE;
+        return;
+    }
     {
         const unsigned piece = urf_scan_piece(a, s, ntiles, sh);
         if (tid == 0) {
@@ -1206,6 +1213,8 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
         const bool mid = (c > URF_STAR_SMALL_CAP || (nr > 2 && c >= 2)) && c <= URF_STAR_MID_CAP_, big = c > URF_STAR_MID_CAP_;
         const unsigned long long bm = __ballot(mid), bb = __ballot(big);
         unsigned pm = 0, pb = 0;
+        if ((a.optimistic & URF_OPT_NO_LISTS) && (bm | bb) && urf_lane() == 0)
+            a.info[s].status = URF_STATUS_REDO_LISTS;   /* nobody sorts the lists in this launch sequence (every writer writes the same value) */
         if (urf_lane() == 0) {
             if (bm)
                 pm = atomicAdd(&a.star_count[0], (unsigned)__popcll(bm));
