@@ -669,7 +669,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     else
         hipLaunchKernelGGL(k_ring_general, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
     mark();
-    hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_LABEL_THREADS), (size_t)C * (24 * sizeof(unsigned) + URF_CURB_LIST * sizeof(float)), st, a, dp);
+    hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_BEAM_THREADS), (size_t)C * (24 * sizeof(unsigned) + URF_CURB_LIST * sizeof(float)), st, a, dp);
     mark();
     hipLaunchKernelGGL(k_label, g_tiles, dim3(URF_LABEL_TILE_THREADS), 0, st, a, dp);
     mark();

@@ -1040,7 +1040,6 @@ __device__ void urf_scan_keys_256(const unsigned* cnt, unsigned* offs, unsigned 
  * total), start[key][tile] = toff[tile][key], and the totals cnt[key], for the 64 keys from k0.  Blocks of 64 keys x 64 tiles are transposed through LDS so that both the
  * reads (rows of toff) and the writes (rows of pre / start) are contiguous. */
 struct urf_index_shared {
-    unsigned pre[64][65];
     uint16_t cnt[64][66];
     uint16_t st[64][66];
     unsigned carry[64];
@@ -1055,36 +1054,42 @@ __device__ void urf_index_family(urf_index_shared& L, const uint16_t* toff, unsi
         if (tid < 64)
             L.carry[tid] = 0;
         for (unsigned t0 = 0; t0 < ntiles; t0 += 64) {
-            /* rows of toff -> counts and starts (wave w: tiles t0 + 4 * pass + w; lane = key) */
-#pragma unroll 4
+            /* rows of toff -> counts and starts (wave w: tiles t0 + 4 * pass + w; lane = key).  All 32 loads of a
+             * thread are in flight at once: unconditional, from clamped addresses (behind a condition the compiler
+             * waits for every single one). */
+            unsigned fv0[16], fv1[16];
+#pragma unroll
             for (unsigned pass = 0; pass < 16; pass++) {
-                const unsigned u = pass * 4 + wave, tt = t0 + u;
-                unsigned v0 = 0, v1 = 0;
-                if (tt < ntiles && key < nkeys) {
-                    v0 = toff[(size_t)tt * rowlen + key];
-                    v1 = toff[(size_t)tt * rowlen + key + 1];
-                }
-                L.cnt[lane][u] = (uint16_t)(v1 - v0);
-                L.st[lane][u] = (uint16_t)v0;
+                const unsigned tt = t0 + pass * 4 + wave;
+                const bool in = tt < ntiles && key < nkeys;
+                const unsigned idx = in ? tt * rowlen + key : 0u;
+                fv0[pass] = toff[idx];
+                fv1[pass] = toff[idx + 1];
+                fv0[pass] = in ? fv0[pass] : 0u;
+                fv1[pass] = in ? fv1[pass] : 0u;
+            }
+#pragma unroll
+            for (unsigned pass = 0; pass < 16; pass++) {
+                const unsigned u = pass * 4 + wave;
+                L.cnt[lane][u] = (uint16_t)(fv1[pass] - fv0[pass]);
+                L.st[lane][u] = (uint16_t)fv0[pass];
             }
             __syncthreads();
-            if (tid < 64) {   /* prefix along the tiles, one key per lane */
-                unsigned run = L.carry[tid];
-                for (unsigned u = 0; u < 64; u++) {
-                    L.pre[tid][u] = run;
-                    run += L.cnt[tid][u];
-                }
-                L.carry[tid] = run;
-            }
-            __syncthreads();
-            /* rows of pre / start (wave w: keys k0 + 4 * pass + w; lane = tile) */
+            /* prefix along the tiles and the rows of pre / start (wave w: keys k0 + 4 * pass + w; lane = tile): one
+             * wave scan per key (r2 / r3: 64 serial steps of one wave through LDS, 8 000 of the kernel's 48 000
+             * cycles on a single sweep).  A wave touches only its own keys' carries. */
 #pragma unroll 4
             for (unsigned pass = 0; pass < 16; pass++) {
                 const unsigned r = pass * 4 + wave, kk = k0 + r, tt = t0 + lane;
+                const unsigned c = L.cnt[r][lane];
+                const unsigned incl = urf_wave_scan_add(c);
+                const unsigned base = L.carry[r];
                 if (kk < nkeys && tt < ntiles) {
-                    pre[(size_t)kk * (tstride + 1) + tt] = L.pre[r][lane];
+                    pre[(size_t)kk * (tstride + 1) + tt] = base + incl - c;
                     start[(size_t)kk * tstride + tt] = L.st[r][lane];
                 }
+                if (lane == 63)
+                    L.carry[r] = base + incl;
             }
             __syncthreads();
         }
@@ -1113,15 +1118,70 @@ __device__ __forceinline__ unsigned urf_scan_piece(const urf_kargs& a, unsigned 
     return piece;
 }
 
+/* size and first two runs of NK sectors per thread (k, k + 256, ...), 16 tiles of each per round: NK x 32 loads in
+ * flight */
+template <unsigned NK>
+__device__ __forceinline__ void urf_index_sectors(const urf_kargs& a, unsigned s, unsigned K, unsigned ntiles)
+{
+    const unsigned tid = threadIdx.x;
+    const uint16_t* toff = a.tsoff + (size_t)s * a.tiles * (K + 1);
+    for (unsigned kp = 0; kp < K; kp += 256 * NK) {
+        unsigned run[NK];
+        urf_sec_run sr[NK];
+#pragma unroll
+        for (unsigned h = 0; h < NK; h++) {
+            run[h] = 0;
+            sr[h] = urf_sec_run{ 0u, 0u, 0u, 0u };
+        }
+        for (unsigned t0 = 0; t0 < ntiles; t0 += 16) {
+            unsigned v0[NK][16], v1[NK][16];
+#pragma unroll
+            for (unsigned h = 0; h < NK; h++)
+#pragma unroll
+                for (unsigned u = 0; u < 16; u++) {
+                    /* (unconditional loads from clamped addresses: behind a condition the compiler waits for every
+                     * single one) */
+                    const unsigned k = kp + h * 256 + tid;
+                    const bool in = t0 + u < ntiles && k < K;
+                    const unsigned idx = in ? (t0 + u) * (K + 1) + k : 0u;
+                    v0[h][u] = (unsigned)toff[idx];
+                    v1[h][u] = (unsigned)toff[idx + 1];
+                    v0[h][u] = in ? v0[h][u] : 0u;
+                    v1[h][u] = in ? v1[h][u] : 0u;
+                }
+#pragma unroll
+            for (unsigned h = 0; h < NK; h++)
+#pragma unroll
+                for (unsigned u = 0; u < 16; u++) {
+                    /* (selects: as branches these 64 steps per key were 12 000 of the kernel's 48 000 cycles on a
+                     * single sweep) */
+                    const unsigned c = v1[h][u] - v0[h][u], ad = (t0 + u) * URF_TILE + v0[h][u];
+                    const bool first = (c != 0u) & (sr[h].nruns == 0u), second = (c != 0u) & (sr[h].nruns == 1u);
+                    sr[h].a0 = first ? ad : sr[h].a0;
+                    sr[h].c0 = first ? c : sr[h].c0;
+                    sr[h].a1 = second ? ad : sr[h].a1;
+                    sr[h].nruns += c != 0u;
+                    run[h] += c;
+                }
+        }
+#pragma unroll
+        for (unsigned h = 0; h < NK; h++) {
+            const unsigned k = kp + h * 256 + tid;
+            if (k < K) {
+                a.sec_cnt[(size_t)s * K + k] = run[h];
+                a.sec_run[(size_t)s * K + k] = sr[h];
+            }
+        }
+    }
+}
+
 /* One workgroup per scan: piece < 30 test (lidar_segmentation.cpp:120-126); the per-ring run tables
  * (urf_index_family) and where every ring starts in the ring-major arrays; the size of every sector
  * (the sort kernels read a sector's runs straight from k_split's per-tile tables: a sector meets
  * only a few tiles) and where it starts in the sector-major arrays; the work lists of the oversized
  * sectors. */
-__global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
+__device__ __forceinline__ void urf_index_body(const urf_kargs& a, const urf_dev_params& dp, urf_index_shared& L, unsigned* sh)
 {
-    __shared__ urf_index_shared L;
-    __shared__ unsigned sh[8];
     const unsigned s = blockIdx.x, tid = threadIdx.x;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
@@ -1148,37 +1208,9 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
     }
     if (dp.p.star_shaped_method) {
         /* sector sizes: column sums of the per-tile tables (rows are read contiguously: thread = key,
-         * 16 tiles in flight) */
-        const uint16_t* toff = a.tsoff + (size_t)s * a.tiles * (K + 1);
-        for (unsigned k = tid; k < K; k += 256) {
-            unsigned run = 0;
-            urf_sec_run sr = { 0u, 0u, 0u, 0u };
-            for (unsigned t0 = 0; t0 < ntiles; t0 += 16) {
-                unsigned v0[16], v1[16];
-#pragma unroll
-                for (unsigned u = 0; u < 16; u++) {
-                    const bool in = t0 + u < ntiles;
-                    v0[u] = in ? (unsigned)toff[(size_t)(t0 + u) * (K + 1) + k] : 0u;
-                    v1[u] = in ? (unsigned)toff[(size_t)(t0 + u) * (K + 1) + k + 1] : 0u;
-                }
-#pragma unroll
-                for (unsigned u = 0; u < 16; u++) {
-                    const unsigned c = v1[u] - v0[u];
-                    if (c) {
-                        if (sr.nruns == 0) {
-                            sr.a0 = (t0 + u) * URF_TILE + v0[u];
-                            sr.c0 = c;
-                        } else if (sr.nruns == 1) {
-                            sr.a1 = (t0 + u) * URF_TILE + v0[u];
-                        }
-                        sr.nruns++;
-                    }
-                    run += c;
-                }
-            }
-            a.sec_cnt[(size_t)s * K + k] = run;
-            a.sec_run[(size_t)s * K + k] = sr;
-        }
+         * 16 tiles in flight.  Two keys per thread and twice the loads in flight bought a single sweep nothing:
+         * 0.0180 vs 0.0183 ms) */
+        urf_index_sectors<1u>(a, s, K, ntiles);
     }
     for (unsigned k0 = 0; k0 < C; k0 += 64)
         urf_index_family(L, a.troff + (size_t)s * a.tiles * (C + 1), C, k0, ntiles, a.tiles, a.rpre + (size_t)s * C * (a.tiles + 1),
@@ -1228,6 +1260,13 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
         if (big)
             a.star_list_big[pb + urf_popc_below(bb)] = s * K + k;
     }
+}
+
+__global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
+{
+    __shared__ urf_index_shared L;
+    __shared__ unsigned sh[8];
+    urf_index_body(a, dp, L, sh);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -3045,9 +3084,18 @@ __device__ __forceinline__ bool urf_blind(const urf_params& p, const float* q, i
 }
 
 /* One thread per integer degree casts the forward and the backward beam that
- * start there and finds the first ring whose window holds a curb point. */
-__global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_dev_params dp)
+ * start there and finds the first ring whose window holds a curb point.
+ * URF_BEAM_PARTS groups of 384 threads share the rings of a scan (group h takes the rings k = h mod URF_BEAM_PARTS in
+ * every ring loop): one workgroup per scan is all a sweep of the callback path has, and its loops over the rings are
+ * chains of LDS round trips and dependent instructions. */
+#ifndef URF_BEAM_PARTS
+#define URF_BEAM_PARTS 2
+#endif
+#define URF_BEAM_THREADS (384 * URF_BEAM_PARTS)
+__global__ __launch_bounds__(URF_BEAM_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_beams(urf_kargs a, urf_dev_params dp)
 {
+    constexpr unsigned NH = URF_BEAM_PARTS;
+    __shared__ int16_t xs[2][NH][384];   /* the groups' first stopping rings, per degree */
     __shared__ double qk[URF_MAX_CHANNELS];
     __shared__ float q[4];
     __shared__ unsigned long long mf[URF_MAX_CHANNELS * 6], mb[URF_MAX_CHANNELS * 6];
@@ -3057,6 +3105,7 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     __shared__ unsigned n_dense;                       /* rings whose list overflowed */
     extern __shared__ unsigned sh_beams[];            /* sfm[channels][12] | sbm[channels][12] | lst[channels][URF_CURB_LIST] */
     const unsigned s = blockIdx.x, tid = threadIdx.x;
+    const unsigned part = tid / 384u, dt = tid % 384u;   /* (a wave lies in one group: 384 = 6 x 64) */
     const unsigned C = (unsigned)dp.p.channels;
     unsigned* const sfm = sh_beams;                   /* per ring: the degrees whose forward / backward beam it stops (bit d) */
     unsigned* const sbm = sfm + C * 12;
@@ -3065,11 +3114,11 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     URF_PHASE_DECL;
     const urf_scan_info in = a.info[s];
     const unsigned v_cnt = tid < C ? a.curb_cnt[(size_t)s * C + tid] : 0u;
-    constexpr unsigned LPT = (URF_MAX_CHANNELS * URF_CURB_LIST + URF_LABEL_THREADS - 1) / URF_LABEL_THREADS;
+    constexpr unsigned LPT = (URF_MAX_CHANNELS * URF_CURB_LIST + URF_BEAM_THREADS - 1) / URF_BEAM_THREADS;
     float v_lst[LPT];
 #pragma unroll
     for (unsigned e = 0; e < LPT; e++) {
-        const unsigned idx = tid + e * URF_LABEL_THREADS;
+        const unsigned idx = tid + e * URF_BEAM_THREADS;
         v_lst[e] = idx < C * URF_CURB_LIST ? a.curb_az[(size_t)s * C * URF_CURB_LIST + idx] : 0.f;   /* (entries behind a ring's count: never looked at) */
     }
     if (in.status != URF_OK)
@@ -3081,17 +3130,17 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
         /* q1..q4 come from sorted ring 1 (blind_spots.cpp:19) */
         q[tid] = (dp.p.blind_spots && nR > 1) ? a.quad[(size_t)s * 4 + tid] : init[tid];
     }
-    for (unsigned k = tid; k < nR; k += URF_LABEL_THREADS)
+    for (unsigned k = tid; k < nR; k += URF_BEAM_THREADS)
         qk[k] = urf_arc_ratio(dp, maxd[0], maxd[k]);
     if (tid < C)
         lcnt[tid] = v_cnt;
 #pragma unroll
     for (unsigned e = 0; e < LPT; e++) {
-        const unsigned idx = tid + e * URF_LABEL_THREADS;
+        const unsigned idx = tid + e * URF_BEAM_THREADS;
         if (idx < C * URF_CURB_LIST)
             lst[idx] = v_lst[e];
     }
-    for (unsigned e = tid; e < nR * 12; e += URF_LABEL_THREADS) {
+    for (unsigned e = tid; e < nR * 12; e += URF_BEAM_THREADS) {
         sfm[e] = 0u;
         sbm[e] = 0u;
     }
@@ -3136,7 +3185,7 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
             }
         };
         const unsigned n_ent = lpre[URF_MAX_CHANNELS];
-        for (unsigned idx = tid; idx < n_ent; idx += URF_LABEL_THREADS) {
+        for (unsigned idx = tid; idx < n_ent; idx += URF_BEAM_THREADS) {
             /* the ring of flat entry idx: the last ring whose start is <= idx and that lists something (bisection
              * over the starts; rings without entries share their successor's start and are stepped over) */
             unsigned lo_k = 0, hi_k = URF_MAX_CHANNELS;
@@ -3188,7 +3237,7 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     }
     __syncthreads();
     URF_PHASE_MARK;
-    const int i = (int)tid;
+    const int i = (int)dt;
     const bool inrange = i <= 360;
     const float fi = (float)i;
     const bool blind = !inrange || urf_blind(dp.p, q, i);
@@ -3196,20 +3245,20 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     const bool cast_b = fi >= dp.bwd_limit && !blind;   /* blind_spots.cpp:177 */
     int sf = cast_f ? (int)nR : -1, sb = cast_b ? (int)nR : -1;
     {
-        const unsigned w = inrange ? tid >> 5 : 11u;
-        const unsigned bit = 1u << (tid & 31);
+        const unsigned w = inrange ? dt >> 5 : 11u;
+        const unsigned bit = 1u << (dt & 31);
         const bool dense_rings = n_dense != 0;   /* (uniform; normally none) */
-        for (unsigned k0 = 0; k0 < nR; k0 += 8) {   /* (the words of eight rings in flight) */
+        for (unsigned k0 = 0; k0 < nR; k0 += 8 * NH) {   /* (the words of eight rings in flight) */
             unsigned wf[8], wb[8];
 #pragma unroll
             for (unsigned u = 0; u < 8; u++) {
-                const unsigned k = k0 + u < nR ? k0 + u : nR - 1;
+                const unsigned k = k0 + u * NH + part < nR ? k0 + u * NH + part : nR - 1;
                 wf[u] = sfm[k * 12 + w];
                 wb[u] = sbm[k * 12 + w];
             }
 #pragma unroll
             for (unsigned u = 0; u < 8; u++) {
-                const unsigned k = k0 + u;
+                const unsigned k = k0 + u * NH + part;
                 bool hf = k < nR && (wf[u] & bit) != 0, hb = k < nR && (wb[u] & bit) != 0;
                 if (dense_rings && k < nR && lcnt[k] == URF_CURB_DENSE) {   /* (uniform) the ring's list overflowed: its per-degree tables */
                     hf = cast_f && sf == (int)nR && a.sufmin[((size_t)s * C + k) * URF_DEG_CELLS + i] <= urf_fwd_hi(dp, i, k, qk[k]);
@@ -3220,7 +3269,18 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
             }
         }
     }
-    if (inrange) {
+    if (NH > 1) {   /* the first stopping ring over all groups ("not cast" = -1 in every group, "none" = n_rings) */
+        xs[0][part][dt] = (int16_t)sf;
+        xs[1][part][dt] = (int16_t)sb;
+        __syncthreads();
+#pragma unroll
+        for (unsigned h = 0; h < NH; h++) {
+            const int of = xs[0][h][dt], ob = xs[1][h][dt];
+            sf = of < sf ? of : sf;
+            sb = ob < sb ? ob : sb;
+        }
+    }
+    if (inrange && part == 0) {
         a.stop_f[(size_t)s * URF_DEG_CELLS + i] = (int16_t)sf;
         a.stop_b[(size_t)s * URF_DEG_CELLS + i] = (int16_t)sb;
     }
@@ -3232,20 +3292,20 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     for (unsigned k0 = 0; k0 < nR; k0 += 64) {
         unsigned long long myf = 0ull, myb = 0ull;
         const unsigned kn = nR - k0 < 64u ? nR - k0 : 64u;
-        for (unsigned u = 0; u < kn; u++) {
+        for (unsigned u = part; u < kn; u += NH) {   /* (uniform per wave) */
             const unsigned long long bf = __ballot(sf > (int)(k0 + u)), bb = __ballot(sb > (int)(k0 + u));
             myf = urf_lane() == u ? bf : myf;
             myb = urf_lane() == u ? bb : myb;
         }
-        if (urf_lane() < kn) {
-            mf[(k0 + urf_lane()) * 6 + (tid >> 6)] = myf;
-            mb[(k0 + urf_lane()) * 6 + (tid >> 6)] = myb;
+        if (urf_lane() < kn && urf_lane() % NH == part) {
+            mf[(k0 + urf_lane()) * 6 + (dt >> 6)] = myf;
+            mb[(k0 + urf_lane()) * 6 + (dt >> 6)] = myb;
         }
     }
     __syncthreads();
     URF_PHASE_MARK;
     /* highest set forward bit in the words below word w / lowest set backward bit in the words above */
-    for (unsigned e = tid; e < nR * 6; e += URF_LABEL_THREADS) {
+    for (unsigned e = tid; e < nR * 6; e += URF_BEAM_THREADS) {
         const unsigned k = e / 6, w = e % 6;
         int below = -1, above = -1;
         for (unsigned v = 0; v < w; v++)
@@ -3260,16 +3320,16 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
     __syncthreads();
     URF_PHASE_MARK;
     if (inrange) {
-        const unsigned w = tid >> 6, b = tid & 63;
+        const unsigned w = dt >> 6, b = dt & 63;
         const unsigned long long le = b == 63 ? ~0ull : ((2ull << b) - 1ull), ge = ~0ull << b;
         urf_win* win = a.win + (size_t)s * C * URF_DEG_CELLS + i;
-        for (unsigned k0 = 0; k0 < nR; k0 += 4) {   /* four rings at a time: their masks and ratios read before any is used */
+        for (unsigned k0 = 0; k0 < nR; k0 += 4 * NH) {   /* four rings at a time: their masks and ratios read before any is used */
             unsigned long long f4[4], g4[4];
             int p4[4], n4[4];
             double q4[4];
 #pragma unroll
             for (unsigned u = 0; u < 4; u++) {
-                const unsigned k = k0 + u < nR ? k0 + u : nR - 1;
+                const unsigned k = k0 + u * NH + part < nR ? k0 + u * NH + part : nR - 1;
                 f4[u] = mf[k * 6 + w] & le;
                 g4[u] = mb[k * 6 + w] & ge;
                 p4[u] = (int)pf[k * 6 + w];
@@ -3278,7 +3338,7 @@ __global__ __launch_bounds__(URF_LABEL_THREADS) void k_beams(urf_kargs a, urf_de
             }
 #pragma unroll
             for (unsigned u = 0; u < 4; u++) {
-                const unsigned k = k0 + u;
+                const unsigned k = k0 + u * NH + part;
                 if (k >= nR)
                     break;
                 const int jf = f4[u] ? (int)(w * 64 + 63 - __clzll((long long)f4[u])) : p4[u];
