@@ -821,13 +821,13 @@ static inline double ht_now()
  * (pcl::PointXYZI and every PointCloud2 layout of the lidar drivers) go four at a time through a 4 x 4 transpose and
  * leave with non-temporal stores (the planes are 16-byte aligned; on the test box's EPYC 9575F: memcpy of the 4 MiB
  * message 108 us, the transpose with ordinary stores 105, with streaming stores 67). */
-static void pc2_to_planes(const uint8_t* data, uint32_t n, uint32_t step, uint32_t ox, uint32_t oy, uint32_t oz, float* X, float* Y,
-                          float* Z)
+static void pc2_to_planes(const uint8_t* data, uint32_t i0, uint32_t n, uint32_t step, uint32_t ox, uint32_t oy, uint32_t oz, float* X,
+                          float* Y, float* Z)   /* points [i0, n); i0 a multiple of 4 */
 {
-    uint32_t i = 0;
+    uint32_t i = i0;
 #if defined(__SSE2__)
     if (oy == ox + 4 && oz == ox + 8 && (uint64_t)ox + 16 <= step) {
-        const uint8_t* p = data + ox;
+        const uint8_t* p = data + (size_t)i0 * step + ox;
         for (; i + 4 <= n; i += 4, p += 4 * (size_t)step) {
             __m128 r0 = _mm_loadu_ps((const float*)p), r1 = _mm_loadu_ps((const float*)(p + step));
             __m128 r2 = _mm_loadu_ps((const float*)(p + 2 * (size_t)step)), r3 = _mm_loadu_ps((const float*)(p + 3 * (size_t)step));
@@ -922,9 +922,16 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
      * 7 540 staged.)  Sweeps of other slots run beside the copy as before. */
     if (planes) {
         /* (urf_pinned_input() lets a producer write into the pinned buffer directly: no staging) */
+        /* in two halves, so that the first one is on its way while the second one is gathered (one 2-D copy per
+         * half: its columns of the three planes; 35 us for the whole, 22 per half) */
         float* X = (float*)sl.h_in;
-        pc2_to_planes(data, n_points, point_step, off_x, off_y, off_z, X, X + n4, X + 2 * n4);
-        URF_HIP(c, hipMemcpyAsync(sl.d_raw, sl.h_in, plane_bytes, hipMemcpyHostToDevice, st));
+        const uint32_t mid = n_points >= 32768 ? (uint32_t)((n4 / 2) & ~(size_t)3) : 0u;
+        const uint32_t cut[3] = { 0u, mid, n_points };
+        for (int h = mid ? 0 : 1; h < 2; h++) {
+            pc2_to_planes(data, cut[h], cut[h + 1], point_step, off_x, off_y, off_z, X, X + n4, X + 2 * n4);
+            const size_t w = (h == 1 ? n4 - cut[1] : cut[1]) * sizeof(float), o = cut[h] * sizeof(float);
+            URF_HIP(c, hipMemcpy2DAsync(sl.d_raw + o, n4 * sizeof(float), sl.h_in + o, n4 * sizeof(float), w, 3, hipMemcpyHostToDevice, st));
+        }
     } else {
         URF_HIP(c, hipMemcpyAsync(sl.d_raw, sl.h_in, bytes, hipMemcpyHostToDevice, st));
     }
