@@ -223,6 +223,19 @@ def e2e_callback_path(u, O, params, n_sweeps=8, reps=40, stream_reps=160):
         ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 8, 1)
         sec, _ = ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, reps, 1)
         out["e2e_latency_ms_native_mean"] = round(1e3 * sec / reps, 4)
+        # the same sweeps with the reference's DEFAULT region of interest (cfg/LidarFilters.cfg:42-51: what a node that
+        # switches libraries runs): fewer points to classify, but the ring table takes its late leaders one at a time
+        p_roi = O.cfg_params("default_roi")
+        ctx.set_params(p_roi)
+        lbr, _, _ = O.run_b(*u.synth_cloud(RINGS, COLS, 1, 9000), p_roi)
+        lgr, _ = ctx.classify_pc2(recs[0], n, 32, 0, 4, 8)
+        if not np.array_equal(lgr, lbr):
+            raise SystemExit("parity failure on the callback path (default ROI)")
+        out["e2e_latency_ms_default_roi"] = round(latency(0), 4)
+        ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 16, IN_FLIGHT)
+        sec, _ = ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT)
+        out["e2e_overlapped_scans_per_s_default_roi"] = round(stream_reps / sec, 1)
+        ctx.set_params(params)
     return out
 
 
