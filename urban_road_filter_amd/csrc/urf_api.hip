@@ -854,13 +854,16 @@ static int slot_launch(urf_ctx* c, urf_ctx::slot_t& sl, uint32_t n_points, uint3
 {
     const uint32_t row = slot_row(c, sl);
     hipStream_t st = slot_stream(c, sl);
-    float *sx = c->sx + (size_t)row * c->max_points, *sy = c->sy + (size_t)row * c->max_points, *sz = c->sz + (size_t)row * c->max_points;
+    float *sx, *sy, *sz;
     if (sl.planes) {
         const size_t n4 = ((size_t)n_points + 3) & ~(size_t)3;
         sx = (float*)sl.d_raw;
         sy = sx + n4;
         sz = sy + n4;
     } else {
+        sx = c->sx + (size_t)row * c->max_points;   /* (ensure_soa_staging: the caller) */
+        sy = c->sy + (size_t)row * c->max_points;
+        sz = c->sz + (size_t)row * c->max_points;
         hipLaunchKernelGGL(k_pc2_to_soa, dim3((n_points + 255) / 256), dim3(256), 0, st, sl.d_raw, (unsigned long long)n_points,
                            point_step, off_x, off_y, off_z, sx, sy, sz);
     }
@@ -908,8 +911,8 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
     const size_t n4 = ((size_t)n_points + 3) & ~(size_t)3;
     const size_t plane_bytes = 3 * sizeof(float) * n4;
     int rc = slot_prepare(c, sl, planes && plane_bytes > bytes ? plane_bytes : bytes);
-    if (rc == URF_OK)
-        rc = ensure_soa_staging(c);
+    if (rc == URF_OK && !planes)
+        rc = ensure_soa_staging(c);   /* where the device gathers the records' x / y / z */
     if (rc != URF_OK)
         return rc;
     hipStream_t st = slot_stream(c, sl);
@@ -921,9 +924,9 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
      * four slots shared a queue and ran one after the other: 7 870 -> 8 670 sweeps/s with a pinned producer, 6 460 ->
      * 7 540 staged.)  Sweeps of other slots run beside the copy as before. */
     if (planes) {
-        /* (urf_pinned_input() lets a producer write into the pinned buffer directly: no staging) */
-        /* in two halves, so that the first one is on its way while the second one is gathered (one 2-D copy per
-         * half: its columns of the three planes; 35 us for the whole, 22 per half) */
+        /* gathered into the pinned planes (pc2_to_planes) in two halves, so that the first one is on its way while the
+         * second one is gathered (one 2-D copy per half: its columns of the three planes; 35 us for the whole, 22 per
+         * half).  (urf_pinned_input() lets a producer write its records into the pinned buffer directly: no staging.) */
         float* X = (float*)sl.h_in;
         const uint32_t mid = n_points >= 32768 ? (uint32_t)((n4 / 2) & ~(size_t)3) : 0u;
         const uint32_t cut[3] = { 0u, mid, n_points };
