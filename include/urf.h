@@ -404,6 +404,12 @@ int urf_selftest_fast(urf_ctx* ctx, uint64_t n_samples, float* err);
  * thresholds on u = -z / rho that decide a point's ring: the same source evaluated on the host, so that
  * its accuracy (1e-15; needed: 1e-7) can be checked without a GPU. */
 double urf_ring_threshold_cot(double angle_deg);
+/* The host-side gather of the callback path by itself (no context, no device): x / y / z of a PointCloud2-layout
+ * message into three arrays of n_points floats.  urf_classify_pc2_async() does this into pinned memory with every
+ * message it has to stage (12 bytes per point then cross PCIe, whatever the point_step); records whose x, y, z lie
+ * side by side with a fourth word behind them inside the record go four at a time through a 4 x 4 transpose. */
+int urf_pc2_to_planes(const uint8_t* data, uint32_t n_points, uint32_t point_step, uint32_t off_x, uint32_t off_y,
+                      uint32_t off_z, float* x, float* y, float* z);
 /* Diagnostics of the callback path.  It launches a short kernel sequence first (no repair kernels behind the
  * speculative ring table, none for the work lists of star sectors of more than 384 points); a sweep that needed what
  * was left out is run again inside urf_classify_pc2_wait() with the full sequence, and so is every later one.

@@ -19,6 +19,7 @@ from .api import (  # noqa: F401
     lib,
     lib_path,
     synth_cloud,
+    pc2_to_planes,
     LABEL_MASK, LABEL_ROAD, LABEL_CURB, FLAG_ROI, FLAG_RING, FLAG_RING10,
     STAGE_VALPHA, STAGE_RING, STAGE_AZIMUTH, STAGE_RANGE2D, STAGE_DETECT, STAGE_SECTOR,
     STAGE_ANGLE_TABLE, STAGE_MAXDIST, STAGE_QUADRANTS, STAGE_BEAM_STOP,

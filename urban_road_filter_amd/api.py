@@ -127,6 +127,7 @@ def lib():
         "urf_enable_stage_capture": [vp, C.c_int],
         "urf_set_debug_flags": [vp, C.c_uint32],
         "urf_callback_path_state": [vp, C.c_void_p, C.c_void_p],
+        "urf_pc2_to_planes": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, fp, fp, fp],
         "urf_enable_kernel_timing": [vp, C.c_int],
         "urf_selftest": [vp, C.c_void_p],
         "urf_selftest_fast": [vp, C.c_uint64, C.c_void_p],
@@ -195,6 +196,19 @@ def clamp_params(p, mp=None):
     if rc != 0:
         raise UrfError(rc, "urf_clamp_params")
     return n.value
+
+
+def pc2_to_planes(data, n_points, point_step, off_x, off_y, off_z, out=None):
+    """x, y, z (float32 arrays) of a PointCloud2-layout message (uint8 array): the host-side gather of the callback
+    path by itself (no GPU).  out: optional (x, y, z) arrays to fill."""
+    buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    assert buf.size >= n_points * point_step
+    x, y, z = out if out is not None else (np.empty(n_points, np.float32) for _ in range(3))
+    rc = lib().urf_pc2_to_planes(buf.ctypes.data, n_points, point_step, off_x, off_y, off_z, x.ctypes.data, y.ctypes.data,
+                                 z.ctypes.data)
+    if rc != 0:
+        raise UrfError(rc, "urf_pc2_to_planes")
+    return x, y, z
 
 
 def synth_cloud(rings, cols, scene=1, seed=1):

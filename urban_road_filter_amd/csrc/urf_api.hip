@@ -828,15 +828,26 @@ static void pc2_to_planes(const uint8_t* data, uint32_t i0, uint32_t n, uint32_t
 #if defined(__SSE2__)
     if (oy == ox + 4 && oz == ox + 8 && (uint64_t)ox + 16 <= step) {
         const uint8_t* p = data + (size_t)i0 * step + ox;
-        for (; i + 4 <= n; i += 4, p += 4 * (size_t)step) {
-            __m128 r0 = _mm_loadu_ps((const float*)p), r1 = _mm_loadu_ps((const float*)(p + step));
-            __m128 r2 = _mm_loadu_ps((const float*)(p + 2 * (size_t)step)), r3 = _mm_loadu_ps((const float*)(p + 3 * (size_t)step));
-            _MM_TRANSPOSE4_PS(r0, r1, r2, r3);
-            _mm_stream_ps(X + i, r0);
-            _mm_stream_ps(Y + i, r1);
-            _mm_stream_ps(Z + i, r2);
+        if ((((uintptr_t)(X + i0) | (uintptr_t)(Y + i0) | (uintptr_t)(Z + i0)) & 15u) == 0) {   /* (the pinned planes: always) */
+            for (; i + 4 <= n; i += 4, p += 4 * (size_t)step) {
+                __m128 r0 = _mm_loadu_ps((const float*)p), r1 = _mm_loadu_ps((const float*)(p + step));
+                __m128 r2 = _mm_loadu_ps((const float*)(p + 2 * (size_t)step)), r3 = _mm_loadu_ps((const float*)(p + 3 * (size_t)step));
+                _MM_TRANSPOSE4_PS(r0, r1, r2, r3);
+                _mm_stream_ps(X + i, r0);
+                _mm_stream_ps(Y + i, r1);
+                _mm_stream_ps(Z + i, r2);
+            }
+            _mm_sfence();   /* before the DMA engine is told to read them */
+        } else {
+            for (; i + 4 <= n; i += 4, p += 4 * (size_t)step) {
+                __m128 r0 = _mm_loadu_ps((const float*)p), r1 = _mm_loadu_ps((const float*)(p + step));
+                __m128 r2 = _mm_loadu_ps((const float*)(p + 2 * (size_t)step)), r3 = _mm_loadu_ps((const float*)(p + 3 * (size_t)step));
+                _MM_TRANSPOSE4_PS(r0, r1, r2, r3);
+                _mm_storeu_ps(X + i, r0);
+                _mm_storeu_ps(Y + i, r1);
+                _mm_storeu_ps(Z + i, r2);
+            }
         }
-        _mm_sfence();   /* before the DMA engine is told to read them */
     }
 #endif
     for (; i < n; i++) {
@@ -845,6 +856,16 @@ static void pc2_to_planes(const uint8_t* data, uint32_t i0, uint32_t n, uint32_t
         std::memcpy(Y + i, p + oy, 4);
         std::memcpy(Z + i, p + oz, 4);
     }
+}
+
+/* the gather by itself (host only, no context): what urf_classify_pc2_async does with a message it stages */
+extern "C" int urf_pc2_to_planes(const uint8_t* data, uint32_t n_points, uint32_t point_step, uint32_t off_x, uint32_t off_y,
+                                 uint32_t off_z, float* x, float* y, float* z)
+{
+    if (!data || !x || !y || !z || !pc2_layout_ok(point_step, off_x, off_y, off_z))
+        return URF_ERR_INVALID_ARG;
+    pc2_to_planes(data, 0, n_points, point_step, off_x, off_y, off_z, x, y, z);
+    return URF_OK;
 }
 
 /* what one sweep of the callback path launches on the compute stream: records -> SoA (unless the message was
