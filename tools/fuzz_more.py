@@ -4,7 +4,7 @@ unorganised clouds / parameter sets (tests/fuzz.py), HIP path in its production 
     python tools/fuzz_more.py [first_seed last_seed]   (on the GPU box)
 Last runs: seeds 10000..12499 and 20000..29999 (round 1), 30000..33999, 40000..79999 and (after k_ring went z-only) 80000..184999 (round 2, after the ring decision on
 cot / position ranking changes), 200000..259999 (round 3, HEAD: one record word per slot, curb lists and interval masks in k_beams, k_ring_table a firing at a
-time, empty-tile shortcuts), 300000..319999 (round 3, final: wave-per-sector sort for two-run sectors only -- these unorganised clouds take the
+time, empty-tile shortcuts), 300000..329999 (round 3, final: wave-per-sector sort for two-run sectors only -- these unorganised clouds take the
 workgroup kernel --, the callback path's short sequence with rerun, messages staged as planes, k_index with wave scans, k_beams in two groups): 0 mismatches."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
