@@ -941,9 +941,10 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
     if (rc != URF_OK)
         return rc;
     /* The message goes to the device on the slot's own stream, in front of the sweep's kernels.  (r2 / r3 used a copy
-     * stream of its own and an event: one stream more than the process has hardware queues -- four -- so that two of the
-     * four slots shared a queue and ran one after the other: 7 870 -> 8 670 sweeps/s with a pinned producer, 6 460 ->
-     * 7 540 staged.)  Sweeps of other slots run beside the copy as before. */
+     * stream of its own and an event per sweep for the slot's stream to wait on: 7 870 -> 8 670 sweeps/s with a pinned
+     * producer, 6 460 -> 7 540 staged without them.  The four streams still map to three hardware queues -- kernel
+     * trace, profiles/r3_callback_trace_after.txt --, but more queues made things worse, see profiles/README.md.)
+     * Sweeps of other slots run beside the copy as before. */
     if (planes) {
         /* gathered into the pinned planes (pc2_to_planes) in two halves, so that the first one is on its way while the
          * second one is gathered (one 2-D copy per half: its columns of the three planes; 35 us for the whole, 22 per
