@@ -161,28 +161,33 @@ def e2e_callback_path(u, O, params, n_sweeps=8, reps=40, stream_reps=160):
            "pcie_bound_scans_per_s_staged": round(56e9 / (12 * n + n), 1)}
     IN_FLIGHT = 4   # URF_MAX_IN_FLIGHT
     out["e2e_sweeps_in_flight"] = IN_FLIGHT
-    with u.Context(n, IN_FLIGHT, params=params) as ctx:   # four scratch rows: the kernels of four sweeps overlap
+    # ctx: the product library (liburf_hip.so) -- latency and the Python-client streams; hctx: the hooks build of the same
+    # sources (liburf_hip_test.so), which alone exports the library-side submit / collect loop and the debug flags
+    with u.Context(n, IN_FLIGHT, params=params) as ctx, u.Context(n, IN_FLIGHT, params=params, hooks=True) as hctx:
         lab = np.empty(n, np.uint8)
         lb, _, _ = O.run_b(*u.synth_cloud(RINGS, COLS, 1, 9000), params)
-        lg, _ = ctx.classify_pc2(recs[0], n, 32, 0, 4, 8)
-        if not np.array_equal(lg, lb):
-            raise SystemExit("parity failure on the callback path")
+        for c in (ctx, hctx):
+            lg, _ = c.classify_pc2(recs[0], n, 32, 0, 4, 8)
+            if not np.array_equal(lg, lb):
+                raise SystemExit("parity failure on the callback path")
 
-        def latency(flags):
-            ctx.set_debug_flags(flags)
+        def latency(c, flags=0):
+            if flags:
+                c.set_debug_flags(flags)
             for k in range(4):
-                ctx.classify_pc2(recs[k % n_sweeps], n, 32, 0, 4, 8)
+                c.classify_pc2(recs[k % n_sweeps], n, 32, 0, 4, 8)
             ts = []
             for k in range(reps):
                 t0 = time.perf_counter()
-                t = ctx.classify_pc2_async(recs[k % n_sweeps], n, 32, 0, 4, 8)
-                ctx.classify_pc2_wait(t, lab)
+                t = c.classify_pc2_async(recs[k % n_sweeps], n, 32, 0, 4, 8)
+                c.classify_pc2_wait(t, lab)
                 ts.append(time.perf_counter() - t0)
-            ctx.set_debug_flags(0)
+            if flags:
+                c.set_debug_flags(0)
             return 1e3 * float(np.median(ts))
 
-        out["e2e_latency_ms"] = round(latency(0), 4)                  # graph replay
-        out["e2e_latency_ms_kernel_by_kernel"] = round(latency(8), 4)  # the same without the captured graph
+        out["e2e_latency_ms"] = round(latency(ctx), 4)                        # graph replay, product library
+        out["e2e_latency_ms_kernel_by_kernel"] = round(latency(hctx, 8), 4)   # the same without the captured graph (debug flag: hooks build)
 
         def stream(zero_copy):
             inflight = []
@@ -211,31 +216,31 @@ def e2e_callback_path(u, O, params, n_sweeps=8, reps=40, stream_reps=160):
         out["e2e_overlapped_scans_per_s_pinned_producer_python_client"] = round(max(stream(True), stream(True)), 1)
         # the same loops inside the library (urf_bench_callback_stream): what a C / C++ client -- the reference is a
         # C++ node -- gets, without a Python interpreter between the calls; the labels of the last sweep are checked
-        ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 16, IN_FLIGHT)
-        sec, labn = ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT)
+        hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 16, IN_FLIGHT)
+        sec, labn = hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT)
         lbn, _, _ = O.run_b(*u.synth_cloud(RINGS, COLS, 1, 9000 + (stream_reps - 1) % n_sweeps), params)
         if not np.array_equal(labn, lbn):
             raise SystemExit("parity failure on the callback path (native loop)")
         out["e2e_overlapped_scans_per_s"] = round(stream_reps / sec, 1)
-        ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 16, IN_FLIGHT, producer_pinned=True)
-        sec, _ = ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT, producer_pinned=True)
+        hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 16, IN_FLIGHT, producer_pinned=True)
+        sec, _ = hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT, producer_pinned=True)
         out["e2e_overlapped_scans_per_s_pinned_producer"] = round(stream_reps / sec, 1)
-        ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 8, 1)
-        sec, _ = ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, reps, 1)
+        hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 8, 1)
+        sec, _ = hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, reps, 1)
         out["e2e_latency_ms_native_mean"] = round(1e3 * sec / reps, 4)
         # the same sweeps with the reference's DEFAULT region of interest (cfg/LidarFilters.cfg:42-51: what a node that
         # switches libraries runs): fewer points to classify, but the ring table takes its late leaders one at a time
         p_roi = O.cfg_params("default_roi")
-        ctx.set_params(p_roi)
         lbr, _, _ = O.run_b(*u.synth_cloud(RINGS, COLS, 1, 9000), p_roi)
-        lgr, _ = ctx.classify_pc2(recs[0], n, 32, 0, 4, 8)
-        if not np.array_equal(lgr, lbr):
-            raise SystemExit("parity failure on the callback path (default ROI)")
-        out["e2e_latency_ms_default_roi"] = round(latency(0), 4)
-        ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 16, IN_FLIGHT)
-        sec, _ = ctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT)
+        for c in (ctx, hctx):
+            c.set_params(p_roi)
+            lgr, _ = c.classify_pc2(recs[0], n, 32, 0, 4, 8)
+            if not np.array_equal(lgr, lbr):
+                raise SystemExit("parity failure on the callback path (default ROI)")
+        out["e2e_latency_ms_default_roi"] = round(latency(ctx), 4)
+        hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 16, IN_FLIGHT)
+        sec, _ = hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT)
         out["e2e_overlapped_scans_per_s_default_roi"] = round(stream_reps / sec, 1)
-        ctx.set_params(params)
     return out
 
 

@@ -211,6 +211,12 @@ int urf_classify_pc2(urf_ctx* ctx, const uint8_t* data, uint32_t n_points,
  *     urf_classify_pc2_wait(ctx, ta, labels_a, &info_a);  // blocks until sweep a is done
  * Sweeps must be waited for in the order they were submitted if the results are to be looked at with
  * urf_read_stage / urf_ordered_indices / urf_marker_points (those see the sweep waited for last).
+ * SHARED ROWS: with max_batch < URF_MAX_IN_FLIGHT the slots share min(max_batch, URF_MAX_IN_FLIGHT) scratch rows
+ * (slot i uses row i modulo that number; slots on one row are serialised).  Labels and summary of every sweep are
+ * right whatever the sharing -- each slot has result buffers of its own --, but the three entry points just named
+ * read the sweep's ROW: once a later sweep has been submitted on that row they return URF_ERR_BUSY instead of mixing
+ * two sweeps' intermediate results.  Create the context with max_batch >= the number of sweeps kept in flight, or
+ * read a sweep's intermediate results before submitting on its row again.
  * Every other entry point of the context that touches its scratch memory (the batch calls, the three
  * just named, urf_compact_indices*) is ordered behind the sweeps still in flight; urf_synchronize()
  * waits for them as well.
@@ -365,41 +371,7 @@ int urf_enable_kernel_timing(urf_ctx* ctx, int on);
 int urf_kernel_timing(urf_ctx* ctx, double* ms_sum, uint32_t* n_calls);
 const char* urf_kernel_name(int index);
 
-/* ---- synthetic sweeps -------------------------------
- * Host-side generator of the benchmark clouds: `rings` x `cols` rays from a
- * sensor 1.8 m above ground, scene 0 = flat plane, 1 = street with 0.15 m
- * curbs at |y| = 4 m, 2 = narrow street (curbs at |y| = 3 m, inside the reach
- * of the innermost rings, so that the blind-spot logic of blind_spots.cpp:17-99
- * engages); column-major "firing order" (idx = col*rings + ring);
- * per-sector radial ties removed.  Writes n = rings*cols floats to x, y, z. */
-int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
-                    float* x, float* y, float* z);
-
-/* Benchmark helper: the submit / collect loop of a C / C++ client of the asynchronous path (what a node's
- * subscriber callback and publisher do, lidar_segmentation.cpp:53,95,612-621), timed inside the library:
- * n_sweeps messages taken round robin from msgs[0..n_msgs) (host buffers of n_points records each), at most
- * in_flight (1..URF_MAX_IN_FLIGHT) submitted before the oldest is collected into labels_out (may be NULL).
- * producer_pinned != 0: the messages are produced in the library's pinned buffers (urf_pinned_input; each
- * buffer is filled once, outside the producer's cost).  *seconds = wall time of the whole loop. */
-int urf_bench_callback_stream(urf_ctx* ctx, const uint8_t* const* msgs, uint32_t n_msgs, uint32_t n_points,
-                              uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
-                              uint32_t n_sweeps, uint32_t in_flight, int producer_pinned, uint8_t* labels_out,
-                              double* seconds);
-
 /* ---- diagnostics --------------------------------------------------------- */
-/* Device self test of the arithmetic shortcuts the kernels take (currently: the
- * 3-operation division by pi against the IEEE division, exhaustively over all
- * floats in [0, 600]).  *n_mismatches must come back 0.  Synchronous. */
-int urf_selftest(urf_ctx* ctx, uint64_t* n_mismatches);
-/* Measured error of the float fast paths that settle ring and sector decisions (k_split) over
- * n_samples pseudo-random points: err[0] = max |approx - exact| of the vertical angle [deg] (k_split: the
- * angle whose cotangent its u = -z / rho is; k_ring_table's look-ahead: a float arc tangent),
- * err[1] of the polar angle [rad], err[2] of the scaled polar angle (at the configured number of
- * sectors), err[3] of the azimuth AS A FRACTION of its margin (which grows towards the x axis, where
- * the reference's own value is ill-conditioned; k_split / k_label).  The first three must stay below
- * the margins the kernels use (3e-4, 2e-6, 2.5e-4 * max(1, sectors / 360)), the last below 1.  err
- * has room for 4 floats.  Synchronous. */
-int urf_selftest_fast(urf_ctx* ctx, uint64_t n_samples, float* err);
 /* The cotangent (of an angle in degrees, clamped to [1, 179]) from which k_ring_table derives the
  * thresholds on u = -z / rho that decide a point's ring: the same source evaluated on the host, so that
  * its accuracy (1e-15; needed: 1e-7) can be checked without a GPU. */
@@ -416,9 +388,6 @@ int urf_pc2_to_planes(const uint8_t* data, uint32_t n_points, uint32_t point_ste
  * n_rerun: sweeps run again so far (per cause the first one and those in flight beside it); sequence: bit 0 the ring table is still speculative,
  * bit 1 the work-list kernels are part of the sequence.  Either pointer may be NULL. */
 int urf_callback_path_state(const urf_ctx* ctx, uint32_t* n_rerun, uint32_t* sequence);
-/* Test hook: bit 2 (value 4) forces the general (comparison network) path of the star-shaped sort
- * for every sector; 0 in production.  Takes effect with the next classify call. */
-int urf_set_debug_flags(urf_ctx* ctx, uint32_t flags);
 const char* urf_strerror(int status);
 const char* urf_last_error(const urf_ctx* ctx);   /* text of the last HIP failure */
 int urf_abi_version(void);

@@ -1,6 +1,7 @@
 /* Runs a short SEQUENCE of sweeps through one urf::Detector with the road_marker output enabled
  * (the marker builder keeps state between sweeps, like the reference) and dumps the MarkerArrays.
- *   usage: marker_demo simple_poly_allow poly_z_avg_allow out.bin  scene:seed [scene:seed ...]
+ *   usage: marker_demo simple_poly_allow poly_z_avg_allow out.bin  cloud.bin [cloud.bin ...]
+ *   cloud.bin: u32 n, float x[n], y[n], z[n]   (links the product library only: the sweeps come from the test)
  *   out: per sweep { u32 published, u32 n_markers, n_markers x { i32 id, action, type; f32 rgba[4];
  *        u32 n_points; f64 xyz[n_points][3] } } */
 #include <cstdio>
@@ -18,9 +19,9 @@ int main(int argc, char** argv)
     mp.simple_poly_allow = atoi(argv[1]);
     mp.poly_z_avg_allow = atoi(argv[2]);
     FILE* f = std::fopen(argv[3], "wb");
-    const uint32_t rings = 64, cols = 2048, n = rings * cols;
+    const uint32_t n_max = 64 * 2048;
     try {
-        urf::Detector det(0, n);
+        urf::Detector det(0, n_max);
         urf_params p = det.params();
         p.min_X = p.min_Y = -200.f;
         p.max_X = p.max_Y = 200.f;
@@ -28,12 +29,14 @@ int main(int argc, char** argv)
         det.enableRoadMarker(true);
         det.setMarkerParams(mp);
         for (int k = 4; k < argc; k++) {
-            int scene = 1;
-            unsigned long long seed = 1;
-            std::sscanf(argv[k], "%d:%llu", &scene, &seed);
-            std::vector<float> x(n), y(n), z(n);
-            if (urf_synth_cloud(rings, cols, scene, seed, x.data(), y.data(), z.data()) != URF_OK)
+            FILE* fi = std::fopen(argv[k], "rb");
+            uint32_t n = 0;
+            if (!fi || std::fread(&n, 4, 1, fi) != 1 || n > n_max)
                 return 3;
+            std::vector<float> x(n), y(n), z(n);
+            if (std::fread(x.data(), 4, n, fi) != n || std::fread(y.data(), 4, n, fi) != n || std::fread(z.data(), 4, n, fi) != n)
+                return 3;
+            std::fclose(fi);
             urf::PointCloud cloud;
             cloud.points.resize(n);
             for (uint32_t i = 0; i < n; i++) {

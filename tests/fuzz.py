@@ -4,8 +4,9 @@
 The clouds deliberately violate everything an organised sweep guarantees: arbitrary point
 order, uneven rings, empty / crowded sectors, points outside the ROI, NaNs, few points.
 What they avoid is only what the REFERENCE ITSELF leaves undefined:
-exact planar-range ties inside a star sector (unstable std::sort), x == y == 0 (NaN azimuth
-inside the Lomuto quicksort), the sector-360 band (null dereference)."""
+exact planar-range ties inside a star sector (unstable std::sort), the sector-360 band (null
+dereference).  Points with x == y == 0 -- a NaN azimuth inside the reference's Lomuto quicksort, which
+handles it deterministically -- are part of a third of the cases (axis_points)."""
 import numpy as np
 
 import urban_road_filter_amd as u
@@ -77,7 +78,33 @@ def random_cloud(rng, n):
     return x[keep], y[keep], z[keep]
 
 
+def axis_points(cloud, rng, count, near=0):
+    """`count` points with x == y == 0 (azimuth NaN, vertical angle exactly 0 or 180 deg: the ring table's end mark) and
+    `near` points almost on the axis (they can share a ring with them when `interval` is large), at random places of the
+    cloud.  The axis points share one z: equal planar ranges (0) inside sector 0 are a tie the reference leaves open."""
+    x, y, z = cloud
+    zs = float(rng.choice([-1.8, -2.5, -1.2, 0.3]))
+    ax = np.zeros(count + near, np.float32)
+    ay = np.zeros(count + near, np.float32)
+    az = np.full(count + near, zs, np.float32)
+    if near:
+        fi = rng.uniform(0, 2 * np.pi, near)
+        rho = rng.uniform(0.004, 0.045, near)   # 0.13 .. 1.4 deg off the axis at 1.8 m
+        ax[count:] = (rho * np.cos(fi)).astype(np.float32)
+        ay[count:] = (rho * np.sin(fi)).astype(np.float32)
+        az[count:] = (-1.8 + 0.2 * rng.random(near) * (rng.random(near) < 0.3)).astype(np.float32)
+        r = np.sqrt(ax[count:] * ax[count:] + ay[count:] * ay[count:])
+        assert len(np.unique(r)) == near   # no planar-range ties
+    at = np.sort(rng.integers(0, len(x) + 1, count + near))
+    order = rng.permutation(count + near)
+    return tuple(np.insert(a, at, b[order]) for a, b in ((x, ax), (y, ay), (z, az)))
+
+
 def case(seed, for_reference=False):
     rng = np.random.default_rng(seed)
     n = int(rng.choice([40, 300, 3000, 20000]))
-    return random_cloud(rng, n), random_params(rng, for_reference)
+    cloud, params = random_cloud(rng, n), random_params(rng, for_reference)
+    rng2 = np.random.default_rng(seed + 7_000_003)   # (a stream of its own: the clouds of a seed stay what they were)
+    if rng2.random() < 1 / 3:
+        cloud = axis_points(cloud, rng2, 1 if for_reference else int(rng2.integers(1, 4)), near=int(rng2.integers(0, 6)))
+    return cloud, params

@@ -10,8 +10,8 @@ import urban_road_filter_amd as u
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "urf.h")).read()
+def declared_functions(header="urf.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(urf_[a-z0-9_]+)\s*\(", src)))
 
@@ -22,6 +22,17 @@ def test_every_declared_symbol_is_exported():
     L = ctypes.CDLL(u.lib_path())
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
+
+
+def test_test_hooks_live_in_their_own_library():
+    """include/urf_test_hooks.h (synthetic sweeps, the benchmark loop, self tests, debug flags) is exported by
+    liburf_hip_test.so only: a node that links the product gets none of it in its symbol table."""
+    hooks = declared_functions("urf_test_hooks.h")
+    assert set(hooks) == set(u.api.HOOK_SYMBOLS)
+    product = ctypes.CDLL(u.lib_path())
+    assert not [n for n in hooks if hasattr(product, n)]
+    tl = ctypes.CDLL(u.lib_path(hooks=True))
+    assert not [n for n in hooks + declared_functions() if not hasattr(tl, n)]
 
 
 def test_abi_version_and_struct_size():

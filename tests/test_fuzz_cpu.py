@@ -7,6 +7,13 @@ import oracles as O
 from fuzz import case
 
 
+# Cases in which ONE label depends on how the host's libm rounds asinf / acosf / atan2f (the
+# reference's own answer is glibc-dependent on a decision boundary; this image's glibc 2.35 and include/urf_libm.h
+# differ by 1 ulp there).  seed -> number of such labels; against the reference built with the shared libm (the test
+# below covers every seed of this one) they are equal too.
+GLIBC_DEPENDENT = {49: 1}
+
+
 @pytest.mark.skipif(not O.has_oracle_a(), reason="oracle A binary (reference build) not available")
 @pytest.mark.parametrize("seed", range(100))
 def test_oracle_b_equals_reference_on_random_input(seed):
@@ -14,6 +21,11 @@ def test_oracle_b_equals_reference_on_random_input(seed):
     la, ia, _, _ = O.run_a([(x, y, z)], p)
     lb, ib, _ = O.run_b(x, y, z, p)
     assert ia[0]["status"] == ib["status"]
+    if seed in GLIBC_DEPENDENT:
+        assert int((la[0] != (lb & O.MASK_NO_RING)).sum()) == GLIBC_DEPENDENT[seed]
+        la2, ia2, _, _ = O.run_a([(x, y, z)], p, libm=True)
+        assert np.array_equal(la2[0], lb & O.MASK_NO_RING)
+        return
     assert np.array_equal(la[0], lb & O.MASK_NO_RING), "seed %d: %d labels differ" % (seed, int((la[0] != (lb & O.MASK_NO_RING)).sum()))
     if ib["status"] == 0:   # with < 30 ROI points the reference publishes nothing, not even its roi cloud
         for k in ("n_roi", "n_road", "n_curb", "n_ring10"):
@@ -21,7 +33,7 @@ def test_oracle_b_equals_reference_on_random_input(seed):
 
 
 @pytest.mark.skipif(not O.has_oracle_a(), reason="oracle A binary (reference build) not available")
-@pytest.mark.parametrize("seed", range(100, 140))
+@pytest.mark.parametrize("seed", range(0, 140))
 def test_oracle_b_equals_reference_with_shared_libm(seed):
     """Same comparison against the reference sources built with the product's definition of
     acosf / asinf / atan2f (oracle/shim/urf_libm_override.h): here equality has to hold for ANY

@@ -36,6 +36,14 @@ def ctx(request):
 
 
 @pytest.fixture(scope="module")
+def hctx():
+    """A context in liburf_hip_test.so (the product's sources + include/urf_test_hooks.h): debug flags, the library-side loop."""
+    c = u.Context(N, 4, params=O.cfg_params("cfg2"), hooks=True)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
 def sweeps():
     p = O.cfg_params("cfg2")
     out = []
@@ -162,7 +170,8 @@ def test_batch_calls_and_readbacks_are_ordered_behind_sweeps_in_flight(sweeps):
             b.free()
 
 
-def test_graph_replay_equals_kernel_by_kernel_launches(ctx, sweeps):
+def test_graph_replay_equals_kernel_by_kernel_launches(hctx, sweeps):
+    ctx = hctx
     ctx.set_params(O.cfg_params("cfg2"))
     rec, lb, _ = sweeps[2]
     a, _ = ctx.classify_pc2(rec, N, 32, 0, 4, 8)
@@ -207,9 +216,10 @@ def test_malformed_layouts_are_refused_before_any_copy(ctx):
 
 
 @pytest.mark.parametrize("pinned", [False, True], ids=["staged", "pinned_producer"])
-def test_native_submit_collect_loop(ctx, sweeps, pinned):
-    """urf_bench_callback_stream: the loop a C / C++ client runs (submit until IN_FLIGHT sweeps are in flight, collect
+def test_native_submit_collect_loop(hctx, sweeps, pinned):
+    """urf_bench_callback_stream (include/urf_test_hooks.h): the loop a C / C++ client runs (submit until IN_FLIGHT sweeps are in flight, collect
     the oldest), inside the library.  The labels it hands back are those of the last message."""
+    ctx = hctx
     ctx.set_params(O.cfg_params("cfg2"))
     msgs = [rec for rec, _, _ in sweeps[:5]]
     for in_flight in (1, 2, IN_FLIGHT):

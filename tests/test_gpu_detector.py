@@ -1,7 +1,9 @@
 """The C++ adapter (urban_road_filter_amd/csrc/detector.hpp), used the way the reference's ROS
-callback would use it: compiled with g++ against the in-tree liburf_hip.so, run on the GPU, and its
-four output clouds compared with oracle B."""
+callback would use it: compiled with g++ against the in-tree PRODUCT library liburf_hip.so, run on the GPU, and its
+four output clouds compared with oracle B point for point -- x, y, z AND intensity (the reference copies whole
+pcl::PointXYZI records into its clouds, lidar_segmentation.cpp:238-242, 354-367)."""
 import os
+import struct
 import subprocess
 
 import numpy as np
@@ -13,17 +15,41 @@ import urban_road_filter_amd as u
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build_demo(tmp_path):
-    exe = str(tmp_path / "detector_demo")
+def build_demo(tmp_path, name="detector_demo"):
+    exe = str(tmp_path / name)
     pkg = os.path.join(ROOT, "urban_road_filter_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "csrc"),
-                           os.path.join(ROOT, "tests", "cpp", "detector_demo.cpp"), "-o", exe,
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
                            "-L" + pkg, "-l:liburf_hip.so", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
+def write_cloud(path, x, y, z, intensity):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(x)))
+        for a in (x, y, z, intensity):
+            f.write(np.ascontiguousarray(a, np.float32).tobytes())
+
+
+def read_runs(path):
+    """-> list of (published, [roi, road, curb, road_probably] as float32 [k, 4] arrays)"""
+    blob = open(path, "rb").read()
+    pos, runs = 0, []
+    while pos < len(blob):
+        (pub,) = struct.unpack_from("<I", blob, pos)
+        pos += 4
+        clouds = []
+        for _ in range(4):
+            (k,) = struct.unpack_from("<I", blob, pos)
+            pos += 4
+            clouds.append(np.frombuffer(blob, np.float32, 4 * k, pos).reshape(-1, 4))
+            pos += 16 * k
+        runs.append((pub, clouds))
+    return runs
+
+
 def test_adapter_links_on_cpu(tmp_path):
-    """No GPU needed: the adapter's symbols are exported by the shared library."""
+    """No GPU needed: the adapter's symbols are exported by the product library."""
     build_demo(tmp_path)
 
 
@@ -31,17 +57,71 @@ def test_adapter_links_on_cpu(tmp_path):
 @pytest.mark.parametrize("scene,seed", [(1, 5), (2, 6)])
 def test_adapter_clouds_equal_oracle(tmp_path, scene, seed):
     exe = build_demo(tmp_path)
-    out = str(tmp_path / "labels.bin")
-    r = subprocess.run([exe, "64", "2048", str(scene), str(seed), out], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stderr
     x, y, z = u.synth_cloud(64, 2048, scene, seed)
+    inten = (np.arange(len(x)) % 251).astype(np.float32) * 0.5 + 1.0   # a sensor-like channel, NOT the index
+    cloud = str(tmp_path / "cloud.bin")
+    out = str(tmp_path / "clouds.bin")
+    write_cloud(cloud, x, y, z, inten)
+    r = subprocess.run([exe, cloud, out], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
     p = O.cfg_params("cfg2")
     lb, ib, st = O.run_b(x, y, z, p, debug=True)
-    blob = open(out, "rb").read()
-    got = np.frombuffer(blob, np.uint8, len(x))
-    assert np.array_equal(got, lb & O.MASK_NO_RING)
-    road_seq = np.frombuffer(blob, np.uint32, ib["n_road"], len(x))
-    assert np.array_equal(road_seq, st["road_order"])   # setReferenceOrder(true): the reference's own order
+    pts = np.stack([x, y, z, inten], axis=1)
+    roi = np.nonzero(lb & 4)[0]
+    road_in = np.nonzero((lb & 3) == 1)[0]
+    curb_in = np.nonzero((lb & 3) == 2)[0]
+    prob_in = np.nonzero(lb & 16)[0]
+    runs = read_runs(out)
+    assert len(runs) == 3 + 6
+    # run 0: pcl::PointCloud overload in the reference's own published order
+    pub, (c_roi, c_road, c_curb, c_prob) = runs[0]
+    assert pub == 1
+    assert np.array_equal(c_roi, pts[roi])
+    assert np.array_equal(c_road, pts[st["road_order"]])
+    assert np.array_equal(c_curb, pts[st["curb_order"]])
+    assert np.array_equal(c_prob, pts[st["ring10_order"]])
+    # run 1: sensor_msgs/PointCloud2 with a permuted field table (intensity z t x ring y), input order
+    for k in [1] + list(range(3, 9)):   # ... and the six sweeps that went through submit() / collect()
+        pub, (c_roi, c_road, c_curb, c_prob) = runs[k]
+        assert pub == 1
+        assert np.array_equal(c_roi, pts[roi]) and np.array_equal(c_road, pts[road_in]), k
+        assert np.array_equal(c_curb, pts[curb_in]) and np.array_equal(c_prob, pts[prob_in]), k
+    # run 2: 23-byte records without an intensity field: pcl::PointXYZI's default (0)
+    bare = pts.copy()
+    bare[:, 3] = 0.0
+    pub, (c_roi, c_road, c_curb, c_prob) = runs[2]
+    assert pub == 1 and np.array_equal(c_roi, bare[roi]) and np.array_equal(c_road, bare[road_in])
+    assert np.array_equal(c_curb, bare[curb_in]) and np.array_equal(c_prob, bare[prob_in])
     assert "road %d curb %d roi %d road_probably %d" % (ib["n_road"], ib["n_curb"], ib["n_roi"], ib["n_ring10"]) in r.stdout
     assert "frame left_os1/os1_lidar" in r.stdout
-    assert "pc2 published 1 same_labels 1" in r.stdout   # sensor_msgs/PointCloud2 with a permuted field table
+    assert "pc2 published 1 same_labels 1" in r.stdout
+    assert "bare published 1 same_labels 1" in r.stdout
+    assert "pipelined sweeps 6 same_labels 6" in r.stdout
+
+
+@pytest.mark.gpu
+def test_adapter_with_a_narrow_region_of_interest(tmp_path):
+    """The reference's default region drops most of a sweep: the label scan skips the empty stretches, the roi cloud is
+    no block copy of the message; and the adapter's timing lines parse."""
+    exe = build_demo(tmp_path)
+    x, y, z = u.synth_cloud(64, 2048, 1, 9)
+    inten = np.cos(np.arange(len(x))).astype(np.float32)
+    cloud = str(tmp_path / "cloud.bin")
+    out = str(tmp_path / "clouds.bin")
+    write_cloud(cloud, x, y, z, inten)
+    r = subprocess.run([exe, cloud, out, "5", "default_roi"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    p = O.cfg_params("default_roi")
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    pts = np.stack([x, y, z, inten], axis=1)
+    runs = read_runs(out)
+    pub, (c_roi, c_road, c_curb, c_prob) = runs[0]
+    assert pub == 1 and 0 < len(c_roi) < len(x) // 2
+    assert np.array_equal(c_roi, pts[np.nonzero(lb & 4)[0]])
+    assert np.array_equal(c_road, pts[st["road_order"]]) and np.array_equal(c_curb, pts[st["curb_order"]])
+    pub, (c_roi, c_road, c_curb, c_prob) = runs[1]
+    assert np.array_equal(c_road, pts[np.nonzero((lb & 3) == 1)[0]]) and np.array_equal(c_prob, pts[np.nonzero(lb & 16)[0]])
+    times = dict(line.split()[1:3] for line in r.stdout.splitlines() if line.startswith("time "))
+    assert set(times) >= {"pointcloud_input_order", "pointcloud2_permuted_fields", "pointcloud_reference_order",
+                          "pointcloud_input_order_with_marker", "pipelined_per_sweep"}
+    assert all(float(v) > 0 for v in times.values())

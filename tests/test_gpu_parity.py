@@ -32,6 +32,14 @@ def ctx_big():
     c.close()
 
 
+@pytest.fixture(scope="module")
+def ctx_hooks():
+    """A context in liburf_hip_test.so (include/urf_test_hooks.h: debug flags, device self tests)."""
+    c = u.Context(64 * 2048, 1, hooks=True)
+    yield c
+    c.close()
+
+
 def info_equal(ig, ib):
     return all(getattr(ig, k) == ib[k] for k in ("status", "n_roi", "n_rings", "n_ring_pts", "n_road", "n_curb", "n_ring10"))
 
@@ -381,7 +389,8 @@ def test_equal_ranges_are_ordered_by_input_index(ctx_big, n_pts):
     assert np.array_equal(lg, lb) and info_equal(ig, ib)
 
 
-def test_star_sort_paths(ctx_big):
+def test_star_sort_paths(ctx_hooks):
+    ctx_big = ctx_hooks
     """k_star_sort_small has a distribution-sort fast path and a general path (in-register block
     sorts merged by ranking).  (a) force the general path on a normal sweep; (b) a cloud whose
     ranges are so clustered that buckets overflow and the kernel falls back by itself."""
@@ -421,9 +430,10 @@ def test_star_sort_paths(ctx_big):
 
 def test_ring_table_zero_sentinel(ctx_big):
     """A point straight below the sensor has vertical angle exactly 0, which the reference's ring
-    table treats as its end-of-table mark (lidar_segmentation.cpp:176).  Ring assignment must
-    follow the reference even then (labels are not compared: that point's azimuth is NaN, see
-    DESIGN.md 'deviations')."""
+    table treats as its end-of-table mark (lidar_segmentation.cpp:176), and an azimuth of NaN, which its
+    per-ring quicksort parks at an input-order-dependent place where the beam scans then stop
+    (:70-93, blind_spots.cpp:107,146,216,255).  Ring assignment, labels, counters and the published
+    order follow the reference through all of it (k_nan_rings)."""
     p = O.cfg_params("cfg2")
     x, y, z = [a[:8192].copy() for a in O.cfg_cloud("cfg2", 61)]
     x[3] = y[3] = 0.0
@@ -437,14 +447,58 @@ def test_ring_table_zero_sentinel(ctx_big):
         assert np.array_equal(ctx_big.read_stage(u.STAGE_RING, len(x)), st["ring"])
     finally:
         ctx_big.enable_stage_capture(0)
-    assert ig.n_rings == ib["n_rings"] and (lg[3] & 3) != 1
-    assert ig.n_nan_azimuth == int(st["ring"][3] >= 0)   # deviation D5 is counted (include/urf.h)
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+    assert ig.n_nan_azimuth == int(st["ring"][3] >= 0)   # such points are counted (include/urf.h)
     x2, y2, z2 = [a.copy() for a in (x, y, z)]
     x2[100:103] = 0.0
     y2[100:103] = 0.0
+    z2[100:103] = z2[100]   # (equal planar ranges inside a sector are a tie the reference leaves open: identical points)
     lb2, ib2, st2 = O.run_b(x2, y2, z2, p, debug=True)
-    _, ig2 = ctx_big.classify_xyz(x2, y2, z2)
+    lg2, ig2 = ctx_big.classify_xyz(x2, y2, z2)
     assert ig2.n_nan_azimuth == int((st2["ring"][[3, 100, 101, 102]] >= 0).sum())
+    assert info_equal(ig2, ib2)
+    same = lg2 == lb2
+    same[100:103] = True   # three identical points of one star sector: which of them the walk marks is the open tie
+    assert same.all()
+
+
+def nan_ring_cloud(seed, n_axis, n_near):
+    """A short organised sweep plus `n_axis` points exactly on the sensor's axis and `n_near` points almost on it,
+    strewn over the input.  With a wide `interval` they share ONE ring -- sorted ring 0 -- whose azimuth-sorted array
+    then holds NaN entries between real ones."""
+    from fuzz import axis_points
+    rng = np.random.default_rng(seed)
+    base = tuple(a[:16384].copy() for a in O.cfg_cloud("narrow" if seed % 2 else "cfg2", 400 + seed))
+    return axis_points(base, rng, n_axis, near=n_near)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_rings_with_nan_azimuths_follow_the_reference(ctx_big, seed):
+    """Deviation D5 of earlier rounds, closed: a ring that holds points with x == y == 0 is sorted by the reference's own
+    Lomuto quicksort (the NaN azimuths land where THAT leaves them) and its beam scans end at the first NaN they meet.
+    Labels, counters, beam stops, published order and marker points equal oracle B, which equals the reference's
+    binary on such input (tests/test_fuzz_cpu.py)."""
+    p = O.cfg_params("cfg2")
+    p.interval = [1.5, 1.5, 0.5, 0.18][seed % 4]
+    p.curbPoints = [5, 2, 5, 9][(seed // 4) % 4]
+    p.curbHeight = 0.02
+    p.channels = 64 if seed % 3 == 0 else 72   # (64: the sweep's own rings fill the table unless an axis point comes first)
+    x, y, z = nan_ring_cloud(seed, 1 + seed % 4, [0, 7, 40, 150][(seed // 2) % 4])
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    axis = (x == 0) & (y == 0)
+    # (several axis points are identical points of star sector 0: which of them the walk marks is a tie the reference leaves open)
+    tie = axis if axis.sum() > 1 else np.zeros(len(x), bool)
+    assert np.array_equal(lg[~tie], lb[~tie]), "%d labels differ" % int((lg != lb)[~tie].sum())
+    assert ig.n_rings == ib["n_rings"] and ig.n_road == ib["n_road"] and ig.n_ring_pts == ib["n_ring_pts"]
+    assert ig.n_nan_azimuth == int((st["ring"][axis] >= 0).sum())
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_BEAM_STOP, len(x)), st["beam_stop"])
+    if axis.sum() == 1:
+        road, curb, prob = ctx_big.ordered_indices(len(x))
+        assert np.array_equal(road, st["road_order"]) and np.array_equal(curb, st["curb_order"])
+        assert np.array_equal(prob, st["ring10_order"])
+        assert np.array_equal(ctx_big.marker_points(), st["marker_pts"])
 
 
 def late_ring_cloud(n=60000, late_at=40000, seed=5):
@@ -613,13 +667,15 @@ def test_full_size_batch_properties():
         assert np.array_equal(L1[s], lb), "scan %d" % s
 
 
-def test_device_arithmetic_selftest(ctx_big):
+def test_device_arithmetic_selftest(ctx_hooks):
+    ctx_big = ctx_hooks
     """The kernels divide by pi with three fma-class operations instead of an f64 division; that
     must equal the IEEE quotient for EVERY float the path can produce (exhaustive over [0, 600])."""
     assert ctx_big.selftest() == 0
 
 
-def test_fast_path_error_bounds(ctx_big):
+def test_fast_path_error_bounds(ctx_hooks):
+    ctx_big = ctx_hooks
     """Ring and sector are decided from float approximations of the angles wherever the
     approximation is clear of every decision boundary by a margin (urf_device.hpp); the margins
     (3e-4 deg, 2e-6 rad, 2.5e-4, the azimuth's 5e-4 + 6e-4 / delta deg) must dominate the error measured on 2^28 pseudo-random points."""

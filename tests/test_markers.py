@@ -99,15 +99,16 @@ def test_gpu_marker_points_random(seed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("simp,zavg", [(1, 1), (0, 0)])
 def test_adapter_marker_array(tmp_path, simp, zavg):
-    from test_gpu_detector import build_demo   # noqa: F401  (same compile line)
-    pkg = os.path.join(ROOT, "urban_road_filter_amd")
-    exe = str(tmp_path / "marker_demo")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "csrc"),
-                           os.path.join(ROOT, "tests", "cpp", "marker_demo.cpp"), "-o", exe,
-                           "-L" + pkg, "-l:liburf_hip.so", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    from test_gpu_detector import build_demo   # (same compile line: g++ against the product library)
+    exe = build_demo(tmp_path, "marker_demo")
     out = str(tmp_path / "markers.bin")
-    r = subprocess.run([exe, str(simp), str(zavg), out] + ["%d:%d" % (scene, seed) for _, scene, seed in SEQ],
-                       capture_output=True, text=True, timeout=180)
+    files = []
+    for k, (_, scene, seed) in enumerate(SEQ):   # the demo links the product library only: the sweeps come from here
+        x, y, z = u.synth_cloud(64, 2048, scene, seed)
+        files.append(str(tmp_path / ("sweep%d.bin" % k)))
+        with open(files[-1], "wb") as f:
+            f.write(struct.pack("<I", len(x)) + x.tobytes() + y.tobytes() + z.tobytes())
+    r = subprocess.run([exe, str(simp), str(zavg), out] + files, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stderr
     blob = open(out, "rb").read()
     mp = O.MarkerParams.default()

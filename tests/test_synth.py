@@ -57,7 +57,7 @@ def test_firing_order_and_geometry():
 
 
 def test_bad_arguments():
-    L = u.lib()
+    L = u.test_lib()   # include/urf_test_hooks.h
     assert L.urf_synth_cloud(0, 10, 0, 1, None, None, None) == -1
     buf = np.zeros(8, np.float32)
     assert L.urf_synth_cloud(2, 4, 5, 1, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data) == -1

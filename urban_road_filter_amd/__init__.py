@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     PARAM_BOOL, PARAM_INT, PARAM_DOUBLE, PARAM_STR,
     lib,
     lib_path,
+    test_lib,
     synth_cloud,
     pc2_to_planes,
     LABEL_MASK, LABEL_ROAD, LABEL_CURB, FLAG_ROI, FLAG_RING, FLAG_RING10,

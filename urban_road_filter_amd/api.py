@@ -1,5 +1,9 @@
-"""ctypes binding of include/urf.h.  No compute happens in Python and there is no
-fallback: if ``liburf_hip.so`` is missing the import of :func:`lib` raises."""
+"""ctypes binding of include/urf.h (and, for tests and bench.py, of include/urf_test_hooks.h).  No compute
+happens in Python and there is no fallback: if ``liburf_hip.so`` is missing the import of :func:`lib` raises.
+
+Two libraries: ``liburf_hip.so`` is the product (exactly include/urf.h); ``liburf_hip_test.so`` is the same
+sources plus the test / benchmark hooks.  ``Context(...)`` lives in the product library, ``Context(..., hooks=True)``
+in the hooks build (needed for set_debug_flags / selftest* / bench_callback_stream)."""
 import ctypes as C
 import os
 import sys
@@ -78,25 +82,32 @@ class ParamDesc(C.Structure):
 
 PARAM_BOOL, PARAM_INT, PARAM_DOUBLE, PARAM_STR = range(4)
 
-_LIB = None
+_LIBS = {}
+
+HOOK_SYMBOLS = ("urf_set_debug_flags", "urf_selftest", "urf_selftest_fast", "urf_synth_cloud", "urf_bench_callback_stream")
 
 
-def lib_path():
-    # URF_LIB_PATH: tuning experiments load an alternative build of the same library
-    return os.environ.get("URF_LIB_PATH") or os.path.join(_HERE, "liburf_hip.so")
+def lib_path(hooks=False):
+    # URF_LIB_PATH: tuning experiments load an alternative build (always one with the hooks) for everything
+    return os.environ.get("URF_LIB_PATH") or os.path.join(_HERE, "liburf_hip_test.so" if hooks else "liburf_hip.so")
 
 
-def lib():
-    """Loads liburf_hip.so.  When torch is (or will be) in the process it must be imported
-    first so that both share ONE HIP runtime (torch bundles libamdhip64.so.7; ours is
+def test_lib():
+    """liburf_hip_test.so: the product's sources plus include/urf_test_hooks.h."""
+    return lib(hooks=True)
+
+
+def lib(hooks=False):
+    """Loads liburf_hip.so (hooks=True: liburf_hip_test.so).  When torch is (or will be) in the process it
+    must be imported first so that both share ONE HIP runtime (torch bundles libamdhip64.so.7; ours is
     resolved by SONAME to whichever copy is already loaded)."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = lib_path()
+    path = lib_path(hooks)
+    if path in _LIBS:
+        return _LIBS[path]
     if not os.path.exists(path):
         raise ImportError("%s not built: run `python -m urban_road_filter_amd.build`" % path)
-    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(path, mode=C.RTLD_LOCAL)   # (both builds export the same names: each keeps to itself, -Bsymbolic)
+    has_hooks = hasattr(L, "urf_synth_cloud")
     vp, u8p, u32p, fp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     sig = {
         "urf_default_params": [C.POINTER(Params)],
@@ -138,6 +149,8 @@ def lib():
         "urf_abi_version": [],
     }
     for name, args in sig.items():
+        if name in HOOK_SYMBOLS and not has_hooks:
+            continue   # the product library exports none of them (tests/test_abi.py)
         f = getattr(L, name)
         f.argtypes = args
         f.restype = C.c_int
@@ -149,7 +162,8 @@ def lib():
     L.urf_kernel_name.restype = C.c_char_p
     L.urf_last_error.argtypes = [vp]
     L.urf_last_error.restype = C.c_char_p
-    _LIB = L
+    L.urf_has_hooks = has_hooks
+    _LIBS[path] = L
     return L
 
 
@@ -204,6 +218,8 @@ def pc2_to_planes(data, n_points, point_step, off_x, off_y, off_z, out=None):
     buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
     assert buf.size >= n_points * point_step
     x, y, z = out if out is not None else (np.empty(n_points, np.float32) for _ in range(3))
+    for a in (x, y, z):   # raw pointers go to C: a float64 or strided array would be filled wrongly or overrun
+        assert isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous and a.size >= n_points
     rc = lib().urf_pc2_to_planes(buf.ctypes.data, n_points, point_step, off_x, off_y, off_z, x.ctypes.data, y.ctypes.data,
                                  z.ctypes.data)
     if rc != 0:
@@ -218,7 +234,7 @@ def synth_cloud(rings, cols, scene=1, seed=1):
     x = np.empty(n, np.float32)
     y = np.empty(n, np.float32)
     z = np.empty(n, np.float32)
-    rc = lib().urf_synth_cloud(rings, cols, scene, seed, x.ctypes.data, y.ctypes.data, z.ctypes.data)
+    rc = test_lib().urf_synth_cloud(rings, cols, scene, seed, x.ctypes.data, y.ctypes.data, z.ctypes.data)
     if rc != 0:
         raise UrfError(rc, "urf_synth_cloud")
     return x, y, z
@@ -240,9 +256,9 @@ def _ptr(obj):
 class Context:
     """One urf_ctx: one device, one stream, all scratch memory."""
 
-    def __init__(self, max_points, max_batch=1, device=0, params=None):
+    def __init__(self, max_points, max_batch=1, device=0, params=None, hooks=False):
         self._h = C.c_void_p()
-        self._lib = lib()
+        self._lib = lib(hooks)   # hooks=True: the context lives in liburf_hip_test.so (include/urf_test_hooks.h)
         rc = self._lib.urf_create(C.byref(self._h), device, max_points, max_batch)
         if rc != 0:
             self._h = None
@@ -298,18 +314,25 @@ class Context:
         self._check(self._lib.urf_callback_path_state(self._h, C.addressof(n), C.addressof(q)), "urf_callback_path_state")
         return n.value, q.value
 
+    def _need_hooks(self, what):
+        if not self._lib.urf_has_hooks:
+            raise RuntimeError("%s is a test hook (include/urf_test_hooks.h): create the context with hooks=True" % what)
+
     def set_debug_flags(self, flags):
+        self._need_hooks("urf_set_debug_flags")
         self._check(self._lib.urf_set_debug_flags(self._h, int(flags)), "urf_set_debug_flags")
 
     NUM_KERNELS = 8
 
     def selftest_fast(self, n_samples=1 << 27):
         """max |approx - exact| of the float fast paths: (vertical angle [deg], polar angle [rad], fi*Kfi, azimuth [deg])."""
+        self._need_hooks("urf_selftest_fast")
         err = np.zeros(4, np.float32)
         self._check(self._lib.urf_selftest_fast(self._h, n_samples, err.ctypes.data), "urf_selftest_fast")
         return tuple(float(v) for v in err)
 
     def selftest(self):
+        self._need_hooks("urf_selftest")
         n = C.c_uint64(0)
         self._check(self._lib.urf_selftest(self._h, C.byref(n)), "urf_selftest")
         return n.value
@@ -325,7 +348,8 @@ class Context:
         names = [self._lib.urf_kernel_name(i).decode() for i in range(self.NUM_KERNELS)]
         return dict(zip(names, list(ms))), n.value
 
-    # -- single scan, asynchronous (two slots: copy of sweep i+1 overlaps kernels of sweep i) ----
+    # -- single scan, asynchronous: URF_MAX_IN_FLIGHT = 4 slots, slot i on scratch row i % min(max_batch, 4) and on that
+    # row's own stream (copy in, kernels, copy out), so that the sweeps in flight overlap ----
     def classify_pc2_async(self, data, n_points, point_step, off_x, off_y, off_z):
         """data: uint8 array (or the int address urf_pinned_input returned).  Returns a ticket."""
         ptr = data if isinstance(data, int) else np.ascontiguousarray(data).view(np.uint8).ctypes.data
@@ -343,6 +367,9 @@ class Context:
 
     def bench_callback_stream(self, msgs, n_points, point_step, off_x, off_y, off_z, n_sweeps, in_flight, producer_pinned=False):
         """Seconds the library's own submit / collect loop takes for n_sweeps messages (uint8 arrays), in_flight at a time."""
+        self._need_hooks("urf_bench_callback_stream")
+        for m in msgs:   # raw pointers go to C
+            assert isinstance(m, np.ndarray) and m.flags.c_contiguous and m.nbytes >= n_points * point_step
         arr = (C.c_void_p * len(msgs))(*[m.ctypes.data for m in msgs])
         lab = np.empty(n_points, np.uint8)
         sec = C.c_double(0.0)

@@ -1,8 +1,13 @@
 """Builds the in-tree native libraries (gfx950 HIP kernels + C ABI).
 
-    python -m urban_road_filter_amd.build            # liburf_hip.so
+    python -m urban_road_filter_amd.build            # liburf_hip.so + liburf_hip_test.so
 
-The shared library is written next to this file so that it travels with a
+liburf_hip.so       the product: exactly the entry points of include/urf.h (+ the C++ adapter)
+liburf_hip_test.so  the same sources compiled with -DURF_ENABLE_TEST_HOOKS plus synth.cpp: additionally
+                    exports include/urf_test_hooks.h (synthetic sweeps, the benchmark's submit / collect
+                    loop, device self tests, debug flags).  tests/ and bench.py use it for those calls only.
+
+The shared libraries are written next to this file so that they travel with a
 snapshot of the repository; nothing is installed into site-packages.
 """
 import os
@@ -14,15 +19,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liburf_hip.so")
+LIB_TEST = os.path.join(HERE, "liburf_hip_test.so")
 
-SOURCES = ["urf_api.hip", "params.cpp", "synth.cpp", "detector.cpp", "marker.cpp"]
+SOURCES = ["urf_api.hip", "params.cpp", "detector.cpp", "marker.cpp"]
+HOOK_SOURCES = ["synth.cpp"]                 # liburf_hip_test.so only
+HOOK_DEFINES = ["URF_ENABLE_TEST_HOOKS=1"]
 HEADERS = ["urf_internal.hpp", "urf_device.hpp", "urf_kernels.hpp", "detector.hpp", "marker.hpp",
-           "../../include/urf.h", "../../include/urf_libm.h"]
+           "../../include/urf.h", "../../include/urf_test_hooks.h", "../../include/urf_libm.h"]
 
 # -ffp-contract=off: the reference is built without FMA contraction and label
 # parity needs the same roundings; no fast-math anywhere.
+# -Bsymbolic: calls between the library's own entry points bind inside the library, so that the product and the
+# hooks build can live in one process (tests) without one resolving into the other.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wl,-Bsymbolic",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
@@ -41,25 +51,35 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.abspath(__file__)]
-    if not force and not _stale(LIB, deps):
-        return LIB
-    cmd = [_hipcc()] + FLAGS + srcs + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    """Both libraries (in parallel); returns the product's path."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    hook_srcs = [os.path.join(CSRC, s) for s in HOOK_SOURCES]
+    deps = srcs + hook_srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.abspath(__file__)]
+    jobs = []
+    if force or _stale(LIB, deps):
+        jobs.append([_hipcc()] + FLAGS + srcs + ["-o", LIB])
+    if force or _stale(LIB_TEST, deps):
+        jobs.append([_hipcc()] + FLAGS + ["-D" + d for d in HOOK_DEFINES] + srcs + hook_srcs + ["-o", LIB_TEST])
+    procs = []
+    for cmd in jobs:
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     return LIB
 
 
 def build_variant(name, defines, verbose=False):
     """A/B builds for kernel experiments: tools/ab/liburf_hip_<name>.so compiled with extra -D flags
-    (select with URF_LIB_PATH; bench.py / the tests then run that library)."""
+    (select with URF_LIB_PATH; bench.py / the tests then run that library for everything: a variant is
+    always built with the test hooks)."""
     out_dir = os.path.join(ROOT, "tools", "ab")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "liburf_hip_%s.so" % name)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    cmd = [_hipcc()] + FLAGS + ["-D" + d for d in defines] + srcs + ["-o", out]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES + HOOK_SOURCES]
+    cmd = [_hipcc()] + FLAGS + ["-D" + d for d in HOOK_DEFINES + list(defines)] + srcs + ["-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -15,9 +15,17 @@
  *     (lidar_segmentation.cpp:612-621)                 clouds carrying the input header
  *
  * A ROS node keeps its subscriber/publishers and calls this class from its
- * callback; see INTEGRATION.md.  Points keep their intensity; the order inside
- * the output clouds is input order, or, after setReferenceOrder(true), exactly
- * the reference's (ring-major, azimuth ascending).
+ * callback; see INTEGRATION.md.  Points keep their intensity (the reference copies whole
+ * pcl::PointXYZI records into its output clouds, lidar_segmentation.cpp:238-242, 354-367); the order
+ * inside the output clouds is input order, or, after setReferenceOrder(true), exactly the
+ * reference's (ring-major, azimuth ascending).
+ *
+ * Nothing is allocated per sweep once the clouds have reached their working size (the reference
+ * allocates channels x piece x 64 B per callback, :207): the sweep goes through the four-slot
+ * asynchronous path of the C ABI (urf_classify_pc2_async / _wait), the label bytes are read in place
+ * from the slot's pinned result buffer (urf_result_labels), the index scratch of the reference
+ * order lives in the object.  submit() / collect() expose the slots: up to URF_MAX_IN_FLIGHT sweeps in
+ * flight, so that a node's subscriber callback returns after the submission.
  */
 #ifndef URF_DETECTOR_HPP
 #define URF_DETECTOR_HPP
@@ -102,33 +110,63 @@ public:
 
     /* lidar_segmentation.cpp:95 Detector::filtered.  Returns false when nothing is published. */
     bool filtered(const PointCloud& cloud);
-    /* The same for a raw sensor_msgs/PointCloud2 payload (data, point_step and the byte offsets of
-     * the x/y/z FLOAT32 fields); the output clouds then carry x,y,z and intensity = input index. */
+    /* The same for a raw sensor_msgs/PointCloud2 payload: data, point_step, the byte offsets of the
+     * x / y / z FLOAT32 fields and (optional, -1 = the message has none) of the FLOAT32 intensity field.
+     * The output clouds carry x, y, z and that intensity (0 without the field: what pcl::fromROSMsg leaves
+     * in a pcl::PointXYZI whose field the message lacks). */
     bool filtered(const uint8_t* data, uint32_t n_points, uint32_t point_step,
-                  uint32_t off_x, uint32_t off_y, uint32_t off_z, const Header& header = Header());
+                  uint32_t off_x, uint32_t off_y, uint32_t off_z, const Header& header = Header(),
+                  int64_t off_intensity = -1);
 
-    /* The wire message itself: resolves the x / y / z FLOAT32 fields by name, as pcl::fromROSMsg does
-     * for pcl::PointXYZI (every other field is ignored), and classifies width*height points. */
+    /* The wire message itself: resolves the x / y / z and intensity FLOAT32 fields by name, as
+     * pcl::fromROSMsg does for pcl::PointXYZI (every other field is ignored), and classifies
+     * width*height points. */
     bool filtered(const PointCloud2& msg);
+
+    /* The same in two halves, up to URF_MAX_IN_FLIGHT sweeps in flight: submit() returns as soon as the
+     * sweep is on its way to the device, collect() blocks until it is done and fills road() ... labels().
+     * Tickets must be collected in the order they were submitted; the message (cloud.points / data /
+     * msg.data) must stay alive and unchanged until its ticket has been collected -- the output clouds are
+     * built from it.  A submission while URF_MAX_IN_FLIGHT sweeps are in flight throws Error(URF_ERR_BUSY). */
+    uint32_t submit(const PointCloud& cloud);
+    uint32_t submit(const uint8_t* data, uint32_t n_points, uint32_t point_step, uint32_t off_x, uint32_t off_y,
+                    uint32_t off_z, const Header& header = Header(), int64_t off_intensity = -1);
+    uint32_t submit(const PointCloud2& msg);
+    bool collect(uint32_t ticket);
 
     const PointCloud& road() const { return road_; }                    /* topic "road" */
     const PointCloud& curb() const { return curb_; }                    /* topic "curb" */
     const PointCloud& roi() const { return roi_; }                      /* topic "roi" */
     const PointCloud& road_probably() const { return road_probably_; }  /* topic "road_probably" */
-    const std::vector<uint8_t>& labels() const { return labels_; }      /* one urf.h label byte per input point */
+    /* one urf.h label byte per input point of the sweep collected last: n_labels() bytes in the library's
+     * pinned result buffer, valid until URF_MAX_IN_FLIGHT further sweeps have been submitted */
+    const uint8_t* labels() const { return labels_; }
+    uint32_t n_labels() const { return n_labels_; }
     const urf_scan_info& info() const { return info_; }
 
 private:
+    struct Pending {
+        const uint8_t* data = nullptr;
+        uint32_t n = 0, step = 0, ox = 0, oy = 0, oz = 0, ticket = 0;
+        int64_t oi = -1;
+        Header header;
+        bool used = false;
+    };
     void check(int rc, const char* what) const;
-    void split(const PointXYZI* pts, uint32_t n, const Header& h);
+    void split(const Pending& m);
+    static void resolve(const PointCloud2& msg, uint32_t off[3], int64_t& off_intensity, uint64_t& n);
     urf_ctx* ctx_ = nullptr;
     bool reference_order_ = false;
     bool marker_on_ = false, marker_published_ = false;
     MarkerBuilder marker_;
     MarkerArray markers_;
-    std::vector<uint8_t> labels_;
+    Pending pending_[URF_MAX_IN_FLIGHT];
+    const uint8_t* labels_ = nullptr;
+    uint32_t n_labels_ = 0;
     urf_scan_info info_{};
     PointCloud road_, curb_, roi_, road_probably_;
+    std::vector<uint32_t> ord_;   /* 3 x max_points: the index lists of the reference order (sized once) */
+    uint32_t max_points_ = 0;
 };
 
 }   // namespace urf

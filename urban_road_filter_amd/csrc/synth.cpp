@@ -22,7 +22,7 @@
 #include <cstring>
 #include <vector>
 
-#include "urf.h"
+#include "urf_test_hooks.h"
 #include "urf_libm.h"
 
 namespace {

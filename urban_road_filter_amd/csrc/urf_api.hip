@@ -18,6 +18,9 @@
 #endif
 
 #include "urf.h"
+#ifdef URF_ENABLE_TEST_HOOKS
+#include "urf_test_hooks.h"
+#endif
 #include "urf_internal.hpp"
 #include "urf_kernels.hpp"
 
@@ -59,6 +62,7 @@ struct urf_ctx {
         urf_kargs cap_a;                /* ... and the kernel arguments / parameters it runs with */
         urf_dev_params cap_dp;
         bool pending = false, used = false;
+        uint64_t gen = 0;               /* the row's submission number of the sweep in this slot */
         uint32_t n_points = 0, ticket = 0;
         uint32_t point_step = 0, off_x = 0, off_y = 0, off_z = 0;   /* layout of the message in d_raw */
         bool planes = false;            /* d_raw holds x[n] y[n] z[n] (a staged message) instead of the records */
@@ -77,6 +81,14 @@ struct urf_ctx {
     hipEvent_t ev_main = nullptr;          /* recorded on `stream` for a row stream to wait on */
     uint64_t main_seq = 1;                 /* bumped by every launch on `stream` that touches scratch rows >= 1 or the staging */
     uint64_t row_seen[URF_ASYNC_SLOTS] = { 0, 0, 0, 0 };
+    /* Slots that share a scratch row (max_batch < URF_ASYNC_SLOTS) are serialised on the row's stream, and a later
+     * sweep overwrites the row.  Labels and summary of every sweep are safe (each slot has its own result buffers,
+     * filled in stream order); what reads the ROW afterwards (urf_read_stage / urf_ordered_indices /
+     * urf_marker_points) checks that the sweep published as "the last call" is still the row's latest submission. */
+    uint64_t row_gen[URF_ASYNC_SLOTS] = { 0, 0, 0, 0 };   /* submissions on the row so far */
+    bool last_is_slot = false;             /* "the last call" is a sweep of the callback path ... */
+    uint32_t last_row = 0;                 /* ... on this row ... */
+    uint64_t last_gen = 0;                 /* ... which was the row's submission number last_gen */
     uint32_t next_ticket = 0;
     uint64_t epoch = 1;             /* bumped by everything a captured sequence depends on */
     /* lazily, sized for the largest number of scans asked for so far: scratch of the index-list and
@@ -111,6 +123,10 @@ struct urf_ctx {
     urf_kargs last_a;
     urf_dev_params last_dp;
     std::string last_error;
+    /* host-side cost of the callback path, phase by phase (only the build with the test hooks fills them:
+     * URF_HOST_TIMES=1, printed by its benchmark loop; the context's layout is the same in both builds) */
+    double ht[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    bool ht_on = false;
 };
 
 #define URF_HIP(ctx, call)                                                              \
@@ -243,6 +259,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.sec_cnt, S * K) A(k.sec_run, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
     A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 4 * URF_ASYNC_SLOTS)   /* four counters per scratch row in use at once */
     A(k.table_upto, S) A(k.table_redo, S) A(k.redo_list, S)
+    A(k.nan_mask, S * 4) A(k.nan_list, 2 * S * C) A(k.vis, S * C)
     A(k.maxdist, S * C) A(k.quad, S * 4)
     A(k.curb_cnt, S * C) A(k.curb_az, S * C * URF_CURB_LIST)
     A(k.sufmin, S * C * URF_DEG_CELLS) A(k.premax, S * C * URF_DEG_CELLS)
@@ -414,55 +431,9 @@ extern "C" int urf_callback_path_state(const urf_ctx* c, uint32_t* n_rerun, uint
     return URF_OK;
 }
 
-extern "C" int urf_set_debug_flags(urf_ctx* c, uint32_t flags)
-{
-    if (!c)
-        return URF_ERR_INVALID_ARG;
-    c->debug_flags = flags;
-    c->dp.exp_flags = flags;
-    c->epoch++;
-    return URF_OK;
-}
-
 extern "C" double urf_ring_threshold_cot(double angle_deg)
 {
     return urf_cot_deg(angle_deg);
-}
-
-extern "C" int urf_selftest(urf_ctx* c, uint64_t* n_mismatches)
-{
-    if (!c || !n_mismatches)
-        return URF_ERR_INVALID_ARG;
-    URF_HIP(c, hipSetDevice(c->device));
-    unsigned long long* d = nullptr;
-    URF_HIP(c, hipMalloc((void**)&d, sizeof(*d)));
-    URF_HIP(c, hipMemsetAsync(d, 0, sizeof(*d), c->stream));
-    hipLaunchKernelGGL(k_selftest_div_pi, dim3(c->n_cus * 8), dim3(256), 0, c->stream, d);
-    unsigned long long h = 0;
-    hipError_t e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    URF_HIP(c, e);
-    *n_mismatches = h;
-    return URF_OK;
-}
-
-extern "C" int urf_selftest_fast(urf_ctx* c, uint64_t n_samples, float* err)
-{
-    if (!c || !err)
-        return URF_ERR_INVALID_ARG;
-    URF_HIP(c, hipSetDevice(c->device));
-    unsigned* d = nullptr;
-    URF_HIP(c, hipMalloc((void**)&d, 4 * sizeof(unsigned)));
-    URF_HIP(c, hipMemsetAsync(d, 0, 4 * sizeof(unsigned), c->stream));
-    hipLaunchKernelGGL(k_selftest_fast, dim3(c->n_cus * 8), dim3(256), 0, c->stream, (unsigned long long)n_samples, c->dp.Kfi, d);
-    hipError_t e = hipMemcpyAsync(err, d, 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    URF_HIP(c, e);
-    return URF_OK;
 }
 
 extern "C" int urf_enable_kernel_timing(urf_ctx* c, int on)
@@ -505,9 +476,9 @@ extern "C" int urf_kernel_timing(urf_ctx* c, double* ms_sum, uint32_t* n_calls)
 
 extern "C" const char* urf_last_error(const urf_ctx* c) { return c ? c->last_error.c_str() : ""; }
 
-/* The context's scratch with every per-scan array advanced by `row` scans (allocation strides):
- * what the second slot of the callback path runs on, so that two sweeps' kernels can be in flight
- * on two streams.  Row 0 = the context's own arguments. */
+/* The context's scratch with every per-scan array advanced by `row` scans (allocation strides): slot i of the
+ * callback path (URF_MAX_IN_FLIGHT slots) runs on row i % min(max_batch, URF_MAX_IN_FLIGHT) and on that row's own
+ * stream, so that the sweeps in flight overlap.  Row 0 = the context's own arguments. */
 static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
 {
     urf_kargs k = c->k;
@@ -526,6 +497,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     k.sec_cnt += r * K; k.sec_run += r * K; k.sec_off += r * (K + 1); k.star_hit += r * K;
     k.star_first += r * K; k.star_list_mid += r * K; k.star_list_big += r * K; k.star_count += 4 * r;
     k.table_upto += r; k.table_redo += r; k.redo_list += r;
+    k.nan_mask += r * 4; k.nan_list += 2 * r * C; k.vis += r * C;
     k.maxdist += r * C; k.quad += r * 4;
     k.curb_cnt += r * C; k.curb_az += r * C * URF_CURB_LIST;
     k.sufmin += r * C * URF_DEG_CELLS; k.premax += r * C * URF_DEG_CELLS;
@@ -568,8 +540,11 @@ static int order_row_after_main(urf_ctx* c, uint32_t row, hipStream_t st)
 static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const float* d_z,
                         const uint32_t* d_offsets, uint32_t n_per_scan, uint32_t max_len, uint32_t n_scans,
                         uint8_t* d_labels, urf_scan_info* d_info, uint32_t row = 0, hipStream_t on_stream = nullptr,
-                        urf_kargs* a_out = nullptr, urf_dev_params* dp_out = nullptr)
+                        urf_kargs* a_out = nullptr, urf_dev_params* dp_out = nullptr, const urf_dev_params* dp_in = nullptr,
+                        int capture_in = -1)
 {
+    /* dp_in / capture_in: the parameters and capture mode a sweep was SUBMITTED with (urf_classify_pc2_wait runs a voided
+     * sweep again: "a sweep in flight keeps its parameters", include/urf.h) */
     if (!d_x || !d_y || !d_z || !d_labels)
         return URF_ERR_INVALID_ARG;
     if (n_scans == 0)
@@ -612,13 +587,13 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
      * lists of oversized star sectors, 20 of a sweep's 200 microseconds -- are left out, k_index voids a sweep that
      * needed them, and urf_classify_pc2_wait() runs it again with them. */
     a.optimistic = on_stream ? ((c->speculate ? URF_OPT_NO_REPAIR : 0u) | (c->slot_lists ? 0u : URF_OPT_NO_LISTS)) : 0u;
-    a.capture = (uint32_t)c->capture;
+    a.capture = (uint32_t)(capture_in >= 0 ? capture_in : c->capture);
     a.labels = d_labels;
-    if (c->capture != 1) {
+    if (a.capture != 1) {
         a.rd2 = nullptr;
         a.caz = nullptr;
     }
-    const urf_dev_params dp = c->dp;
+    const urf_dev_params dp = dp_in ? *dp_in : c->dp;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
     const dim3 g_tiles(a.tiles, n_scans), g_scan(n_scans);
@@ -668,6 +643,8 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         hipLaunchKernelGGL(k_ring, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
     else
         hipLaunchKernelGGL(k_ring_general, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
+    /* the rings that hold a point with a NaN azimuth (k_split listed them: normally none, the kernel returns at once) */
+    hipLaunchKernelGGL(k_nan_rings, dim3(32), dim3(256), URF_NAN_LDS * sizeof(unsigned long long), st, a, dp);
     mark();
     hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_BEAM_THREADS), (size_t)C * (24 * sizeof(unsigned) + URF_CURB_LIST * sizeof(float)), st, a, dp);
     mark();
@@ -683,6 +660,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         c->last_scans = n_scans;
         c->last_a = a;
         c->last_dp = dp;
+        c->last_is_slot = false;
     }
     return URF_OK;
 }
@@ -804,16 +782,19 @@ static int slot_prepare(urf_ctx* c, urf_ctx::slot_t& sl, size_t bytes)
     return URF_OK;
 }
 
-/* host-side cost of the callback path, phase by phase (URF_HOST_TIMES=1: printed by urf_bench_callback_stream) */
-static double g_ht[8];
-static bool g_ht_on = false;
+#ifdef URF_ENABLE_TEST_HOOKS
 static inline double ht_now()
 {
     struct timespec t;
     clock_gettime(CLOCK_MONOTONIC, &t);
     return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
-#define HT(k, t0) do { if (g_ht_on) { const double ht_t = ht_now(); g_ht[k] += ht_t - (t0); (t0) = ht_t; } } while (0)
+#define HT_START double ht0 = c->ht_on ? ht_now() : 0.0
+#define HT(k, t0) do { if (c->ht_on) { const double ht_t = ht_now(); c->ht[k] += ht_t - (t0); (t0) = ht_t; } } while (0)
+#else
+#define HT_START
+#define HT(k, t0)
+#endif
 
 /* A message that has to be staged anyway is staged as three planes x[n4] y[n4] z[n4], n4 = n rounded up to 4: 12 of
  * its (typically) 32 bytes per point cross PCIe (84 -> 35 us for a 64 x 2048 sweep), and the device needs no
@@ -871,7 +852,7 @@ extern "C" int urf_pc2_to_planes(const uint8_t* data, uint32_t n_points, uint32_
 /* what one sweep of the callback path launches on the compute stream: records -> SoA (unless the message was
  * staged as planes), the pipeline, results to the pinned host buffers */
 static int slot_launch(urf_ctx* c, urf_ctx::slot_t& sl, uint32_t n_points, uint32_t point_step, uint32_t off_x,
-                       uint32_t off_y, uint32_t off_z)
+                       uint32_t off_y, uint32_t off_z, const urf_dev_params* dp_in = nullptr, int capture_in = -1)
 {
     const uint32_t row = slot_row(c, sl);
     hipStream_t st = slot_stream(c, sl);
@@ -888,9 +869,13 @@ static int slot_launch(urf_ctx* c, urf_ctx::slot_t& sl, uint32_t n_points, uint3
         hipLaunchKernelGGL(k_pc2_to_soa, dim3((n_points + 255) / 256), dim3(256), 0, st, sl.d_raw, (unsigned long long)n_points,
                            point_step, off_x, off_y, off_z, sx, sy, sz);
     }
-    const int rc = run_pipeline(c, sx, sy, sz, nullptr, n_points, n_points, 1, sl.d_labels, nullptr, row, st, &sl.cap_a, &sl.cap_dp);
+    urf_kargs a_run;
+    urf_dev_params dp_run;   /* (dp_in may point at sl.cap_dp) */
+    const int rc = run_pipeline(c, sx, sy, sz, nullptr, n_points, n_points, 1, sl.d_labels, nullptr, row, st, &a_run, &dp_run, dp_in, capture_in);
     if (rc != URF_OK)
         return rc;
+    sl.cap_a = a_run;
+    sl.cap_dp = dp_run;
     URF_HIP(c, hipMemcpyAsync(sl.h_labels, sl.d_labels, n_points, hipMemcpyDeviceToHost, st));
     URF_HIP(c, hipMemcpyAsync(sl.h_info, kargs_row(c, row).info, sizeof(urf_scan_info), hipMemcpyDeviceToHost, st));
     return URF_OK;
@@ -923,7 +908,7 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
         return URF_ERR_BUSY;          /* every slot in flight: urf_classify_pc2_wait() the oldest one first */
     URF_HIP(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)n_points * point_step;
-    double ht0 = g_ht_on ? ht_now() : 0.0;
+    HT_START;
     /* a message inside the slot's pinned buffer must be the buffer urf_pinned_input() handed out, and
      * fit it: a larger one would make slot_prepare() free the very memory it is about to read */
     if (sl.h_in && data >= sl.h_in && data < sl.h_in + sl.h_in_cap && (data != sl.h_in || bytes > sl.h_in_cap))
@@ -1018,6 +1003,7 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
     sl.off_y = off_y;
     sl.off_z = off_z;
     sl.ticket = c->next_ticket;
+    sl.gen = ++c->row_gen[slot_row(c, sl)];
     *ticket = c->next_ticket++;
     return URF_OK;
 }
@@ -1030,7 +1016,7 @@ extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* label
     if (!sl.pending || sl.ticket != ticket)
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
-    double ht0 = g_ht_on ? ht_now() : 0.0;
+    HT_START;
     URF_HIP(c, hipEventSynchronize(sl.ev_done));
     HT(4, ht0);
     /* the short launch sequence left out something this sweep needed (run_pipeline): once more, with it --
@@ -1042,18 +1028,33 @@ extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* label
             c->slot_lists = true;
         c->epoch++;   /* the captured sequences are rebuilt */
         c->n_rerun++;
-        const int rc = slot_launch(c, sl, sl.n_points, sl.point_step, sl.off_x, sl.off_y, sl.off_z);
-        if (rc != URF_OK)
+        /* with the parameters and capture mode the sweep was submitted with (urf_set_params may have been called since),
+         * behind whatever the context's stream still does with the row */
+        const urf_dev_params dp_sub = sl.cap_dp;
+        int rc = order_row_after_main(c, slot_row(c, sl), slot_stream(c, sl));
+        if (rc == URF_OK)
+            rc = slot_launch(c, sl, sl.n_points, sl.point_step, sl.off_x, sl.off_y, sl.off_z, &dp_sub, (int)sl.cap_a.capture);
+        if (rc == URF_OK && hipStreamSynchronize(slot_stream(c, sl)) != hipSuccess) {
+            c->last_error = "hipStreamSynchronize (rerun of a voided sweep)";
+            rc = URF_ERR_HIP;
+        }
+        if (rc != URF_OK) {
+            sl.pending = false;   /* the slot must not stay busy for ever */
             return rc;
-        URF_HIP(c, hipStreamSynchronize(slot_stream(c, sl)));
+        }
     }
-    if (sl.h_info->status == URF_STATUS_REDO_TABLE || sl.h_info->status == URF_STATUS_REDO_LISTS)
+    if (sl.h_info->status == URF_STATUS_REDO_TABLE || sl.h_info->status == URF_STATUS_REDO_LISTS) {
+        sl.pending = false;
         return URF_ERR_HIP;   /* (cannot happen: the full sequence raises neither) */
+    }
     /* only now is the sweep "the last call": urf_read_stage / urf_marker_points / urf_ordered_indices look at
      * its scratch row, which stays untouched until the slot (or a batch call) is used again */
     c->last_scans = 1;
     c->last_a = sl.cap_a;
     c->last_dp = sl.cap_dp;
+    c->last_is_slot = true;
+    c->last_row = slot_row(c, sl);
+    c->last_gen = sl.gen;
     if (labels_out)
         std::memcpy(labels_out, sl.h_labels, sl.n_points);
     if (info)
@@ -1098,67 +1099,15 @@ extern "C" int urf_classify_pc2(urf_ctx* c, const uint8_t* data, uint32_t n_poin
     return urf_classify_pc2_wait(c, ticket, labels_out, info);
 }
 
-/* Benchmark helper: the submit / collect loop of a C or C++ client of the callback path (a ROS node's
- * subscriber callback and publisher), timed natively -- `n_sweeps` messages (taken round robin from
- * `msgs`), at most `in_flight` of them submitted before the oldest is collected. */
-extern "C" int urf_bench_callback_stream(urf_ctx* c, const uint8_t* const* msgs, uint32_t n_msgs, uint32_t n_points,
-                                         uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
-                                         uint32_t n_sweeps, uint32_t in_flight, int producer_pinned, uint8_t* labels_out,
-                                         double* seconds)
+/* urf_read_stage / urf_ordered_indices / urf_marker_points read the scratch ROW of the last call.  For a sweep of the
+ * callback path that row is only intact while no later sweep has been submitted on it (slots that share a row:
+ * max_batch < URF_MAX_IN_FLIGHT and more sweeps in flight than rows). */
+static int last_row_intact(urf_ctx* c)
 {
-    if (!c || !msgs || n_msgs == 0 || !seconds || in_flight == 0 || in_flight > URF_ASYNC_SLOTS)
-        return URF_ERR_INVALID_ARG;
-    for (uint32_t k = 0; k < n_msgs; k++)
-        if (!msgs[k])
-            return URF_ERR_INVALID_ARG;
-    const size_t bytes = (size_t)n_points * point_step;
-    uint32_t tickets[URF_ASYNC_SLOTS];
-    uint32_t head = 0, count = 0;   /* ring of tickets in flight */
-    urf_scan_info info;
-    struct timespec t0, t1;
-    g_ht_on = getenv("URF_HOST_TIMES") != nullptr;
-    for (double& v : g_ht)
-        v = 0.0;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (uint32_t k = 0; k < n_sweeps; k++) {
-        if (count == in_flight) {
-            const int rc = urf_classify_pc2_wait(c, tickets[head], labels_out, &info);
-            if (rc != URF_OK)
-                return rc;
-            head = (head + 1) % URF_ASYNC_SLOTS;
-            count--;
-        }
-        const uint8_t* data = msgs[k % n_msgs];
-        if (producer_pinned) {   /* the producer fills the library's pinned buffer itself (each slot's once: producing the data is not what is timed) */
-            uint8_t* pin = nullptr;
-            const int rc = urf_pinned_input(c, bytes, &pin);
-            if (rc != URF_OK)
-                return rc;
-            if (k < URF_ASYNC_SLOTS)
-                std::memcpy(pin, data, bytes);
-            data = pin;
-        }
-        uint32_t t = 0;
-        const int rc = urf_classify_pc2_async(c, data, n_points, point_step, off_x, off_y, off_z, &t);
-        if (rc != URF_OK)
-            return rc;
-        tickets[(head + count) % URF_ASYNC_SLOTS] = t;
-        count++;
-    }
-    while (count) {
-        const int rc = urf_classify_pc2_wait(c, tickets[head], labels_out, &info);
-        if (rc != URF_OK)
-            return rc;
-        head = (head + 1) % URF_ASYNC_SLOTS;
-        count--;
-    }
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-    if (g_ht_on) {
-        fprintf(stderr, "host us per sweep (pinned %d, in flight %u): total %.1f | stage+h2d %.1f order %.1f launch %.1f record %.1f wait %.1f rest-of-wait %.1f\n",
-                producer_pinned, in_flight, 1e6 * *seconds / n_sweeps, 1e6 * g_ht[0] / n_sweeps, 1e6 * g_ht[1] / n_sweeps, 1e6 * g_ht[2] / n_sweeps,
-                1e6 * g_ht[3] / n_sweeps, 1e6 * g_ht[4] / n_sweeps, 1e6 * g_ht[5] / n_sweeps);
-        g_ht_on = false;
+    if (c->last_is_slot && c->row_gen[c->last_row] != c->last_gen) {
+        c->last_error = "the scratch row of the sweep waited for last has been resubmitted (create the context with max_batch >= "
+                        "the number of sweeps in flight, or read its intermediate results before submitting on its row again)";
+        return URF_ERR_BUSY;
     }
     return URF_OK;
 }
@@ -1225,7 +1174,9 @@ static int ensure_order_scratch(urf_ctx* c, uint32_t n_scans)
 static int launch_ordered(urf_ctx* c, uint32_t s0, uint32_t n, uint32_t* d_road, uint32_t* d_curb, uint32_t* d_r10,
                           uint32_t stride, uint32_t* d_counts)
 {
-    int rc = order_after_slots(c);
+    int rc = last_row_intact(c);
+    if (rc == URF_OK)
+        rc = order_after_slots(c);
     if (rc == URF_OK)
         rc = ensure_order_scratch(c, n);
     if (rc != URF_OK)
@@ -1287,6 +1238,9 @@ extern "C" int urf_ordered_indices(urf_ctx* c, uint32_t scan, uint32_t* road, ui
 static int launch_markers(urf_ctx* c, uint32_t s0, uint32_t n, float* d_pts, uint32_t* d_counts)
 {
     {
+        const int irc = last_row_intact(c);
+        if (irc != URF_OK)
+            return irc;
         const int orc = order_after_slots(c);
         if (orc != URF_OK)
             return orc;
@@ -1393,6 +1347,9 @@ extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* h
         return URF_ERR_INVALID_ARG;
     URF_HIP(c, hipSetDevice(c->device));
     {
+        const int irc = last_row_intact(c);
+        if (irc != URF_OK)
+            return irc;
         const int orc = order_after_slots(c);   /* (sweeps still in flight on other rows' streams) */
         if (orc != URF_OK)
             return orc;
@@ -1493,3 +1450,129 @@ extern "C" int urf_read_stage(urf_ctx* c, urf_stage what, uint32_t scan, void* h
     }
     return URF_ERR_INVALID_ARG;
 }
+
+/* ---- test and benchmark hooks (include/urf_test_hooks.h) --------------------------------------------
+ * Compiled only into liburf_hip_test.so (-DURF_ENABLE_TEST_HOOKS, urban_road_filter_amd/build.py): the product
+ * library liburf_hip.so exports none of them. */
+#ifdef URF_ENABLE_TEST_HOOKS
+extern "C" int urf_set_debug_flags(urf_ctx* c, uint32_t flags)
+{
+    if (!c)
+        return URF_ERR_INVALID_ARG;
+    c->debug_flags = flags;
+    c->dp.exp_flags = flags;
+    c->epoch++;
+    return URF_OK;
+}
+
+extern "C" int urf_selftest(urf_ctx* c, uint64_t* n_mismatches)
+{
+    if (!c || !n_mismatches)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    URF_HIP(c, hipMalloc((void**)&d, sizeof(*d)));
+    URF_HIP(c, hipMemsetAsync(d, 0, sizeof(*d), c->stream));
+    hipLaunchKernelGGL(k_selftest_div_pi, dim3(c->n_cus * 8), dim3(256), 0, c->stream, d);
+    unsigned long long h = 0;
+    hipError_t e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    URF_HIP(c, e);
+    *n_mismatches = h;
+    return URF_OK;
+}
+
+extern "C" int urf_selftest_fast(urf_ctx* c, uint64_t n_samples, float* err)
+{
+    if (!c || !err)
+        return URF_ERR_INVALID_ARG;
+    URF_HIP(c, hipSetDevice(c->device));
+    unsigned* d = nullptr;
+    URF_HIP(c, hipMalloc((void**)&d, 4 * sizeof(unsigned)));
+    URF_HIP(c, hipMemsetAsync(d, 0, 4 * sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(k_selftest_fast, dim3(c->n_cus * 8), dim3(256), 0, c->stream, (unsigned long long)n_samples, c->dp.Kfi, d);
+    hipError_t e = hipMemcpyAsync(err, d, 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    URF_HIP(c, e);
+    return URF_OK;
+}
+
+/* Benchmark helper: the submit / collect loop of a C or C++ client of the callback path (a ROS node's
+ * subscriber callback and publisher), timed natively -- `n_sweeps` messages (taken round robin from
+ * `msgs`), at most `in_flight` of them submitted before the oldest is collected. */
+extern "C" int urf_bench_callback_stream(urf_ctx* c, const uint8_t* const* msgs, uint32_t n_msgs, uint32_t n_points,
+                                         uint32_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                                         uint32_t n_sweeps, uint32_t in_flight, int producer_pinned, uint8_t* labels_out,
+                                         double* seconds)
+{
+    if (!c || !msgs || n_msgs == 0 || !seconds || in_flight == 0 || in_flight > URF_ASYNC_SLOTS)
+        return URF_ERR_INVALID_ARG;
+    for (uint32_t k = 0; k < n_msgs; k++)
+        if (!msgs[k])
+            return URF_ERR_INVALID_ARG;
+    const size_t bytes = (size_t)n_points * point_step;
+    uint32_t tickets[URF_ASYNC_SLOTS];
+    uint32_t head = 0, count = 0;   /* ring of tickets in flight */
+    urf_scan_info info;
+    struct timespec t0, t1;
+    c->ht_on = getenv("URF_HOST_TIMES") != nullptr;
+    for (double& v : c->ht)
+        v = 0.0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    auto loop = [&]() -> int {
+        for (uint32_t k = 0; k < n_sweeps; k++) {
+            if (count == in_flight) {
+                const int rc = urf_classify_pc2_wait(c, tickets[head], labels_out, &info);
+                if (rc != URF_OK)
+                    return rc;
+                head = (head + 1) % URF_ASYNC_SLOTS;
+                count--;
+            }
+            const uint8_t* data = msgs[k % n_msgs];
+            if (producer_pinned) {   /* the producer fills the library's pinned buffer itself (each slot's once: producing the data is not what is timed) */
+                uint8_t* pin = nullptr;
+                const int rc = urf_pinned_input(c, bytes, &pin);
+                if (rc != URF_OK)
+                    return rc;
+                if (k < URF_ASYNC_SLOTS)
+                    std::memcpy(pin, data, bytes);
+                data = pin;
+            }
+            uint32_t t = 0;
+            const int rc = urf_classify_pc2_async(c, data, n_points, point_step, off_x, off_y, off_z, &t);
+            if (rc != URF_OK)
+                return rc;
+            tickets[(head + count) % URF_ASYNC_SLOTS] = t;
+            count++;
+        }
+        while (count) {
+            const int rc = urf_classify_pc2_wait(c, tickets[head], labels_out, &info);
+            if (rc != URF_OK)
+                return rc;
+            head = (head + 1) % URF_ASYNC_SLOTS;
+            count--;
+        }
+        return URF_OK;
+    };
+    const int lrc = loop();
+    if (lrc != URF_OK) {
+        c->ht_on = false;   /* (every exit path: a later call must not pay for the clock reads) */
+        return lrc;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    if (c->ht_on) {
+        fprintf(stderr, "host us per sweep (pinned %d, in flight %u): total %.1f | stage+h2d %.1f order %.1f launch %.1f record %.1f wait %.1f rest-of-wait %.1f\n",
+                producer_pinned, in_flight, 1e6 * *seconds / n_sweeps, 1e6 * c->ht[0] / n_sweeps, 1e6 * c->ht[1] / n_sweeps, 1e6 * c->ht[2] / n_sweeps,
+                1e6 * c->ht[3] / n_sweeps, 1e6 * c->ht[4] / n_sweeps, 1e6 * c->ht[5] / n_sweeps);
+        c->ht_on = false;
+    }
+    return URF_OK;
+}
+
+#endif   /* URF_ENABLE_TEST_HOOKS */
+

@@ -110,6 +110,12 @@ struct urf_sec_run { uint32_t a0, c0, a1, nruns; };
 /* k_star_sort_* -> k_star_walk, per point of a sector in sorted order */
 struct alignas(8) urf_sg { float slp, g; };
 
+/* What the reference's beam scans see of a ring whose azimuth-sorted array holds NaN entries: the forward scans
+ * (blind_spots.cpp:107,124,146,164: "alpha <= window end" ends the loop, and is false for a NaN) only the points in
+ * front of the first NaN -- the smallest azimuths, up to f_hi --, the backward scans (:216,233,255,273) only those
+ * behind the last one -- the largest, from b_lo.  A ring without such a point: (+inf, -inf). */
+struct alignas(8) urf_vis { float f_hi, b_lo; };
+
 /* k_beams -> k_label, per (ring, integer degree) */
 struct urf_win { float hi, lo; };
 
@@ -179,7 +185,7 @@ struct urf_kargs {
     uint32_t* star_first;       /* [S][sectors] last sorted index the walk may visit */
     uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 385..2048 points */
     uint32_t* star_list_big;    /* [S*sectors] ... with more than 2048 points */
-    uint32_t* star_count;       /* [4] lengths of the two lists, [2] = length of redo_list (zeroed per call) */
+    uint32_t* star_count;       /* [4] lengths of the two lists, [2] = length of redo_list, [3] = length of nan_list (zeroed per call) */
     uint32_t* table_upto;       /* [S] first point a speculative k_ring_table did not look at (0xffffffff: none) */
     uint32_t* table_redo;       /* [S] k_split: the speculative table of the scan is incomplete */
     uint32_t* redo_list;        /* [S] such scans (k_table_repair) */
@@ -187,6 +193,11 @@ struct urf_kargs {
     float*    big_r;            /* sector-major copies of the sectors on the "big" list (sorted in place) */
     float*    big_z;
     uint32_t* big_i;
+    /* rings that hold a point with x == y == 0, whose azimuth is NaN (normally none): the reference's per-ring quicksort
+     * parks such a point at an input-order-dependent place and its beam scans stop there -- k_nan_rings reproduces both */
+    uint32_t* nan_mask;         /* [S][4] bit c: ring c of the scan holds such a point (k_split's exact pass; zeroed by k_ring_table) */
+    uint32_t* nan_list;         /* [2 * S * channels] scan * channels + ring of the rings whose bit was newly set (k_split -> k_nan_rings) */
+    urf_vis*  vis;              /* [S][channels] what of ring c the beam scans see (k_ring: everything; k_nan_rings; -> k_beams) */
     float*    maxdist;          /* [S][channels] */
     float*    quad;             /* [S][4] */
     uint32_t* curb_cnt;         /* [S][channels] curb points of the ring with a valid azimuth; 0xffffffff: more than k_ring's list holds, see sufmin / premax */

@@ -184,6 +184,8 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
         sh_nmatch = 0;
         sh_zero = 0;
     }
+    if (tid < 4)
+        a.nan_mask[(size_t)s * 4 + tid] = 0;   /* (k_table_repair: the bits k_split set against the old table are void) */
     __syncthreads();
 
     const float interval = dp.p.interval;
@@ -797,6 +799,15 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             a.valpha[sb + i] = ek.valpha;   /* stage capture only */
         if (ek.ring == URF_RING_NONE && i >= upto)
             a.table_redo[s] = 1u;
+        /* a ring point straight above or below the sensor: its azimuth is NaN, and the reference's per-ring quicksort and
+         * beam scans treat the ring in a way of their own (k_nan_rings).  Such a point always gets here (urf_fast_cot
+         * refuses x == y == 0), so the test costs the main pass nothing. */
+        if (x == 0.0f && y == 0.0f && ek.ring != URF_RING_NONE) {
+            const unsigned bit = 1u << (ek.ring & 31u);
+            const unsigned old = atomicOr(&a.nan_mask[(size_t)s * 4 + (ek.ring >> 5)], bit);
+            if (!(old & bit))
+                a.nan_list[atomicAdd(&a.star_count[3], 1u)] = s * C + ek.ring;
+        }
         keyr[li] = (uint8_t)ek.ring;
         keys[li] = (uint16_t)sk;
     }
@@ -2658,6 +2669,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
     if (tid < 2 * (CH / 32))
         (&S.hb[0][0])[tid] = 0;
     if (tid == 0) {
+        a.vis[(size_t)s * C + c] = urf_vis{ __builtin_inff(), -__builtin_inff() };   /* the beam scans see the whole ring (k_nan_rings) */
         sh_q[0] = (int)urf_fbits(0.f);
         sh_q[1] = (int)urf_fbits(180.f);
         sh_q[2] = (int)urf_fbits(180.f);
@@ -3067,6 +3079,169 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
 }
 
 /* ------------------------------------------------------------------------- */
+/* k_nan_rings                                                                 */
+/* ------------------------------------------------------------------------- */
+/* A ring point with x == y == 0 has the azimuth asin(0 / 0) = NaN (lidar_segmentation.cpp:245-269).  The reference
+ * sorts every ring with a Lomuto quicksort (:70-93) whose only comparison, alpha < pivot, is false for a NaN on either
+ * side: the non-NaN azimuths still come out ascending, but every NaN ends up at a place that depends on the order of
+ * the input, and the beam scans of blind_spots.cpp (:107,124,146,164 forwards, :216,233,255,273 backwards) end at the
+ * first NaN they meet -- the forward beams see only what lies in front of the first NaN of the sorted ring, the backward
+ * beams only what lies behind the last one.  Deterministic, hence part of the contract: for the listed rings (k_split:
+ * normally none, and this kernel returns at once) the quicksort is run LITERALLY -- same pivot, same comparison,
+ * same swaps, on (exact azimuth, position in the ring) pairs -- and what comes out of it is
+ *   vis[ring]    = (largest azimuth in front of the first NaN, smallest azimuth behind the last NaN), with which
+ *                  k_beams limits what a curb point of the ring can stop and what a beam can mark on it;
+ *   ssrt[ring..] = the ring in the reference's final order (positions), for the published order (k_ring_order).
+ * (Two non-NaN points of one ring with bit-identical azimuths on either side of such a boundary would need the
+ * positions themselves; the limits are compared as values.)
+ *
+ * One workgroup per listed ring, persistent over the list.  The pairs live in LDS (rings of up to URF_NAN_LDS
+ * points) or in the ring's stretch of wsg, which nobody reads after k_star_walk.  Wave 0 runs the partition loop 64
+ * elements at a time: a step in which no element is smaller than the pivot moves nothing, one in which all are and
+ * the block of not-smaller elements is empty only swaps elements with themselves -- an ascending run with its
+ * largest element as the pivot (what the recursion meets on an organised sweep) costs n / 64 steps per partition;
+ * anything else goes element by element, exactly as written in the reference. */
+#define URF_NAN_LDS 6144u   /* pairs of 8 bytes: 48 KB */
+__device__ __forceinline__ float urf_pair_alpha(unsigned long long e) { return __uint_as_float((unsigned)(e >> 32)); }
+
+/* lidar_segmentation.cpp:69-82 partition(low, high) on A, by one wave (all 64 lanes call it with uniform arguments) */
+__device__ int urf_lomuto_partition(unsigned long long* A, int low, int high)
+{
+    const int lane = (int)urf_lane();
+    const float pivot = urf_pair_alpha(A[high]);
+    int i = low - 1;
+    for (int j0 = low; j0 <= high - 1; j0 += 64) {
+        const int j = j0 + lane;
+        const bool in = j <= high - 1;
+        const unsigned long long e = in ? A[j] : 0ull;
+        const bool less = in && urf_pair_alpha(e) < pivot;
+        const unsigned long long m = __ballot(less), vm = __ballot(in);
+        if (m == 0ull)
+            continue;                                   /* no element of the step is swapped */
+        if (m == vm && i == j0 - 1) {
+            i += (int)__popcll(vm);                     /* every swap of the step is a swap with itself */
+            continue;
+        }
+        if (lane == 0) {
+            const int jend = j0 + 63 < high - 1 ? j0 + 63 : high - 1;
+            for (int jj = j0; jj <= jend; jj++) {
+                const unsigned long long ej = A[jj];
+                if (urf_pair_alpha(ej) < pivot) {
+                    i++;
+                    const unsigned long long ei = A[i];
+                    A[i] = ej;
+                    A[jj] = ei;
+                }
+            }
+        }
+        __threadfence_block();
+        i = __shfl(i, 0);
+    }
+    if (lane == 0) {
+        const unsigned long long t = A[i + 1];
+        A[i + 1] = A[high];
+        A[high] = t;
+    }
+    __threadfence_block();
+    return i + 1;
+}
+
+__global__ __launch_bounds__(256) void k_nan_rings(urf_kargs a, urf_dev_params dp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sh_pairs[];
+    __shared__ int stk[2 * 64];
+    __shared__ unsigned n_nan, first_nan, last_nan;
+    const unsigned n_list = a.star_count[3];
+    if (n_list == 0)
+        return;
+    const unsigned tid = threadIdx.x, C = (unsigned)dp.p.channels;
+    for (unsigned w = blockIdx.x; w < n_list; w += gridDim.x) {
+        const unsigned ent = a.nan_list[w], s = ent / C, c = ent % C;
+        const urf_scan_info in = a.info[s];
+        if (in.status != URF_OK || c >= in.n_rings)
+            continue;   /* (uniform) */
+        unsigned off, len;
+        urf_scan_range(a, s, off, len);
+        const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
+        const unsigned sb = urf_sbase(a, s);
+        const unsigned n = a.ring_cnt[(size_t)s * C + c], ro = a.ring_off[(size_t)s * (C + 1) + c];
+        unsigned long long* const A = n <= URF_NAN_LDS ? sh_pairs : (unsigned long long*)(a.wsg + sb + ro);
+        if (tid == 0) {
+            n_nan = 0;
+            first_nan = 0xffffffffu;
+            last_nan = 0;
+        }
+        __syncthreads();
+        /* the ring in bucket order (input order: what the reference sorts), exact azimuths */
+        unsigned mine = 0;
+        for (unsigned j = tid; j < n; j += 256) {
+            const unsigned slot = sb + urf_ring_slot(a, s, C, c, ntiles, j);
+            float d2;
+            const float az = urf_azimuth(a.rx[slot], a.ry[slot], &d2);
+            A[j] = ((unsigned long long)__float_as_uint(az) << 32) | j;
+            mine += !(az == az);
+        }
+        if (mine)
+            atomicAdd(&n_nan, mine);
+        __threadfence_block();
+        __syncthreads();
+        if (n_nan == 0) {   /* (uniform) a bit set against a ring table that was rebuilt afterwards */
+            if (tid == 0)
+                atomicAnd(&a.nan_mask[(size_t)s * 4 + (c >> 5)], ~(1u << (c & 31u)));
+            __syncthreads();
+            continue;
+        }
+        if (tid < 64 && n >= 2) {
+            /* quickSort(0, n - 1), lidar_segmentation.cpp:85-93: the two halves of a partition are disjoint, so the order
+             * in which they are sorted does not matter -- the smaller one first, the larger one on a stack (<= log2 n deep) */
+            int top = 0, low = 0, high = (int)n - 1;
+            for (;;) {
+                while (low < high) {
+                    const int pi = urf_lomuto_partition(A, low, high);
+                    const int l0 = low, h0 = pi - 1, l1 = pi + 1, h1 = high;
+                    const bool left_small = (h0 - l0) < (h1 - l1);
+                    const int pl = left_small ? l1 : l0, ph = left_small ? h1 : h0;   /* pushed */
+                    low = left_small ? l0 : l1;
+                    high = left_small ? h0 : h1;
+                    if (pl < ph && top < 64) {
+                        if (tid == 0) {
+                            stk[2 * top] = pl;
+                            stk[2 * top + 1] = ph;
+                        }
+                        top++;
+                    }
+                }
+                if (top == 0)
+                    break;
+                top--;
+                __threadfence_block();
+                low = stk[2 * top];
+                high = stk[2 * top + 1];
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (unsigned j = tid; j < n; j += 256) {
+            const unsigned long long e = A[j];
+            a.ssrt[sb + ro + j] = (unsigned)e;   /* the ring in the reference's final order */
+            const float az = urf_pair_alpha(e);
+            if (!(az == az)) {
+                atomicMin(&first_nan, j);
+                atomicMax(&last_nan, j);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            urf_vis v;
+            v.f_hi = first_nan > 0 ? urf_pair_alpha(A[first_nan - 1]) : -__builtin_inff();
+            v.b_lo = last_nan + 1 < n ? urf_pair_alpha(A[last_nan + 1]) : __builtin_inff();
+            a.vis[(size_t)s * C + c] = v;
+        }
+        __syncthreads();   /* the pairs / the counters are reused by the next listed ring */
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* k_beams                                                                     */
 /* ------------------------------------------------------------------------- */
 /* blind_spots.cpp:72-99 / :181-208 */
@@ -3103,6 +3278,8 @@ __global__ __launch_bounds__(URF_BEAM_THREADS) __attribute__((amdgpu_waves_per_e
     __shared__ unsigned lcnt[URF_MAX_CHANNELS];   /* curb points of ring k (URF_CURB_DENSE: see its per-degree tables) */
     __shared__ unsigned lpre[URF_MAX_CHANNELS + 1];   /* listed curb points on the rings in front of ring k */
     __shared__ unsigned n_dense;                       /* rings whose list overflowed */
+    /* rings that hold a point with a NaN azimuth (k_nan_rings; normally none): what the forward / backward scans see of them */
+    __shared__ float vfh[URF_MAX_CHANNELS], vbl[URF_MAX_CHANNELS];
     extern __shared__ unsigned sh_beams[];            /* sfm[channels][12] | sbm[channels][12] | lst[channels][URF_CURB_LIST] */
     const unsigned s = blockIdx.x, tid = threadIdx.x;
     const unsigned part = tid / 384u, dt = tid % 384u;   /* (a wave lies in one group: 384 = 6 x 64) */
@@ -3114,6 +3291,8 @@ __global__ __launch_bounds__(URF_BEAM_THREADS) __attribute__((amdgpu_waves_per_e
     URF_PHASE_DECL;
     const urf_scan_info in = a.info[s];
     const unsigned v_cnt = tid < C ? a.curb_cnt[(size_t)s * C + tid] : 0u;
+    const uint4 nanm = *(const uint4*)(a.nan_mask + (size_t)s * 4);
+    const bool has_nan = (nanm.x | nanm.y | nanm.z | nanm.w) != 0u;   /* (uniform) */
     constexpr unsigned LPT = (URF_MAX_CHANNELS * URF_CURB_LIST + URF_BEAM_THREADS - 1) / URF_BEAM_THREADS;
     float v_lst[LPT];
 #pragma unroll
@@ -3134,6 +3313,11 @@ __global__ __launch_bounds__(URF_BEAM_THREADS) __attribute__((amdgpu_waves_per_e
         qk[k] = urf_arc_ratio(dp, maxd[0], maxd[k]);
     if (tid < C)
         lcnt[tid] = v_cnt;
+    if (has_nan && tid < nR && tid < C) {
+        const urf_vis v = a.vis[(size_t)s * C + tid];
+        vfh[tid] = v.f_hi;
+        vbl[tid] = v.b_lo;
+    }
 #pragma unroll
     for (unsigned e = 0; e < LPT; e++) {
         const unsigned idx = tid + e * URF_BEAM_THREADS;
@@ -3207,7 +3391,9 @@ __global__ __launch_bounds__(URF_BEAM_THREADS) __attribute__((amdgpu_waves_per_e
             /* the window ends away from the limit beams (which are added below): monotone in the degree */
             auto hi_of = [&](int d) { return k == 0 ? (float)d + dp.p.beamZone : (float)((double)d + qq); };
             auto lo_of = [&](int d) { return k == 0 ? (float)d - dp.p.beamZone : (float)((double)d - qq); };
-            {   /* forward: [dmin, a0] */
+            /* (a ring with NaN azimuths: the forward scans end at its first NaN, the backward scans at its last) */
+            const bool seen_f = !has_nan || az <= vfh[k], seen_b = !has_nan || az >= vbl[k];
+            if (seen_f) {   /* forward: [dmin, a0] */
                 const float est = __builtin_ceilf(az - wd);
                 int d = !(est >= 0.0f) ? 0 : (est > (float)(a0 + 1) ? a0 + 1 : (int)est);
                 int guard = 0;
@@ -3220,7 +3406,7 @@ __global__ __launch_bounds__(URF_BEAM_THREADS) __attribute__((amdgpu_waves_per_e
                 if (k != 0 && fl_int && (int)dp.fwd_limit <= a0)   /* fi == limit: the window reaches 360 >= az */
                     set_bits(&sfm[k * 12], (int)dp.fwd_limit, (int)dp.fwd_limit);
             }
-            {   /* backward: [a1, dmax] */
+            if (seen_b) {   /* backward: [a1, dmax] */
                 const float est = __builtin_floorf(az + wd);
                 int d = !(est <= 360.0f) ? 360 : (est < (float)(a1 - 1) ? a1 - 1 : (int)est);
                 int guard = 0;
@@ -3261,8 +3447,13 @@ __global__ __launch_bounds__(URF_BEAM_THREADS) __attribute__((amdgpu_waves_per_e
                 const unsigned k = k0 + u * NH + part;
                 bool hf = k < nR && (wf[u] & bit) != 0, hb = k < nR && (wb[u] & bit) != 0;
                 if (dense_rings && k < nR && lcnt[k] == URF_CURB_DENSE) {   /* (uniform) the ring's list overflowed: its per-degree tables */
-                    hf = cast_f && sf == (int)nR && a.sufmin[((size_t)s * C + k) * URF_DEG_CELLS + i] <= urf_fwd_hi(dp, i, k, qk[k]);
-                    hb = cast_b && sb == (int)nR && a.premax[((size_t)s * C + k) * URF_DEG_CELLS + i] >= urf_bwd_lo(dp, i, k, qk[k]);
+                    float whi = urf_fwd_hi(dp, i, k, qk[k]), wlo = urf_bwd_lo(dp, i, k, qk[k]);
+                    if (has_nan) {   /* (selects that keep a NaN window end a NaN) */
+                        whi = vfh[k] < whi ? vfh[k] : whi;
+                        wlo = vbl[k] > wlo ? vbl[k] : wlo;
+                    }
+                    hf = cast_f && sf == (int)nR && a.sufmin[((size_t)s * C + k) * URF_DEG_CELLS + i] <= whi;
+                    hb = cast_b && sb == (int)nR && a.premax[((size_t)s * C + k) * URF_DEG_CELLS + i] >= wlo;
                 }
                 sf = (sf == (int)nR && hf) ? (int)k : sf;
                 sb = (sb == (int)nR && hb) ? (int)k : sb;
@@ -3346,6 +3537,10 @@ __global__ __launch_bounds__(URF_BEAM_THREADS) __attribute__((amdgpu_waves_per_e
                 urf_win o;
                 o.hi = jf >= 0 ? urf_fwd_hi(dp, jf, k, q4[u]) : -__builtin_inff();
                 o.lo = jb >= 0 ? urf_bwd_lo(dp, jb, k, q4[u]) : __builtin_inff();
+                if (has_nan) {   /* (uniform) a beam marks only what its scan of the ring sees (blind_spots.cpp:124,164,233,273) */
+                    o.hi = vfh[k] < o.hi ? vfh[k] : o.hi;
+                    o.lo = vbl[k] > o.lo ? vbl[k] : o.lo;
+                }
                 win[(size_t)k * URF_DEG_CELLS] = o;
             }
         }
@@ -3809,7 +4004,16 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
         return src | (cls << 30);
     };
     unsigned my_road = 0, my_curb = 0;
-    if (n <= CAP) {
+    if ((a.nan_mask[(size_t)s * 4 + (c >> 5)] >> (c & 31u)) & 1u) {
+        /* (uniform) a ring with NaN azimuths: k_nan_rings ran the reference's quicksort literally and left the ring in
+         * its final order -- where a NaN lands is no function of the azimuths */
+        for (unsigned j = tid; j < n; j += NT) {
+            unsigned cls;
+            rord[rel + j] = entry_of(a.ssrt[sb + rel + j], cls);
+            my_road += cls == URF_LABEL_ROAD;
+            my_curb += cls == URF_LABEL_CURB;
+        }
+    } else if (n <= CAP) {
         unsigned long long key[EPT];
         unsigned slot[EPT];
         float px[EPT], py[EPT];
@@ -4171,6 +4375,7 @@ __global__ __launch_bounds__(384) void k_marker_bins(urf_kargs a, urf_dev_params
         *count = wsum[0] + wsum[1] + wsum[2] + wsum[3] + wsum[4] + wsum[5];
 }
 
+#ifdef URF_ENABLE_TEST_HOOKS   /* liburf_hip_test.so only (include/urf_test_hooks.h) */
 /* ------------------------------------------------------------------------- */
 /* self test                                                                   */
 /* ------------------------------------------------------------------------- */
@@ -4256,5 +4461,6 @@ __global__ __launch_bounds__(256) void k_selftest_fast(unsigned long long n, flo
     atomicMax(&out[2], __float_as_uint(eu));
     atomicMax(&out[3], __float_as_uint(ez));
 }
+#endif   /* URF_ENABLE_TEST_HOOKS */
 
 #endif /* URF_KERNELS_HPP */
