@@ -43,6 +43,16 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def _compile_lib(out, defines, sources, verbose):
+    _run([_hipcc()] + FLAGS + ["-D" + d for d in defines] + sources + ["-o", out], verbose)
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -57,17 +67,17 @@ def build(force=False, verbose=True):
     deps = srcs + hook_srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.abspath(__file__)]
     jobs = []
     if force or _stale(LIB, deps):
-        jobs.append([_hipcc()] + FLAGS + srcs + ["-o", LIB])
+        jobs.append((LIB, [], srcs))
     if force or _stale(LIB_TEST, deps):
-        jobs.append([_hipcc()] + FLAGS + ["-D" + d for d in HOOK_DEFINES] + srcs + hook_srcs + ["-o", LIB_TEST])
-    procs = []
-    for cmd in jobs:
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        jobs.append((LIB_TEST, HOOK_DEFINES, srcs + hook_srcs))
+    if len(jobs) == 2:   # side by side
+        import concurrent.futures as cf
+        with cf.ThreadPoolExecutor(2) as ex:
+            for f in [ex.submit(_compile_lib, out, d, sr, verbose) for out, d, sr in jobs]:
+                f.result()
+    else:
+        for out, d, sr in jobs:
+            _compile_lib(out, d, sr, verbose)
     return LIB
 
 
@@ -79,10 +89,7 @@ def build_variant(name, defines, verbose=False):
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "liburf_hip_%s.so" % name)
     srcs = [os.path.join(CSRC, s) for s in SOURCES + HOOK_SOURCES]
-    cmd = [_hipcc()] + FLAGS + ["-D" + d for d in HOOK_DEFINES + list(defines)] + srcs + ["-o", out]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    _compile_lib(out, HOOK_DEFINES + list(defines), srcs, verbose)
     return out
 
 
