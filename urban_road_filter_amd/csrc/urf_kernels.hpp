@@ -474,14 +474,14 @@ __global__ __launch_bounds__(256) void k_table_repair(urf_kargs a, urf_dev_param
 
 __host__ __device__ inline unsigned urf_align16(unsigned v) { return (v + 15u) & ~15u; }
 
-/* LDS carve of k_split: tab | ul | thr | lut | koff[C+1] | soff[Ks+1] | misc[16] | tmax[C] u64 |
+/* LDS carve of k_split: tab | ul | thr | lut | koff[C+1] | soff[Ks+1] | misc[64] | tmax[C] u64 |
  * union { keyr[T] u8, keys[T] u16, pending[T] u16, wcnt_r[W][C] u16, wcnt_s[W][Ks] u16 ;
  *         staging x y z record [URF_SLOTS] u32 } */
 __host__ __device__ inline size_t urf_split_lds_bytes(unsigned C, unsigned K, bool star)
 {
     const unsigned Ks = star ? K : 0;
     const size_t fixed = URF_MAX_CHANNELS * (4 + 4 + 16) + urf_align16(URF_LUT_CELLS) + urf_align16((C + 1) * 4) +
-                         urf_align16((Ks + 1) * 4) + 128 + urf_align16(C * 8);
+                         urf_align16((Ks + 1) * 4) + 256 + urf_align16(C * 8);
     const size_t phase_a = 5 * (size_t)URF_TILE + urf_align16(2 * URF_TILE_WAVES * (C + Ks));
     const size_t phase_b = 4 * (size_t)URF_SLOTS * 4;
     return fixed + (phase_a > phase_b ? phase_a : phase_b);
@@ -584,9 +584,10 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     uint8_t* lut = (uint8_t*)(thr + URF_MAX_CHANNELS);
     unsigned* koff = (unsigned*)(lut + urf_align16(URF_LUT_CELLS));
     unsigned* soff = koff + urf_align16((C + 1) * 4) / 4;
-    unsigned* misc = soff + urf_align16((Ks + 1) * 4) / 4;   /* [0] ROI points, [1] pending, [2 + wave] wave sums */
-    static_assert(2 + URF_TILE_WAVES <= 32, "misc[2 + wave]");
-    unsigned long long* tmax = (unsigned long long*)(misc + 32);   /* largest x*x + y*y per ring (binary64 bits: non-negative doubles order like integers) */
+    unsigned* misc = soff + urf_align16((Ks + 1) * 4) / 4;   /* [0] ROI points, [1] pending, [2 + wave] wave sums, [31] "not organised", [32 + step] step keys */
+    static_assert(2 + URF_TILE_WAVES <= 31 && URF_TILE_GROUPS <= 32, "misc[2 + wave], misc[32 + step]");
+    unsigned* const stepkey = misc + 32;
+    unsigned long long* tmax = (unsigned long long*)(misc + 64);   /* largest x*x + y*y per ring (binary64 bits: non-negative doubles order like integers) */
     unsigned char* un = (unsigned char*)(tmax + urf_align16(C * 8) / 8);
     uint8_t* keyr = un;
     uint16_t* keys = (uint16_t*)(un + URF_TILE);
@@ -814,6 +815,74 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     __syncthreads();
     URF_PHASE_MARK;
 
+    /* the points the exact pass decided; stage capture */
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned li = wave * URF_WAVE_PTS + q * 64 + lane, i = tbase + li;
+        if (openmask & (1u << q)) {
+            rkey[q] = (unsigned)keyr[li];
+            skey[q] = star ? (unsigned)keys[li] : URF_SEC_NONE;
+        }
+        if (a.capture && i < len) {   /* stage capture only */
+            a.ringkey[sb + i] = (uint8_t)rkey[q];
+            a.seckey[sb + i] = (uint16_t)skey[q];
+        }
+    }
+    /* ORGANISED TILE (every benchmark sweep, every spinning LiDAR that reports in firing order): point li of the tile
+     * lies on ring li mod C (C a power of two: a firing holds every ring once, in order) and -- where the star-shaped
+     * search runs -- every 64-point step shares ONE sector, the steps' sectors not falling along the tile.  Then both
+     * sorted orders are closed-form functions of the input order:
+     *     ring-sorted slot   = (li mod C) * (2048 / C) + li / C         (a 64 x 32 transpose for C = 64)
+     *     sector-sorted slot = li                                       (the stable split by sector is the identity)
+     * and the whole ranking machinery below -- match_any per step, per-wave counters, the scans over waves and
+     * keys, three barriers -- has nothing to compute.  Decided per tile from the keys themselves (one ballot per step
+     * and family, the step keys compared across the tile), so any other tile simply takes the general path. */
+    bool organised = false;
+#ifndef URF_EXP_NO_ORGANISED
+    {
+        const bool shape = (C & (C - 1u)) == 0u && tbase + URF_TILE <= len;   /* (uniform) */
+        bool mine = shape;
+#pragma unroll
+        for (unsigned q = 0; q < Q; q++) {
+            const unsigned li = wave * URF_WAVE_PTS + q * 64 + lane;
+            mine = mine & (rkey[q] == (li & (C - 1u)));
+            if (star) {
+                const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)skey[q]);
+                mine = mine & (skey[q] == f) & (f != URF_SEC_NONE);
+                if (lane == 0)
+                    stepkey[wave * Q + q] = f;
+            }
+        }
+        if (__ballot(!mine) != 0ull && lane == 0)
+            misc[31] = 1u;   /* (every writer writes the same value) */
+        __syncthreads();
+        static_assert(URF_TILE_GROUPS == 32, "one lane per step of the tile compares it with the next");
+        const bool falls = star && lane < URF_TILE_GROUPS - 1u && stepkey[lane] > stepkey[lane + 1];
+        organised = misc[31] == 0u && __ballot(falls) == 0ull;   /* (uniform over the workgroup) */
+    }
+#endif
+    unsigned lp[Q], sp[Q];
+    const unsigned logC = 31u - (unsigned)__clz((int)C);
+    if (organised) {
+        const unsigned P = URF_TILE >> logC;
+        /* (the slots are computed where they are used, below; so is the rings' largest range) */
+#pragma unroll
+        for (unsigned q = 0; q < Q; q++)
+            lp[q] = sp[q] = 0;
+        /* the run tables: ring c starts at slot c * P; sector k at the first step whose sector is >= k (the step keys
+         * do not fall: bisection over the 32 of them) */
+        for (unsigned k = tid; k <= C; k += URF_TILE_THREADS)
+            koff[k] = k * P;
+        if (star)
+            for (unsigned k = tid; k <= K; k += URF_TILE_THREADS) {
+                unsigned lo = 0;   /* number of steps with a sector < k */
+#pragma unroll
+                for (unsigned step = URF_TILE_GROUPS / 2; step > 0; step >>= 1)
+                    lo += stepkey[lo + step - 1] < k ? step : 0u;
+                lo += (lo == URF_TILE_GROUPS - 1u && stepkey[lo] < k) ? 1u : 0u;
+                soff[k] = lo * 64u;
+            }
+    } else {
     /* step 1: ranks inside the wave's own 256 points.  The lanes of a step that share a key read
      * the key's running count (one LDS address: a broadcast), the first of them adds the group's
      * size; a wave touches only its own row, in program order. */
@@ -822,15 +891,6 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     uint16_t* my_s = wcnt_s + wave * K;
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
-        const unsigned li = wave * URF_WAVE_PTS + q * 64 + lane, i = tbase + li;
-        if (openmask & (1u << q)) {   /* decided by the exact pass */
-            rkey[q] = (unsigned)keyr[li];
-            skey[q] = star ? (unsigned)keys[li] : URF_SEC_NONE;
-        }
-        if (a.capture && i < len) {   /* stage capture only */
-            a.ringkey[sb + i] = (uint8_t)rkey[q];
-            a.seckey[sb + i] = (uint16_t)skey[q];
-        }
         {
             const bool on = rkey[q] != URF_RING_NONE;
             const unsigned long long m = urf_match_any_on(rkey[q], on, dp.ring_keybits);
@@ -918,7 +978,6 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     URF_PHASE_MARK;
 
     /* step 4: slot in the tile's ring-sorted order (lp) and sector-sorted order (sp) */
-    unsigned lp[Q], sp[Q];
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {   /* unconditional reads (entry 0 for "none"), then a select */
         const bool ron = rkey[q] != URF_RING_NONE, son = skey[q] != URF_SEC_NONE;
@@ -931,6 +990,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
             sp[q] = son ? ls : 0xffffffffu;
         }
     }
+    }   /* (general path) */
     __syncthreads();   /* keys and wcnt are dead: their memory becomes the staging buffers */
     URF_PHASE_MARK;
     unsigned* stx = (unsigned*)un;
@@ -945,6 +1005,12 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     for (unsigned q = 0; q < Q; q++) {
         const unsigned li = wave * URF_WAVE_PTS + q * 64 + lane;
         const float x = px[q], y = py[q], z = pz[q];
+        if (organised) {   /* (uniform) closed-form slots; maxDistance as on the general path (lidar_segmentation.cpp:271-274) */
+            lp[q] = (li & (C - 1u)) * (URF_TILE >> logC) + (li >> logC);
+            sp[q] = star ? li : 0xffffffffu;
+            const double s2 = (double)x * (double)x + (double)y * (double)y;
+            atomicMax(&tmax[li & (C - 1u)], (unsigned long long)__double_as_longlong(s2));
+        }
         if (lp[q] != 0xffffffffu) {
             const unsigned sl = URF_SLOT(lp[q]);
             stx[sl] = __float_as_uint(x);
