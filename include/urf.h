@@ -383,10 +383,11 @@ double urf_ring_threshold_cot(double angle_deg);
 int urf_pc2_to_planes(const uint8_t* data, uint32_t n_points, uint32_t point_step, uint32_t off_x, uint32_t off_y,
                       uint32_t off_z, float* x, float* y, float* z);
 /* Diagnostics of the callback path.  It launches a short kernel sequence first (no repair kernels behind the
- * speculative ring table, none for the work lists of star sectors of more than 384 points); a sweep that needed what
+ * speculative ring table, none for the work lists of star sectors of more than 384 points, none for rings that hold a
+ * point with a NaN azimuth); a sweep that needed what
  * was left out is run again inside urf_classify_pc2_wait() with the full sequence, and so is every later one.
  * n_rerun: sweeps run again so far (per cause the first one and those in flight beside it); sequence: bit 0 the ring table is still speculative,
- * bit 1 the work-list kernels are part of the sequence.  Either pointer may be NULL. */
+ * bit 1 the work-list kernels are part of the sequence, bit 2 so is the kernel for rings with NaN azimuths.  Either pointer may be NULL. */
 int urf_callback_path_state(const urf_ctx* ctx, uint32_t* n_rerun, uint32_t* sequence);
 const char* urf_strerror(int status);
 const char* urf_last_error(const urf_ctx* ctx);   /* text of the last HIP failure */

@@ -72,6 +72,7 @@ struct urf_ctx {
      * kernels for the work lists of oversized star sectors (run_pipeline); a sweep that needed one of them comes back
      * with an internal status and is run again with it, as are all later ones (urf_classify_pc2_wait) */
     bool slot_lists = false;
+    bool slot_nan = false;          /* ... k_nan_rings (a sweep with a ring point on the sensor's axis) */
     uint32_t n_rerun = 0;           /* sweeps urf_classify_pc2_wait had to run again */
     /* Slot i works on scratch row i % rows, rows = min(max_batch, URF_ASYNC_SLOTS); row 0 runs on the
      * context's stream, every other row on a stream of its own (slots that share a row share its
@@ -427,7 +428,7 @@ extern "C" int urf_callback_path_state(const urf_ctx* c, uint32_t* n_rerun, uint
     if (n_rerun)
         *n_rerun = c->n_rerun;
     if (sequence)
-        *sequence = (c->speculate ? 1u : 0u) | (c->slot_lists ? 2u : 0u);
+        *sequence = (c->speculate ? 1u : 0u) | (c->slot_lists ? 2u : 0u) | (c->slot_nan ? 4u : 0u);
     return URF_OK;
 }
 
@@ -586,7 +587,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
      * normally find nothing to do -- the two repair kernels behind the speculative ring table, the two for the work
      * lists of oversized star sectors, 20 of a sweep's 200 microseconds -- are left out, k_index voids a sweep that
      * needed them, and urf_classify_pc2_wait() runs it again with them. */
-    a.optimistic = on_stream ? ((c->speculate ? URF_OPT_NO_REPAIR : 0u) | (c->slot_lists ? 0u : URF_OPT_NO_LISTS)) : 0u;
+    a.optimistic = on_stream ? ((c->speculate ? URF_OPT_NO_REPAIR : 0u) | (c->slot_lists ? 0u : URF_OPT_NO_LISTS) | (c->slot_nan ? 0u : URF_OPT_NO_NAN)) : 0u;
     a.capture = (uint32_t)(capture_in >= 0 ? capture_in : c->capture);
     a.labels = d_labels;
     if (a.capture != 1) {
@@ -614,11 +615,11 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         stage++;
     };
     mark();
-    hipLaunchKernelGGL(k_ring_table, g_scan, dim3(256), 0, st, a, dp);
+    hipLaunchKernelGGL(k_ring_table, g_scan, dim3(URF_TABLE_THREADS), 0, st, a, dp);
     mark();
     hipLaunchKernelGGL(k_split, g_tiles, dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
     if (a.table_lookahead && !(a.optimistic & URF_OPT_NO_REPAIR)) {   /* normally both find nothing to do */
-        hipLaunchKernelGGL(k_table_repair, g_scan, dim3(256), 0, st, a, dp);
+        hipLaunchKernelGGL(k_table_repair, g_scan, dim3(URF_TABLE_THREADS), 0, st, a, dp);
         hipLaunchKernelGGL(k_split_repair, dim3(c->n_cus), dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
     }
     mark();
@@ -644,7 +645,8 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     else
         hipLaunchKernelGGL(k_ring_general, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
     /* the rings that hold a point with a NaN azimuth (k_split listed them: normally none, the kernel returns at once) */
-    hipLaunchKernelGGL(k_nan_rings, dim3(32), dim3(256), URF_NAN_LDS * sizeof(unsigned long long), st, a, dp);
+    if (!(a.optimistic & URF_OPT_NO_NAN))
+        hipLaunchKernelGGL(k_nan_rings, dim3(32), dim3(256), URF_NAN_LDS * sizeof(unsigned long long), st, a, dp);
     mark();
     hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_BEAM_THREADS), (size_t)C * (24 * sizeof(unsigned) + URF_CURB_LIST * sizeof(float)), st, a, dp);
     mark();
@@ -1021,11 +1023,14 @@ extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* label
     HT(4, ht0);
     /* the short launch sequence left out something this sweep needed (run_pipeline): once more, with it --
      * the message is still in the slot's device buffer -- and from now on for every sweep */
-    for (int tries = 0; tries < 3 && (sl.h_info->status == URF_STATUS_REDO_TABLE || sl.h_info->status == URF_STATUS_REDO_LISTS); tries++) {
+    auto redo = [](int st) { return st == URF_STATUS_REDO_TABLE || st == URF_STATUS_REDO_LISTS || st == URF_STATUS_REDO_NAN; };
+    for (int tries = 0; tries < 4 && redo(sl.h_info->status); tries++) {
         if (sl.h_info->status == URF_STATUS_REDO_TABLE)
             c->speculate = false;
-        else
+        else if (sl.h_info->status == URF_STATUS_REDO_LISTS)
             c->slot_lists = true;
+        else
+            c->slot_nan = true;
         c->epoch++;   /* the captured sequences are rebuilt */
         c->n_rerun++;
         /* with the parameters and capture mode the sweep was submitted with (urf_set_params may have been called since),
@@ -1043,7 +1048,7 @@ extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* label
             return rc;
         }
     }
-    if (sl.h_info->status == URF_STATUS_REDO_TABLE || sl.h_info->status == URF_STATUS_REDO_LISTS) {
+    if (redo(sl.h_info->status)) {
         sl.pending = false;
         return URF_ERR_HIP;   /* (cannot happen: the full sequence raises neither) */
     }

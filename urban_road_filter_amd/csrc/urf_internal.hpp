@@ -52,9 +52,11 @@
 /* (urf_kargs::optimistic) */
 #define URF_OPT_NO_REPAIR 1u   /* k_table_repair / k_split_repair do not follow k_split */
 #define URF_OPT_NO_LISTS 2u    /* k_star_sort_mid / k_star_sort_big do not follow k_star_sort_small */
+#define URF_OPT_NO_NAN 4u      /* k_nan_rings does not follow k_ring */
 /* internal values of urf_scan_info::status: never seen by a caller */
 #define URF_STATUS_REDO_TABLE 0x7f000001
 #define URF_STATUS_REDO_LISTS 0x7f000002
+#define URF_STATUS_REDO_NAN 0x7f000003
 #define URF_AZ_UNKNOWN      -1.0f     /* decoded value of URF_REC_AZ_UNKNOWN */
 #define URF_RING_NONE       0xFFu
 #define URF_SEC_NONE        0x3FFu

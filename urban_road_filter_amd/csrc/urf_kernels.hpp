@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_pc2_to_soa(const uint8_t* __restrict__ 
  * One workgroup per scan, two alternating modes:
  *   serial   one wave takes the next 64 points; a new leader costs one ballot
  *            (an organised sweep fills the table within its first firing);
- *   scan     when a 64-point step brought no new leader, all four waves look
+ *   scan     when a 64-point step brought no new leader, all waves look
  *            ahead 2048 points at a time for the first point that no leader
  *            matches (usually there is none: sweeps whose region of interest
  *            cuts off the outer rings never fill the table).
@@ -142,6 +142,13 @@ __device__ __forceinline__ bool urf_leader_match_point(const float* SL, unsigned
 }
 
 #define URF_TABLE_SCAN_PPT 8
+/* threads of k_ring_table: the look-ahead takes URF_TABLE_THREADS x 8 points per round trip.  (1024 threads -- two
+ * rounds instead of eight for a sweep of the reference's default region of interest, which looks at ~14 700 points before
+ * the speculation gives up -- gain a single sweep 2 us and cost a batch of 1024 sweeps 0.05 ms: the work is the same and
+ * sixteen-wave workgroups wait longer at their barriers.  r4, measured.) */
+#ifndef URF_TABLE_THREADS
+#define URF_TABLE_THREADS 256
+#endif
 /* Speculation (lookahead > 0): when `lookahead` points in a row brought no new leader the walk stops
  * and hands the rest of the scan to k_split, which classifies every point against the table anyway:
  * a region-of-interest point behind the stop that matches no entry of a table that is not full
@@ -154,7 +161,7 @@ struct urf_table_shared {
     float L[URF_MAX_CHANNELS];    /* leaders in insertion order (the reference's angle[]) */
     float SL[URF_MAX_CHANNELS];   /* the matchable ones, ascending */
     unsigned nL, nmatch, zero, fresh;
-    unsigned mins[4];
+    unsigned mins[URF_TABLE_THREADS / 64];
 };
 __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp, unsigned s, unsigned lookahead, urf_table_shared& T)
 {
@@ -277,7 +284,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
             float px[URF_TABLE_SCAN_PPT], py[URF_TABLE_SCAN_PPT], pz[URF_TABLE_SCAN_PPT];
 #pragma unroll
             for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++) {   /* all loads in flight first */
-                const unsigned i = pos + q * 256 + tid;
+                const unsigned i = pos + q * URF_TABLE_THREADS + tid;
                 const bool on = i < len;
                 px[q] = on ? a.x[off + i] : 0.f;
                 py[q] = on ? a.y[off + i] : 0.f;
@@ -292,8 +299,14 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
                 unsigned lb[URF_TABLE_SCAN_PPT], okm = 0, roim = 0;
 #pragma unroll
                 for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++) {
-                    const unsigned i = pos + q * 256 + tid;
+                    const unsigned i = pos + q * URF_TABLE_THREADS + tid;
                     roim |= (unsigned)((i < len) & urf_in_roi(dp.p, px[q], py[q], pz[q])) << q;
+                }
+                /* (a wave none of whose 512 points lies in the region of interest has nothing to match: the reference's
+                 * default region drops whole azimuth ranges of a sweep, i.e. whole firings) */
+                if (__ballot(roim != 0u) != 0ull) {
+#pragma unroll
+                for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++) {
                     okm |= (unsigned)urf_fast_vertical_angle(px[q], py[q], pz[q], &vt[q]) << q;
                     lb[q] = 0;
                 }
@@ -316,7 +329,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
                     lb[q] += (lb[q] == URF_MAX_CHANNELS - 1 && lb[q] < nmatch && !(cv[q] - vt[q] >= -(interval + e))) ? 1u : 0u;
 #pragma unroll
                 for (unsigned q = 0; q < URF_TABLE_SCAN_PPT; q++) {
-                    const unsigned i = pos + q * 256 + tid;
+                    const unsigned i = pos + q * URF_TABLE_THREADS + tid;
                     if (!((roim >> q) & 1u))
                         continue;
                     /* (lb can reach nmatch only through entries < nmatch, so lb <= nmatch <= 128; an index of 128
@@ -333,6 +346,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
                     if (!matched && i < first)
                         first = i;
                 }
+                }
             }
             for (int o = 32; o > 0; o >>= 1) {
                 const unsigned w = __shfl_xor(first, o);
@@ -342,15 +356,15 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
                 sh_min[wave] = first;
             __syncthreads();
             unsigned m = sh_min[0];
-            for (int w = 1; w < 4; w++)
+            for (int w = 1; w < URF_TABLE_THREADS / 64; w++)
                 m = sh_min[w] < m ? sh_min[w] : m;
             __syncthreads();
             if (m != 0xffffffffu) {
                 pos = m;   /* the serial step resumes exactly there */
                 break;
             }
-            pos += 256 * URF_TABLE_SCAN_PPT;
-            quiet += 256 * URF_TABLE_SCAN_PPT;
+            pos += URF_TABLE_THREADS * URF_TABLE_SCAN_PPT;
+            quiet += URF_TABLE_THREADS * URF_TABLE_SCAN_PPT;
             if (lookahead && quiet >= lookahead && !sh_zero && pos < len) {
                 upto = pos;
                 break;
@@ -389,7 +403,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
     {
         const float e = URF_FAST_VALPHA_ERR + 2.0e-5f;
         /* one cotangent (a binary64 polynomial and two divisions) per thread: entry tid / 4, threshold tid % 4 */
-        for (unsigned k = tid; k < 4 * n; k += 256) {
+        for (unsigned k = tid; k < 4 * n; k += URF_TABLE_THREADS) {
             const float t = urf_ring_threshold(SL[k >> 2], interval, e, k & 3u);
             a.ring_thr[((size_t)s * C) * 4 + k] = t;
             if ((k & 3u) == 0)
@@ -399,12 +413,12 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
         uint8_t* lut = a.ring_lut + (size_t)s * URF_LUT_CELLS;
         /* four cells per thread at a time, their bisections step by step together (the dependent LDS reads of
          * one cell after the other were the longest chain of this kernel) */
-        for (unsigned c0 = tid; c0 < URF_LUT_CELLS; c0 += 4 * 256) {
+        for (unsigned c0 = tid; c0 < URF_LUT_CELLS; c0 += 4 * URF_TABLE_THREADS) {
             float u1[4];
             unsigned lo[4];
 #pragma unroll
             for (unsigned q = 0; q < 4; q++) {
-                u1[q] = (float)(c0 + q * 256 + 1) * (1.0f / URF_LUT_SCALE) - URF_LUT_UMAX;   /* exact */
+                u1[q] = (float)(c0 + q * URF_TABLE_THREADS + 1) * (1.0f / URF_LUT_SCALE) - URF_LUT_UMAX;   /* exact */
                 lo[q] = 0;
             }
 #pragma unroll
@@ -419,13 +433,13 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
             }
 #pragma unroll
             for (unsigned q = 0; q < 4; q++)
-                if (c0 + q * 256 < URF_LUT_CELLS)
-                    lut[c0 + q * 256] = (uint8_t)lo[q];
+                if (c0 + q * URF_TABLE_THREADS < URF_LUT_CELLS)
+                    lut[c0 + q * URF_TABLE_THREADS] = (uint8_t)lo[q];
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params dp)
+__global__ __launch_bounds__(URF_TABLE_THREADS) void k_ring_table(urf_kargs a, urf_dev_params dp)
 {
     __shared__ urf_table_shared T;
     if (blockIdx.x == 0 && threadIdx.x < 4)
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(256) void k_ring_table(urf_kargs a, urf_dev_params 
 }
 
 /* the scans whose speculative table k_split found incomplete: the whole walk, listed for k_split_repair */
-__global__ __launch_bounds__(256) void k_table_repair(urf_kargs a, urf_dev_params dp)
+__global__ __launch_bounds__(URF_TABLE_THREADS) void k_table_repair(urf_kargs a, urf_dev_params dp)
 {
     __shared__ urf_table_shared T;
     const unsigned s = blockIdx.x;
@@ -1270,6 +1284,16 @@ __device__ __forceinline__ void urf_index_body(const urf_kargs& a, const urf_dev
         if (tid == 0)
             a.info[s].status = URF_STATUS_REDO_TABLE;
         return;
+    }
+    if (a.optimistic & URF_OPT_NO_NAN) {
+        /* a ring holds a point with a NaN azimuth and nothing will run the reference's quicksort for it (callback path):
+         * void, run again with the full sequence */
+        const uint4 nm = *(const uint4*)(a.nan_mask + (size_t)s * 4);
+        if (nm.x | nm.y | nm.z | nm.w) {   /* (uniform) */
+            if (tid == 0)
+                a.info[s].status = URF_STATUS_REDO_NAN;
+            return;
+        }
     }
     {
         const unsigned piece = urf_scan_piece(a, s, ntiles, sh);
