@@ -1827,9 +1827,13 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
     static_assert(NB % NT == 0 && NT / 64 <= 8, "bucket scan layout");
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
-        sh->rmin = 0xffffffffu;
-        sh->rmax = 0;
-        sh->maxc = 0;
+        /* (materialised here: hoisted out of the persistent loop of k_star_sort_mid, these three constants sat in registers
+         * the kernel does not have and went through scratch memory) */
+        unsigned ones = 0xffffffffu, zero = 0u;
+        asm volatile("" : "+v"(ones), "+v"(zero));
+        sh->rmin = ones;
+        sh->rmax = zero;
+        sh->maxc = zero;
     }
     for (unsigned c = tid; c <= NB; c += NT)
         cnt[c] = 0;
