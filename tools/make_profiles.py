@@ -47,12 +47,12 @@ def main(src, tag):
     for f in glob.glob(os.path.join(src, "pmc", "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0]
-            if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
                 vals[(k, row["Counter_Name"])].append(float(row["Counter_Value"]))
     def avg(k, c):
         v = vals.get((k, c), [0.0])
         return sum(v) / len(v)
-    pipeline = ("k_ring_table", "k_split", "k_table_repair", "k_split_repair", "k_index", "k_star_sort_small", "k_star_sort_mid",
+    pipeline = ("k_ring_table", "k_split", "k_table_repair", "k_split_repair", "k_index", "k_star_sort_small", "k_star_sort_mid", "k_nan_rings",
                 "k_star_sort_big", "k_star_walk", "k_ring", "k_beams", "k_label")
     kernels = sorted({k for k, _ in vals if k in pipeline})
     per = {k: int(2 * avg(k, "FETCH_SIZE") * 1024 + avg(k, "WRITE_SIZE") * 1024) for k in kernels}
@@ -62,7 +62,11 @@ def main(src, tag):
     out = {"kernel": dom, "scans_per_launch": bench["config"]["scans_per_gpu"],
            "hbm_bytes_per_launch": sum(per[k] for k in doms),
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
-           "all_kernels_bytes_per_launch": per, "pipeline_bytes_per_step": sum(per.values()), "tag": tag}
+           "all_kernels_bytes_per_launch": per, "pipeline_bytes_per_step": sum(per.values()), "tag": tag,
+           # wave-level VALU instructions per launch (SQ_INSTS_VALU): bench.py prices them with the issue rates measured by
+           # tools/bench_micro/valubench.hip (roofline.valu_issue)
+           "valu_insts_per_launch": {k: int(avg(k, "SQ_INSTS_VALU")) for k in kernels},
+           "valu_insts_per_step": int(sum(avg(k, "SQ_INSTS_VALU") for k in kernels))}
     json.dump(out, open(os.path.join(prof, "hbm_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
     print("value", bench["value"], "ms/step", bench["ms_per_step"], "dominant", dom, bench["roofline"])
