@@ -709,6 +709,39 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         const bool fast = urf_fast_cot(x, y, z, &u, &planar) & roi & !exact_all;
         uu[q] = fast ? u : 0.f;
         fastm |= (unsigned)fast << q;
+    }
+    /* THE EXPECTED RING FIRST.  In firing order point li of the tile belongs to ring li mod C (C a power of two: what an
+     * organised tile is made of, see below).  "u lies surely inside the window of entry e, and surely above the window of
+     * entry e - 1" settles ring e -- the entries in front of e - 1 lie lower still -- with two LDS reads and four
+     * comparisons instead of the lookup cell, its two probes and the five comparisons of the search.  A wave in which some
+     * point of the fast path does not pass (another sensor layout, a cut firing, rings closer together than `interval`)
+     * takes the search, for all its points. */
+    bool searched = true;
+#ifndef URF_EXP_NO_EXPECTED
+    if ((C & (C - 1u)) == 0u) {   /* (uniform) */
+        unsigned okm = 0;
+#pragma unroll
+        for (unsigned q = 0; q < Q; q++) {
+            const unsigned e = (wave * URF_WAVE_PTS + q * 64 + lane) & (C - 1u);
+            const urf_ring_thr tv = thr[e];
+            const float below = ul[(e - 1u) & (URF_MAX_CHANNELS - 1)];   /* (entry e - 1 lies surely below the window of every u < its .x) */
+            const float u = uu[q];
+            okm |= (unsigned)((e < nR) & (u >= tv.y) & (u <= tv.z) & ((e == 0u) | (u < below))) << q;
+        }
+        if (__ballot((fastm & ~okm) != 0u) == 0ull) {   /* (uniform) every point of the fast path sits on its expected ring */
+            searched = false;
+#pragma unroll
+            for (unsigned q = 0; q < Q; q++) {
+                const bool fast = (fastm >> q) & 1u;
+                rkey[q] = fast ? ((wave * URF_WAVE_PTS + q * 64 + lane) & (C - 1u)) : URF_RING_NONE;
+            }
+            openm |= roim & ~fastm;
+        }
+    }
+#endif
+    if (searched) {
+#pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
         /* lo = number of table entries surely below the point's window: the cell's count from the
          * lookup table, plus up to two entries between the cell's end and u (a third one is rare
          * and left to the exact pass) */
@@ -731,6 +764,7 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         const bool roi = (roim >> q) & 1u, fast = (fastm >> q) & 1u;
         openm |= (unsigned)(roi & (!fast | unsettled | !(none | match))) << q;
         rkey[q] = match ? lo[q] : URF_RING_NONE;
+    }
     }
 #pragma unroll
     for (unsigned q = 0; q < Q; q++) {
