@@ -51,8 +51,13 @@ extern "C" {
 
 /* 2 (round 3): URF_MAX_IN_FLIGHT sweeps on the asynchronous path (tickets map to slots modulo it),
  * urf_result_labels() validates its ticket, URF_NUM_KERNELS / kernel names as listed below,
- * urf_enable_stage_capture() takes a mode 0..2, urf_scan_info::n_nan_azimuth is written. */
-#define URF_ABI_VERSION 2
+ * urf_enable_stage_capture() takes a mode 0..2, urf_scan_info::n_nan_azimuth is written.
+ * 3 (round 4): the test / benchmark hooks (urf_synth_cloud, urf_bench_callback_stream, urf_selftest*,
+ * urf_set_debug_flags) left this header and the product library (include/urf_test_hooks.h, liburf_hip_test.so);
+ * rings that hold a point with x == y == 0 follow the reference (deviation D5 of earlier versions is gone);
+ * urf_read_stage / urf_ordered_indices / urf_marker_points answer URF_ERR_BUSY for a sweep whose scratch row has
+ * been resubmitted; urf_callback_path_state reports a third sequence bit. */
+#define URF_ABI_VERSION 3
 
 /* ---- label byte --------------------------------------------------------- */
 #define URF_LABEL_MASK   0x03u
@@ -157,15 +162,16 @@ typedef struct urf_scan_info {
     uint32_t n_nan_azimuth; /* ring points with x == y == 0 (azimuth NaN): the one input on which this
                                library deliberately differs from the reference, see below */
 } urf_scan_info;
-/* Deviation D5.  A ring point with x == y == 0 has d = 0 and azimuth asin(0/0) = NaN
- * (lidar_segmentation.cpp:245-269).  In the reference that NaN goes through the per-ring Lomuto
- * quicksort (:70-93), where every comparison with it is false: the point ends up at an
- * input-order-dependent place and the beam scans of blind_spots.cpp stop or resume there.  That
- * behaviour is deterministic but an accident of the sort; here such a point simply never becomes
- * road and never blocks or truncates a beam (its curb flags and its effect on the ring table are
- * the reference's).  n_nan_azimuth counts these points so that a caller can tell when a sweep's
- * labels may differ from the reference's for this reason (0 on every real sweep: a return at the
- * sensor's own axis). */
+/* A ring point with x == y == 0 has d = 0 and azimuth asin(0 / 0) = NaN (lidar_segmentation.cpp:245-269).  In the
+ * reference that NaN goes through the per-ring Lomuto quicksort (:70-93), where every comparison with it is false: the
+ * point ends up at an input-order-dependent place of the sorted ring, and the beam scans of blind_spots.cpp
+ * (:107,146,216,255) end there -- forward beams see only what stands in front of the ring's first NaN, backward beams only
+ * what stands behind its last one.  Deterministic, hence followed: for such a ring the library runs the reference's
+ * quicksort literally (k_nan_rings) and limits the beams accordingly; labels, counters and the published order
+ * (urf_ordered_indices) equal the reference's.  (Up to round 3 this was "deviation D5": such a point simply never became
+ * road and never cut a beam short.)  n_nan_azimuth counts these points (0 on every real sweep: a return at the sensor's
+ * own axis).  One residue: two points of such a ring with bit-identical azimuths on either side of a NaN's place are told
+ * apart by position in the reference and by value here. */
 
 typedef struct urf_ctx urf_ctx;
 
