@@ -393,7 +393,8 @@ int urf_pc2_to_planes(const uint8_t* data, uint32_t n_points, uint32_t point_ste
  * point with a NaN azimuth); a sweep that needed what
  * was left out is run again inside urf_classify_pc2_wait() with the full sequence, and so is every later one.
  * n_rerun: sweeps run again so far (per cause the first one and those in flight beside it); sequence: bit 0 the ring table is still speculative,
- * bit 1 the work-list kernels are part of the sequence, bit 2 so is the kernel for rings with NaN azimuths.  Either pointer may be NULL. */
+ * bit 1 the work-list kernels are part of the sequence, bit 2 so is the kernel for rings with NaN azimuths, bit 3 the ring table also
+ * stops at the ring count of the previous sweep (a stream of sweeps from one sensor shows the same rings).  Either pointer may be NULL. */
 int urf_callback_path_state(const urf_ctx* ctx, uint32_t* n_rerun, uint32_t* sequence);
 const char* urf_strerror(int status);
 const char* urf_last_error(const urf_ctx* ctx);   /* text of the last HIP failure */

@@ -562,6 +562,49 @@ def test_speculative_ring_table_is_repaired():
             assert np.array_equal(lg, lb_ok)
 
 
+def test_ring_count_hint_and_its_failure():
+    """Second speculation of k_ring_table (r4): the walk also stops once the table holds as many rings as the previous call
+    found -- a stream of sweeps from one sensor shows the same rings sweep after sweep.  (i) default-ROI sweeps one after the
+    other: the hint is in use from the second one on, labels and ring tables stay the reference's; (ii) a sweep whose 9th
+    ring shows up 3 000 points in, behind a sweep with 8 rings: the hint stops the walk too early, k_split notices, the scan
+    is repaired (batch call) / run again (callback path), and only the HINT is switched off: the look-ahead speculation
+    stays."""
+    q = O.cfg_params("default_roi")
+    clouds = [O.cfg_cloud("default_roi", 90 + k) for k in range(4)]
+    with u.Context(64 * 2048, 1, params=q) as ctx:
+        for rep in range(2):
+            for c in clouds:
+                lb, ib, _ = O.run_b(*c, q)
+                lg, ig = ctx.classify_xyz(*c)
+                assert np.array_equal(lg, lb) and info_equal(ig, ib)
+        assert ctx.callback_path_state() == (0, 1 | 8)   # nothing was run again, both speculations still on
+    p = O.cfg_params("cfg2")
+    late = late_ring_cloud(late_at=3000)
+    lb_late, ib_late, _ = O.run_b(*late, p)
+    assert ib_late["n_rings"] == 9
+    x, y, z = late
+    el = np.degrees(np.arctan2(-z, np.hypot(x, y)))
+    eight = tuple(a[el > 5.0].copy() for a in late)   # the same sweep without the points of the late ring (elevation -4 deg)
+    lb8, ib8, _ = O.run_b(*eight, p)
+    assert ib8["n_rings"] == 8
+    with u.Context(len(x), 2, params=p) as ctx:
+        labels, infos = run_batch(ctx, [eight, eight], p)
+        assert np.array_equal(labels[0], lb8) and infos[1][2] == 8
+        labels, infos = run_batch(ctx, [late, eight], p, ragged=True)      # the hint (8) ends scan 0's walk in front of its 9th ring: repaired
+        assert np.array_equal(labels[0], lb_late) and infos[0][2] == 9 and np.array_equal(labels[1], lb8)
+        labels, infos = run_batch(ctx, [eight, late], p, ragged=True)      # (the hint is off now, the look-ahead finds the ring 3 000 points in)
+        assert np.array_equal(labels[1], lb_late) and np.array_equal(labels[0], lb8)
+        assert ctx.callback_path_state()[1] & 9 == 1
+    with u.Context(len(x), 1, params=p) as ctx:               # the callback path: voided, run again without the hint
+        lg, ig = ctx.classify_xyz(*eight)
+        assert np.array_equal(lg, lb8) and ctx.callback_path_state() == (0, 1 | 8)
+        lg, ig = ctx.classify_xyz(*late)
+        assert np.array_equal(lg, lb_late) and info_equal(ig, ib_late)
+        assert ctx.callback_path_state() == (1, 1)
+        lg, ig = ctx.classify_xyz(*eight)
+        assert np.array_equal(lg, lb8)
+
+
 def test_storage_order_invariance(ctx_big):
     p = O.cfg_params("cfg2")
     x, y, z = O.cfg_cloud("cfg2", 71)

@@ -116,8 +116,9 @@ struct urf_ctx {
     /* k_ring_table speculates (stops when no new ring has shown up for a while, k_split checks);
      * a scan that proves it wrong is repaired in the same call and raises this host-visible flag,
      * after which the context builds its tables the long way */
-    uint32_t* h_spec_failed = nullptr;  /* pinned, device-mapped */
+    uint32_t* h_spec_failed = nullptr;  /* pinned, device-mapped: [0] look-ahead, [1] ring-count hint */
     bool speculate = true;
+    bool use_hint = true;           /* k_ring_table also stops at the ring count of the row's previous call (until that fails once) */
     /* last call, for the entry points that read its intermediate results (urf_read_stage,
      * urf_ordered_indices, urf_marker_points): the kernel arguments and parameters it ran with */
     uint32_t last_scans = 0;
@@ -259,7 +260,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.angle, S * C) A(k.ring_thr, S * C * 4) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_run, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
     A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 4 * URF_ASYNC_SLOTS)   /* four counters per scratch row in use at once */
-    A(k.table_upto, S) A(k.table_redo, S) A(k.redo_list, S)
+    A(k.table_upto, S) A(k.table_redo, S) A(k.redo_list, S) A(k.table_cause, S) A(k.ring_hint, URF_ASYNC_SLOTS)
     A(k.nan_mask, S * 4) A(k.nan_list, 2 * S * C) A(k.vis, S * C)
     A(k.maxdist, S * C) A(k.quad, S * 4)
     A(k.curb_cnt, S * C) A(k.curb_az, S * C * URF_CURB_LIST)
@@ -274,10 +275,12 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     k.sstride = c->sstride;
     {
         void* hp = nullptr;
-        if (hipHostMalloc(&hp, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess)
+        if (hipHostMalloc(&hp, 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess)
             return fail(URF_ERR_HIP);
         c->h_spec_failed = (uint32_t*)hp;
-        *c->h_spec_failed = 0;
+        c->h_spec_failed[0] = c->h_spec_failed[1] = 0;
+        if (hipMemset(k.ring_hint, 0, URF_ASYNC_SLOTS * sizeof(uint32_t)) != hipSuccess)
+            return fail(URF_ERR_HIP);
         void* dp_ = nullptr;
         if (hipHostGetDevicePointer(&dp_, hp, 0) != hipSuccess)
             return fail(URF_ERR_HIP);
@@ -372,6 +375,9 @@ extern "C" int urf_set_params(urf_ctx* c, const urf_params* p)
     for (hipStream_t st : c->row_stream)
         if (st)
             URF_HIP(c, hipStreamSynchronize(st));   /* a sweep in flight on another row keeps its parameters */
+    /* the ring counts of earlier calls say nothing about sweeps classified with OTHER parameters (region of interest, interval) */
+    if (std::memcmp(&c->params, p, sizeof(*p)) != 0)
+        URF_HIP(c, hipMemsetAsync(c->k.ring_hint, 0, URF_ASYNC_SLOTS * sizeof(uint32_t), c->stream));
     c->params = *p;
     c->epoch++;
     return upload_params(c);
@@ -428,7 +434,7 @@ extern "C" int urf_callback_path_state(const urf_ctx* c, uint32_t* n_rerun, uint
     if (n_rerun)
         *n_rerun = c->n_rerun;
     if (sequence)
-        *sequence = (c->speculate ? 1u : 0u) | (c->slot_lists ? 2u : 0u) | (c->slot_nan ? 4u : 0u);
+        *sequence = (c->speculate ? 1u : 0u) | (c->slot_lists ? 2u : 0u) | (c->slot_nan ? 4u : 0u) | (c->speculate && c->use_hint ? 8u : 0u);
     return URF_OK;
 }
 
@@ -497,7 +503,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     k.angle += r * C; k.ring_thr += r * C * 4; k.ring_lut += r * URF_LUT_CELLS; k.ring_cnt += r * C; k.ring_off += r * (C + 1);
     k.sec_cnt += r * K; k.sec_run += r * K; k.sec_off += r * (K + 1); k.star_hit += r * K;
     k.star_first += r * K; k.star_list_mid += r * K; k.star_list_big += r * K; k.star_count += 4 * r;
-    k.table_upto += r; k.table_redo += r; k.redo_list += r;
+    k.table_upto += r; k.table_redo += r; k.redo_list += r; k.table_cause += r; k.ring_hint += r;
     k.nan_mask += r * 4; k.nan_list += 2 * r * C; k.vis += r * C;
     k.maxdist += r * C; k.quad += r * 4;
     k.curb_cnt += r * C; k.curb_az += r * C * URF_CURB_LIST;
@@ -578,11 +584,16 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     if (a.tiles == 0)
         a.tiles = 1;
     a.sstride = c->sstride;
-    if (c->speculate && *c->h_spec_failed) {   /* an earlier call had to repair a speculative ring table */
+    if (c->speculate && c->h_spec_failed[0]) {   /* an earlier call had to repair a speculative ring table */
         c->speculate = false;
         c->epoch++;
     }
+    if (c->use_hint && c->h_spec_failed[1]) {    /* ... or one that stopped at the previous call's ring count */
+        c->use_hint = false;
+        c->epoch++;
+    }
     a.table_lookahead = c->speculate ? URF_TABLE_LOOKAHEAD : 0u;
+    a.table_hint = (c->speculate && c->use_hint) ? 1u : 0u;
     /* A sweep of the callback path is waited for by the host before anybody sees its result: the kernels that
      * normally find nothing to do -- the two repair kernels behind the speculative ring table, the two for the work
      * lists of oversized star sectors, 20 of a sweep's 200 microseconds -- are left out, k_index voids a sweep that
@@ -953,8 +964,12 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
     HT(0, ht0);   /* staging + H2D enqueue */
     /* a sweep that defeated the speculative ring table (k_table_repair raised the host-visible flag) ends
      * the speculation for replayed sequences as well: the captured ones are rebuilt without it */
-    if (c->speculate && *c->h_spec_failed) {
+    if (c->speculate && c->h_spec_failed[0]) {
         c->speculate = false;
+        c->epoch++;
+    }
+    if (c->use_hint && c->h_spec_failed[1]) {
+        c->use_hint = false;
         c->epoch++;
     }
     /* the launch sequence of a sweep of this shape is captured once and replayed (one graph launch
@@ -1023,10 +1038,14 @@ extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* label
     HT(4, ht0);
     /* the short launch sequence left out something this sweep needed (run_pipeline): once more, with it --
      * the message is still in the slot's device buffer -- and from now on for every sweep */
-    auto redo = [](int st) { return st == URF_STATUS_REDO_TABLE || st == URF_STATUS_REDO_LISTS || st == URF_STATUS_REDO_NAN; };
-    for (int tries = 0; tries < 4 && redo(sl.h_info->status); tries++) {
+    auto redo = [](int st) {
+        return st == URF_STATUS_REDO_TABLE || st == URF_STATUS_REDO_LISTS || st == URF_STATUS_REDO_NAN || st == URF_STATUS_REDO_HINT;
+    };
+    for (int tries = 0; tries < 5 && redo(sl.h_info->status); tries++) {
         if (sl.h_info->status == URF_STATUS_REDO_TABLE)
             c->speculate = false;
+        else if (sl.h_info->status == URF_STATUS_REDO_HINT)
+            c->use_hint = false;
         else if (sl.h_info->status == URF_STATUS_REDO_LISTS)
             c->slot_lists = true;
         else

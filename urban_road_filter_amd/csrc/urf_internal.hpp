@@ -57,6 +57,7 @@
 #define URF_STATUS_REDO_TABLE 0x7f000001
 #define URF_STATUS_REDO_LISTS 0x7f000002
 #define URF_STATUS_REDO_NAN 0x7f000003
+#define URF_STATUS_REDO_HINT 0x7f000004   /* the table was incomplete because the walk stopped at the previous call's ring count */
 #define URF_AZ_UNKNOWN      -1.0f     /* decoded value of URF_REC_AZ_UNKNOWN */
 #define URF_RING_NONE       0xFFu
 #define URF_SEC_NONE        0x3FFu
@@ -133,6 +134,7 @@ struct urf_kargs {
     uint32_t tiles;             /* tiles per scan = ceil(max_len / URF_TILE): stride of the per-tile tables */
     uint32_t sstride;           /* scratch elements per scan */
     uint32_t table_lookahead;   /* k_ring_table: stop after this many points without a new leader (0: never), see there */
+    uint32_t table_hint;        /* ... and as soon as the table holds as many rings as the row's previous call found (*ring_hint), see there */
     uint32_t optimistic;        /* the callback path's short launch sequence: URF_OPT_* of what it leaves out; k_index turns a scan that
                                    needed it into URF_STATUS_REDO_*, which urf_classify_pc2_wait() answers with the full sequence */
     uint32_t capture;           /* 0 production; 1 every point takes the exact sequence, values recorded;
@@ -191,7 +193,10 @@ struct urf_kargs {
     uint32_t* table_upto;       /* [S] first point a speculative k_ring_table did not look at (0xffffffff: none) */
     uint32_t* table_redo;       /* [S] k_split: the speculative table of the scan is incomplete */
     uint32_t* redo_list;        /* [S] such scans (k_table_repair) */
-    uint32_t* spec_failed;      /* host-mapped flag: some speculation failed */
+    uint32_t* table_cause;      /* [S] which rule ended a speculative walk: 1 the quiet look-ahead, 2 the ring-count hint */
+    uint32_t* ring_hint;        /* [1] per scratch row: the largest n_rings of the row's previous call (k_ring_table reads it, k_split
+                                 * zeroes it, k_index collects the new one) */
+    uint32_t* spec_failed;      /* host-mapped flags: [0] a look-ahead speculation failed, [1] a ring-count hint did */
     float*    big_r;            /* sector-major copies of the sectors on the "big" list (sorted in place) */
     float*    big_z;
     uint32_t* big_i;

@@ -196,8 +196,19 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
     __syncthreads();
 
     const float interval = dp.p.interval;
+    /* Second speculation: a stream of sweeps from one sensor shows the same rings sweep after sweep.  Once the table holds as
+     * many entries as the row's previous call found, the walk stops as it would after a quiet look-ahead -- a sweep of the
+     * reference's default region finds its 61st and last ring 4 200 points in and then looked at 8 192 more for nothing.
+     * k_split checks the rest of the scan either way; a failure of THIS rule only switches the rule off (urf_api.hip). */
+    const unsigned hint = (lookahead && a.table_hint) ? *a.ring_hint : 0u;
     unsigned pos = 0, upto = 0xffffffffu;   /* upto: first point the walk did not look at (speculation) */
+    unsigned cause = 0;
     while (pos < len && sh_nL < C) {
+        if (hint && pos && sh_nL >= hint && !sh_zero) {   /* (uniform: LDS values behind a barrier) */
+            upto = pos;
+            cause = 2;
+            break;
+        }
         /* ---- serial step: wave 0, points [pos, pos + 64) ---- */
         if (wave == 0) {
             const unsigned i = pos + lane;
@@ -367,6 +378,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
             quiet += URF_TABLE_THREADS * URF_TABLE_SCAN_PPT;
             if (lookahead && quiet >= lookahead && !sh_zero && pos < len) {
                 upto = pos;
+                cause = 1;
                 break;
             }
         }
@@ -377,6 +389,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
     if (tid == 0) {
         a.table_upto[s] = upto;
         a.table_redo[s] = 0;
+        a.table_cause[s] = cause;
     }
 
     /* std::sort(angle, angle + index), lidar_segmentation.cpp:205 (rank sort) */
@@ -454,10 +467,11 @@ __global__ __launch_bounds__(URF_TABLE_THREADS) void k_table_repair(urf_kargs a,
     const unsigned s = blockIdx.x;
     if (!a.table_redo[s])
         return;
+    const unsigned cause = a.table_cause[s];   /* (before the walk below overwrites it) */
     urf_ring_table_scan(a, dp, s, 0, T);
     if (threadIdx.x == 0) {
         a.redo_list[atomicAdd(&a.star_count[2], 1u)] = s;
-        *a.spec_failed = 1u;   /* host-visible: the context stops speculating */
+        a.spec_failed[cause == 2u ? 1 : 0] = 1u;   /* host-visible: the context stops using the rule that failed */
     }
 }
 
@@ -1109,6 +1123,8 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
 __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_SPLIT_WAVES_PER_EU, URF_SPLIT_WAVES_PER_EU))) void k_split(urf_kargs a, urf_dev_params dp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_split[];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *a.ring_hint = 0;   /* k_ring_table has read the previous call's ring count; k_index collects this call's */
     urf_split_tile(a, dp, blockIdx.y, blockIdx.x, sh_split, threadIdx.x);
 }
 
@@ -1316,7 +1332,7 @@ __device__ __forceinline__ void urf_index_body(const urf_kargs& a, const urf_dev
         /* the speculative ring table was incomplete and nothing has repaired it (callback path): the scan is void,
          * every later kernel skips it, the host runs it again without the speculation */
         if (tid == 0)
-            a.info[s].status = URF_STATUS_REDO_TABLE;
+            a.info[s].status = a.table_cause[s] == 2u ? URF_STATUS_REDO_HINT : URF_STATUS_REDO_TABLE;
         return;
     }
     if (a.optimistic & URF_OPT_NO_NAN) {
@@ -1364,6 +1380,7 @@ __device__ __forceinline__ void urf_index_body(const urf_kargs& a, const urf_dev
             urf_scan_info* o = &a.info[s];
             o->n_ring_pts = sh[4] + sh[5] + sh[6] + sh[7];
             o->n_ring10 = o->n_rings > 10 ? a.ring_cnt[(size_t)s * C + 10] : 0;
+            atomicMax(a.ring_hint, o->n_rings);   /* for the row's next call (k_ring_table) */
         }
     }
     if (!dp.p.star_shaped_method)
