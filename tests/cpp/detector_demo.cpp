@@ -7,7 +7,8 @@
  *   cloud.bin: u32 n, float x[n], y[n], z[n], intensity[n]
  *   out.bin:   per run { u32 published; 4 x { u32 count; float xyzi[count][4] } }  (roi, road, curb, road_probably)
  *              runs: 0 PointCloud, reference order; 1 PointCloud2 with a permuted field table, input order;
- *                    2 PointCloud2 without an intensity field (point_step 23); 3.. six sweeps through submit() / collect()
+ *                    2 PointCloud2 without an intensity field (point_step 23); 3 PointCloud2 in the Velodyne driver's layout;
+ *                    4.. six sweeps through submit() / collect()
  *   stdout: "time <what> <median ms>" lines when reps > 0 */
 #include <algorithm>
 #include <chrono>
@@ -95,6 +96,29 @@ int main(int argc, char** argv)
             std::memcpy(&msg.data[(size_t)i * 32], rec, 32);
         }
     }
+    /* ... as a Velodyne driver publishes it: x y z intensity (FLOAT32 at 0 / 4 / 8 / 12), ring (UINT16 at 16), time (FLOAT32 at 18), 22 bytes */
+    urf::PointCloud2 velo;
+    {
+        velo.header = cloud.header;
+        velo.width = n;
+        velo.point_step = 22;
+        const char* names[6] = { "x", "y", "z", "intensity", "ring", "time" };
+        const uint32_t offs[6] = { 0, 4, 8, 12, 16, 18 };
+        const uint8_t types[6] = { urf::PointField::FLOAT32, urf::PointField::FLOAT32, urf::PointField::FLOAT32,
+                                   urf::PointField::FLOAT32, urf::PointField::UINT16, urf::PointField::FLOAT32 };
+        for (int k = 0; k < 6; k++) {
+            urf::PointField pf;
+            pf.name = names[k];
+            pf.offset = offs[k];
+            pf.datatype = types[k];
+            velo.fields.push_back(pf);
+        }
+        velo.data.assign((size_t)n * 22, 0);
+        for (uint32_t i = 0; i < n; i++) {
+            const float rec[4] = { x[i], y[i], z[i], in[i] };
+            std::memcpy(&velo.data[(size_t)i * 22], rec, 16);
+        }
+    }
     /* ... and with unaligned 23-byte records that carry no intensity (x at 3, y at 11, z at 17) */
     urf::PointCloud2 bare;
     {
@@ -142,6 +166,10 @@ int main(int argc, char** argv)
         std::printf("bare published %d same_labels %d\n", (int)published,
                     (int)(det.n_labels() == lab0.size() && std::memcmp(det.labels(), lab0.data(), lab0.size()) == 0));
         dump(f, published, det);
+        published = det.filtered(velo);
+        std::printf("velodyne published %d same_labels %d\n", (int)published,
+                    (int)(det.n_labels() == lab0.size() && std::memcmp(det.labels(), lab0.data(), lab0.size()) == 0));
+        dump(f, published, det);
         /* six sweeps, four in flight (the subscriber callback submits, the publisher collects) */
         {
             uint32_t tickets[6];
@@ -170,6 +198,7 @@ int main(int argc, char** argv)
             det.setReferenceOrder(false);
             std::printf("time pointcloud_input_order %.4f\n", median_ms(reps, [&] { det.filtered(cloud); }));
             std::printf("time pointcloud2_permuted_fields %.4f\n", median_ms(reps, [&] { det.filtered(msg); }));
+            std::printf("time pointcloud2_velodyne_layout %.4f\n", median_ms(reps, [&] { det.filtered(velo); }));
             std::printf("time pointcloud2_xyz_only_step23 %.4f\n", median_ms(reps, [&] { det.filtered(bare); }));
             det.setReferenceOrder(true);
             std::printf("time pointcloud_reference_order %.4f\n", median_ms(reps, [&] { det.filtered(cloud); }));

@@ -72,7 +72,7 @@ def test_adapter_clouds_equal_oracle(tmp_path, scene, seed):
     curb_in = np.nonzero((lb & 3) == 2)[0]
     prob_in = np.nonzero(lb & 16)[0]
     runs = read_runs(out)
-    assert len(runs) == 3 + 6
+    assert len(runs) == 4 + 6
     # run 0: pcl::PointCloud overload in the reference's own published order
     pub, (c_roi, c_road, c_curb, c_prob) = runs[0]
     assert pub == 1
@@ -81,7 +81,7 @@ def test_adapter_clouds_equal_oracle(tmp_path, scene, seed):
     assert np.array_equal(c_curb, pts[st["curb_order"]])
     assert np.array_equal(c_prob, pts[st["ring10_order"]])
     # run 1: sensor_msgs/PointCloud2 with a permuted field table (intensity z t x ring y), input order
-    for k in [1] + list(range(3, 9)):   # ... and the six sweeps that went through submit() / collect()
+    for k in [1] + list(range(3, 10)):   # ... the Velodyne driver's layout, and the six sweeps that went through submit() / collect()
         pub, (c_roi, c_road, c_curb, c_prob) = runs[k]
         assert pub == 1
         assert np.array_equal(c_roi, pts[roi]) and np.array_equal(c_road, pts[road_in]), k
@@ -96,6 +96,7 @@ def test_adapter_clouds_equal_oracle(tmp_path, scene, seed):
     assert "frame left_os1/os1_lidar" in r.stdout
     assert "pc2 published 1 same_labels 1" in r.stdout
     assert "bare published 1 same_labels 1" in r.stdout
+    assert "velodyne published 1 same_labels 1" in r.stdout
     assert "pipelined sweeps 6 same_labels 6" in r.stdout
 
 

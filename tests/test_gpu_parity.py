@@ -562,6 +562,35 @@ def test_speculative_ring_table_is_repaired():
             assert np.array_equal(lg, lb_ok)
 
 
+def test_a_long_ring_with_nan_azimuths(ctx_big):
+    """More points on the NaN ring than k_nan_rings keeps in LDS (6 144): the literal quicksort runs in global memory."""
+    rng = np.random.default_rng(77)
+    n = 9000
+    fi = rng.uniform(0, 2 * np.pi, n)
+    rho = np.linspace(0.004, 0.044, n)[rng.permutation(n)]   # distinct planar ranges
+    x, y = (rho * np.cos(fi)).astype(np.float32), (rho * np.sin(fi)).astype(np.float32)
+    z = (-1.8 + 0.2 * rng.random(n) * (rng.random(n) < 0.3)).astype(np.float32)
+    r = np.sqrt(x * x + y * y)
+    _, first = np.unique(r, return_index=True)
+    keep = np.sort(first)
+    x, y, z = x[keep], y[keep], z[keep]
+    base = tuple(a[:4096].copy() for a in O.cfg_cloud("cfg2", 431))
+    x, y, z = (np.concatenate([b, v]) for b, v in zip(base, (x, y, z)))
+    x, y, z = (np.insert(a, 6000, v) for a, v in ((x, 0.0), (y, 0.0), (z, -1.8)))
+    p = O.cfg_params("cfg2")
+    p.interval, p.curbHeight, p.channels = 1.5, 0.02, 72
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    nan_ring = st["ring"][6000]
+    assert nan_ring >= 0 and (st["ring"] == nan_ring).sum() > 6144
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(lg, lb) and info_equal(ig, ib) and ig.n_nan_azimuth == 1
+    road, curb, prob = ctx_big.ordered_indices(len(x))
+    assert same_order_up_to_ties(road, st["road_order"], st) and same_order_up_to_ties(curb, st["curb_order"], st)
+    for got, want in ((road, st["road_order"]), (curb, st["curb_order"])):
+        assert np.array_equal(got[st["ring"][got] == nan_ring], want[st["ring"][want] == nan_ring])
+
+
 def test_ring_count_hint_and_its_failure():
     """Second speculation of k_ring_table (r4): the walk also stops once the table holds as many rings as the previous call
     found -- a stream of sweeps from one sensor shows the same rings sweep after sweep.  (i) default-ROI sweeps one after the

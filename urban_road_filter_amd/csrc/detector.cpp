@@ -57,13 +57,38 @@ struct RecordsAny {    /* any point_step and field offsets; intensity optional *
         out = q;
     }
 };
+struct RecordsXYZ_I {   /* x y z side by side and intensity right behind them (the layout of the Velodyne / Ouster drivers' messages) */
+    const uint8_t* data;
+    uint32_t step, ox;
+    inline void get(uint32_t i, PointXYZI& out) const
+    {
+        const uint8_t* p = data + (size_t)i * step + ox;
+        PointXYZI q;
+        float v[4];
+        std::memcpy(v, p, 16);
+        q.x = v[0];
+        q.y = v[1];
+        q.z = v[2];
+        q.intensity = v[3];
+        out = q;
+    }
+};
 
-/* lidar_segmentation.cpp:354-367, 605-608, 620: the four clouds from the label bytes, input order.  Eight labels
- * at a time: a region of interest that drops whole azimuth ranges leaves long runs of zero bytes. */
+/* lidar_segmentation.cpp:354-367, 605-608, 620: the four clouds from the label bytes, input order.  The clouds have
+ * their final sizes already (the sweep's summary holds the four counts), so every point is ONE indexed store -- no
+ * push_back, no capacity check; eight labels at a time: a region of interest that drops whole azimuth ranges leaves long
+ * runs of zero bytes.  Returns false if the labels do not add up to the counts (cannot happen). */
 template <class REC>
-void materialise(const REC& rec, const uint8_t* lab, uint32_t n, bool all_roi, bool lists, std::vector<PointXYZI>& roi,
+bool materialise(const REC& rec, const uint8_t* lab, uint32_t n, bool all_roi, bool lists, std::vector<PointXYZI>& roi,
                  std::vector<PointXYZI>& road, std::vector<PointXYZI>& curb, std::vector<PointXYZI>& probably)
 {
+    PointXYZI* const o_roi = roi.data();
+    PointXYZI* const o_road = road.data();
+    PointXYZI* const o_curb = curb.data();
+    PointXYZI* const o_prob = probably.data();
+    size_t k_roi = all_roi ? roi.size() : 0, k_road = 0, k_curb = 0, k_prob = 0;
+    const size_t c_roi = roi.size(), c_road = lists ? road.size() : 0, c_curb = lists ? curb.size() : 0, c_prob = lists ? probably.size() : 0;
+    bool ok = true;
     PointXYZI q;
     auto one = [&](uint32_t i, uint8_t l) {
         if (!(l & URF_FLAG_ROI))
@@ -72,15 +97,26 @@ void materialise(const REC& rec, const uint8_t* lab, uint32_t n, bool all_roi, b
         if (!need)
             return;
         rec.get(i, q);
-        if (!all_roi)
-            roi.push_back(q);
+        if (!all_roi) {
+            if (k_roi < c_roi)
+                o_roi[k_roi] = q;
+            k_roi++;
+        }
         if (lists) {
-            if ((l & URF_LABEL_MASK) == URF_LABEL_ROAD)
-                road.push_back(q);
-            else if ((l & URF_LABEL_MASK) == URF_LABEL_CURB)
-                curb.push_back(q);
-            if (l & URF_FLAG_RING10)
-                probably.push_back(q);
+            if ((l & URF_LABEL_MASK) == URF_LABEL_ROAD) {
+                if (k_road < c_road)
+                    o_road[k_road] = q;
+                k_road++;
+            } else if ((l & URF_LABEL_MASK) == URF_LABEL_CURB) {
+                if (k_curb < c_curb)
+                    o_curb[k_curb] = q;
+                k_curb++;
+            }
+            if (l & URF_FLAG_RING10) {
+                if (k_prob < c_prob)
+                    o_prob[k_prob] = q;
+                k_prob++;
+            }
         }
     };
     uint32_t i = 0;
@@ -94,40 +130,50 @@ void materialise(const REC& rec, const uint8_t* lab, uint32_t n, bool all_roi, b
     }
     for (; i < n; i++)
         one(i, lab[i]);
+    ok = k_roi == c_roi && (!lists || (k_road == c_road && k_curb == c_curb && k_prob == c_prob));
+    return ok;
 }
 
 }   // namespace
 
 void Detector::split(const Pending& m)
 {
-    road_.points.clear();
-    curb_.points.clear();
-    roi_.points.clear();
-    road_probably_.points.clear();
     road_.header = curb_.header = roi_.header = road_probably_.header = m.header;   /* lidar_segmentation.cpp:612-615 */
     marker_published_ = false;
-    if (info_.status != URF_OK)
+    if (info_.status != URF_OK) {
+        road_.points.clear();
+        curb_.points.clear();
+        roi_.points.clear();
+        road_probably_.points.clear();
         return;
-    road_.points.reserve(info_.n_road);
-    curb_.points.reserve(info_.n_curb);
-    roi_.points.reserve(info_.n_roi);
-    road_probably_.points.reserve(info_.n_ring10);
+    }
+    /* the clouds at their final sizes (a vector that shrinks or stays keeps its storage and initialises nothing: in a stream of
+     * sweeps only growth beyond the largest sweep so far costs anything) */
+    const bool lists = !reference_order_;   /* in the reference's order they come from the index lists below */
+    roi_.points.resize(info_.n_roi);
+    road_.points.resize(info_.n_road);
+    curb_.points.resize(info_.n_curb);
+    road_probably_.points.resize(info_.n_ring10);
     const uint32_t n = m.n;
     const bool xyzi = m.step == sizeof(PointXYZI) && m.ox == 0 && m.oy == 4 && m.oz == 8 && m.oi == 16;
     /* every point inside the region of interest and the message already an array of pcl::PointXYZI: "roi" is the message */
     const bool all_roi = xyzi && info_.n_roi == n && ((uintptr_t)m.data % alignof(PointXYZI)) == 0;
-    if (all_roi) {
-        const PointXYZI* src = (const PointXYZI*)m.data;
-        roi_.points.assign(src, src + n);   /* (trivially copyable: one block copy) */
-    }
-    const bool lists = !reference_order_;   /* in the reference's order they come from the index lists below */
+    if (all_roi)
+        std::memcpy((void*)roi_.points.data(), m.data, (size_t)n * sizeof(PointXYZI));
+    const bool xyz_i = !xyzi && m.oy == m.ox + 4 && m.oz == m.ox + 8 && m.oi == (int64_t)m.ox + 12 && (uint64_t)m.ox + 16 <= m.step;
+    bool ok = true;
     if (all_roi && !lists)
         ;   /* nothing left for the label scan */
     else if (xyzi)
-        materialise(RecordsXYZI{ m.data }, labels_, n, all_roi, lists, roi_.points, road_.points, curb_.points, road_probably_.points);
+        ok = materialise(RecordsXYZI{ m.data }, labels_, n, all_roi, lists, roi_.points, road_.points, curb_.points, road_probably_.points);
+    else if (xyz_i)
+        ok = materialise(RecordsXYZ_I{ m.data, m.step, m.ox }, labels_, n, false, lists, roi_.points, road_.points, curb_.points,
+                         road_probably_.points);
     else
-        materialise(RecordsAny{ m.data, m.step, m.ox, m.oy, m.oz, m.oi }, labels_, n, false, lists, roi_.points, road_.points, curb_.points,
-                    road_probably_.points);
+        ok = materialise(RecordsAny{ m.data, m.step, m.ox, m.oy, m.oz, m.oi }, labels_, n, false, lists, roi_.points, road_.points, curb_.points,
+                         road_probably_.points);
+    if (!ok)
+        throw Error(URF_ERR_HIP, "label bytes and summary counters disagree");
     if (marker_on_) {
         float mp[361 * 4];
         uint32_t k = 0;
@@ -146,12 +192,14 @@ void Detector::split(const Pending& m)
         const RecordsXYZI recx{ m.data };
         PointXYZI q;
         auto fill = [&](std::vector<PointXYZI>& out, const uint32_t* idx, uint32_t c) {
+            out.resize(c);   /* (= the summary's count) */
+            PointXYZI* const o = out.data();
             for (uint32_t i = 0; i < c; i++) {
                 if (xyzi)
                     recx.get(idx[i], q);
                 else
                     rec.get(idx[i], q);
-                out.push_back(q);
+                o[i] = q;
             }
         };
         fill(road_.points, ro, cnt[0]);

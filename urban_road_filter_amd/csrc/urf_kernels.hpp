@@ -3250,7 +3250,7 @@ __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_e
 __device__ __forceinline__ float urf_pair_alpha(unsigned long long e) { return __uint_as_float((unsigned)(e >> 32)); }
 
 /* lidar_segmentation.cpp:69-82 partition(low, high) on A, by one wave (all 64 lanes call it with uniform arguments) */
-__device__ int urf_lomuto_partition(unsigned long long* A, int low, int high)
+__device__ int urf_lomuto_partition(volatile unsigned long long* A, int low, int high)   /* (volatile: one lane writes what the others read next, LDS or global memory) */
 {
     const int lane = (int)urf_lane();
     const float pivot = urf_pair_alpha(A[high]);
@@ -3310,7 +3310,7 @@ __global__ __launch_bounds__(256) void k_nan_rings(urf_kargs a, urf_dev_params d
         const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
         const unsigned sb = urf_sbase(a, s);
         const unsigned n = a.ring_cnt[(size_t)s * C + c], ro = a.ring_off[(size_t)s * (C + 1) + c];
-        unsigned long long* const A = n <= URF_NAN_LDS ? sh_pairs : (unsigned long long*)(a.wsg + sb + ro);
+        volatile unsigned long long* const A = n <= URF_NAN_LDS ? sh_pairs : (unsigned long long*)(a.wsg + sb + ro);
         if (tid == 0) {
             n_nan = 0;
             first_nan = 0xffffffffu;
