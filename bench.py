@@ -121,7 +121,9 @@ def cpu_baseline(params, budget_scans=6):
                 sweep[P] = float(sum(rates))
         P = max(sweep, key=lambda q: sweep[q])
         sample = ("%d x 64x2048 street sweeps per process after 1 excluded warm-up call; value = sum over P concurrent "
-                  "single-threaded processes, best of P in %s: P = %d" % (2 * (1 + budget_scans // 2) - 1, sorted(sweep), P))
+                  "single-threaded processes, best of P in %s: P = %d.  The reference's timed call is its whole Detector::filtered, "
+                  "which also holds the marker search and line strips (lidar_segmentation.cpp:295-351, 369-602) that the timed GPU "
+                  "step does not: a stated baseline, not a like-for-like ratio" % (2 * (1 + budget_scans // 2) - 1, sorted(sweep), P))
         return {"value": round(sweep[P], 3), "unit": "scans/s", "cores": P, "kind": kind, "sample": sample,
                 "single_core_value": round(single, 3), "host_cores_available": cores_avail,
                 "value_by_processes": {str(q): round(v, 3) for q, v in sorted(sweep.items())},

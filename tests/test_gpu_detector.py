@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def build_demo(tmp_path, name="detector_demo"):
     exe = str(tmp_path / name)
     pkg = os.path.join(ROOT, "urban_road_filter_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "csrc"),
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "csrc"),
                            os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
                            "-L" + pkg, "-l:liburf_hip.so", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
@@ -126,3 +126,31 @@ def test_adapter_with_a_narrow_region_of_interest(tmp_path):
     assert set(times) >= {"pointcloud_input_order", "pointcloud2_permuted_fields", "pointcloud_reference_order",
                           "pointcloud_input_order_with_marker", "pipelined_per_sweep"}
     assert all(float(v) > 0 for v in times.values())
+
+
+@pytest.mark.gpu
+def test_one_context_per_thread_from_cpp(tmp_path):
+    """tests/cpp/two_contexts_demo.cpp: two contexts in one process, one host thread each (context i on device i modulo the
+    number of devices), four sweeps in flight per context, different parameters per context -- the C-level shape of the
+    multi-GPU benchmark (one context per GPU, counters the only thing exchanged).  Labels equal oracle B sweep by sweep."""
+    exe = build_demo(tmp_path, "two_contexts_demo")
+    clouds = [u.synth_cloud(64, 2048, 1 + k % 2, 200 + k) for k in range(10)]
+    files = []
+    for k, (x, y, z) in enumerate(clouds):
+        files.append(str(tmp_path / ("c%d.bin" % k)))
+        with open(files[-1], "wb") as f:
+            f.write(struct.pack("<I", len(x)) + x.tobytes() + y.tobytes() + z.tobytes())
+    out = str(tmp_path / "labels.bin")
+    r = subprocess.run([exe, out] + files, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    blob = np.fromfile(out, np.uint8).reshape(len(clouds), -1)
+    road = curb = 0
+    for k, (x, y, z) in enumerate(clouds):
+        p = O.cfg_params("cfg2")
+        if k % 2 == 1:
+            p.curbHeight = 0.06
+        lb, ib, _ = O.run_b(x, y, z, p)
+        assert np.array_equal(blob[k], lb), k
+        road += ib["n_road"]
+        curb += ib["n_curb"]
+    assert "contexts 2 sweeps 5 + 5 road %d curb %d" % (road, curb) in r.stdout
