@@ -108,3 +108,32 @@ def case(seed, for_reference=False):
     if rng2.random() < 1 / 3:
         cloud = axis_points(cloud, rng2, 1 if for_reference else int(rng2.integers(1, 4)), near=int(rng2.integers(0, 6)))
     return cloud, params
+
+
+def cloud_with_identical_points(seed, n, pairs):
+    """A street sweep in which `pairs` points have been overwritten by copies of other points: two identical points are
+    neighbours in their star sector's sorted order, the slope between them is 0 / 0 = NaN, which the walk counts and
+    skips (star_shaped_search.cpp:131-132).  Returns the cloud and the indices involved (which of two identical points
+    the walk marks is the tie the reference leaves open)."""
+    import oracles as O
+    x, y, z = [a[:n].copy() for a in O.cfg_cloud("cfg2", seed)]
+    rng = np.random.default_rng(seed)
+    src = rng.choice(n, pairs, replace=False)
+    dst = (src + rng.integers(1, n, pairs)) % n
+    dst = np.setdiff1d(dst, src)
+    src = src[:len(dst)]
+    x[dst], y[dst], z[dst] = x[src], y[src], z[src]
+    return (x, y, z), np.concatenate([src, dst])
+
+
+def assert_equal_up_to_identical_points(lg, lb, scan, involved):
+    same = lg == lb
+    if not same.all():
+        # a disagreement may only swap the labels of identical points
+        x, y, z = scan
+        bad = np.flatnonzero(~same)
+        assert np.isin(bad, involved).all(), bad[:10]
+        key = lambda i: (x[i].tobytes(), y[i].tobytes(), z[i].tobytes())
+        for i in bad:
+            twins = [j for j in involved if key(j) == key(i)]
+            assert sorted(lg[twins]) == sorted(lb[twins]), (i, twins)

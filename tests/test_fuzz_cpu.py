@@ -46,3 +46,19 @@ def test_oracle_b_equals_reference_with_shared_libm(seed):
     if ib["status"] == 0:
         for key in ("road_order", "curb_order", "ring10_order"):
             assert np.array_equal(ia[0][key], st[key]), key
+
+
+@pytest.mark.skipif(not O.has_oracle_a(), reason="oracle A binary (reference build) not available")
+@pytest.mark.parametrize("seed,pairs", [(201, 1500), (202, 40), (203, 1500)])
+def test_oracle_b_equals_reference_with_nan_slopes(seed, pairs):
+    """Identical points in a star sector: the slope between them is 0 / 0, which the reference counts and skips
+    (star_shaped_search.cpp:131-132).  Oracle B follows it; only WHICH of two identical points carries the mark is left
+    to the reference's unstable sort (the same tolerance the GPU tests of these clouds use)."""
+    from fuzz import assert_equal_up_to_identical_points, cloud_with_identical_points
+    p = O.cfg_params("cfg2")
+    scan, involved = cloud_with_identical_points(seed, 64 * 2048, pairs)
+    la, ia, _, _ = O.run_a([scan], p, libm=True)
+    lb, ib, _ = O.run_b(*scan, p)
+    assert_equal_up_to_identical_points(la[0], lb & O.MASK_NO_RING, scan, involved)
+    for k in ("n_roi", "n_road", "n_curb", "n_ring10"):
+        assert ia[0][k] == ib[k], k

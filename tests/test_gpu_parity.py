@@ -11,6 +11,7 @@ import os
 import numpy as np
 import pytest
 
+import fuzz
 import oracles as O
 import urban_road_filter_amd as u
 from golden.make_golden import CASES, case_params, cloud_sha
@@ -460,6 +461,37 @@ def test_ring_table_zero_sentinel(ctx_big):
     same = lg2 == lb2
     same[100:103] = True   # three identical points of one star sector: which of them the walk marks is the open tie
     assert same.all()
+
+
+@pytest.mark.parametrize("pairs", [40, 1500])
+def test_nan_slopes_single_sweep(ctx_big, pairs):
+    """NaN slopes in one sweep: the three-wave walk of the callback path (k_star_walk_few) hands the sectors over to
+    the sequential walk at the chunk in which a NaN mean shows up."""
+    p = O.cfg_params("cfg2")
+    for seed in (201, 202, 203):
+        scan, involved = fuzz.cloud_with_identical_points(seed, 64 * 2048, pairs)
+        lb, ib, _ = O.run_b(*scan, p)
+        ctx_big.set_params(p)
+        lg, ig = ctx_big.classify_xyz(*scan)
+        assert info_equal(ig, ib), seed
+        fuzz.assert_equal_up_to_identical_points(lg, lb, scan, involved)
+
+
+def test_nan_slopes_in_a_batch():
+    """The same through the batch walk (k_star_walk: more than URF_WALK_FEW_SCANS = 32 scans) and through the
+    three-wave walk with several scans in the grid (8 scans)."""
+    p = O.cfg_params("cfg2")
+    n = 16 * 2048
+    made = [fuzz.cloud_with_identical_points(300 + k, n, 25 if k % 2 else 400) for k in range(40)]
+    scans = [m[0] for m in made]
+    want = [O.run_b(*sc, p) for sc in scans]
+    with u.Context(n, 40, params=p) as ctx:
+        for count in (40, 8):
+            labels, infos = run_batch(ctx, scans[:count], p)
+            for k in range(count):
+                lb, ib, _ = want[k]
+                assert tuple(infos[k][:7]) == tuple(ib[f] for f in ("status", "n_roi", "n_rings", "n_ring_pts", "n_road", "n_curb", "n_ring10")), k
+                fuzz.assert_equal_up_to_identical_points(labels[k], lb, scans[k], made[k][1])
 
 
 def same_order_up_to_ties(got, want, st):

@@ -272,6 +272,14 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(c->compact_cnt, S * tiles * 4)
     A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
 #undef A
+    {
+        urf_wu* tab = nullptr;
+        const size_t nt = (size_t)max_points + 32;
+        if ((rc = dev_alloc(c, &tab, nt)) != URF_OK)
+            return fail(rc);
+        hipLaunchKernelGGL(k_walk_table, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, tab, (unsigned)nt);
+        k.walk_tab = tab;
+    }
     k.sstride = c->sstride;
     {
         void* hp = nullptr;
@@ -647,8 +655,12 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         }
     }
     mark();   /* "k_star_sort" = the three sort kernels (mid / big run over normally empty work lists) */
-    if (star)
-        hipLaunchKernelGGL(k_star_walk, dim3((K + 63) / 64, n_scans), dim3(64), 0, st, a, dp);
+    if (star) {
+        if (n_scans <= URF_WALK_FEW_SCANS)   /* an empty device: three waves per 64 sectors, one chunk apart */
+            hipLaunchKernelGGL(k_star_walk_few, dim3((K + 63) / 64, n_scans), dim3(URF_WALK_FEW_THREADS), 0, st, a, dp);
+        else
+            hipLaunchKernelGGL(k_star_walk, dim3((K + 63) / 64, n_scans), dim3(64), 0, st, a, dp);
+    }
     mark();
     const dim3 g_ring(C, n_scans);
     if (dp.p.curbPoints == 5)   /* the reference's default: four points per thread, z only */

@@ -112,6 +112,7 @@ struct urf_sec_run { uint32_t a0, c0, a1, nruns; };
 
 /* k_star_sort_* -> k_star_walk, per point of a sector in sorted order */
 struct alignas(8) urf_sg { float slp, g; };
+struct alignas(8) urf_wu { float w, u; };   /* (float)(i - 1), 1 / (float)i: the factors of step i of a walk */
 
 /* What the reference's beam scans see of a ring whose azimuth-sorted array holds NaN entries: the forward scans
  * (blind_spots.cpp:107,124,146,164: "alpha <= window end" ends the loop, and is false for a NaN) only the points in
@@ -165,6 +166,7 @@ struct urf_kargs {
                                  * sorted order, 0xffffffff = on no ring */
     urf_sg*   wsg;              /* .x slope between the (i-1)-th and i-th point of the sector in sorted order, .y (r_i - r_{i-1}) * kdist:
                                  * side by side, so that the walk fetches both with one 8-byte load (16 steps of a sector = one 128-byte line) */
+    const urf_wu* walk_tab;     /* [max_points + 32] ((float)(i - 1), 1 / (float)i): the walk's wave-uniform factors (k_walk_table, once per context) */
     /* per scan x tile (k_split) */
     uint32_t* tile_roi;         /* [S][tiles] ROI points of the tile */
     uint16_t* troff;            /* [S][tiles][C+1] first ring-sorted slot of ring c in the tile; [C] = ring points of the tile */

@@ -2288,77 +2288,125 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
 }
 
 /* star_shaped_search.cpp:123-149, one LANE per (sector, scan), one wave per 64
- * sectors.  wslp = slopes, wg = distance terms, both in sorted order; the walk of
- * a sector visits i = 1..star_first.  A lane reading its own sector directly
+ * sectors.  wsg = (slope, distance term) pairs in sorted order; the walk of a
+ * sector visits i = 1..star_first.  A lane reading its own sector directly
  * would touch 64 different cache lines per load, so the wave fetches the next
- * 16 steps of all its sectors cooperatively (16 consecutive floats = one line
- * per sector) into LDS and every lane then reads its own row. */
+ * 16 steps of all its sectors cooperatively (16 consecutive pairs = one line
+ * per sector) into LDS and every lane then reads its own row.
+ *
+ * With one wave per SIMD (a single sweep: six waves on the whole device) every
+ * instruction of the chain costs 5-8 cycles (profiles/r4_valubench.txt, W = 1),
+ * so the chunk is written for the fewest instructions: the running mean and
+ * deviation advance unconditionally (what follows a sector's curb point or its
+ * last step is never looked at), the sixteen hit tests leave as lane masks and
+ * the first one is picked afterwards; the wave-uniform (i - 1, 1 / i) come from a
+ * table in global memory through scalar loads (a.walk_tab); a NaN slope shows as
+ * a NaN mean at the end of the chunk, which is then walked again by the general
+ * version from the state it started with. */
 #define URF_WALK_CHUNK 16
-#define URF_WALK_INV 512
 /* the running state of one sector's walk (star_shaped_search.cpp:123-149) */
 struct urf_walk_state {
     float avg, dev, nan;
     unsigned hit_i;   /* sorted index of the sector's curb point, 0 = none */
     unsigned lim;     /* last index this lane still walks; 0 = done */
 };
-/* One chunk of URF_WALK_CHUNK steps from index c0 (wave-uniform) of every lane's sector: slopes sl[], distance
- * terms gg[], the wave-uniform 1 / i in uu[].  All lanes step through the chunk in lockstep; a lane that is past
- * its sector's end or has found its curb point just stops updating its state (lim = 0). */
-__device__ __forceinline__ void urf_walk_chunk(urf_walk_state& w_, unsigned c0, const float (&sl)[URF_WALK_CHUNK], const float (&gg)[URF_WALK_CHUNK],
-                                               const float (&uu)[URF_WALK_CHUNK], bool anynan, float kdev, float slope_param, int dmin)
+/* a * b, rounded once, out of reach of the SLP vectoriser (which pairs the multiplications of the hit test into
+ * v_pk_mul_f32 and pays two v_mov per pair to line the operands up) */
+__device__ __forceinline__ float urf_mul_f32(float x, float y)
+{
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ float urf_add_f32(float x, float y)
+{
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+/* x + |y - z| in two instructions, each rounded once */
+__device__ __forceinline__ float urf_add_absdiff_f32(float x, float y, float z)
+{
+    float d, r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(y), "v"(z));
+    asm("v_add_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(x), "v"(d));
+    return r;
+}
+/* One chunk of URF_WALK_CHUNK steps from index c0 (wave-uniform) of every lane's sector, no NaN slope so far in any
+ * sector of the wave: pairs sg[], the wave-uniform (i - 1, 1 / i) in wu[].  ABOVE: every step of the chunk is past
+ * dmin_param (and c0 != 0), which leaves the test without its wave-uniform part.  The hit tests do not look at the
+ * sector's end: the first raw hit either lies inside the walk, and is the walk's, or nothing inside does.  Returns
+ * false (state untouched) if a lane that is still walking ended the chunk with a NaN mean. */
+template <bool ABOVE>
+__device__ __forceinline__ bool urf_walk_chunk_fast(urf_walk_state& w_, unsigned c0, const urf_sg (&sg)[URF_WALK_CHUNK],
+                                                    const urf_wu* __restrict__ wu, float kdev, float slope_param, int dmin)
+{
+    float avg = w_.avg, dev = w_.dev;
+    const unsigned lim = w_.lim;
+    bool h[URF_WALK_CHUNK];
+#pragma unroll
+    for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
+        const unsigned i = c0 + j;
+        h[j] = false;
+        if (!ABOVE && j == 0 && c0 == 0)
+            continue;   /* the walk starts at 1 */
+        const float slp = sg[j].slp;
+        const float w = wu[j].w, u = wu[j].u;                  /* (float)i - 0 - 1 and 1 / (float)i */
+        float na = avg * w;                                    /* star_shaped_search.cpp:135-140 */
+        na = na + slp;
+        na = na * u;
+        float nd = dev * w;
+        nd = nd + __builtin_fabsf(slp - na);
+        nd = nd * u;
+        avg = na;
+        dev = nd;
+        const bool dyn = urf_mul_f32(urf_mul_f32(urf_mul_f32(slp, slp) - urf_mul_f32(na, na), kdev), sg[j].g) > nd;
+        h[j] = (slp > slope_param) | ((ABOVE || (int)i > dmin) & dyn);   /* :142-143 */
+    }
+    if (__any(lim != 0u && avg != avg))
+        return false;
+    unsigned hit = 0;
+#pragma unroll
+    for (int j = URF_WALK_CHUNK - 1; j >= 0; j--)
+        hit = h[j] ? c0 + (unsigned)j : hit;                   /* the first one: :146 */
+    w_.avg = avg;
+    w_.dev = dev;
+    if (hit && hit <= lim) {
+        w_.hit_i = hit;
+        w_.lim = 0;
+    }
+    return true;
+}
+/* The same chunk with NaN slopes in it (or before it): they are counted and skipped, star_shaped_search.cpp:131-132. */
+__device__ __forceinline__ void urf_walk_chunk_general(urf_walk_state& w_, unsigned c0, const urf_sg* sg /* the lane's row of the LDS tile */, float kdev,
+                                                       float slope_param, int dmin)
 {
     float avg = w_.avg, dev = w_.dev, nan = w_.nan;
     unsigned hit_i = w_.hit_i, lim = w_.lim;
-    if (!__any(anynan)) {
-        /* straight-line version: no NaN slope so far in any sector of the wave */
-#pragma unroll
-        for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
-            const unsigned i = c0 + j;
-            if (i == 0)
-                continue;   /* the walk starts at 1 (compile-time j, uniform c0) */
-            const float slp = sl[j];
-            const float w = (float)(int)(i - 1);               /* == (float)i - 0 - 1, exact */
-            float na = avg * w;                                /* star_shaped_search.cpp:135-140 */
-            na = na + slp;
-            na = na * uu[j];
-            float nd = dev * w;
-            nd = nd + __builtin_fabsf(slp - na);
-            nd = nd * uu[j];
-            const bool active = i <= lim;
-            avg = active ? na : avg;
-            dev = active ? nd : dev;
-            const bool h = (slp > slope_param) |               /* :142-143 */
-                           (((int)i > dmin) & ((slp * slp - avg * avg) * kdev * gg[j] > dev));
-            const bool hit_now = active & h;
-            hit_i = hit_now ? i : hit_i;                       /* :146 */
-            lim = hit_now ? 0u : lim;
-        }
-    } else {
 #pragma unroll 1
-        for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
-            const unsigned i = c0 + j;
-            const bool active = i >= 1 && i <= lim;
-            const float slp = sl[j];
-            if (active) {
-                if (slp != slp) {
-                    nan += 1.0f;                               /* :131-132 */
-                } else {
-                    const float w = (float)(int)i - nan - 1.0f;
-                    const float u = 1.0f / ((float)(int)i - nan);
-                    avg *= w;
-                    avg += slp;
-                    avg *= u;
-                    dev *= w;
-                    dev += __builtin_fabsf(slp - avg);
-                    dev *= u;
-                }
+    for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
+        const unsigned i = c0 + j;
+        const bool active = i >= 1 && i <= lim;
+        const float slp = sg[j].slp;
+        if (active) {
+            if (slp != slp) {
+                nan += 1.0f;                               /* :131-132 */
+            } else {
+                const float w = (float)(int)i - nan - 1.0f;
+                const float u = 1.0f / ((float)(int)i - nan);
+                avg *= w;
+                avg += slp;
+                avg *= u;
+                dev *= w;
+                dev += __builtin_fabsf(slp - avg);
+                dev *= u;
             }
-            const bool h = slp > slope_param ||
-                           ((int)i > dmin && (slp * slp - avg * avg) * kdev * gg[j] > dev);
-            if (active && h) {
-                hit_i = i;
-                lim = 0;
-            }
+        }
+        const bool h = slp > slope_param ||
+                       ((int)i > dmin && (slp * slp - avg * avg) * kdev * sg[j].g > dev);
+        if (active && h) {
+            hit_i = i;
+            lim = 0;
         }
     }
     w_.avg = avg;
@@ -2406,11 +2454,127 @@ __device__ __forceinline__ int urf_walk_report(const urf_kargs& a, unsigned s, u
     return hit;
 }
 
+/* (float)(i - 1) and 1 / (float)i for every step a walk can take, star_shaped_search.cpp:137; filled once per context */
+__global__ __launch_bounds__(256) void k_walk_table(urf_wu* tab, unsigned n)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        tab[i] = i ? urf_wu{ (float)(int)i - 1.0f, 1.0f / (float)(int)i } : urf_wu{ 0.f, 0.f };   /* [0]: no step of a walk; k_star_walk_few runs it as a no-op */
+}
+
+typedef urf_sg urf_walk_tile[64][URF_WALK_CHUNK + 2];   /* rows of 36 words: 16-byte reads of a lane's own row without bank conflicts */
+/* LDS of the two walk kernels: the chunk of pairs, a row per sector, and the sectors' places */
+__shared__ urf_walk_tile walk_tile;
+__shared__ unsigned walk_sbase[64], walk_slast[64];
+
+/* LDS hand-over between the lanes of ONE wave (its LDS operations execute in order): nothing but the compiler has to be held back */
+__device__ __forceinline__ void urf_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* One wave walks its 64 sectors from chunk c_start (W = the state in front of it) to the end, fetching for itself:
+ * the next 16 steps of all 64 sectors are 16 eight-byte loads in flight, parked in registers until the LDS tile is
+ * free again (chunk c+1 loads while chunk c is walked; the walk itself runs out of registers, so one tile suffices
+ * -- a second one would halve the resident workgroups).  A step past the sector's last one reads the last one again
+ * (the same line: no traffic), never past the sector.  The other waves of the workgroup may have left already: only
+ * wave-level ordering is used (k_star_walk is this loop from chunk 0 for a workgroup of one wave). */
+__device__ __forceinline__ void urf_walk_sequential(urf_walk_state& W, unsigned c_start, unsigned last, unsigned maxlast, const urf_sg* __restrict__ wsg,
+                                                    const urf_wu* __restrict__ tab, unsigned lane, float kdev, float slope_param, int dmin)
+{
+    urf_walk_tile& tile = walk_tile;
+    const unsigned* sbase = walk_sbase;
+    const unsigned* slast = walk_slast;
+    urf_sg v[16];
+    unsigned fo[16], fe[16];   /* the 16 sectors this lane loads for: its own step of the chunk / the sector's last step, as indices into wsg */
+#pragma unroll
+    for (unsigned r = 0; r < 16; r++) {
+        const unsigned sec = r * 4 + (lane >> 4);
+        fo[r] = sbase[sec] + (lane & 15);
+        fe[r] = sbase[sec] + slast[sec];
+    }
+    auto fetch = [&](unsigned c0) {
+#pragma unroll
+        for (unsigned r = 0; r < 16; r++) {
+            const unsigned e = fo[r] + c0;
+            v[r] = wsg[e < fe[r] ? e : fe[r]];   /* slope and distance term: one 8-byte load */
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (unsigned r = 0; r < 16; r++)
+            tile[r * 4 + (lane >> 4)][lane & 15] = v[r];
+    };
+    fetch(c_start);
+    park();
+    urf_wave_lds_sync();
+    for (unsigned c0 = c_start; c0 <= maxlast; c0 += URF_WALK_CHUNK) {
+        if (!__any(W.lim != 0))
+            break;
+        const bool more = c0 + URF_WALK_CHUNK <= maxlast;
+        if (more)
+            fetch(c0 + URF_WALK_CHUNK);
+        urf_sg sg[URF_WALK_CHUNK];
+        {
+            const float4* row = reinterpret_cast<const float4*>(&tile[lane][0]);
+#pragma unroll
+            for (unsigned j = 0; j < URF_WALK_CHUNK / 2; j++) {
+                const float4 q = row[j];
+                sg[2 * j] = urf_sg{ q.x, q.y };
+                sg[2 * j + 1] = urf_sg{ q.z, q.w };
+            }
+        }
+        bool walked = false;
+        if (!__any(W.nan != 0.0f))
+            walked = (c0 != 0 && (int)c0 > dmin) ? urf_walk_chunk_fast<true>(W, c0, sg, tab + c0, kdev, slope_param, dmin)
+                                                 : urf_walk_chunk_fast<false>(W, c0, sg, tab + c0, kdev, slope_param, dmin);
+        if (!walked)
+            urf_walk_chunk_general(W, c0, &tile[lane][0], kdev, slope_param, dmin);
+        if (c0 + URF_WALK_CHUNK > last)
+            W.lim = 0;
+        urf_wave_lds_sync();   /* the tile has been read: it may take the next chunk */
+        if (more)
+            park();
+        urf_wave_lds_sync();
+    }
+}
+
+/* what every wave of a walk kernel starts with: its 64 sectors' places (sbase / slast in LDS, by wave 0) and the longest walk among them */
+struct urf_walk_sectors {
+    unsigned k, n, base, last, maxlast;
+    bool have;
+};
+__device__ __forceinline__ urf_walk_sectors urf_walk_prologue(const urf_kargs& a, unsigned s, unsigned K, unsigned lane, bool publish)
+{
+    unsigned* sbase = walk_sbase;
+    unsigned* slast = walk_slast;
+    urf_walk_sectors q;
+    q.k = blockIdx.x * 64 + lane;
+    q.have = q.k < K;
+    q.n = q.have ? a.sec_cnt[(size_t)s * K + q.k] : 0;
+    const unsigned rel = q.have ? a.sec_off[(size_t)s * (K + 1) + q.k] : 0;
+    q.base = urf_sbase(a, s) + rel;
+    q.last = q.n >= 2 ? a.star_first[(size_t)s * K + q.k] : 0;
+    if (publish) {
+        sbase[lane] = q.last ? rel : 0u;   /* a sector without a walk reads the scan's first pair, whatever it is */
+        slast[lane] = q.last;
+    }
+    unsigned maxlast = q.last;
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned w = __shfl_xor(maxlast, o);
+        maxlast = w > maxlast ? w : maxlast;
+    }
+    q.maxlast = (unsigned)__builtin_amdgcn_readfirstlane((int)maxlast);
+    return q;
+}
+
 __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp)
 {
-    __shared__ float tS[64][URF_WALK_CHUNK + 1], tG[64][URF_WALK_CHUNK + 1];
-    __shared__ unsigned sbase[64], slast[64];
-    __shared__ float sinv[URF_WALK_INV];   /* 1.0f / (float)i, star_shaped_search.cpp:137 */
+    urf_walk_tile& tile = walk_tile;
+    unsigned* sbase = walk_sbase;
+    unsigned* slast = walk_slast;
     const unsigned K = (unsigned)dp.p.sectors;
     const unsigned s = blockIdx.y, lane = threadIdx.x;
     const unsigned k = blockIdx.x * 64 + lane;
@@ -2419,51 +2583,46 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
     const unsigned C = (unsigned)dp.p.channels;
     const bool have = k < K;
     const unsigned n = have ? a.sec_cnt[(size_t)s * K + k] : 0;
-    const unsigned base = have ? urf_sbase(a, s) + a.sec_off[(size_t)s * (K + 1) + k] : 0;
-    unsigned last = n >= 2 ? a.star_first[(size_t)s * K + k] : 0;
-    sbase[lane] = base;
+    const unsigned rel = have ? a.sec_off[(size_t)s * (K + 1) + k] : 0;
+    const unsigned base = urf_sbase(a, s) + rel;
+    const unsigned last = n >= 2 ? a.star_first[(size_t)s * K + k] : 0;
+    sbase[lane] = last ? rel : 0u;   /* a sector without a walk reads the scan's first pair, whatever it is */
     slast[lane] = last;
     unsigned maxlast = last;
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned w = __shfl_xor(maxlast, o);
         maxlast = w > maxlast ? w : maxlast;
     }
+    maxlast = (unsigned)__builtin_amdgcn_readfirstlane((int)maxlast);
     __syncthreads();
 
-    /* the next 16 steps of all 64 sectors: 32 loads in flight, then parked in registers until the
-     * LDS tile is free again (chunk c+1 loads while chunk c is walked; the walk itself runs out of
-     * registers, so one tile suffices -- a second one would halve the resident workgroups) */
-    float vs[16], vg[16];
-    unsigned rbase[16], rlast[16];   /* the 16 sectors this lane loads for: fixed for the whole walk */
+    /* urf_walk_sequential from chunk 0, written out: the compiler keeps this form in 149 registers (three waves
+     * per SIMD) and the inlined function in 211 */
+    const urf_sg* __restrict__ wsg = a.wsg + urf_sbase(a, s);
+    urf_sg v[16];
+    unsigned fo[16], fe[16];
 #pragma unroll
     for (unsigned r = 0; r < 16; r++) {
-        rbase[r] = sbase[r * 4 + (lane >> 4)];
-        rlast[r] = slast[r * 4 + (lane >> 4)];
+        const unsigned sec = r * 4 + (lane >> 4);
+        fo[r] = sbase[sec] + (lane & 15);
+        fe[r] = sbase[sec] + slast[sec];
     }
     auto fetch = [&](unsigned c0) {
-        const unsigned e = c0 + (lane & 15);
 #pragma unroll
         for (unsigned r = 0; r < 16; r++) {
-            const bool on = e >= 1 && e <= rlast[r];
-            const urf_sg sg = on ? a.wsg[rbase[r] + e] : urf_sg{ 0.f, 0.f };   /* slope and distance term: one 8-byte load */
-            vs[r] = sg.slp;
-            vg[r] = sg.g;
+            const unsigned e = fo[r] + c0;
+            v[r] = wsg[e < fe[r] ? e : fe[r]];   /* slope and distance term: one 8-byte load */
         }
     };
     auto park = [&]() {
 #pragma unroll
-        for (unsigned r = 0; r < 16; r++) {
-            const unsigned sec = r * 4 + (lane >> 4);
-            tS[sec][lane & 15] = vs[r];
-            tG[sec][lane & 15] = vg[r];
-        }
+        for (unsigned r = 0; r < 16; r++)
+            tile[r * 4 + (lane >> 4)][lane & 15] = v[r];
     };
 
     const float kdev = dp.p.kdev_param, slope_param = dp.slope_param;
     const int dmin = dp.p.dmin_param;
     urf_walk_state W = { 0.f, 0.f, 0.f, 0u, last };
-    for (unsigned t = lane; t < URF_WALK_INV; t += 64)
-        sinv[t] = 1.0f / (float)(int)t;   /* [0] is never used */
     fetch(0);
     park();
     __syncthreads();
@@ -2473,29 +2632,25 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
         const bool more = c0 + URF_WALK_CHUNK <= maxlast;
         if (more)
             fetch(c0 + URF_WALK_CHUNK);
-        /* the chunk's operands first: slopes, distance terms and the wave-uniform 1 / i (LDS
-         * table; anything fetched inside the dependent chain below would cost more than the step) */
-        float sl[URF_WALK_CHUNK], gg[URF_WALK_CHUNK], uu[URF_WALK_CHUNK];
-        bool anynan = W.nan != 0.0f;
+        urf_sg sg[URF_WALK_CHUNK];
+        {
+            const float4* row = reinterpret_cast<const float4*>(&tile[lane][0]);
 #pragma unroll
-        for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
-            sl[j] = tS[lane][j];
-            gg[j] = tG[lane][j];
-            anynan = anynan || sl[j] != sl[j];
+            for (unsigned j = 0; j < URF_WALK_CHUNK / 2; j++) {
+                const float4 q = row[j];
+                sg[2 * j] = urf_sg{ q.x, q.y };
+                sg[2 * j + 1] = urf_sg{ q.z, q.w };
+            }
         }
-        if (c0 + URF_WALK_CHUNK <= URF_WALK_INV) {
-#pragma unroll
-            for (unsigned j = 0; j < URF_WALK_CHUNK; j++)
-                uu[j] = sinv[c0 + j];
-        } else {
-#pragma unroll
-            for (unsigned j = 0; j < URF_WALK_CHUNK; j++)
-                uu[j] = 1.0f / (float)(int)(c0 + j);
-        }
-        __syncthreads();   /* the tile has been read: it may take the next chunk */
-        urf_walk_chunk(W, c0, sl, gg, uu, anynan, kdev, slope_param, dmin);
+        bool walked = false;
+        if (!__any(W.nan != 0.0f))
+            walked = (c0 != 0 && (int)c0 > dmin) ? urf_walk_chunk_fast<true>(W, c0, sg, a.walk_tab + c0, kdev, slope_param, dmin)
+                                                 : urf_walk_chunk_fast<false>(W, c0, sg, a.walk_tab + c0, kdev, slope_param, dmin);
+        if (!walked)
+            urf_walk_chunk_general(W, c0, &tile[lane][0], kdev, slope_param, dmin);
         if (c0 + URF_WALK_CHUNK > last)
             W.lim = 0;
+        __syncthreads();   /* the tile has been read: it may take the next chunk (one wave per workgroup: no s_barrier in the code) */
         if (more)
             park();
         __syncthreads();
@@ -2503,6 +2658,237 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
     const int hit = urf_walk_report(a, s, K, C, k, n, base, W.hit_i);
     if (have)
         a.star_hit[(size_t)s * K + k] = hit;
+}
+
+/* The same walk for a handful of sweeps (the callback path: one), where the device is empty and the time is the
+ * chain of one wave's instructions: a wave that has its SIMD to itself issues an independent instruction every 4.7
+ * cycles, a dependent one every 9.3, a mix like the walk's every 7 (tools/bench_micro/lonewave.hip,
+ * profiles/r4_lonewave.txt): the two chains of a step (mean: three instructions, deviation: four) take 49 cycles, the
+ * whole step of k_star_walk 130.  Five waves share the 64 sectors' chunk instead, one chunk apart, one barrier per
+ * chunk, tile / X / hits double-buffered:
+ *   wave 0       nothing but the chains of chunk c: running mean and deviation after each step, left in LDS (X);
+ *   waves 1..4   the hit tests of chunk c - 1, four steps each, from X and the pairs they kept from the tile; a
+ *                quarter of the loads of chunk c + 2 and of the parking of chunk c + 1 each;
+ *   wave 1       also keeps the walks' state: merges the published hits (chunk c - 2) and tells the others through
+ *                ctl when no sector is walking any more (they leave one chunk later, all in the same iteration).
+ * A NaN mean in a sector with a walk (a NaN slope: star_shaped_search.cpp:131-132) ends the pipeline: wave 0 goes on
+ * alone from the chunk it appeared in, with the state it had in front of it and the hits merged so far
+ * (urf_walk_sequential). */
+#define URF_WALK_FEW_THREADS 320
+#ifndef URF_WALK_FEW_SCANS
+#define URF_WALK_FEW_SCANS 32u
+#endif
+/* The hit tests of four steps, stage by stage: the opaque multiplications stay in the order they are written in, and a
+ * lone wave waits 9 cycles for a result it needs at once, 5 for one it needs a few instructions later. */
+template <bool ABOVE>
+__device__ __forceinline__ unsigned urf_walk_tests_quarter(unsigned i0, const urf_sg (&sg)[4], const float4 (&x)[2], float kdev, float slope_param, int dmin)
+{
+    float t[4], q[4];
+#pragma unroll
+    for (unsigned j = 0; j < 4; j++)
+        t[j] = urf_mul_f32(sg[j].slp, sg[j].slp);
+#pragma unroll
+    for (unsigned j = 0; j < 4; j++) {
+        const float na = (j & 1) ? x[j >> 1].z : x[j >> 1].x;
+        q[j] = urf_mul_f32(na, na);
+    }
+#pragma unroll
+    for (unsigned j = 0; j < 4; j++)
+        t[j] = t[j] - q[j];
+#pragma unroll
+    for (unsigned j = 0; j < 4; j++)
+        t[j] = urf_mul_f32(t[j], kdev);
+#pragma unroll
+    for (unsigned j = 0; j < 4; j++)
+        t[j] = urf_mul_f32(t[j], sg[j].g);
+    bool h[4];
+#pragma unroll
+    for (unsigned j = 0; j < 4; j++) {
+        const unsigned i = i0 + j;
+        const float nd = (j & 1) ? x[j >> 1].w : x[j >> 1].y;
+        h[j] = (ABOVE || i != 0) & ((sg[j].slp > slope_param) | ((ABOVE || (int)i > dmin) & (t[j] > nd)));   /* :142-143; the walk starts at 1 */
+    }
+    unsigned hit = 0;
+#pragma unroll
+    for (int j = 3; j >= 0; j--)
+        hit = h[j] ? i0 + (unsigned)j : hit;
+    return hit;
+}
+
+__global__ __launch_bounds__(URF_WALK_FEW_THREADS) void k_star_walk_few(urf_kargs a, urf_dev_params dp)
+{
+    const unsigned* sbase = walk_sbase;
+    const unsigned* slast = walk_slast;
+    __shared__ urf_walk_tile tile2;                                 /* chunks c odd (walk_tile: c even) */
+    __shared__ __attribute__((aligned(16))) float X[2][64][2 * URF_WALK_CHUNK + 4];   /* (mean, deviation) after each step of the chunk, a row per sector */
+    __shared__ __attribute__((aligned(16))) unsigned hitb[2][64][4];   /* first raw hit of each quarter of the chunk, 0 = none */
+    __shared__ unsigned ctl[2], nan_at, fin_hit[64], fin_lim[64];
+    const unsigned K = (unsigned)dp.p.sectors;
+    const unsigned s = blockIdx.y, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (a.info[s].status != URF_OK)
+        return;
+    const urf_walk_sectors q = urf_walk_prologue(a, s, K, lane, wave == 0);
+    if (threadIdx.x == 0) {
+        nan_at = 0xffffffffu;
+        ctl[0] = 1u;
+        ctl[1] = 1u;
+    }
+    __syncthreads();
+    const urf_sg* __restrict__ wsg = a.wsg + urf_sbase(a, s);
+    const float kdev = dp.p.kdev_param, slope_param = dp.slope_param;
+    const int dmin = dp.p.dmin_param;
+    const unsigned last = q.last, nchunks = q.maxlast / URF_WALK_CHUNK + 1;
+    const unsigned b = wave ? wave - 1u : 0u;   /* waves 1..4: quarter b of every chunk */
+
+    /* waves 1..4: four of the sixteen loads of a chunk each */
+    urf_sg v[4];
+    unsigned fo[4], fe[4];
+#pragma unroll
+    for (unsigned r = 0; r < 4; r++) {
+        const unsigned sec = (4 * b + r) * 4 + (lane >> 4);
+        fo[r] = sbase[sec] + (lane & 15);
+        fe[r] = sbase[sec] + slast[sec];
+    }
+    auto fetch = [&](unsigned c0) {
+#pragma unroll
+        for (unsigned r = 0; r < 4; r++) {
+            const unsigned e = fo[r] + c0;
+            v[r] = wsg[e < fe[r] ? e : fe[r]];
+        }
+    };
+    auto park = [&](urf_walk_tile& t) {
+#pragma unroll
+        for (unsigned r = 0; r < 4; r++)
+            t[(4 * b + r) * 4 + (lane >> 4)][lane & 15] = v[r];
+    };
+    if (wave) {
+        fetch(0);
+        park(walk_tile);
+        if (nchunks > 1)
+            fetch(URF_WALK_CHUNK);
+    }
+    /* wave 0: the (i - 1, 1 / i) of its next chunk, asked for as soon as the previous chunk's are used up (they come from
+     * the far side of the L2); [0] = (0, 0), which with a slope of 0 leaves the state at 0: step 0 needs no exception */
+    urf_wu wu[URF_WALK_CHUNK];
+#pragma unroll
+    for (unsigned j = 0; j < URF_WALK_CHUNK; j++)
+        wu[j] = a.walk_tab[j];
+    float avg = 0.f, dev = 0.f;      /* wave 0: the state behind the chunk it walked last */
+    unsigned lim = last, hit_i = 0;  /* wave 1: the walks' state */
+    urf_sg sgp[4];                   /* waves 1..4: their steps' pairs of the chunk they test next */
+#pragma unroll
+    for (unsigned j = 0; j < 4; j++)
+        sgp[j] = urf_sg{ 0.f, 0.f };
+    unsigned stop = 0xffffffffu;
+    for (unsigned c = 0;; c++) {
+        __syncthreads();   /* tile[c & 1] holds chunk c, X[(c - 1) & 1] chunk c - 1, hitb[(c - 1) & 1] the hits of chunk c - 2 */   /* tile[c & 1] holds chunk c, X[(c - 1) & 1] chunk c - 1, hitb[(c - 1) & 1] the hits of chunk c - 2 */
+        stop = nan_at;
+        const unsigned walking = ctl[(c - 1) & 1];   /* wave 1's word of the iteration before */
+        if (wave == 1 && c >= 2) {
+            const uint4 h = *reinterpret_cast<const uint4*>(&hitb[(c - 1) & 1][lane][0]);
+            const unsigned hit = h.x ? h.x : h.y ? h.y : h.z ? h.z : h.w;
+            if (lim != 0 && hit != 0 && hit <= lim) {
+                hit_i = hit;
+                lim = 0;
+            }
+            if ((c - 1) * URF_WALK_CHUNK > last)
+                lim = 0;
+        }
+        if (!walking || stop != 0xffffffffu || c > nchunks + 2)
+            break;
+        if (wave == 1) {
+            const unsigned alive = __any(lim != 0) ? 1u : 0u;
+            if (lane == 0)
+                ctl[c & 1] = alive;
+        }
+        urf_walk_tile& tc = (c & 1) ? tile2 : walk_tile;
+        if (wave == 0) {
+            if (c < nchunks) {
+                float sl[URF_WALK_CHUNK];
+                {
+                    const float4* row = reinterpret_cast<const float4*>(&tc[lane][0]);
+#pragma unroll
+                    for (unsigned j = 0; j < URF_WALK_CHUNK / 2; j++) {
+                        const float4 t = row[j];
+                        sl[2 * j] = t.x;
+                        sl[2 * j + 1] = t.z;
+                    }
+                }
+                if (c == 0)
+                    sl[0] = 0.f;   /* the walk starts at 1 */
+                const float avg0 = avg, dev0 = dev;
+                float4* xw = reinterpret_cast<float4*>(&X[c & 1][lane][0]);
+                float na_[URF_WALK_CHUNK], nd_[URF_WALK_CHUNK];
+#pragma unroll
+                for (unsigned j = 0; j < URF_WALK_CHUNK; j++) {
+                    /* star_shaped_search.cpp:135-140; through urf_mul_f32 & co. because the SLP vectoriser otherwise pairs
+                     * mean and deviation into v_pk_* chains (three dependent packed operations and four v_mov per step) */
+                    const float na = urf_mul_f32(urf_add_f32(urf_mul_f32(avg, wu[j].w), sl[j]), wu[j].u);
+                    const float nd = urf_mul_f32(urf_add_absdiff_f32(urf_mul_f32(dev, wu[j].w), sl[j], na), wu[j].u);
+                    avg = na;
+                    dev = nd;
+                    na_[j] = na;
+                    nd_[j] = nd;
+                }
+#pragma unroll
+                for (unsigned j = 0; j < URF_WALK_CHUNK; j++)
+                    wu[j] = a.walk_tab[(c + 1) * URF_WALK_CHUNK + j];   /* the table is longer than any walk by two chunks */
+#pragma unroll
+                for (unsigned j = 0; j < URF_WALK_CHUNK / 2; j++)
+                    xw[j] = make_float4(na_[2 * j], nd_[2 * j], na_[2 * j + 1], nd_[2 * j + 1]);
+                /* (a sector that has found its curb point walks on over real pairs, one without a walk over whatever the
+                 * scan's first pair holds: only the former's mean says anything) */
+                if (__any(last != 0u && avg != avg)) {
+                    avg = avg0;
+                    dev = dev0;
+                    if (lane == 0)
+                        nan_at = c;
+                }
+            }
+        } else {
+            urf_sg sgn[4];
+            float4 x[2];
+            {
+                const float4* row = reinterpret_cast<const float4*>(&tc[lane][4 * b]);
+                const float4* xr = reinterpret_cast<const float4*>(&X[(c - 1) & 1][lane][8 * b]);
+#pragma unroll
+                for (unsigned j = 0; j < 2; j++) {
+                    const float4 t = row[j];
+                    sgn[2 * j] = urf_sg{ t.x, t.y };
+                    sgn[2 * j + 1] = urf_sg{ t.z, t.w };
+                    x[j] = xr[j];
+                }
+            }
+            if (c + 1 < nchunks) {
+                park((c & 1) ? walk_tile : tile2);   /* chunk c + 1 */
+                if (c + 2 < nchunks)
+                    fetch((c + 2) * URF_WALK_CHUNK);
+            }
+            if (c >= 1 && c <= nchunks) {
+                const unsigned i0 = (c - 1) * URF_WALK_CHUNK + 4 * b;
+                const unsigned hit = (i0 != 0 && (int)i0 > dmin) ? urf_walk_tests_quarter<true>(i0, sgp, x, kdev, slope_param, dmin)
+                                                                 : urf_walk_tests_quarter<false>(i0, sgp, x, kdev, slope_param, dmin);
+                hitb[c & 1][lane][b] = hit;
+            }
+#pragma unroll
+            for (unsigned j = 0; j < 4; j++)
+                sgp[j] = sgn[j];
+        }
+    }
+    /* all five left in the same iteration: the walks' state goes from wave 1 to wave 0 */
+    if (wave == 1) {
+        fin_hit[lane] = hit_i;
+        fin_lim[lane] = lim;
+    }
+    __syncthreads();
+    if (wave != 0)
+        return;
+    urf_walk_state W = { avg, dev, 0.f, fin_hit[lane], fin_lim[lane] };
+    if (stop != 0xffffffffu && __any(W.lim != 0))
+        urf_walk_sequential(W, stop * URF_WALK_CHUNK, last, q.maxlast, wsg, a.walk_tab, lane, kdev, slope_param, dmin);
+    const int hit = urf_walk_report(a, s, K, (unsigned)dp.p.channels, q.k, q.n, q.base, W.hit_i);
+    if (q.have)
+        a.star_hit[(size_t)s * K + q.k] = hit;
 }
 
 /* ------------------------------------------------------------------------- */
