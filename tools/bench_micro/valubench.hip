@@ -2,8 +2,8 @@
 // (DESIGN.md assumed four -- a SIMD16 issuing a wave64 over four cycles, as on GCN --, MI355X_MICROARCH.md "Wave
 // scheduling" says two: SIMD32.)  Every wave runs a loop of N independent instruction chains of one kind; W waves per
 // SIMD run side by side (grid = CUs x W workgroups of 256 threads, one wave per SIMD each).  Two clocks:
-//   - s_memtime around the loop inside the kernel (it ticks at the 100 MHz wall clock; scaled to shader cycles with the
-//     nominal clockRate): cycles per instruction and SIMD = cycles / (W x instructions per wave) once the SIMD is saturated;
+//   - s_memtime around the loop inside the kernel (it counts shader cycles -- tools/bench_micro/lonewave.hip compares it
+//     with the 100 MHz s_memrealtime --; the table below is computed from the second clock and the nominal clockRate);
 //   - hipEvents around the launch: wave-instructions per second and SIMD.
 //   hipcc --offload-arch=gfx950 -O3 tools/bench_micro/valubench.hip -o tools/bench_micro/valubench && tools/bench_micro/valubench
 #include <hip/hip_runtime.h>
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k(unsigned iters, float seed, unsigned lo
         cyc[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-static double wall_mhz = 100.0;   // rate of s_memtime (hipDeviceAttributeWallClockRate)
+static double wall_mhz = 100.0;   // hipDeviceAttributeWallClockRate: the rate of s_memrealtime (s_memtime counts shader cycles: lonewave.hip)
 template <int OP>
 static int run(int n_cus, unsigned iters, unsigned long long* d_cyc, float* d_sink, double clock_mhz)
 {
@@ -226,7 +226,7 @@ int main()
     (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
     if (wall_khz > 0)
         wall_mhz = wall_khz * 1e-3;
-    printf("device %s, %d CUs, clockRate %.0f MHz, wall clock %.0f MHz (s_memtime ticks at the wall-clock rate on gfx9)\n", prop.name, n_cus,
+    printf("device %s, %d CUs, clockRate %.0f MHz, wall clock %.0f MHz (s_memrealtime; s_memtime counts shader cycles, see lonewave.hip)\n", prop.name, n_cus,
            prop.clockRate * 1e-3, wall_khz * 1e-3);
     unsigned long long* d_cyc;
     float* d_sink;
