@@ -6,7 +6,7 @@ Last runs: seeds 10000..12499 and 20000..29999 (round 1), 30000..33999, 40000..7
 cot / position ranking changes), 200000..259999 (round 3, HEAD: one record word per slot, curb lists and interval masks in k_beams, k_ring_table a firing at a
 time, empty-tile shortcuts), 300000..329999 (round 3, final: wave-per-sector sort for two-run sectors only -- these unorganised clouds take the
 workgroup kernel --, the callback path's short sequence with rerun, messages staged as planes, k_index with wave scans, k_beams in two groups),
-400000..414999, 500000..559999, 600000..799999 (round 4, HEAD: a third of the clouds with points on the sensor's axis -- NaN azimuths, k_nan_rings --, organised-tile path in k_split): 0 mismatches."""
+400000..414999, 500000..559999, 600000..799999, 900000..919999, 1000000..1199999 (round 4: a third of the clouds with points on the sensor's axis -- NaN azimuths, k_nan_rings --, organised-tile path in k_split): 0 mismatches."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
 import numpy as np, oracles as O, urban_road_filter_amd as u
