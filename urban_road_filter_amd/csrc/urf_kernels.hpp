@@ -2782,7 +2782,10 @@ __global__ __launch_bounds__(URF_WALK_FEW_THREADS) void k_star_walk_few(urf_karg
     unsigned stop = 0xffffffffu;
     for (unsigned c = 0;; c++) {
         __syncthreads();   /* tile[c & 1] holds chunk c, X[(c - 1) & 1] chunk c - 1, hitb[(c - 1) & 1] the hits of chunk c - 2 */   /* tile[c & 1] holds chunk c, X[(c - 1) & 1] chunk c - 1, hitb[(c - 1) & 1] the hits of chunk c - 2 */
+        /* (wave 0 may write nan_at = c while a late wave is still here: only a word of an EARLIER iteration counts, so that
+         * all five see the same thing in the same iteration) */
         stop = nan_at;
+        stop = stop < c ? stop : 0xffffffffu;
         const unsigned walking = ctl[(c - 1) & 1];   /* wave 1's word of the iteration before */
         if (wave == 1 && c >= 2) {
             const uint4 h = *reinterpret_cast<const uint4*>(&hitb[(c - 1) & 1][lane][0]);
