@@ -80,3 +80,26 @@ def test_product_does_not_reference_the_oracle():
             if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in txt.lower(), fn
+
+
+@pytest.mark.parametrize("client", ["detector_demo", "marker_demo", "two_contexts_demo"])
+def test_cpp_clients_build_against_the_product_library(tmp_path, client):
+    """What a maintainer's node does with the library -- csrc/detector.hpp and include/urf.h compiled with g++ and linked
+    against liburf_hip.so (no hipcc, no test hooks) -- builds here without a GPU; tests/test_gpu_detector.py and
+    tests/test_markers.py run the same clients on one."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    u.lib()   # (built)
+    pkg = os.path.join(ROOT, "urban_road_filter_amd")
+    exe = str(tmp_path / client)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", client + ".cpp"), "-o", exe,
+                           "-L" + pkg, "-l:liburf_hip.so", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    assert os.path.exists(exe)
+    # the client needs nothing the product library does not export
+    undefined = subprocess.run(["nm", "-u", exe], capture_output=True, text=True).stdout.split()
+    wanted = {w.split("@")[0] for w in undefined if "urf" in w}          # C entry points and the adapter's C++ members
+    exported = set(subprocess.run(["nm", "-D", "--defined-only", u.lib_path()], capture_output=True, text=True).stdout.split())
+    assert wanted and wanted <= exported, wanted - exported
