@@ -218,15 +218,20 @@ def e2e_callback_path(u, O, params, n_sweeps=8, reps=40, stream_reps=160):
         out["e2e_overlapped_scans_per_s_pinned_producer_python_client"] = round(max(stream(True), stream(True)), 1)
         # the same loops inside the library (urf_bench_callback_stream): what a C / C++ client -- the reference is a
         # C++ node -- gets, without a Python interpreter between the calls; the labels of the last sweep are checked
+        # (the better of two passes, like the Python client's figures above: the host's side of the staged path -- a gather of
+        # 4 MiB per sweep -- varies with whatever else the box's cores are doing)
         hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 16, IN_FLIGHT)
-        sec, labn = hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT)
         lbn, _, _ = O.run_b(*u.synth_cloud(RINGS, COLS, 1, 9000 + (stream_reps - 1) % n_sweeps), params)
-        if not np.array_equal(labn, lbn):
-            raise SystemExit("parity failure on the callback path (native loop)")
-        out["e2e_overlapped_scans_per_s"] = round(stream_reps / sec, 1)
+        best = None
+        for _ in range(2):
+            sec, labn = hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT)
+            if not np.array_equal(labn, lbn):
+                raise SystemExit("parity failure on the callback path (native loop)")
+            best = sec if best is None else min(best, sec)
+        out["e2e_overlapped_scans_per_s"] = round(stream_reps / best, 1)
         hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 16, IN_FLIGHT, producer_pinned=True)
-        sec, _ = hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT, producer_pinned=True)
-        out["e2e_overlapped_scans_per_s_pinned_producer"] = round(stream_reps / sec, 1)
+        best = min(hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT, producer_pinned=True)[0] for _ in range(2))
+        out["e2e_overlapped_scans_per_s_pinned_producer"] = round(stream_reps / best, 1)
         hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 8, 1)
         sec, _ = hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, reps, 1)
         out["e2e_latency_ms_native_mean"] = round(1e3 * sec / reps, 4)
