@@ -2,7 +2,7 @@
 own sources built with the shared libm (oracle/_ref/urf_ref_libm) on further random clouds / parameter sets of tests/fuzz.py --
 labels, summaries and the three published orders.  Needs /root/reference at build time only (oracle/Makefile).
     python tools/fuzz_cpu_more.py [first_seed last_seed]
-Last run: seeds 2000..5999 (round 4): see profiles/README.md."""
+Last run: seeds 2000..105999 (round 4): 0 mismatches (profiles/README.md)."""
 import os
 import sys
 
