@@ -103,3 +103,16 @@ def test_cpp_clients_build_against_the_product_library(tmp_path, client):
     wanted = {w.split("@")[0] for w in undefined if "urf" in w}          # C entry points and the adapter's C++ members
     exported = set(subprocess.run(["nm", "-D", "--defined-only", u.lib_path()], capture_output=True, text=True).stdout.split())
     assert wanted and wanted <= exported, wanted - exported
+    from conftest import gpu_available
+    if client == "detector_demo" and not gpu_available():
+        # no device: the adapter says so and gives up -- there is no host path behind it
+        import struct
+        import numpy as np
+        cloud = tmp_path / "cloud.bin"
+        with open(cloud, "wb") as f:
+            f.write(struct.pack("<I", 4096))
+            for _ in range(4):
+                f.write(np.zeros(4096, np.float32).tobytes())
+        r = subprocess.run([exe, str(cloud), str(tmp_path / "out.bin"), "1"], capture_output=True, text=True)
+        assert r.returncode != 0 and "no usable HIP device" in (r.stderr + r.stdout)
+        assert not os.path.exists(tmp_path / "out.bin")
