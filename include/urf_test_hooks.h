@@ -21,7 +21,10 @@ extern "C" {
  * curbs at |y| = 4 m, 2 = narrow street (curbs at |y| = 3 m, inside the reach
  * of the innermost rings, so that the blind-spot logic of blind_spots.cpp:17-99
  * engages); column-major "firing order" (idx = col*rings + ring);
- * per-sector radial ties removed.  Writes n = rings*cols floats to x, y, z. */
+ * per-sector radial ties removed.  Scenes 3 / 4 = scenes 1 / 2 as a sensor's driver
+ * delivers them: range noise (sigma 1 cm), range quantised to 2 mm, 1.5 % drop-outs,
+ * the planar-range ties LEFT IN (~10 000 per 64 x 2048 sweep).
+ * Writes n = rings*cols floats to x, y, z. */
 int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
                     float* x, float* y, float* z);
 

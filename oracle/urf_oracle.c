@@ -17,8 +17,9 @@
  *   D1  star sector index == sectors (azimuth in (-5e-7,0) rad) wraps to
  *       sector 0 instead of dereferencing beamp[360] == nullptr
  *       (star_shaped_search.cpp:20,157,171-173);
- *   D2  sector points are ordered by (r, ROI index): std::sort's order of
- *       equal r is unspecified (star_shaped_search.cpp:109);
+ *   (D2 of rounds 1-4 -- equal planar ranges of a sector ordered by ROI index -- is gone: the
+ *       sector is sorted by a literal restatement of libstdc++'s std::sort, urf_stdsort.h, whose
+ *       order of equal ranges is a deterministic function of the input and decides labels;)
  *   D3  array3D[k][-1] / [n] over-reads of blind_spots.cpp:107,216,... are
  *       not performed (the value read is never used);
  *   D4  array3D[1] / array3D[10] are only touched when channels > 1 / > 10
@@ -34,6 +35,7 @@
 #include "urf_oracle.h"
 #include "urf_libm.h"
 #include "urf_rdp.h"
+#include "urf_stdsort.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -55,11 +57,7 @@ typedef struct {
 } pt3;
 
 /* data_structures.hpp:51-56 */
-typedef struct {
-    int id;
-    float r;
-    float fi;
-} polar;
+typedef urf_polar polar;
 
 /* data_structures.hpp:58-64 */
 typedef struct {
@@ -78,14 +76,23 @@ static void box_push(box* b, polar v)
     b->p[b->n++] = v;
 }
 
-/* star_shaped_search.cpp:22 ptcmpr, made total by the ROI index (deviation D2) */
-static int polar_cmp(const void* a, const void* b)
+/* star_shaped_search.cpp:22 ptcmpr and :109 std::sort: urf_stdsort.h.  Exported for tests/test_stdsort.py, which holds
+ * the restatement against the real std::sort (oracle/stdsort_ref.cpp). */
+long urf_oracle_std_sort_heap_sorts(void) { return urf_ss_heap_sorts; }
+void urf_oracle_std_sort(float* r, int* id, int n)
 {
-    const polar* pa = (const polar*)a;
-    const polar* pb = (const polar*)b;
-    if (pa->r < pb->r) return -1;
-    if (pb->r < pa->r) return 1;
-    return (pa->id > pb->id) - (pa->id < pb->id);
+    polar* p = (polar*)malloc((size_t)(n > 0 ? n : 1) * sizeof(polar));
+    for (int i = 0; i < n; i++) {
+        p[i].id = id[i];
+        p[i].r = r[i];
+        p[i].fi = 0.f;
+    }
+    urf_std_sort_polar(p, n);
+    for (int i = 0; i < n; i++) {
+        id[i] = p[i].id;
+        r[i] = p[i].r;
+    }
+    free(p);
 }
 
 /* star_shaped_search.cpp:32-66 beam_init: per-sector constants.  `fi` is a
@@ -134,7 +141,7 @@ static void beamfunc(box* bm, pt3* array2D, const urf_params* prm, float slope_p
         s = bm->n = w;
     }
 
-    qsort(bm->p, (size_t)s, sizeof(polar), polar_cmp);   /* :109 */
+    urf_std_sort_polar(bm->p, s);   /* :109, libstdc++'s introsort literally (urf_stdsort.h) */
 
     if (s > 1) {   /* :112-150 */
         float kdev = prm->kdev_param;

@@ -76,6 +76,11 @@ int urf_oracle_classify(const float* x, const float* y, const float* z, uint32_t
                         const urf_params* params, uint8_t* labels,
                         urf_scan_info* info, urf_oracle_debug* dbg);
 
+/* star_shaped_search.cpp:109: libstdc++'s std::sort by r (urf_stdsort.h) on n (r, id) records, in place; for
+ * tests/test_stdsort.py */
+void urf_oracle_std_sort(float* r, int* id, int n);
+long urf_oracle_std_sort_heap_sorts(void);   /* calls of the heap-sort fallback so far (depth limit reached) */
+
 /* The three libm replacements, exported for tests/test_libm.py. */
 float urf_oracle_acosf(float x);
 float urf_oracle_asinf(float x);

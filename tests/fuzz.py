@@ -3,10 +3,12 @@
 
 The clouds deliberately violate everything an organised sweep guarantees: arbitrary point
 order, uneven rings, empty / crowded sectors, points outside the ROI, NaNs, few points.
-What they avoid is only what the REFERENCE ITSELF leaves undefined:
-exact planar-range ties inside a star sector (unstable std::sort), the sector-360 band (null
-dereference).  Points with x == y == 0 -- a NaN azimuth inside the reference's Lomuto quicksort, which
-handles it deterministically -- are part of a third of the cases (axis_points)."""
+What they avoid is only what the REFERENCE ITSELF leaves undefined: the
+sector-360 band (null dereference).  Points with x == y == 0 -- a NaN azimuth inside the reference's
+Lomuto quicksort, which handles it deterministically -- are part of a third of the cases (axis_points);
+exact planar-range ties inside a star sector -- ordered by libstdc++'s std::sort, deterministic as well
+and followed since r5 (oracle/urf_stdsort.h, k_star_ties) -- of two fifths of them (x / y snapped to a
+grid: many points share their (x, y) and differ in z, the kind of tie that decides labels)."""
 import numpy as np
 
 import urban_road_filter_amd as u
@@ -42,7 +44,8 @@ def random_params(rng, for_reference=False):
     return p
 
 
-def random_cloud(rng, n):
+def random_cloud(rng, n, tie_grid=0.0):
+    """tie_grid > 0: x and y are snapped to multiples of it and equal planar ranges stay in."""
     kind = rng.integers(0, 3)
     if kind == 0:      # scattered returns from a ground-like sheet with steps
         x = rng.uniform(-40, 40, n)
@@ -65,14 +68,18 @@ def random_cloud(rng, n):
     bad = rng.integers(0, n, max(1, n // 200))
     x[bad[: len(bad) // 2]] = np.nan
     z[bad[len(bad) // 2:]] = 50.0
-    # what the reference leaves undefined: planar-range ties inside a sector, x == y == 0
+    if tie_grid:
+        x = (np.round(x / np.float32(tie_grid)) * np.float32(tie_grid)).astype(np.float32)
+        y = (np.round(y / np.float32(tie_grid)) * np.float32(tie_grid)).astype(np.float32)
+    # x == y == 0 comes in through axis_points() only; tie-free clouds: no two equal planar ranges
     keep = ~((x == 0) & (y == 0))
-    r = np.sqrt(x * x + y * y)
-    _, first = np.unique(np.where(np.isnan(r), -1.0, r), return_index=True)
-    m = np.zeros(n, bool)
-    m[first] = True
-    m |= np.isnan(r)
-    keep &= m
+    if not tie_grid:
+        r = np.sqrt(x * x + y * y)
+        _, first = np.unique(np.where(np.isnan(r), -1.0, r), return_index=True)
+        m = np.zeros(n, bool)
+        m[first] = True
+        m |= np.isnan(r)
+        keep &= m
     fi = np.arctan2(y.astype(np.float64), x.astype(np.float64))
     keep &= ~((fi < 0) & (fi > -1e-5))   # stay clear of the sector-360 band
     return x[keep], y[keep], z[keep]
@@ -103,7 +110,9 @@ def axis_points(cloud, rng, count, near=0):
 def case(seed, for_reference=False):
     rng = np.random.default_rng(seed)
     n = int(rng.choice([40, 300, 3000, 20000]))
-    cloud, params = random_cloud(rng, n), random_params(rng, for_reference)
+    rng3 = np.random.default_rng(seed + 9_000_011)   # (a stream of its own, as below)
+    tie_grid = float(rng3.choice([1 / 64, 1 / 16, 1 / 4])) if rng3.random() < 0.4 else 0.0
+    cloud, params = random_cloud(rng, n, tie_grid), random_params(rng, for_reference)
     rng2 = np.random.default_rng(seed + 7_000_003)   # (a stream of its own: the clouds of a seed stay what they were)
     if rng2.random() < 1 / 3:
         cloud = axis_points(cloud, rng2, 1 if for_reference else int(rng2.integers(1, 4)), near=int(rng2.integers(0, 6)))
@@ -114,7 +123,7 @@ def cloud_with_identical_points(seed, n, pairs):
     """A street sweep in which `pairs` points have been overwritten by copies of other points: two identical points are
     neighbours in their star sector's sorted order, the slope between them is 0 / 0 = NaN, which the walk counts and
     skips (star_shaped_search.cpp:131-132).  Returns the cloud and the indices involved (which of two identical points
-    the walk marks is the tie the reference leaves open)."""
+    the walk marks is decided by std::sort's order of equal ranges)."""
     import oracles as O
     x, y, z = [a[:n].copy() for a in O.cfg_cloud("cfg2", seed)]
     rng = np.random.default_rng(seed)
@@ -137,3 +146,33 @@ def assert_equal_up_to_identical_points(lg, lb, scan, involved):
         for i in bad:
             twins = [j for j in involved if key(j) == key(i)]
             assert sorted(lg[twins]) == sorted(lb[twins]), (i, twins)
+
+
+def killer_sector_cloud(n, dup, seed):
+    """n points of ONE star sector (polar angle 10.2 .. 10.8 deg) whose planar ranges, in input order, are an input on
+    which libstdc++'s std::sort reaches its depth limit (McIlroy's adversary against the real std::sort,
+    oracle/stdsort_ref.cpp), a fraction `dup` of them lowered onto their neighbour in value so that equal ranges occur
+    (0.05 / 0.1: the limit is still reached, tests assert it); plus a thin sweep around it so that rings and the other
+    sectors exist.  Equal adversary values share their (x, y) exactly; heights differ."""
+    import ctypes as C
+    import os
+    import oracles as O
+    O.ensure_built()
+    ref = C.CDLL(os.path.join(O.ORACLE_DIR, "libstdsort_ref.so"))
+    ref.urf_ref_killer.argtypes = [C.c_void_p, C.c_int]
+    v = np.zeros(n, np.float32)
+    ref.urf_ref_killer(v.ctypes.data, n)
+    rng = np.random.default_rng(n)
+    j = rng.choice(n, int(dup * n), replace=False)
+    v[j] = np.maximum(v[j] - 1, 0)
+    rng = np.random.default_rng(seed)
+    r = 4.0 + 30.0 * v / max(1.0, float(v.max()))
+    fi = np.deg2rad(10.2 + 0.6 * (v * 0.6180339887 % 1.0))          # a function of the value: equal values, equal (x, y)
+    xs, ys = (r * np.cos(fi)).astype(np.float32), (r * np.sin(fi)).astype(np.float32)
+    rr = np.sqrt(xs * xs + ys * ys)
+    order = np.argsort(v, kind="stable")                               # the float ranges must rise with the values
+    assert np.all(np.diff(rr[order]) >= 0) and np.all((np.diff(rr[order]) == 0) == (np.diff(v[order]) == 0))
+    zs = (-1.8 + 0.25 * rng.random(n) * (rng.random(n) < 0.5)).astype(np.float32)
+    bx, by, bz = [a[::9].copy() for a in O.cfg_cloud("narrow", seed)]
+    keep = ~((np.degrees(np.arctan2(by, bx)) > 9.5) & (np.degrees(np.arctan2(by, bx)) < 11.5))
+    return (np.concatenate([xs, bx[keep]]), np.concatenate([ys, by[keep]]), np.concatenate([zs, bz[keep]]))

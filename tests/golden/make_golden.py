@@ -46,6 +46,14 @@ CASES = [
     ("boundary_s3_starbeam_xdir1", "boundary", 3, {"starbeam_filter": 1, "xDirection": 1}),
     ("boundary_s3_ch20", "boundary", 3, {"channels": 20}),
     ("boundary_hi_s3", "boundary_hi", 3, {}),
+    # sensor-like sweeps: the planar-range ties of a real driver's output left in (r5; the order of equal ranges is
+    # std::sort's and decides several hundred labels per sweep)
+    ("sensor_s1", "sensor", 1, {}),
+    ("sensor_s2", "sensor", 2, {}),
+    ("sensor_narrow_s1", "sensor_narrow", 1, {}),
+    ("sensor_narrow_s1_starbeam_xdir2", "sensor_narrow", 1, {"starbeam_filter": 1, "xDirection": 2}),
+    ("sensor_default_roi_s3", "sensor_default_roi", 3, {}),
+    ("sensor5_s1", "sensor5", 1, {}),
 ]
 
 
@@ -64,7 +72,10 @@ def cloud_sha(x, y, z):
 
 
 def main():
+    only = sys.argv[1:]
     for name, cfg, seed, tweak in CASES:
+        if only and not any(name.startswith(o) for o in only):
+            continue
         p = case_params(cfg, tweak)
         x, y, z = O.cfg_cloud(cfg, seed)
         # boundary clouds sit on decisions that one ulp of acosf / asinf / atan2f flips, so their

@@ -224,10 +224,12 @@ def cfg_params(name):
     p = default_params().wide_roi()
     if name == "cfg1":      # 16x1024 flat, z_zero only
         p.x_zero_method, p.star_shaped_method, p.blind_spots = 0, 0, 0
-    elif name in ("cfg2", "narrow"):    # 64x2048 street, all detectors + blind_spots
+    elif name in ("cfg2", "narrow", "sensor", "sensor_narrow"):    # 64x2048 street, all detectors + blind_spots
         pass
-    elif name == "cfg5":    # 128x4096, channels 128, interval 0.05
+    elif name in ("cfg5", "sensor5"):    # 128x4096, channels 128, interval 0.05
         p.channels, p.interval = 128, 0.05
+    elif name == "sensor_default_roi":
+        p = default_params()
     elif name == "default_roi":
         p = default_params()
     elif name in ("boundary", "boundary_hi"):   # boundary_cloud(): points on the decisions of the float fast paths
@@ -250,6 +252,13 @@ def cfg_cloud(name, seed=1):
         return synth_cloud(64, 2048, 2, seed)
     if name == "cfg5":
         return synth_cloud(128, 4096, 1, seed)
+    # sensor-like sweeps (range noise, 2 mm range steps, drop-outs, ~10 000 planar-range ties per 64 x 2048 sweep)
+    if name in ("sensor", "sensor_default_roi"):
+        return synth_cloud(64, 2048, 3, seed)
+    if name == "sensor_narrow":
+        return synth_cloud(64, 2048, 4, seed)
+    if name == "sensor5":
+        return synth_cloud(128, 4096, 3, seed)
     if name in BOUNDARY_SCALE:
         return boundary_cloud(BOUNDARY_SCALE[name], seed)
     raise KeyError(name)

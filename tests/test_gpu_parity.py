@@ -369,10 +369,12 @@ def test_mid_size_sector_scattered_over_many_tiles(ctx_big):
 
 
 @pytest.mark.parametrize("n_pts", [300, 1500, 6000])
-def test_equal_ranges_are_ordered_by_input_index(ctx_big, n_pts):
-    """Exact planar-range ties inside a sector: the reference's std::sort leaves their order open
-    (star_shaped_search.cpp:109); this implementation and oracle B order them by input index
-    (DESIGN.md deviation D2).  Duplicated points exercise that rule on all three sort paths."""
+def test_equal_ranges_follow_std_sort(ctx_big, n_pts):
+    """Exact planar-range ties inside a sector are ordered as libstdc++'s std::sort orders them
+    (star_shaped_search.cpp:109; oracle/urf_stdsort.h pins the algorithm against the real one, k_star_ties follows it
+    on the device).  Duplicated (x, y) with another height -- the slope between the two is +-inf, the sign depends on
+    the order -- on all three sizes: one wave's LDS (<= 512 points per sector), the big instance's LDS (<= 2048) and
+    global memory."""
     p = O.cfg_params("cfg2")
     p.interval = 1.0
     x, y, z = crowded_cloud(n_pts, seed=9)
@@ -388,6 +390,68 @@ def test_equal_ranges_are_ordered_by_input_index(ctx_big, n_pts):
     lg, ig = ctx_big.classify_xyz(x, y, z)
     assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, len(x)), st["detect"])
     assert np.array_equal(lg, lb) and info_equal(ig, ib)
+    # the same through the batch entry point (the full kernel sequence at once), twice in one batch
+    with u.Context(len(x), 2, params=p) as ctx:
+        labels, infos = run_batch(ctx, [(x, y, z), (x[::-1].copy(), y[::-1].copy(), z[::-1].copy())], p)
+        assert np.array_equal(labels[0], lb)
+        lr, _, _ = O.run_b(x[::-1].copy(), y[::-1].copy(), z[::-1].copy(), p)
+        assert np.array_equal(labels[1], lr)
+
+
+@pytest.mark.parametrize("n,dup", [(364, 0.0), (364, 0.1), (500, 0.05), (1024, 0.1), (2048, 0.05), (4000, 0.05)])
+def test_std_sort_depth_limit_on_the_device(ctx_big, n, dup):
+    """A sector whose ranges are an adversarial input for libstdc++'s introsort: the depth limit 2 * floor(log2 n) is
+    reached and the segment is heap sorted (stl_algo.h __partial_sort), which k_star_ties does statement by statement
+    on one lane; with equal ranges in it, whose final order is the heap's."""
+    import ctypes as C
+    x, y, z = fuzz.killer_sector_cloud(n, dup, seed=n)
+    if dup == 0.0:   # tie-free: nothing flags the sector -- one duplicated pair in front of the walk's stop does
+        x, y, z = np.concatenate([x[:1], x]), np.concatenate([y[:1], y]), np.concatenate([z[:1] + np.float32(0.3), z])
+    p = O.cfg_params("cfg2")
+    p.interval = 1.0
+    hs = O.oracle_b().urf_oracle_std_sort_heap_sorts
+    hs.restype = C.c_long
+    before = hs()
+    lb, ib, st = O.run_b(x, y, z, p, debug=True)
+    if dup in (0.05, 0.1) and n != 500 and n != 2048:
+        assert hs() > before
+    ctx_big.set_params(p)
+    lg, ig = ctx_big.classify_xyz(x, y, z)
+    assert np.array_equal(ctx_big.read_stage(u.STAGE_DETECT, len(x)), st["detect"])
+    assert np.array_equal(lg, lb) and info_equal(ig, ib)
+
+
+def test_sensor_like_batch_and_callback_sequence():
+    """Sweeps as a driver delivers them (ties in every star sector).  Batch: 48 sweeps = 17 280 sectors, k_star_ties'
+    64-sectors-per-wave scan of the flags (a smaller batch takes one workgroup per sector).  Callback path: the short launch
+    sequence has no k_star_ties -- the first sweep comes back void and is run again with it, every later one takes it at
+    once (urf_callback_path_state: bit 4)."""
+    p = O.cfg_params("sensor")
+    clouds = [O.cfg_cloud("sensor" if k % 3 else "sensor_narrow", 20 + k) for k in range(6)]
+    ref = [O.run_b(*c, p) for c in clouds]
+    n = len(clouds[0][0])
+    with u.Context(n, 48, params=p) as ctx:
+        labels, infos = run_batch(ctx, [clouds[k % 6] for k in range(48)], p)
+        for k in range(48):
+            assert np.array_equal(labels[k], ref[k % 6][0]), k
+        labels, infos = run_batch(ctx, clouds[:5], p)
+        for k in range(5):
+            assert np.array_equal(labels[k], ref[k][0]), k
+        # tie-free sweeps in the same context afterwards: nothing flagged, nothing left over from the flags of the call before
+        free = [O.cfg_cloud("cfg2", 30 + k) for k in range(5)]
+        labels, infos = run_batch(ctx, free, p)
+        for k in range(5):
+            assert np.array_equal(labels[k], O.run_b(*free[k], p)[0]), k
+    with u.Context(n, 4, params=p) as ctx:
+        free = O.cfg_cloud("cfg2", 31)
+        lg, ig = ctx.classify_xyz(*free)
+        assert np.array_equal(lg, O.run_b(*free, p)[0]) and ctx.callback_path_state() == (0, 1 | 8)
+        for k in range(6):
+            lg, ig = ctx.classify_xyz(*clouds[k])
+            assert np.array_equal(lg, ref[k][0]) and info_equal(ig, ref[k][1])
+            assert ctx.callback_path_state() == (1, 1 | 8 | 16)
+        lg, ig = ctx.classify_xyz(*free)
+        assert np.array_equal(lg, O.run_b(*free, p)[0])
 
 
 def test_star_sort_paths(ctx_hooks):

@@ -7,14 +7,18 @@
  * 1.8 m above a flat ground plane or a street with two curbs, sampled on a
  * rings x cols grid and stored in firing order.
  *
- * Two properties are required for the clouds to be usable as parity fixtures
- * (hard part 2 and 5):
+ * Scenes 0-2 are the analytic benchmark clouds of SURVEY.md section 8d:
  *   - no two points of one star-shaped sector share the same float planar
- *     range r = sqrtf(x*x+y*y): the reference orders equal r with an unstable
- *     std::sort (star_shaped_search.cpp:109), so its own output is
- *     implementation-defined on ties;
+ *     range r = sqrtf(x*x+y*y) (the survey's rule for the benchmark clouds; the
+ *     reference orders equal r with std::sort, star_shaped_search.cpp:109);
  *   - no azimuth in (-5e-7, 0) rad (sector index 360, a null dereference at
  *     star_shaped_search.cpp:171-173) and no point with x == y == 0.
+ * Scenes 3 and 4 (r5) are the SENSOR-LIKE versions of scenes 1 and 2: what a
+ * spinning LiDAR's driver delivers -- Gaussian range noise (sigma 1 cm), the
+ * range quantised to 2 mm along the ray, 1.5 % of the returns dropped -- and
+ * nothing removed afterwards: a sweep holds ~10 000 exact planar-range ties
+ * inside its star sectors (neighbouring firings of a ring on flat ground),
+ * whose order under the reference's std::sort decides labels.
  */
 #include <algorithm>
 #include <cmath>
@@ -100,8 +104,11 @@ inline int sector_of(float x, float y)
 extern "C" int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_t seed,
                                float* x, float* y, float* z)
 {
-    if (!x || !y || !z || rings == 0 || cols == 0 || scene < 0 || scene > 2)
+    if (!x || !y || !z || rings == 0 || cols == 0 || scene < 0 || scene > 4)
         return URF_ERR_INVALID_ARG;
+    const bool sensor_like = scene >= 3;
+    if (sensor_like)
+        scene -= 2;
     const double h = 1.8;             /* sensor height above the road */
     const double curb_y = scene == 2 ? 3.0 : 4.0;   /* |y| of the curb faces */
     const double curb_h = 0.15;       /* curb height */
@@ -133,8 +140,20 @@ extern "C" int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_
                 }
             }
             const size_t idx = (size_t)c * rings + r;
-            t *= 1.0 + 1e-4 * unit(seed, idx);
-            if (!(t < max_range)) {
+            bool dropped = false;
+            if (sensor_like) {
+                /* Gaussian by Irwin-Hall (12 uniforms: basic operations only, bit-identical on every host), sigma 1 cm;
+                 * quantised to 2 mm along the ray; 1.5 % drop-outs */
+                double g = 0.0;
+                for (uint64_t u = 0; u < 12; u++)
+                    g += unit(seed ^ 0x5eed5eedULL, idx * 16 + u);
+                t += 0.01 * (g * 0.5);   /* the sum of 12 uniforms on [-1, 1) has variance 4 */
+                t = std::floor(t / 0.002 + 0.5) * 0.002;
+                dropped = unit(seed ^ 0xd509ULL, idx) > 0.97;   /* P = 0.015 */
+            } else {
+                t *= 1.0 + 1e-4 * unit(seed, idx);
+            }
+            if (!(t < max_range) || dropped) {
                 x[idx] = y[idx] = z[idx] = 0.0f;
             } else {
                 x[idx] = (float)(t * dx);
@@ -144,6 +163,8 @@ extern "C" int urf_synth_cloud(uint32_t rings, uint32_t cols, int scene, uint64_
         }
     }
 
+    if (sensor_like)
+        return URF_OK;   /* ties stay in */
     /* remove radial ties inside every sector: scale the later point of a tie
      * by (1 + k*2^-21) and re-check, until every sector is tie-free */
     struct Ent { float r; uint32_t idx; };

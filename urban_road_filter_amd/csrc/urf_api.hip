@@ -73,6 +73,7 @@ struct urf_ctx {
      * with an internal status and is run again with it, as are all later ones (urf_classify_pc2_wait) */
     bool slot_lists = false;
     bool slot_nan = false;          /* ... k_nan_rings (a sweep with a ring point on the sensor's axis) */
+    bool slot_ties = false;         /* ... k_star_ties (a sweep with equal planar ranges in a star sector: any real sensor's) */
     uint32_t n_rerun = 0;           /* sweeps urf_classify_pc2_wait had to run again */
     /* Slot i works on scratch row i % rows, rows = min(max_batch, URF_ASYNC_SLOTS); row 0 runs on the
      * context's stream, every other row on a stream of its own (slots that share a row share its
@@ -259,7 +260,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles)
     A(k.angle, S * C) A(k.ring_thr, S * C * 4) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_run, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
-    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 4 * URF_ASYNC_SLOTS)   /* four counters per scratch row in use at once */
+    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 8 * URF_ASYNC_SLOTS)   /* eight counters per scratch row in use at once */
     A(k.table_upto, S) A(k.table_redo, S) A(k.redo_list, S) A(k.table_cause, S) A(k.ring_hint, URF_ASYNC_SLOTS)
     A(k.nan_mask, S * 4) A(k.nan_list, 2 * S * C) A(k.vis, S * C)
     A(k.maxdist, S * C) A(k.quad, S * 4)
@@ -442,7 +443,7 @@ extern "C" int urf_callback_path_state(const urf_ctx* c, uint32_t* n_rerun, uint
     if (n_rerun)
         *n_rerun = c->n_rerun;
     if (sequence)
-        *sequence = (c->speculate ? 1u : 0u) | (c->slot_lists ? 2u : 0u) | (c->slot_nan ? 4u : 0u) | (c->speculate && c->use_hint ? 8u : 0u);
+        *sequence = (c->speculate ? 1u : 0u) | (c->slot_lists ? 2u : 0u) | (c->slot_nan ? 4u : 0u) | (c->speculate && c->use_hint ? 8u : 0u) | (c->slot_ties ? 16u : 0u);
     return URF_OK;
 }
 
@@ -510,7 +511,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     k.rpre += r * C * (tiles + 1); k.rstart += r * C * tiles;
     k.angle += r * C; k.ring_thr += r * C * 4; k.ring_lut += r * URF_LUT_CELLS; k.ring_cnt += r * C; k.ring_off += r * (C + 1);
     k.sec_cnt += r * K; k.sec_run += r * K; k.sec_off += r * (K + 1); k.star_hit += r * K;
-    k.star_first += r * K; k.star_list_mid += r * K; k.star_list_big += r * K; k.star_count += 4 * r;
+    k.star_first += r * K; k.star_list_mid += r * K; k.star_list_big += r * K; k.star_count += 8 * r;
     k.table_upto += r; k.table_redo += r; k.redo_list += r; k.table_cause += r; k.ring_hint += r;
     k.nan_mask += r * 4; k.nan_list += 2 * r * C; k.vis += r * C;
     k.maxdist += r * C; k.quad += r * 4;
@@ -606,7 +607,8 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
      * normally find nothing to do -- the two repair kernels behind the speculative ring table, the two for the work
      * lists of oversized star sectors, 20 of a sweep's 200 microseconds -- are left out, k_index voids a sweep that
      * needed them, and urf_classify_pc2_wait() runs it again with them. */
-    a.optimistic = on_stream ? ((c->speculate ? URF_OPT_NO_REPAIR : 0u) | (c->slot_lists ? 0u : URF_OPT_NO_LISTS) | (c->slot_nan ? 0u : URF_OPT_NO_NAN)) : 0u;
+    a.optimistic = on_stream ? ((c->speculate ? URF_OPT_NO_REPAIR : 0u) | (c->slot_lists ? 0u : URF_OPT_NO_LISTS) | (c->slot_nan ? 0u : URF_OPT_NO_NAN) |
+                               (c->slot_ties ? 0u : URF_OPT_NO_TIES)) : 0u;
     a.capture = (uint32_t)(capture_in >= 0 ? capture_in : c->capture);
     a.labels = d_labels;
     if (a.capture != 1) {
@@ -652,6 +654,14 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
             hipLaunchKernelGGL(k_star_sort_mid, dim3(c->n_cus * (URF_MID_WAVES * 256 / URF_STAR_MID_THREADS)), dim3(URF_STAR_MID_THREADS), 0, st,
                                a, dp);   /* as many workgroups as are resident */
             hipLaunchKernelGGL(k_star_sort_big, dim3(c->n_cus * 2), dim3(256), 0, st, a, dp);
+        }
+        /* sectors whose sorted prefix holds equal planar ranges (URF_TIE_FLAG): the order libstdc++'s std::sort leaves them
+         * in.  Benchmark clouds hold none (both kernels return at once); a real sensor's sweep holds them in every sector. */
+        if (!(a.optimistic & URF_OPT_NO_TIES)) {
+            const unsigned total = K * n_scans, per = total <= 16384u ? 1u : 64u, nblk = (total + per - 1) / per;
+            const unsigned g_small = nblk < c->n_cus * 16u ? nblk : c->n_cus * 16u, g_big = nblk < c->n_cus * 4u ? nblk : c->n_cus * 4u;
+            hipLaunchKernelGGL(k_star_ties<URF_TIE_SMALL_CAP>, dim3(g_small), dim3(64), 0, st, a, dp, per);
+            hipLaunchKernelGGL(k_star_ties<URF_TIE_BIG_CAP>, dim3(g_big), dim3(64), 0, st, a, dp, per);
         }
     }
     mark();   /* "k_star_sort" = the three sort kernels (mid / big run over normally empty work lists) */
@@ -1051,15 +1061,18 @@ extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* label
     /* the short launch sequence left out something this sweep needed (run_pipeline): once more, with it --
      * the message is still in the slot's device buffer -- and from now on for every sweep */
     auto redo = [](int st) {
-        return st == URF_STATUS_REDO_TABLE || st == URF_STATUS_REDO_LISTS || st == URF_STATUS_REDO_NAN || st == URF_STATUS_REDO_HINT;
+        return st == URF_STATUS_REDO_TABLE || st == URF_STATUS_REDO_LISTS || st == URF_STATUS_REDO_NAN || st == URF_STATUS_REDO_HINT ||
+               st == URF_STATUS_REDO_TIES;
     };
-    for (int tries = 0; tries < 5 && redo(sl.h_info->status); tries++) {
+    for (int tries = 0; tries < 6 && redo(sl.h_info->status); tries++) {
         if (sl.h_info->status == URF_STATUS_REDO_TABLE)
             c->speculate = false;
         else if (sl.h_info->status == URF_STATUS_REDO_HINT)
             c->use_hint = false;
         else if (sl.h_info->status == URF_STATUS_REDO_LISTS)
             c->slot_lists = true;
+        else if (sl.h_info->status == URF_STATUS_REDO_TIES)
+            c->slot_ties = true;
         else
             c->slot_nan = true;
         c->epoch++;   /* the captured sequences are rebuilt */

@@ -121,6 +121,14 @@ __device__ __forceinline__ unsigned urf_wave_scan_max(unsigned v)
     return v;
 }
 
+/* LDS hand-over between the lanes of ONE wave (its LDS operations execute in order): nothing but the compiler has to be held back */
+__device__ __forceinline__ void urf_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 /* scan s occupies [off, off+len) of the CALLER's per-point arrays (x, y, z, labels); a scan longer
  * than the max_len the host sized the grids and tables for is cut there */
 __device__ __forceinline__ void urf_scan_range(const urf_kargs& a, unsigned s, unsigned& off, unsigned& len)

@@ -53,11 +53,19 @@
 #define URF_OPT_NO_REPAIR 1u   /* k_table_repair / k_split_repair do not follow k_split */
 #define URF_OPT_NO_LISTS 2u    /* k_star_sort_mid / k_star_sort_big do not follow k_star_sort_small */
 #define URF_OPT_NO_NAN 4u      /* k_nan_rings does not follow k_ring */
+#define URF_OPT_NO_TIES 8u     /* k_star_ties does not follow the sort kernels */
 /* internal values of urf_scan_info::status: never seen by a caller */
 #define URF_STATUS_REDO_TABLE 0x7f000001
 #define URF_STATUS_REDO_LISTS 0x7f000002
 #define URF_STATUS_REDO_NAN 0x7f000003
 #define URF_STATUS_REDO_HINT 0x7f000004   /* the table was incomplete because the walk stopped at the previous call's ring count */
+#define URF_STATUS_REDO_TIES 0x7f000005   /* a star sector holds equal planar ranges where the walk looks: needs k_star_ties */
+/* star_first[]: set by the sort kernels when the sector's sorted prefix (up to the walk's last index + 1) holds two equal
+ * planar ranges -- their order is the one libstdc++'s std::sort leaves (star_shaped_search.cpp:109), which k_star_ties
+ * reproduces; it rewrites the sector's outputs and clears the bit before the walk runs */
+#define URF_TIE_FLAG 0x80000000u
+#define URF_TIE_SMALL_CAP 512u   /* sectors of up to this many points: the small instance of k_star_ties (8 KB of LDS) */
+#define URF_TIE_BIG_CAP 2048u    /* ... up to this many: the big instance's LDS; beyond: in global memory */
 #define URF_AZ_UNKNOWN      -1.0f     /* decoded value of URF_REC_AZ_UNKNOWN */
 #define URF_RING_NONE       0xFFu
 #define URF_SEC_NONE        0x3FFu
@@ -191,7 +199,8 @@ struct urf_kargs {
     uint32_t* star_first;       /* [S][sectors] last sorted index the walk may visit */
     uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 385..2048 points */
     uint32_t* star_list_big;    /* [S*sectors] ... with more than 2048 points */
-    uint32_t* star_count;       /* [4] lengths of the two lists, [2] = length of redo_list, [3] = length of nan_list (zeroed per call) */
+    uint32_t* star_count;       /* [8] lengths of the two lists, [2] = length of redo_list, [3] = length of nan_list, [4] / [5] != 0: some
+                                 * sector of at most / more than URF_TIE_SMALL_CAP points carries URF_TIE_FLAG (zeroed per call) */
     uint32_t* table_upto;       /* [S] first point a speculative k_ring_table did not look at (0xffffffff: none) */
     uint32_t* table_redo;       /* [S] k_split: the speculative table of the scan is incomplete */
     uint32_t* redo_list;        /* [S] such scans (k_table_repair) */

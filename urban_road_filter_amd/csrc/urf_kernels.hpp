@@ -455,7 +455,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
 __global__ __launch_bounds__(URF_TABLE_THREADS) void k_ring_table(urf_kargs a, urf_dev_params dp)
 {
     __shared__ urf_table_shared T;
-    if (blockIdx.x == 0 && threadIdx.x < 4)
+    if (blockIdx.x == 0 && threadIdx.x < 8)
         a.star_count[threadIdx.x] = 0;   /* the call's work-list lengths (k_table_repair, k_index): first kernel of the sequence */
     urf_ring_table_scan(a, dp, blockIdx.x, a.table_lookahead, T);
 }
@@ -1539,7 +1539,7 @@ __device__ __forceinline__ unsigned urf_sector_runs(const urf_kargs& a, unsigned
  * general path: every 64-key block is sorted in registers by an in-wave
  * bitonic network and the blocks are merged by ranking. */
 template <unsigned MAXB>
-__device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const urf_dev_params& dp, unsigned sb, unsigned obase, unsigned n,
+__device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const urf_dev_params& dp, unsigned sb, unsigned obase, unsigned n,
                                                      const urf_sec_run& two, unsigned long long* A, unsigned* cnt,
                                                      unsigned* sh_first, uint32_t* star_first_out)
 {
@@ -1763,6 +1763,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
     /* tail: slopes / distance terms / ring positions in sorted order; the walk can never pass the first
      * "static" hit (slope > slope_param): stop after the 64-element chunk that holds it */
     const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
+    bool tie = false;   /* two equal planar ranges next to each other where the walk may look: their order is std::sort's (k_star_ties) */
 #pragma unroll
     for (unsigned q = 0; q < MAXB; q++) {
         const unsigned i = q * 64 + lane;
@@ -1775,6 +1776,7 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
                 const float ax = __uint_as_float(pa.x), bx = __uint_as_float(pb.x);
                 slp = (__uint_as_float(pb.y) - __uint_as_float(pa.y)) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
                 g = (bx - ax) * kdist;
+                tie = tie || pa.x == pb.x;
                 if (slp > slope_param)
                     atomicMin(sh_first, i);
             }
@@ -1786,13 +1788,28 @@ __device__ __forceinline__ void urf_star_sort_sector(const urf_kargs& a, const u
             break;
     }
     const unsigned first = *sh_first;
+    /* (the point behind the walk's last one may take its place if the two are equal) */
+    if (lane == 0 && first + 1 < n && RZ[first + 1].x == RZ[first].x)
+        tie = true;
+    const bool any_tie = __any(tie);
     if (lane == 0)
-        *star_first_out = first < n - 1 ? first : n - 1;   /* last index the walk may visit */
+        *star_first_out = (first < n - 1 ? first : n - 1) | (any_tie ? URF_TIE_FLAG : 0u);   /* last index the walk may visit */
     URF_PHASE_ACC(5);
 #ifdef URF_EXP_PHASE_CLOCK
     if (threadIdx.x == 0 && blockIdx.y == gridDim.y / 2 && blockIdx.x >= 100 && blockIdx.x < 104)
         printf("k_star_sort_small sector %u n %u: load %llu count %llu scan %llu rank %llu place %llu tail %llu\n", blockIdx.x, n, ph_t[0], ph_t[1], ph_t[2], ph_t[3], ph_t[4], ph_t[5]);
 #endif
+    return any_tie;
+}
+
+/* a sector was flagged with URF_TIE_FLAG: tell k_star_ties' instance for its size that there is work -- or, in a launch
+ * sequence without it (callback path), void the sweep: urf_classify_pc2_wait() runs it again with the kernel (every writer
+ * writes the same value) */
+__device__ __forceinline__ void urf_tie_found(const urf_kargs& a, unsigned s, unsigned n)
+{
+    a.star_count[4 + (n > URF_TIE_SMALL_CAP ? 1 : 0)] = 1u;
+    if (a.optimistic & URF_OPT_NO_TIES)
+        a.info[s].status = URF_STATUS_REDO_TIES;
 }
 
 
@@ -1832,7 +1849,9 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
     /* per-lane element count fixed at compile time: 6 covers a sector of a 64 x 2048 sweep.  (An
      * 8-per-lane instance for sectors of up to 512 points made the kernel spill 68 bytes per lane at
      * its 80 registers; such sectors take the workgroup path now.) */
-    urf_star_sort_sector<URF_STAR_SMALL_CAP / 64>(a, dp, sb, obase, n, two, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
+    const bool tie = urf_star_sort_sector<URF_STAR_SMALL_CAP / 64>(a, dp, sb, obase, n, two, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
+    if (tie && lane == 0)
+        urf_tie_found(a, s, n);
 }
 
 template <int NT>
@@ -2043,7 +2062,7 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
     __shared__ unsigned long long A[URF_STAR_MID_CAP];
     __shared__ unsigned cnt[NB + 1];
     __shared__ urf_sort_shared ssh;
-    __shared__ unsigned sh_first, sh_nruns;
+    __shared__ unsigned sh_first, sh_nruns, sh_tie;
     const unsigned K = (unsigned)dp.p.sectors;
     const unsigned count = a.star_count[0];
     const unsigned tid = threadIdx.x;
@@ -2078,8 +2097,10 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
             if (tid == 0)
                 sh_nruns = nr;
         }
-        if (tid == 0)
+        if (tid == 0) {
             sh_first = n;
+            sh_tie = 0;
+        }
         __syncthreads();
         URF_PHASE_ACC(0);
         const unsigned nruns = simple ? 0u : sh_nruns;
@@ -2155,6 +2176,8 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
                     const float ax = __uint_as_float(R[i - 1]), bx = __uint_as_float(R[i]);
                     slp = (Z[i] - Z[i - 1]) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
                     g = (bx - ax) * kdist;
+                    if (R[i - 1] == R[i])
+                        sh_tie = 1u;   /* equal planar ranges where the walk may look: k_star_ties */
                     if (slp > slope_param)
                         atomicMin(&sh_first, i);
                 }
@@ -2169,8 +2192,12 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
                 break;
         }
         const unsigned first = sh_first;
-        if (tid == 0)
-            a.star_first[sk] = first < n - 1 ? first : n - 1;
+        if (tid == 0) {
+            const bool tie = sh_tie != 0u || (first + 1 < n && R[first + 1] == R[first]);
+            a.star_first[sk] = (first < n - 1 ? first : n - 1) | (tie ? URF_TIE_FLAG : 0u);
+            if (tie)
+                urf_tie_found(a, s, n);
+        }
         __syncthreads();
         URF_PHASE_ACC(3);
     }
@@ -2186,7 +2213,7 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
  * position in the sector = input order); then slopes in a second sweep. */
 __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_params dp)
 {
-    __shared__ unsigned sh_first;
+    __shared__ unsigned sh_first, sh_tie;
     __shared__ unsigned P[URF_MAX_TILES + 1];   /* the sector's points in the tiles before t */
     __shared__ uint16_t ST[URF_MAX_TILES];      /* first slot of its run in tile t */
     const unsigned K = (unsigned)dp.p.sectors;
@@ -2221,8 +2248,10 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
         float* Z = a.big_z + base;
         unsigned* I = a.big_i + base;
         unsigned* Pq = a.ssrt + base;   /* original position in the sector = input order: the tie-break */
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             sh_first = n;
+            sh_tie = 0;
+        }
         for (unsigned i = threadIdx.x; i < n; i += 256) {
             unsigned lo = 0, hi = ntiles;   /* largest tile t with P[t] <= i (its run is not empty) */
             while (hi - lo > 1) {
@@ -2271,6 +2300,8 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
             if (i >= 1) {
                 slp = (Z[i] - Z[i - 1]) / (R[i] - R[i - 1]);
                 g = (R[i] - R[i - 1]) * kdist;
+                if (R[i] == R[i - 1])
+                    sh_tie = 1u;   /* equal planar ranges anywhere in the sector: k_star_ties */
                 if (slp > slope_param && i < first)
                     first = i;
             }
@@ -2281,9 +2312,338 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
             a.ssrt[base + i] = I[i];
         atomicMin(&sh_first, first);
         __syncthreads();
-        if (threadIdx.x == 0)
-            a.star_first[sk] = sh_first < n - 1 ? sh_first : n - 1;
+        if (threadIdx.x == 0) {
+            a.star_first[sk] = (sh_first < n - 1 ? sh_first : n - 1) | (sh_tie ? URF_TIE_FLAG : 0u);
+            if (sh_tie)
+                urf_tie_found(a, s, n);
+        }
         __syncthreads();
+    }
+}
+
+/* ---- equal planar ranges: the order std::sort leaves them in ------------------------------------------------
+ * star_shaped_search.cpp:109 sorts a sector with std::sort(.., ptcmpr), ptcmpr(a, b) = a.r < b.r (:22-25).  Where two
+ * points of a sector share their float range the result depends on the ALGORITHM -- libstdc++'s introsort is not stable
+ * but it is deterministic, the walk divides by the difference of neighbouring ranges (a tie is +-inf or NaN, and which of
+ * the two points comes second decides the sign), so the reference's labels depend on that order.  The benchmark clouds
+ * are tie-free by construction; a real sensor's sweep -- ranges quantised to millimetres,
+ * neighbouring firings of a ring on flat ground -- holds such pairs in every sector.  The sort kernels above order equal
+ * ranges by position (the stable order) and flag a sector whose sorted prefix, as far as the walk may look plus one, holds
+ * equal neighbours (URF_TIE_FLAG in star_first); this kernel then sorts the flagged sector AGAIN, as libstdc++ does
+ * (bits/stl_algo.h of GCC 5 .. 13: __sort -> __introsort_loop -> __unguarded_partition_pivot / __partial_sort,
+ * __final_insertion_sort), and rewrites everything the sort kernels wrote for it.
+ *
+ * One wave per sector.  What has to be followed literally is the introsort loop: only it moves equal elements past each
+ * other.  (a) __move_median_to_first on (first + 1, mid, last - 1).  (b) __unguarded_partition against the pivot now at
+ * `first`, in two data-parallel passes: with L = the positions of [first + 1, last) holding an element >= pivot in
+ * ascending order and R = those holding one <= pivot in descending order, the sequential loop swaps exactly the pairs
+ * (L[k], R[k]) with L[k] < R[k] -- what lies between the two pointers is untouched until they get there, and such k form a
+ * prefix k < k* -- and returns cut = min(L[k*], R[k* - 1]).  (c) [cut, last) and [first, cut) go on while longer than 16
+ * elements, depth limit 2 * floor(log2 n); a segment that reaches the limit is heap sorted (__partial_sort = __make_heap +
+ * __sort_heap) by ONE lane, statement by statement -- an adversarial input's business.  (d) __final_insertion_sort is a
+ * stable sort of what the loop leaves, and that is a sequence of segments of at most 16 elements (or heap sorted ones),
+ * each <= the next: every element's final place is its segment's start + the smaller elements of the segment + the equal
+ * ones in front of it.  tests/test_stdsort.py pins the same formulation on the CPU against the real std::sort.
+ *
+ * The arrays (range bits, address in the sector-sorted arrays, two work arrays of positions) live in LDS up to CAP points
+ * per sector -- two instances, URF_TIE_SMALL_CAP and URF_TIE_BIG_CAP: 8 and 32 KB -- and beyond that in the sector's
+ * stretch of big_r / big_i / big_z / ssrt. */
+struct urf_tie_lds {
+    typedef unsigned* ptr;
+    static __device__ __forceinline__ void sync() { urf_wave_lds_sync(); }
+};
+struct urf_tie_glb {
+    typedef volatile unsigned* ptr;   /* (volatile: one lane writes what the others read next) */
+    static __device__ __forceinline__ void sync()
+    {
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+/* stl_heap.h: __adjust_heap + __push_heap on the segment starting at f (one lane) */
+template <class PTR>
+__device__ void urf_tie_adjust_heap(PTR R, PTR P, unsigned f, int hole, int len, unsigned v, unsigned pv)
+{
+    const int top = hole;
+    int second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (R[f + second] < R[f + second - 1])
+            second--;
+        R[f + hole] = R[f + second];
+        P[f + hole] = P[f + second];
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        R[f + hole] = R[f + second - 1];
+        P[f + hole] = P[f + second - 1];
+        hole = second - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && R[f + parent] < v) {
+        R[f + hole] = R[f + parent];
+        P[f + hole] = P[f + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    R[f + hole] = v;
+    P[f + hole] = pv;
+}
+/* stl_algo.h __partial_sort(first, last, last): __make_heap, then __sort_heap */
+template <class PTR>
+__device__ void urf_tie_heap_sort(PTR R, PTR P, unsigned f, unsigned l)
+{
+    const int len = (int)(l - f);
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        for (;;) {
+            urf_tie_adjust_heap(R, P, f, parent, len, R[f + parent], P[f + parent]);
+            if (parent == 0)
+                break;
+            parent--;
+        }
+    }
+    for (int last = len - 1; last >= 1; last--) {
+        const unsigned v = R[f + last], pv = P[f + last];
+        R[f + last] = R[f];
+        P[f + last] = P[f];
+        urf_tie_adjust_heap(R, P, f, 0, last, v, pv);
+    }
+}
+
+template <class MEM>
+__device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const urf_dev_params& dp, unsigned sk, unsigned s, unsigned k, unsigned n,
+                                                    typename MEM::ptr R, typename MEM::ptr P, typename MEM::ptr LP, typename MEM::ptr RP, int* stk)
+{
+    typedef typename MEM::ptr PTR;
+    const unsigned lane = threadIdx.x, K = (unsigned)dp.p.sectors;
+    const unsigned sb = urf_sbase(a, s), base = sb + a.sec_off[(size_t)s * (K + 1) + k];
+    const urf_sec_run two = a.sec_run[sk];
+    const bool simple = two.nruns <= 2;
+    /* the sector in the reference's order (ROI order = tiles in order, input order inside): range bits and the point's
+     * address in the sector-sorted arrays */
+    {
+        unsigned nruns = 0;
+        if (!simple) {
+            unsigned off, len;
+            urf_scan_range(a, s, off, len);
+            nruns = urf_sector_runs(a, s, K, k, (len + URF_TILE - 1) / URF_TILE, urf_sector_run_row(a, s, K, k, 0), (unsigned*)LP, (unsigned*)RP);
+            MEM::sync();
+        }
+        unsigned r = 0;
+        for (unsigned i = lane; i < n; i += 64) {
+            unsigned adr = i < two.c0 ? two.a0 + i : two.a1 + (i - two.c0);
+            if (!simple) {
+                while (r + 1 < nruns && i >= LP[r + 1])
+                    r++;
+                adr = RP[r] + i;
+            }
+            R[i] = urf_fbits(a.sr[sb + adr]);
+            P[i] = adr;
+        }
+        MEM::sync();
+    }
+    /* ---- __introsort_loop ---- */
+    {
+        const unsigned limit = 2u * (31u - (unsigned)__clz((int)n));
+        int top = 0;
+        unsigned f = 0, l = n, d = 0;
+        for (;;) {
+            while (l - f > 16u) {
+                if (d == limit) {
+                    if (lane == 0)
+                        urf_tie_heap_sort<PTR>(R, P, f, l);
+                    for (unsigned j = f + lane; j < l; j += 64) {   /* sorted: every element a segment of its own */
+                        LP[j] = j;
+                        RP[j] = j + 1;
+                    }
+                    MEM::sync();
+                    f = l;
+                    break;
+                }
+                d++;
+                {   /* __move_median_to_first(first, first + 1, mid, last - 1) */
+                    const unsigned mid = f + (l - f) / 2;
+                    const unsigned va = R[f + 1], vb = R[mid], vc = R[l - 1];
+                    unsigned m;
+                    if (va < vb)
+                        m = vb < vc ? mid : (va < vc ? l - 1 : f + 1);
+                    else if (va < vc)
+                        m = f + 1;
+                    else if (vb < vc)
+                        m = l - 1;
+                    else
+                        m = mid;
+                    if (lane == 0) {
+                        const unsigned r0 = R[f], p0 = P[f];
+                        R[f] = R[m];
+                        P[f] = P[m];
+                        R[m] = r0;
+                        P[m] = p0;
+                    }
+                    MEM::sync();
+                }
+                const unsigned pv = R[f];
+                /* __unguarded_partition(first + 1, last, first): where the left pointer can stop (>= pivot), where the right one (<= pivot) */
+                unsigned tL = 0, tR = 0;
+                for (unsigned c0 = f + 1; c0 < l; c0 += 64) {
+                    const unsigned p = c0 + lane;
+                    const bool in = p < l;
+                    const unsigned v = in ? R[p] : 0u;
+                    const bool isL = in && v >= pv, isR = in && v <= pv;
+                    const unsigned long long mL = __ballot(isL), mR = __ballot(isR);
+                    if (isL)
+                        LP[f + 1 + tL + urf_popc_below(mL)] = p;
+                    if (isR)
+                        RP[f + 1 + tR + urf_popc_below(mR)] = p;   /* ascending; the k-th from the right is entry tR - 1 - k */
+                    tL += (unsigned)__popcll(mL);
+                    tR += (unsigned)__popcll(mR);
+                }
+                MEM::sync();
+                const unsigned mn = tL < tR ? tL : tR;
+                unsigned ks = 0;
+                for (unsigned k0 = 0; k0 < mn; k0 += 64) {
+                    const unsigned kk = k0 + lane;
+                    const bool in = kk < mn;
+                    const unsigned lp = in ? LP[f + 1 + kk] : 0u, rp = in ? RP[f + tR - kk] : 0u;
+                    const bool ok = in && lp < rp;
+                    const unsigned long long mo = __ballot(ok), mi = __ballot(in);
+                    if (ok) {   /* iter_swap: the positions of all pairs are distinct */
+                        const unsigned r0 = R[lp], p0 = P[lp], r1 = R[rp], p1 = P[rp];
+                        R[lp] = r1;
+                        P[lp] = p1;
+                        R[rp] = r0;
+                        P[rp] = p0;
+                    }
+                    ks += (unsigned)__popcll(mo);
+                    if (mo != mi)
+                        break;
+                }
+                MEM::sync();
+                const unsigned Lk = ks < tL ? LP[f + 1 + ks] : 0xffffffffu;
+                const unsigned Rk = ks > 0 ? RP[f + 1 + tR - ks] : 0xffffffffu;
+                const unsigned cut = Lk < Rk ? Lk : Rk;
+                if (l - cut > 16u) {   /* __introsort_loop(cut, last, depth_limit): later */
+                    if (lane == 0) {
+                        stk[3 * top] = (int)cut;
+                        stk[3 * top + 1] = (int)l;
+                        stk[3 * top + 2] = (int)d;
+                    }
+                    top++;
+                } else {
+                    const unsigned j = cut + lane;
+                    if (j < l) {
+                        LP[j] = cut;
+                        RP[j] = l;
+                    }
+                }
+                l = cut;
+            }
+            if (l > f) {   /* at most 16 elements: left to the final insertion sort */
+                const unsigned j = f + lane;
+                if (j < l) {
+                    LP[j] = f;
+                    RP[j] = l;
+                }
+            }
+            if (top == 0)
+                break;
+            top--;
+            urf_wave_lds_sync();
+            f = (unsigned)stk[3 * top];
+            l = (unsigned)stk[3 * top + 1];
+            d = (unsigned)stk[3 * top + 2];
+        }
+        MEM::sync();
+    }
+    /* ---- __final_insertion_sort: stable, and every element stays inside its segment ---- */
+    for (unsigned j = lane; j < n; j += 64) {
+        const unsigned sa = LP[j], se = RP[j], v = R[j];
+        unsigned rank = sa;
+        for (unsigned i = sa; i < se; i++) {
+            const unsigned u = R[i];
+            rank += (u < v || (u == v && i < j)) ? 1u : 0u;
+        }
+        LP[j] = rank;
+    }
+    MEM::sync();
+    for (unsigned j = lane; j < n; j += 64)
+        RP[LP[j]] = P[j];            /* address of the i-th point in sorted order */
+    MEM::sync();
+    for (unsigned j = lane; j < n; j += 64)
+        P[LP[j]] = R[j];             /* its range bits */
+    MEM::sync();
+    for (unsigned i = lane; i < n; i += 64)
+        R[i] = __float_as_uint(a.sz[sb + RP[i]]);   /* its height */
+    MEM::sync();
+    /* ---- what the sort kernels publish: slopes, distance terms, the point's position / ring-sorted index ---- */
+    const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
+    const bool fmt16 = simple && n <= URF_STAR_MID_CAP_;   /* (urf_walk_report) */
+    unsigned first = n;
+    for (unsigned i0 = 0; i0 < n; i0 += 64) {
+        const unsigned i = i0 + lane;
+        bool hit = false;
+        if (i < n) {
+            float slp = 0.f, g = 0.f;
+            if (i >= 1) {
+                const float ax = __uint_as_float(P[i - 1]), bx = __uint_as_float(P[i]);
+                slp = (__uint_as_float(R[i]) - __uint_as_float(R[i - 1])) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
+                g = (bx - ax) * kdist;
+                hit = slp > slope_param;
+            }
+            const unsigned adr = RP[i];
+            if (fmt16) {
+                a.ssrt16[base + i] = (uint16_t)((two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0);
+            } else {
+                const unsigned sl = a.sslot[sb + adr];
+                a.ssrt[base + i] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;   /* (RP may BE this stretch of ssrt: own element) */
+            }
+            a.wsg[base + i] = urf_sg{ slp, g };
+        }
+        const unsigned long long mh = __ballot(hit);
+        if (mh) {
+            first = i0 + (unsigned)__ffsll((long long)mh) - 1u;
+            break;   /* the walk can never pass the first slope above the threshold */
+        }
+    }
+    if (lane == 0)
+        a.star_first[sk] = first < n - 1 ? first : n - 1;   /* (without the flag) */
+    MEM::sync();
+}
+
+template <unsigned CAP>
+__global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp, unsigned per_block)
+{
+    __shared__ unsigned W[4 * CAP];
+    __shared__ int stk[3 * 64];
+    constexpr bool BIG = CAP > URF_TIE_SMALL_CAP;
+    if (a.star_count[4 + (BIG ? 1 : 0)] == 0u)
+        return;   /* (uniform) no sector of this instance's sizes is flagged */
+    const unsigned K = (unsigned)dp.p.sectors, total = a.n_scans * K, lane = threadIdx.x;
+    const unsigned nblk = (total + per_block - 1) / per_block;
+    for (unsigned blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const unsigned e = blk * per_block + lane;
+        const unsigned sf = (lane < per_block && e < total) ? a.star_first[e] : 0u;
+        unsigned long long m = __ballot((sf & URF_TIE_FLAG) != 0u);
+        while (m) {
+            const unsigned sk = blk * per_block + (unsigned)__ffsll((long long)m) - 1u;
+            m &= m - 1ull;
+            const unsigned s = sk / K, k = sk % K;
+            if (a.info[s].status != URF_OK)
+                continue;   /* (a void scan's entries are leftovers of an earlier call) */
+            const unsigned n = a.sec_cnt[sk];
+            if ((n > URF_TIE_SMALL_CAP) != BIG || n < 2)
+                continue;
+            if (n <= CAP) {
+                urf_tie_sector_body<urf_tie_lds>(a, dp, sk, s, k, n, W, W + CAP, W + 2 * CAP, W + 3 * CAP, stk);
+            } else if (BIG) {
+                const unsigned base = urf_sbase(a, s) + a.sec_off[(size_t)s * (K + 1) + k];
+                urf_tie_sector_body<urf_tie_glb>(a, dp, sk, s, k, n, (unsigned*)a.big_r + base, a.big_i + base, (unsigned*)a.big_z + base,
+                                                 a.ssrt + base, stk);
+            }
+        }
     }
 }
 
@@ -2466,14 +2826,6 @@ typedef urf_sg urf_walk_tile[64][URF_WALK_CHUNK + 2];   /* rows of 36 words: 16-
 /* LDS of the two walk kernels: the chunk of pairs, a row per sector, and the sectors' places */
 __shared__ urf_walk_tile walk_tile;
 __shared__ unsigned walk_sbase[64], walk_slast[64];
-
-/* LDS hand-over between the lanes of ONE wave (its LDS operations execute in order): nothing but the compiler has to be held back */
-__device__ __forceinline__ void urf_wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 /* One wave walks its 64 sectors from chunk c_start (W = the state in front of it) to the end, fetching for itself:
  * the next 16 steps of all 64 sectors are 16 eight-byte loads in flight, parked in registers until the LDS tile is
