@@ -371,6 +371,30 @@ def other_configs(u, O, torch, ctx, stream, dev, dx, dy, dz, dl, di, X, Y, Z, S)
         gate(lambda s: l5[s].cpu().numpy(), lambda s: (X5[s], Y5[s], Z5[s]), p5, picked5, "cfg5")
         res["cfg5"] = run(c5, fn5, n5, S5, 5, 2, WORKLOADS["cfg5"]["text"] % S5, picked5)
     del ex5, ey5, ez5, l5
+    # ---- sensor-like sweeps: what a driver delivers (range noise, 2 mm range steps, drop-outs) -- ~10 000 exact planar-range
+    # ties per sweep, in EVERY star sector, whose order is libstdc++'s std::sort's (star_shaped_search.cpp:109): every sector
+    # is sorted a second time by k_star_ties.  The headline's clouds are tie-free by SURVEY.md 8d's rule.
+    Ss = 256 if S >= 256 else S
+    Xs = np.empty((Ss, N_PTS), np.float32)
+    Ys = np.empty_like(Xs)
+    Zs = np.empty_like(Xs)
+
+    def one_s(s):
+        Xs[s], Ys[s], Zs[s] = u.synth_cloud(RINGS, COLS, 3, 1 + s)
+
+    with cf.ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        list(ex.map(one_s, range(Ss)))
+    sx, sy, sz = (torch.from_numpy(a).to(dev) for a in (Xs, Ys, Zs))
+    ctx.set_params(p2)
+    fns = lambda: ctx.classify_batch_soa(sx, sy, sz, N_PTS, Ss, dl, di)   # noqa: E731
+    fns()
+    torch.cuda.synchronize()
+    pickeds = sorted(np.random.default_rng(13).choice(Ss, min(4, Ss), replace=False).tolist())
+    gate(lambda s: dl[s].cpu().numpy(), lambda s: (Xs[s], Ys[s], Zs[s]), p2, pickeds, "sensor_like")
+    res["sensor_like"] = run(ctx, fns, N_PTS, Ss, 10, 2, "batch of %d 64x2048 street sweeps as a sensor's driver delivers them: range noise "
+                             "(sigma 1 cm), 2 mm range steps, 1.5 %% drop-outs, ~10 000 planar-range ties per sweep left in (every star sector "
+                             "is sorted again in std::sort's order by k_star_ties), ROI +-200 m" % Ss, pickeds)
+    del sx, sy, sz
     return res
 
 
@@ -382,7 +406,7 @@ def main():
     ap.add_argument("--scans", type=int, default=0, help="sweeps per GPU per step (default: the workload's, cfg3: 1024)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parity-scans", type=int, default=8)
+    ap.add_argument("--parity-scans", type=int, default=32)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("URF_BENCH_BACKEND", "nccl"))
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-outputs", action="store_true")
@@ -464,9 +488,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.enable_kernel_timing(True)
-    ctx.kernel_timing()                     # reset
-    ctx.enable_kernel_timing(True)
 
     def barrier():
         if use_dist:
@@ -485,6 +506,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     step_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
+    # per-kernel times come from a SECOND pass of the same K steps with the library's event brackets on (hipEvent pairs
+    # around every kernel on the launch stream): `value` above is from a pass without them
+    ctx.enable_kernel_timing(True)
+    ctx.kernel_timing()                     # reset
+    ctx.enable_kernel_timing(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
     kms, kcalls = ctx.kernel_timing()
     ctx.enable_kernel_timing(False)
 
@@ -539,13 +568,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["text"] % S,
                        "scans_per_gpu": S, "points_per_scan": N_PTS, "sharding": "one batch per GPU, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "hbm_roofline_frac_whole_pipeline": round(whole / HBM_PEAK_GBS, 5),   # 13 B/point x points/s over the WHOLE step / 8 TB/s: the honest figure
+            "roofline": {"bound": "hbm", "whole_pipeline_frac": round(whole / HBM_PEAK_GBS, 5), "whole_pipeline_achieved": round(whole, 2),
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac_note": "achieved / frac are the contract's: the WHOLE algorithm's bytes over the DOMINANT kernel's time; "
+                                      "whole_pipeline_frac divides the same bytes by the whole step and is the figure to compare with the north-star's 40 %",
                          "kernel": dom, "kernel_ms": round(dom_ms, 4),
                          "kernel_ms_source": "hipEvent pairs around the kernel on the launch stream, mean over the timed steps "
                                              "(rocprofv3 --kernel-trace of the same command: profiles/*_kernel_stats.txt)",
-                         "algorithmic_bytes_per_launch": alg_bytes_launch,
-                         "whole_pipeline_achieved": round(whole, 2), "whole_pipeline_frac": round(whole / HBM_PEAK_GBS, 5)},
+                         "algorithmic_bytes_per_launch": alg_bytes_launch},
             "kernel_ms": {k: round(v / max(kcalls, 1), 4) for k, v in kms.items()},
             "outputs_ms_per_batch": outputs_ms,
             "counters": dict(zip(sharding.COUNTER_NAMES, [int(v) for v in counters])),
@@ -560,6 +592,8 @@ def main():
         if os.path.exists(traffic_file):
             try:
                 tr = json.load(open(traffic_file))
+                if tr.get("scans_per_launch") == S and tr.get("pipeline_bytes_per_step"):
+                    out["roofline"]["traffic_pipeline"] = tr["pipeline_bytes_per_step"]   # all kernels of one step
                 if tr.get("kernel") == dom and tr.get("scans_per_launch") == S:
                     out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc, corrected per MI355X_MICROARCH.md)"

@@ -167,3 +167,30 @@ def test_more_sweeps_in_flight_than_scratch_rows(rows):
         assert np.array_equal(lab, want[0][0])
         road, _, _ = ctx.ordered_indices(N)
         assert np.array_equal(road, want[0][2]["road_order"])
+
+
+def test_rerun_of_a_voided_sweep_counts_as_the_rows_latest_submission():
+    """One scratch row, two sweeps in flight, the FIRST one needs a kernel the short launch sequence leaves out (a ring
+    point on the sensor's axis: k_nan_rings): its rerun inside urf_classify_pc2_wait() is queued behind the second sweep
+    and overwrites the row.  The read-backs of the second sweep must then refuse (URF_ERR_BUSY) instead of returning the
+    first sweep's intermediates; the first sweep's own read-backs are served (the row holds its rerun)."""
+    p = O.cfg_params("cfg2")
+    first = list(O.cfg_cloud("cfg2", 120))
+    for a, v in zip(first, (0.0, 0.0, -1.8)):
+        a[5000] = v                                   # x == y == 0 on a ring: NaN azimuth
+    second = O.cfg_cloud("narrow", 121)
+    wa, wb = O.run_b(*first, p, debug=True), O.run_b(*second, p, debug=True)
+    with u.Context(N, 1, params=p) as ctx:
+        ta = ctx.classify_pc2_async(records(*first), N, 32, 0, 4, 8)
+        tb = ctx.classify_pc2_async(records(*second), N, 32, 0, 4, 8)
+        lab = np.empty(N, np.uint8)
+        ctx.classify_pc2_wait(ta, lab)
+        assert np.array_equal(lab, wa[0]) and ctx.callback_path_state()[0] >= 1
+        road, curb, _ = ctx.ordered_indices(N)        # the rerun was the row's last submission
+        assert np.array_equal(road, wa[2]["road_order"]) and np.array_equal(curb, wa[2]["curb_order"])
+        ctx.classify_pc2_wait(tb, lab)
+        assert np.array_equal(lab, wb[0])             # labels and summary live in the slot's own buffers
+        for call in (lambda: ctx.ordered_indices(N), lambda: ctx.marker_points(), lambda: ctx.read_stage(u.STAGE_QUADRANTS, N)):
+            with pytest.raises(u.UrfError) as e:
+                call()
+            assert e.value.code == -7

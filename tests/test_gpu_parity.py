@@ -517,14 +517,12 @@ def test_ring_table_zero_sentinel(ctx_big):
     x2, y2, z2 = [a.copy() for a in (x, y, z)]
     x2[100:103] = 0.0
     y2[100:103] = 0.0
-    z2[100:103] = z2[100]   # (equal planar ranges inside a sector are a tie the reference leaves open: identical points)
+    z2[100:103] = z2[100]   # (identical points: equal planar ranges inside a sector, ordered as std::sort leaves them)
     lb2, ib2, st2 = O.run_b(x2, y2, z2, p, debug=True)
     lg2, ig2 = ctx_big.classify_xyz(x2, y2, z2)
     assert ig2.n_nan_azimuth == int((st2["ring"][[3, 100, 101, 102]] >= 0).sum())
     assert info_equal(ig2, ib2)
-    same = lg2 == lb2
-    same[100:103] = True   # three identical points of one star sector: which of them the walk marks is the open tie
-    assert same.all()
+    assert np.array_equal(lg2, lb2)
 
 
 @pytest.mark.parametrize("pairs", [40, 1500])
@@ -538,7 +536,7 @@ def test_nan_slopes_single_sweep(ctx_big, pairs):
         ctx_big.set_params(p)
         lg, ig = ctx_big.classify_xyz(*scan)
         assert info_equal(ig, ib), seed
-        fuzz.assert_equal_up_to_identical_points(lg, lb, scan, involved)
+        assert np.array_equal(lg, lb)   # (r5: which of two identical points carries the mark is std::sort's order, followed exactly)
 
 
 def test_nan_slopes_in_a_batch():
@@ -555,17 +553,13 @@ def test_nan_slopes_in_a_batch():
             for k in range(count):
                 lb, ib, _ = want[k]
                 assert tuple(infos[k][:7]) == tuple(ib[f] for f in ("status", "n_roi", "n_rings", "n_ring_pts", "n_road", "n_curb", "n_ring10")), k
-                fuzz.assert_equal_up_to_identical_points(labels[k], lb, scans[k], made[k][1])
+                assert np.array_equal(labels[k], lb), k
 
 
-def same_order_up_to_ties(got, want, st):
-    """Two published orders are the same list up to the order of points of one ring with bit-identical azimuths (which the
-    reference's unstable quicksort leaves to the input order in its own way, include/urf.h: urf_ordered_indices).  NaN
-    azimuths compare by their bits: WHERE they stand in a ring is part of the comparison."""
-    if len(got) != len(want) or not np.array_equal(np.sort(got), np.sort(want)):
-        return False
-    az = st["azimuth"].view(np.uint32)
-    return np.array_equal(st["ring"][got], st["ring"][want]) and np.array_equal(az[got], az[want])
+def same_order(got, want, st=None):
+    """r5: the published order is the reference's, the order of bit-identical azimuths included (its Lomuto quicksort is run
+    literally for a ring that holds such points: k_ring_order)."""
+    return np.array_equal(got, want)
 
 
 def nan_ring_cloud(seed, n_axis, n_near):
@@ -594,24 +588,18 @@ def test_rings_with_nan_azimuths_follow_the_reference(ctx_big, seed):
     ctx_big.set_params(p)
     lg, ig = ctx_big.classify_xyz(x, y, z)
     axis = (x == 0) & (y == 0)
-    # (several axis points are identical points of star sector 0: which of them the walk marks is a tie the reference leaves open)
-    tie = axis if axis.sum() > 1 else np.zeros(len(x), bool)
-    assert np.array_equal(lg[~tie], lb[~tie]), "%d labels differ" % int((lg != lb)[~tie].sum())
+    # (several axis points are identical points of star sector 0: which of them the walk marks is std::sort's order of equal ranges)
+    assert np.array_equal(lg, lb), "%d labels differ" % int((lg != lb).sum())
     assert ig.n_rings == ib["n_rings"] and ig.n_road == ib["n_road"] and ig.n_ring_pts == ib["n_ring_pts"]
     assert ig.n_nan_azimuth == int((st["ring"][axis] >= 0).sum())
     assert np.array_equal(ctx_big.read_stage(u.STAGE_BEAM_STOP, len(x)), st["beam_stop"])
-    if axis.sum() == 1:
+    if True:
         road, curb, prob = ctx_big.ordered_indices(len(x))
         # (a wide `interval` merges lasers into one ring: points of one firing then share an azimuth to the bit)
-        assert same_order_up_to_ties(road, st["road_order"], st) and same_order_up_to_ties(curb, st["curb_order"], st)
-        assert same_order_up_to_ties(prob, st["ring10_order"], st)
-        nan_ring = st["ring"][axis][0]
-        if nan_ring >= 0:   # the ring of the NaN itself: exactly the reference's order, ties included (its quicksort is run literally)
-            for got, want in ((road, st["road_order"]), (curb, st["curb_order"]), (prob, st["ring10_order"])):
-                assert np.array_equal(got[st["ring"][got] == nan_ring], want[st["ring"][want] == nan_ring])
+        assert same_order(road, st["road_order"], st) and same_order(curb, st["curb_order"], st)
+        assert same_order(prob, st["ring10_order"], st)
         mg, mw = ctx_big.marker_points(), st["marker_pts"]
-        assert mg.shape == mw.shape and np.array_equal(mg[:, 3], mw[:, 3])   # (equal ranges: which of two tied points is "the farthest" is open)
-        assert np.array_equal(np.hypot(mg[:, 0], mg[:, 1]), np.hypot(mw[:, 0], mw[:, 1]))
+        assert mg.shape == mw.shape and np.array_equal(mg, mw)
 
 
 def late_ring_cloud(n=60000, late_at=40000, seed=5):
@@ -682,7 +670,7 @@ def test_a_long_ring_with_nan_azimuths(ctx_big):
     lg, ig = ctx_big.classify_xyz(x, y, z)
     assert np.array_equal(lg, lb) and info_equal(ig, ib) and ig.n_nan_azimuth == 1
     road, curb, prob = ctx_big.ordered_indices(len(x))
-    assert same_order_up_to_ties(road, st["road_order"], st) and same_order_up_to_ties(curb, st["curb_order"], st)
+    assert same_order(road, st["road_order"], st) and same_order(curb, st["curb_order"], st)
     for got, want in ((road, st["road_order"]), (curb, st["curb_order"])):
         assert np.array_equal(got[st["ring"][got] == nan_ring], want[st["ring"][want] == nan_ring])
 
@@ -966,3 +954,25 @@ def test_capacity_and_argument_errors():
         p.size = 8
         with pytest.raises(u.UrfError):
             ctx.set_params(p)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_published_order_and_markers_with_equal_azimuths(seed):
+    """Clouds whose x / y lie on a grid: many points of a ring share their azimuth to the bit (and their planar range).  The
+    published order and the marker points then depend on the order the reference's Lomuto quicksort leaves equal azimuths in
+    (lidar_segmentation.cpp:70-93; deterministic): k_ring_order / k_marker_ring run it literally for such a ring."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([300, 3000, 20000]))
+    cloud = fuzz.random_cloud(rng, n, tie_grid=float(rng.choice([1 / 16, 1 / 4, 1.0])))
+    p = fuzz.random_params(rng)
+    p.channels = int(rng.choice([16, 64]))
+    lb, ib, st = O.run_b(*cloud, p, debug=True)
+    with u.Context(max(len(cloud[0]), 64), 1, params=p) as ctx:
+        lg, ig = ctx.classify_xyz(*cloud)
+        assert np.array_equal(lg, lb)
+        if ib["status"] == 0:
+            road, curb, prob = ctx.ordered_indices(len(cloud[0]))
+            assert np.array_equal(road, st["road_order"]) and np.array_equal(curb, st["curb_order"])
+            assert np.array_equal(prob, st["ring10_order"])
+            mg = ctx.marker_points()
+            assert mg.shape == st["marker_pts"].shape and np.array_equal(mg, st["marker_pts"])

@@ -1080,6 +1080,9 @@ extern "C" int urf_classify_pc2_wait(urf_ctx* c, uint32_t ticket, uint8_t* label
         /* with the parameters and capture mode the sweep was submitted with (urf_set_params may have been called since),
          * behind whatever the context's stream still does with the row */
         const urf_dev_params dp_sub = sl.cap_dp;
+        /* the rerun is the row's LATEST submission: with fewer rows than sweeps in flight a later sweep shares this row, and
+         * what it left there is overwritten now -- its read-backs of the row must answer URF_ERR_BUSY, not this sweep's data */
+        sl.gen = ++c->row_gen[slot_row(c, sl)];
         int rc = order_row_after_main(c, slot_row(c, sl), slot_stream(c, sl));
         if (rc == URF_OK)
             rc = slot_launch(c, sl, sl.n_points, sl.point_step, sl.off_x, sl.off_y, sl.off_z, &dp_sub, (int)sl.cap_a.capture);
@@ -1307,7 +1310,7 @@ static int launch_markers(urf_ctx* c, uint32_t s0, uint32_t n, float* d_pts, uin
         void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
         URF_HIP(c, hipMalloc(&p0, n * cells * sizeof(float)));
         URF_HIP(c, hipMalloc(&p1, n * cells * sizeof(uint32_t)));
-        URF_HIP(c, hipMalloc(&p2, n * cells));
+        URF_HIP(c, hipMalloc(&p2, n * (cells + URF_MAX_CHANNELS)));   /* + one flag per ring: its order decides (k_marker_ring_literal) */
         c->mk_d = (float*)p0;
         c->mk_pos = (uint32_t*)p1;
         c->mk_red = (uint8_t*)p2;
@@ -1315,8 +1318,11 @@ static int launch_markers(urf_ctx* c, uint32_t s0, uint32_t n, float* d_pts, uin
     }
     const urf_kargs a = c->last_a;
     const urf_dev_params dp = c->last_dp;
+    uint8_t* const mk_lit = c->mk_red + (size_t)c->mk_scans * cells;
     hipLaunchKernelGGL(k_marker_ring, dim3((unsigned)dp.p.channels, n), dim3(256), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), c->stream, a, dp, s0,
-                       c->mk_d, c->mk_pos, c->mk_red);
+                       c->mk_d, c->mk_pos, c->mk_red, mk_lit);
+    /* rings in which the ORDER of equal azimuths decides a marker point (normally none: every workgroup returns at once) */
+    hipLaunchKernelGGL(k_marker_ring_literal, dim3((unsigned)dp.p.channels, n), dim3(256), 0, c->stream, a, dp, s0, mk_lit, c->mk_d, c->mk_pos, c->mk_red);
     hipLaunchKernelGGL(k_marker_bins, dim3(n), dim3(384), 0, c->stream, a, dp, s0, c->mk_d, c->mk_pos, c->mk_red, d_pts, d_counts);
     URF_HIP(c, hipGetLastError());
     return URF_OK;

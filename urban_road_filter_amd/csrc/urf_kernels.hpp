@@ -4032,6 +4032,38 @@ __device__ int urf_lomuto_partition(volatile unsigned long long* A, int low, int
     return i + 1;
 }
 
+/* quickSort(0, n - 1), lidar_segmentation.cpp:85-93, by one wave (all 64 lanes call it): the two halves of a partition are
+ * disjoint, so the order in which they are sorted does not matter -- the smaller one first, the larger one on a stack
+ * (<= log2 n deep; stk: 2 * 64 ints of LDS) */
+__device__ __noinline__ void urf_lomuto_sort(volatile unsigned long long* A, unsigned n, int* stk)
+{
+    const unsigned lane = urf_lane();
+    int top = 0, low = 0, high = (int)n - 1;
+    for (;;) {
+        while (low < high) {
+            const int pi = urf_lomuto_partition(A, low, high);
+            const int l0 = low, h0 = pi - 1, l1 = pi + 1, h1 = high;
+            const bool left_small = (h0 - l0) < (h1 - l1);
+            const int pl = left_small ? l1 : l0, ph = left_small ? h1 : h0;   /* pushed */
+            low = left_small ? l0 : l1;
+            high = left_small ? h0 : h1;
+            if (pl < ph && top < 64) {
+                if (lane == 0) {
+                    stk[2 * top] = pl;
+                    stk[2 * top + 1] = ph;
+                }
+                top++;
+            }
+        }
+        if (top == 0)
+            break;
+        top--;
+        __threadfence_block();
+        low = stk[2 * top];
+        high = stk[2 * top + 1];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_nan_rings(urf_kargs a, urf_dev_params dp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sh_pairs[];
@@ -4077,34 +4109,8 @@ __global__ __launch_bounds__(256) void k_nan_rings(urf_kargs a, urf_dev_params d
             __syncthreads();
             continue;
         }
-        if (tid < 64 && n >= 2) {
-            /* quickSort(0, n - 1), lidar_segmentation.cpp:85-93: the two halves of a partition are disjoint, so the order
-             * in which they are sorted does not matter -- the smaller one first, the larger one on a stack (<= log2 n deep) */
-            int top = 0, low = 0, high = (int)n - 1;
-            for (;;) {
-                while (low < high) {
-                    const int pi = urf_lomuto_partition(A, low, high);
-                    const int l0 = low, h0 = pi - 1, l1 = pi + 1, h1 = high;
-                    const bool left_small = (h0 - l0) < (h1 - l1);
-                    const int pl = left_small ? l1 : l0, ph = left_small ? h1 : h0;   /* pushed */
-                    low = left_small ? l0 : l1;
-                    high = left_small ? h0 : h1;
-                    if (pl < ph && top < 64) {
-                        if (tid == 0) {
-                            stk[2 * top] = pl;
-                            stk[2 * top + 1] = ph;
-                        }
-                        top++;
-                    }
-                }
-                if (top == 0)
-                    break;
-                top--;
-                __threadfence_block();
-                low = stk[2 * top];
-                high = stk[2 * top + 1];
-            }
-        }
+        if (tid < 64 && n >= 2)
+            urf_lomuto_sort(A, n, stk);
         __threadfence_block();
         __syncthreads();
         for (unsigned j = tid; j < n; j += 256) {
@@ -4835,9 +4841,10 @@ __global__ __launch_bounds__(URF_COMPACT_THREADS) void k_compact_write(const uin
  * its road / curb / road_probably clouds ring by ring in that order (:354-367, 605-608).  The
  * labels do not need that sort; callers that want the clouds in the reference's order do.
  * k_ring_order: one workgroup per ring of ONE scan sorts (azimuth bits, position in the ring)
- * -- equal azimuths stay in input order, where the reference's unstable quicksort leaves their
- * order open -- and writes the ring-major position of the i-th point of the ring in azimuth
- * order.  Rings of up to 2048 points sort in LDS, longer ones in global memory. */
+ * and writes the ring-major position of the i-th point of the ring in azimuth order; a ring in
+ * which two points share their azimuth bit for bit is then sorted AGAIN, literally as the
+ * reference's Lomuto quicksort does it, whose order of equal azimuths is what gets published
+ * (r5).  Rings of up to 2048 points sort in LDS, longer ones in global memory. */
 __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params dp, unsigned s0,
                                                     unsigned long long* gkeys_all, unsigned* rord_all, unsigned* rcls_all)
 {
@@ -4845,7 +4852,8 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
     __shared__ unsigned long long A[CAP];
     __shared__ unsigned cnt[NB + 1];
     __shared__ urf_sort_shared ssh;
-    __shared__ unsigned ncls[2];
+    __shared__ unsigned ncls[2], sh_tie;
+    __shared__ int lom_stk[2 * 64];
     extern __shared__ unsigned sh_ord_tab[];   /* P[tiles + 1], radd[tiles] (urf_ring_map) */
     const unsigned c = blockIdx.x, s = s0 + blockIdx.y, tid = threadIdx.x;
     unsigned long long* gkeys = gkeys_all + (size_t)blockIdx.y * a.sstride;   /* per scan of the launch: sstride entries */
@@ -4880,8 +4888,35 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
     }
     if (tid < 2)
         ncls[tid] = 0;
+    if (tid == 0)
+        sh_tie = 0;
     __syncthreads();
     const urf_ring_map map = { mapP, mapA, ntiles, (float)ntiles / (float)(n > 0 ? n : 1) };
+    /* Two points of the ring with bit-identical azimuths: their order is the one the reference's Lomuto quicksort
+     * (lidar_segmentation.cpp:70-93; deterministic, not stable) leaves.  SORTED = the (azimuth, position) keys in
+     * ascending order; if two neighbours share their azimuth the keys go back into bucket order (the ring's stretch of wsg,
+     * which nobody reads after k_star_walk), one wave runs the quicksort literally (urf_lomuto_sort, as k_nan_rings does for
+     * rings with NaN azimuths) and the ring is published in that order. */
+    volatile unsigned long long* const LIT = (volatile unsigned long long*)(a.wsg + sb + rel);
+    auto literal_order = [&](const unsigned long long* SORTED) -> bool {
+        for (unsigned j = tid; j + 1 < n; j += NT)
+            if ((unsigned)(SORTED[j] >> 32) == (unsigned)(SORTED[j + 1] >> 32))
+                sh_tie = 1u;
+        __syncthreads();
+        if (!sh_tie)
+            return false;   /* (uniform) */
+        for (unsigned j = tid; j < n; j += NT) {
+            const unsigned long long k = SORTED[j];
+            LIT[(unsigned)k] = k;
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (tid < 64)
+            urf_lomuto_sort(LIT, n, lom_stk);
+        __threadfence_block();
+        __syncthreads();
+        return true;
+    };
     /* what is published for position i of the ring: the point's input index | its class << 30 */
     auto entry_of = [&](unsigned i, unsigned& cls) {
         const unsigned slot = map.at(i);
@@ -4920,12 +4955,13 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
             }
         }
         urf_block_sort_keys<NT, EPT, NB>(key, n, A, cnt, &ssh, false);
+        const bool lit = literal_order(A);
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++) {
             const unsigned j = tid + e * NT;
             if (j < n) {
                 unsigned cls;
-                rord[rel + j] = entry_of((unsigned)A[j], cls);
+                rord[rel + j] = entry_of(lit ? (unsigned)LIT[j] : (unsigned)A[j], cls);
                 my_road += cls == URF_LABEL_ROAD;
                 my_curb += cls == URF_LABEL_CURB;
             }
@@ -4956,9 +4992,10 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
                 __threadfence_block();
                 __syncthreads();
             }
+        const bool lit = literal_order(G);
         for (unsigned j = tid; j < n; j += NT) {
             unsigned cls;
-            rord[rel + j] = entry_of((unsigned)G[j], cls);
+            rord[rel + j] = entry_of(lit ? (unsigned)LIT[j] : (unsigned)G[j], cls);
             my_road += cls == URF_LABEL_ROAD;
             my_curb += cls == URF_LABEL_CURB;
         }
@@ -5058,19 +5095,23 @@ __global__ __launch_bounds__(256) void k_ordered_lists(urf_kargs a, urf_dev_para
  * in front of it (ties: the first in azimuth order).  k_marker_ring builds these two tables per ring
  * in LDS (no sort needed), k_marker_bins walks the rings per degree. */
 __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params dp, unsigned s0,
-                                                     float* m_d_all, unsigned* m_pos_all, uint8_t* m_red_all)
+                                                     float* m_d_all, unsigned* m_pos_all, uint8_t* m_red_all, uint8_t* m_lit_all)
 {
     __shared__ int nrmin[URF_DEG_CELLS];
     __shared__ unsigned long long best[URF_DEG_CELLS];
     __shared__ unsigned bestpos[URF_DEG_CELLS];
+    __shared__ unsigned need_lit;   /* the ring's order decides (k_marker_ring_literal) */
     const unsigned c = blockIdx.x, s = s0 + blockIdx.y, tid = threadIdx.x;
     const size_t cells = (size_t)URF_MAX_CHANNELS * URF_DEG_CELLS;   /* per scan of the launch */
     float* m_d = m_d_all + blockIdx.y * cells;
     unsigned* m_pos = m_pos_all + blockIdx.y * cells;
     uint8_t* m_red = m_red_all + blockIdx.y * cells;
     const urf_scan_info in = a.info[s];
-    if (in.status != URF_OK || c >= in.n_rings)
+    if (in.status != URF_OK || c >= in.n_rings) {
+        if (tid == 0)
+            m_lit_all[(size_t)blockIdx.y * URF_MAX_CHANNELS + c] = 0;
         return;
+    }
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned C = (unsigned)dp.p.channels;
@@ -5084,6 +5125,8 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
         best[i] = 0;
         bestpos[i] = 0xffffffffu;
     }
+    if (tid == 0)
+        need_lit = 0;
     constexpr unsigned EPT = 8;
     if (n <= 256 * EPT) {
         /* The usual ring (at most 2048 points): every point is looked at ONCE -- its slot through the
@@ -5143,8 +5186,10 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++) {
             key[e] = 0;
-            if (tid + e * 256 < n && az[e] == az[e] && ((labs >> (2 * e)) & 3u) == URF_LABEL_ROAD &&
-                (int)urf_fbits(az[e]) < nrmin[bin[e]]) {
+            const bool road = tid + e * 256 < n && az[e] == az[e] && ((labs >> (2 * e)) & 3u) == URF_LABEL_ROAD;
+            if (road && (int)urf_fbits(az[e]) == nrmin[bin[e]])
+                need_lit = 1u;   /* the very azimuth of the degree's first non-road point: in front of it or behind? */
+            if (road && (int)urf_fbits(az[e]) < nrmin[bin[e]]) {
                 const float x = px[e], y = py[e];
                 const float d = (float)__builtin_sqrt((double)(0.f - x) * (double)(0.f - x) + (double)(0.f - y) * (double)(0.f - y));
                 if (d > 0.0f) {   /* "d > maxDistanceRoad" with maxDistanceRoad starting at 0 */
@@ -5157,8 +5202,11 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
 #pragma unroll
         for (unsigned e = 0; e < EPT; e++)
             if (key[e] != 0 && key[e] == best[bin[e]])
-                atomicMin(&bestpos[bin[e]], tid + e * 256);
+                if (atomicMin(&bestpos[bin[e]], tid + e * 256) != 0xffffffffu)
+                    need_lit = 1u;   /* two road points with this distance AND azimuth: which comes first? */
         __syncthreads();
+        if (tid == 0)
+            m_lit_all[(size_t)blockIdx.y * URF_MAX_CHANNELS + c] = (uint8_t)need_lit;
         for (unsigned i = tid; i < URF_DEG_CELLS; i += 256) {
             const size_t o = (size_t)c * URF_DEG_CELLS + i;
             m_d[o] = __uint_as_float((unsigned)(best[i] >> 32));
@@ -5189,6 +5237,8 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
             if (az == az && lab == URF_LABEL_ROAD) {
                 int bin = (int)__builtin_floorf(az);
                 bin = bin < 0 ? 0 : (bin > 360 ? 360 : bin);
+                if ((int)urf_fbits(az) == nrmin[bin])
+                    need_lit = 1u;
                 if ((int)urf_fbits(az) < nrmin[bin]) {
                     const float x = a.rx[sb + slot], y = a.ry[sb + slot];
                     const float d = (float)__builtin_sqrt((double)(0.f - x) * (double)(0.f - x) + (double)(0.f - y) * (double)(0.f - y));
@@ -5196,9 +5246,87 @@ __global__ __launch_bounds__(256) void k_marker_ring(urf_kargs a, urf_dev_params
                         const unsigned long long key = ((unsigned long long)urf_fbits(d) << 32) | (0xffffffffu - urf_fbits(az));
                         if (pass == 0)
                             atomicMax(&best[bin], key);
-                        else if (key == best[bin])
-                            atomicMin(&bestpos[bin], p);
+                        else if (key == best[bin] && atomicMin(&bestpos[bin], p) != 0xffffffffu)
+                            need_lit = 1u;
                     }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0)
+        m_lit_all[(size_t)blockIdx.y * URF_MAX_CHANNELS + c] = (uint8_t)need_lit;
+    for (unsigned i = tid; i < URF_DEG_CELLS; i += 256) {
+        const size_t o = (size_t)c * URF_DEG_CELLS + i;
+        m_d[o] = __uint_as_float((unsigned)(best[i] >> 32));
+        m_pos[o] = bestpos[i] == 0xffffffffu ? 0xffffffffu : sb + urf_ring_slot(a, s, C, c, ntiles, bestpos[i]);
+        m_red[o] = nrmin[i] != URF_INT_NONE_MIN;
+    }
+}
+
+/* The same tables when the ring's ORDER decides -- a road point shares its azimuth, bit for bit, with the first non-road
+ * point of its degree, or two road points share azimuth and distance: which comes first is what the reference's Lomuto
+ * quicksort (lidar_segmentation.cpp:70-93) leaves.  k_marker_ring flags such a ring (m_lit); this kernel, launched behind
+ * it on the same grid, returns at once for every other ring.  The ring is sorted literally (urf_lomuto_sort on (azimuth,
+ * position) pairs in the ring's stretch of wsg, as k_nan_rings / k_ring_order do) and the three passes compare places in
+ * that order instead of azimuths.  Rare: never on a spinning sensor's sweep. */
+__global__ __launch_bounds__(256) void k_marker_ring_literal(urf_kargs a, urf_dev_params dp, unsigned s0, const uint8_t* m_lit_all,
+                                                             float* m_d_all, unsigned* m_pos_all, uint8_t* m_red_all)
+{
+    const unsigned c = blockIdx.x, s = s0 + blockIdx.y, tid = threadIdx.x;
+    if (!m_lit_all[(size_t)blockIdx.y * URF_MAX_CHANNELS + c])
+        return;
+    __shared__ int nrmin[URF_DEG_CELLS];
+    __shared__ unsigned long long best[URF_DEG_CELLS];
+    __shared__ unsigned bestpos[URF_DEG_CELLS];
+    __shared__ int stk[2 * 64];
+    const size_t cells = (size_t)URF_MAX_CHANNELS * URF_DEG_CELLS;
+    float* m_d = m_d_all + blockIdx.y * cells;
+    unsigned* m_pos = m_pos_all + blockIdx.y * cells;
+    uint8_t* m_red = m_red_all + blockIdx.y * cells;
+    unsigned off, len;
+    urf_scan_range(a, s, off, len);
+    const unsigned C = (unsigned)dp.p.channels;
+    const unsigned n = a.ring_cnt[(size_t)s * C + c];
+    const unsigned sb = urf_sbase(a, s);
+    const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
+    const unsigned rel = a.ring_off[(size_t)s * (C + 1) + c];
+    volatile unsigned long long* const LIT = (volatile unsigned long long*)(a.wsg + sb + rel);
+    for (unsigned i = tid; i < URF_DEG_CELLS; i += 256) {
+        nrmin[i] = URF_INT_NONE_MIN;
+        best[i] = 0;
+        bestpos[i] = 0xffffffffu;
+    }
+    for (unsigned p = tid; p < n; p += 256)
+        LIT[p] = ((unsigned long long)urf_fbits(urf_exact_az(a, sb + urf_ring_slot(a, s, C, c, ntiles, p))) << 32) | p;
+    __threadfence_block();
+    __syncthreads();
+    if (tid < 64 && n >= 2)
+        urf_lomuto_sort(LIT, n, stk);
+    __threadfence_block();
+    __syncthreads();
+    for (int pass = 0; pass < 3; pass++) {
+        for (unsigned j = tid; j < n; j += 256) {
+            const unsigned long long e = LIT[j];
+            const float az = urf_pair_alpha(e);
+            const unsigned p = (unsigned)e, slot = urf_ring_slot(a, s, C, c, ntiles, p);
+            const unsigned lab = a.labels[off + (slot & ~(URF_TILE - 1u)) + (a.rec[sb + slot] & URF_REC_SRC_MASK)] & URF_LABEL_MASK;
+            if (!(az == az))
+                continue;
+            int bin = (int)__builtin_floorf(az);
+            bin = bin < 0 ? 0 : (bin > 360 ? 360 : bin);
+            if (pass == 0) {
+                if (lab != URF_LABEL_ROAD)
+                    atomicMin(&nrmin[bin], (int)j);   /* :318 the scan of this ring stops here */
+            } else if (lab == URF_LABEL_ROAD && (int)j < nrmin[bin]) {
+                const float x = a.rx[sb + slot], y = a.ry[sb + slot];
+                const float d = (float)__builtin_sqrt((double)(0.f - x) * (double)(0.f - x) + (double)(0.f - y) * (double)(0.f - y));
+                if (d > 0.0f) {
+                    const unsigned long long key = ((unsigned long long)urf_fbits(d) << 32) | (0xffffffffu - j);   /* (d, first in the ring's order) */
+                    if (pass == 1)
+                        atomicMax(&best[bin], key);
+                    else if (key == best[bin])
+                        bestpos[bin] = p;
                 }
             }
         }
