@@ -56,8 +56,12 @@ extern "C" {
  * urf_set_debug_flags) left this header and the product library (include/urf_test_hooks.h, liburf_hip_test.so);
  * rings that hold a point with x == y == 0 follow the reference (deviation D5 of earlier versions is gone);
  * urf_read_stage / urf_ordered_indices / urf_marker_points answer URF_ERR_BUSY for a sweep whose scratch row has
- * been resubmitted; urf_callback_path_state reports a third sequence bit. */
-#define URF_ABI_VERSION 3
+ * been resubmitted; urf_callback_path_state reports sequence bits 2 and 3.
+ * 4 (round 5): equal planar ranges inside a star sector are ordered as libstdc++'s std::sort orders them
+ * (star_shaped_search.cpp:109) and equal azimuths inside a ring as the reference's Lomuto quicksort does
+ * (lidar_segmentation.cpp:70-93): "deviation D2" of earlier versions is gone, labels on real sensor data (range ties in
+ * every sector) and the published order equal the reference's; urf_callback_path_state reports sequence bit 4. */
+#define URF_ABI_VERSION 4
 
 /* ---- label byte --------------------------------------------------------- */
 #define URF_LABEL_MASK   0x03u
@@ -159,8 +163,8 @@ typedef struct urf_scan_info {
     uint32_t n_road;     /* size of the "road" cloud */
     uint32_t n_curb;     /* size of the "curb" cloud */
     uint32_t n_ring10;   /* size of "road_probably" */
-    uint32_t n_nan_azimuth; /* ring points with x == y == 0 (azimuth NaN): the one input on which this
-                               library deliberately differs from the reference, see below */
+    uint32_t n_nan_azimuth; /* ring points with x == y == 0 (azimuth NaN): 0 on every real sweep; followed as the
+                               reference treats them, see below */
 } urf_scan_info;
 /* A ring point with x == y == 0 has d = 0 and azimuth asin(0 / 0) = NaN (lidar_segmentation.cpp:245-269).  In the
  * reference that NaN goes through the per-ring Lomuto quicksort (:70-93), where every comparison with it is false: the
@@ -285,8 +289,9 @@ int urf_compact_indices_batch(urf_ctx* ctx, const uint8_t* d_labels, uint32_t n_
  * ring index ascending), each ring in ascending azimuth (its per-ring quicksort,
  * lidar_segmentation.cpp:70-93, 289-291, 354-367, 605-608); "roi" is in input
  * order.  After a classify call this returns the input indices of scan `scan`
- * in exactly that order (points of equal azimuth stay in input order; the
- * reference's unstable sort leaves their order open).  Host buffers with room
+ * in exactly that order (points of one ring with bit-identical azimuths in the
+ * order the reference's quicksort leaves them in: it is run literally for such a
+ * ring).  Host buffers with room
  * for n_points entries each (any may be NULL); counts[3] = {road, curb,
  * road_probably}.  Synchronous; costs one extra per-ring sort.
  * LIFETIME: urf_ordered_indices*, urf_marker_points* and urf_read_stage run kernels over the LAST
@@ -390,11 +395,13 @@ int urf_pc2_to_planes(const uint8_t* data, uint32_t n_points, uint32_t point_ste
                       uint32_t off_z, float* x, float* y, float* z);
 /* Diagnostics of the callback path.  It launches a short kernel sequence first (no repair kernels behind the
  * speculative ring table, none for the work lists of star sectors of more than 384 points, none for rings that hold a
- * point with a NaN azimuth); a sweep that needed what
+ * point with a NaN azimuth, none for star sectors with equal planar ranges); a sweep that needed what
  * was left out is run again inside urf_classify_pc2_wait() with the full sequence, and so is every later one.
  * n_rerun: sweeps run again so far (per cause the first one and those in flight beside it); sequence: bit 0 the ring table is still speculative,
  * bit 1 the work-list kernels are part of the sequence, bit 2 so is the kernel for rings with NaN azimuths, bit 3 the ring table also
- * stops at the ring count of the previous sweep (a stream of sweeps from one sensor shows the same rings).  Either pointer may be NULL. */
+ * stops at the ring count of the previous sweep (a stream of sweeps from one sensor shows the same rings), bit 4 the kernel that orders
+ * equal planar ranges of a star sector as std::sort does is part of the sequence (a real sensor's first sweep switches it on).
+ * Either pointer may be NULL. */
 int urf_callback_path_state(const urf_ctx* ctx, uint32_t* n_rerun, uint32_t* sequence);
 const char* urf_strerror(int status);
 const char* urf_last_error(const urf_ctx* ctx);   /* text of the last HIP failure */

@@ -25,8 +25,7 @@
  *   D4  array3D[1] / array3D[10] are only touched when channels > 1 / > 10
  *       (blind_spots.cpp:19, lidar_segmentation.cpp:605).
  * Points with x == y == 0 (NaN azimuth) are sorted exactly as the reference's
- * Lomuto quicksort sorts them; the GPU implementation defines them away
- * differently, fixtures contain none.
+ * Lomuto quicksort sorts them (the HIP path follows: k_nan_rings).
  */
 #include <math.h>
 #include <stdlib.h>

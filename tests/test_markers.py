@@ -3,7 +3,8 @@
        sequences of sweeps (ghostcount and the member linestring carry over between callbacks);
   GPU: urf_marker_points against oracle B, and the C++ adapter's MarkerArray against oracle B.
 boost::geometry::simplify is not available here: the stand-in header of oracle A, oracle B and the
-product each restate Douglas-Peucker (oracle/urf_rdp.h), so that one step is consistent but unpinned."""
+product each restate Douglas-Peucker (oracle/urf_rdp.h); that one step is pinned by known answers instead
+(tests/test_simplify_kat.py: the worked example of Boost.Geometry's documentation and hand-derived cases)."""
 import os
 import struct
 import subprocess

@@ -658,10 +658,11 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         /* sectors whose sorted prefix holds equal planar ranges (URF_TIE_FLAG): the order libstdc++'s std::sort leaves them
          * in.  Benchmark clouds hold none (both kernels return at once); a real sensor's sweep holds them in every sector. */
         if (!(a.optimistic & URF_OPT_NO_TIES)) {
-            const unsigned total = K * n_scans, per = total <= 16384u ? 1u : 64u, nblk = (total + per - 1) / per;
-            const unsigned g_small = nblk < c->n_cus * 16u ? nblk : c->n_cus * 16u, g_big = nblk < c->n_cus * 4u ? nblk : c->n_cus * 4u;
-            hipLaunchKernelGGL(k_star_ties<URF_TIE_SMALL_CAP>, dim3(g_small), dim3(64), 0, st, a, dp, per);
-            hipLaunchKernelGGL(k_star_ties<URF_TIE_BIG_CAP>, dim3(g_big), dim3(64), 0, st, a, dp, per);
+            /* as many one-wave workgroups as are resident (LDS: 5 KB / 32 KB), each over blocks of `per` consecutive sectors */
+            const unsigned total = K * n_scans, per = total <= 16384u ? 1u : 4u, nblk = (total + per - 1) / per;
+            const unsigned g_small = nblk < c->n_cus * 24u ? nblk : c->n_cus * 24u, g_big = nblk < c->n_cus * 4u ? nblk : c->n_cus * 4u;
+            hipLaunchKernelGGL(k_star_ties<false>, dim3(g_small), dim3(64), 0, st, a, dp, per);
+            hipLaunchKernelGGL(k_star_ties<true>, dim3(g_big), dim3(64), 0, st, a, dp, per);
         }
     }
     mark();   /* "k_star_sort" = the three sort kernels (mid / big run over normally empty work lists) */

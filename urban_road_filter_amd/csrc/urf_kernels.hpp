@@ -1439,8 +1439,10 @@ __global__ __launch_bounds__(256) void k_index(urf_kargs a, urf_dev_params dp)
  *                  per wave.
  *
  * Sort key = (range bits << 32 | position in the sector-major array); the
- * position grows with the input index (the split is stable), so the order is
- * total where the reference's std::sort leaves ties unspecified (:109).
+ * position grows with the input index (the split is stable).  Equal ranges are
+ * thereby in input order, which is NOT the order the reference's std::sort
+ * leaves them in (:109): a sector whose sorted prefix holds equal neighbours is
+ * flagged and sorted again by k_star_ties, below.
  * Small sectors (<= 384 points, <= 6 per lane): every 64-element block is
  * sorted in registers by an in-wave bitonic network (shuffles, no LDS traffic),
  * then each element finds its final rank by binary search in the other blocks
@@ -1805,9 +1807,10 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
 /* a sector was flagged with URF_TIE_FLAG: tell k_star_ties' instance for its size that there is work -- or, in a launch
  * sequence without it (callback path), void the sweep: urf_classify_pc2_wait() runs it again with the kernel (every writer
  * writes the same value) */
-__device__ __forceinline__ void urf_tie_found(const urf_kargs& a, unsigned s, unsigned n)
+__device__ __forceinline__ bool urf_tie_big(unsigned n, unsigned nruns) { return n > URF_TIE_SMALL_CAP || nruns > 2u; }
+__device__ __forceinline__ void urf_tie_found(const urf_kargs& a, unsigned s, unsigned n, unsigned nruns)
 {
-    a.star_count[4 + (n > URF_TIE_SMALL_CAP ? 1 : 0)] = 1u;
+    a.star_count[4 + (urf_tie_big(n, nruns) ? 1 : 0)] = 1u;
     if (a.optimistic & URF_OPT_NO_TIES)
         a.info[s].status = URF_STATUS_REDO_TIES;
 }
@@ -1851,7 +1854,7 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
      * its 80 registers; such sectors take the workgroup path now.) */
     const bool tie = urf_star_sort_sector<URF_STAR_SMALL_CAP / 64>(a, dp, sb, obase, n, two, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
     if (tie && lane == 0)
-        urf_tie_found(a, s, n);
+        urf_tie_found(a, s, n, two.nruns);
 }
 
 template <int NT>
@@ -2196,7 +2199,7 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
             const bool tie = sh_tie != 0u || (first + 1 < n && R[first + 1] == R[first]);
             a.star_first[sk] = (first < n - 1 ? first : n - 1) | (tie ? URF_TIE_FLAG : 0u);
             if (tie)
-                urf_tie_found(a, s, n);
+                urf_tie_found(a, s, n, simple ? 2u : 3u);
         }
         __syncthreads();
         URF_PHASE_ACC(3);
@@ -2315,7 +2318,7 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
         if (threadIdx.x == 0) {
             a.star_first[sk] = (sh_first < n - 1 ? sh_first : n - 1) | (sh_tie ? URF_TIE_FLAG : 0u);
             if (sh_tie)
-                urf_tie_found(a, s, n);
+                urf_tie_found(a, s, n, 3u);
         }
         __syncthreads();
     }
@@ -2345,15 +2348,27 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
  * each <= the next: every element's final place is its segment's start + the smaller elements of the segment + the equal
  * ones in front of it.  tests/test_stdsort.py pins the same formulation on the CPU against the real std::sort.
  *
- * The arrays (range bits, address in the sector-sorted arrays, two work arrays of positions) live in LDS up to CAP points
- * per sector -- two instances, URF_TIE_SMALL_CAP and URF_TIE_BIG_CAP: 8 and 32 KB -- and beyond that in the sector's
- * stretch of big_r / big_i / big_z / ssrt. */
+ * The arrays (range bits, the points, two work arrays of positions) live in LDS -- two instances: sectors of at most two runs
+ * and URF_TIE_SMALL_CAP points, 5 KB per wave; anything else up to URF_TIE_BIG_CAP points, 32 KB -- and beyond that in the
+ * sector's stretch of big_r / big_i / big_z / ssrt. */
+/* three memory policies: the small instance (sectors of at most two runs and URF_TIE_SMALL_CAP points: the index arrays hold
+ * positions inside the sector, 16 bits), the big instance's LDS and global memory (the index arrays hold addresses) */
+struct urf_tie_small {
+    typedef unsigned* rptr;
+    typedef uint16_t* iptr;
+    static constexpr bool POS = true;
+    static __device__ __forceinline__ void sync() { urf_wave_lds_sync(); }
+};
 struct urf_tie_lds {
-    typedef unsigned* ptr;
+    typedef unsigned* rptr;
+    typedef unsigned* iptr;
+    static constexpr bool POS = false;
     static __device__ __forceinline__ void sync() { urf_wave_lds_sync(); }
 };
 struct urf_tie_glb {
-    typedef volatile unsigned* ptr;   /* (volatile: one lane writes what the others read next) */
+    typedef volatile unsigned* rptr;   /* (volatile: one lane writes what the others read next) */
+    typedef volatile unsigned* iptr;
+    static constexpr bool POS = false;
     static __device__ __forceinline__ void sync()
     {
         __threadfence_block();
@@ -2362,8 +2377,8 @@ struct urf_tie_glb {
 };
 
 /* stl_heap.h: __adjust_heap + __push_heap on the segment starting at f (one lane) */
-template <class PTR>
-__device__ void urf_tie_adjust_heap(PTR R, PTR P, unsigned f, int hole, int len, unsigned v, unsigned pv)
+template <class RP_, class IP_>
+__device__ void urf_tie_adjust_heap(RP_ R, IP_ P, unsigned f, int hole, int len, unsigned v, unsigned pv)
 {
     const int top = hole;
     int second = hole;
@@ -2392,8 +2407,8 @@ __device__ void urf_tie_adjust_heap(PTR R, PTR P, unsigned f, int hole, int len,
     P[f + hole] = pv;
 }
 /* stl_algo.h __partial_sort(first, last, last): __make_heap, then __sort_heap */
-template <class PTR>
-__device__ void urf_tie_heap_sort(PTR R, PTR P, unsigned f, unsigned l)
+template <class RP_, class IP_>
+__device__ __noinline__ void urf_tie_heap_sort(RP_ R, IP_ P, unsigned f, unsigned l)
 {
     const int len = (int)(l - f);
     if (len >= 2) {
@@ -2413,18 +2428,155 @@ __device__ void urf_tie_heap_sort(PTR R, PTR P, unsigned f, unsigned l)
     }
 }
 
+/* __introsort_loop on R (range bits) with P (the points) moved along; LP / RP: work arrays of n entries each.  Leaves, for
+ * every element j, the segment [LP[j], RP[j]) the final insertion sort will keep it in. */
 template <class MEM>
-__device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const urf_dev_params& dp, unsigned sk, unsigned s, unsigned k, unsigned n,
-                                                    typename MEM::ptr R, typename MEM::ptr P, typename MEM::ptr LP, typename MEM::ptr RP, int* stk)
+__device__ __forceinline__ void urf_tie_introsort_loop(unsigned n, typename MEM::rptr R, typename MEM::iptr P, typename MEM::iptr LP,
+                                                       typename MEM::iptr RP, int* stk)
 {
-    typedef typename MEM::ptr PTR;
+    const unsigned lane = threadIdx.x;
+    const unsigned limit = 2u * (31u - (unsigned)__clz((int)n));
+    int top = 0;
+    unsigned f = 0, l = n, d = 0;
+    for (;;) {
+        while (l - f > 16u) {
+            if (d == limit) {
+                if (lane == 0)
+                    urf_tie_heap_sort<typename MEM::rptr, typename MEM::iptr>(R, P, f, l);
+                for (unsigned j = f + lane; j < l; j += 64) {   /* sorted: every element a segment of its own */
+                    LP[j] = j;
+                    RP[j] = j + 1;
+                }
+                MEM::sync();
+                f = l;
+                break;
+            }
+            d++;
+            {   /* __move_median_to_first(first, first + 1, mid, last - 1) */
+                const unsigned mid = f + (l - f) / 2;
+                const unsigned va = R[f + 1], vb = R[mid], vc = R[l - 1];
+                unsigned m;
+                if (va < vb)
+                    m = vb < vc ? mid : (va < vc ? l - 1 : f + 1);
+                else if (va < vc)
+                    m = f + 1;
+                else if (vb < vc)
+                    m = l - 1;
+                else
+                    m = mid;
+                if (lane == 0) {
+                    const unsigned r0 = R[f], p0 = P[f];
+                    R[f] = R[m];
+                    P[f] = P[m];
+                    R[m] = r0;
+                    P[m] = p0;
+                }
+                MEM::sync();
+            }
+            const unsigned pv = R[f];
+            /* __unguarded_partition(first + 1, last, first): where the left pointer can stop (>= pivot), where the right one (<= pivot) */
+            unsigned tL = 0, tR = 0;
+            for (unsigned c0 = f + 1; c0 < l; c0 += 64) {
+                const unsigned p = c0 + lane;
+                const bool in = p < l;
+                const unsigned v = in ? R[p] : 0u;
+                const bool isL = in && v >= pv, isR = in && v <= pv;
+                const unsigned long long mL = __ballot(isL), mR = __ballot(isR);
+                if (isL)
+                    LP[f + 1 + tL + urf_popc_below(mL)] = p;
+                if (isR)
+                    RP[f + 1 + tR + urf_popc_below(mR)] = p;   /* ascending; the k-th from the right is entry tR - 1 - k */
+                tL += (unsigned)__popcll(mL);
+                tR += (unsigned)__popcll(mR);
+            }
+            MEM::sync();
+            const unsigned mn = tL < tR ? tL : tR;
+            unsigned ks = 0;
+            for (unsigned k0 = 0; k0 < mn; k0 += 64) {
+                const unsigned kk = k0 + lane;
+                const bool in = kk < mn;
+                const unsigned lp = in ? LP[f + 1 + kk] : 0u, rp = in ? RP[f + tR - kk] : 0u;
+                const bool ok = in && lp < rp;
+                const unsigned long long mo = __ballot(ok), mi = __ballot(in);
+                if (ok) {   /* iter_swap: the positions of all pairs are distinct */
+                    const unsigned r0 = R[lp], p0 = P[lp], r1 = R[rp], p1 = P[rp];
+                    R[lp] = r1;
+                    P[lp] = p1;
+                    R[rp] = r0;
+                    P[rp] = p0;
+                }
+                ks += (unsigned)__popcll(mo);
+                if (mo != mi)
+                    break;
+            }
+            MEM::sync();
+            const unsigned Lk = ks < tL ? LP[f + 1 + ks] : 0xffffffffu;
+            const unsigned Rk = ks > 0 ? RP[f + 1 + tR - ks] : 0xffffffffu;
+            const unsigned cut = Lk < Rk ? Lk : Rk;
+            if (l - cut > 16u) {   /* __introsort_loop(cut, last, depth_limit): later */
+                if (lane == 0) {
+                    stk[3 * top] = (int)cut;
+                    stk[3 * top + 1] = (int)l;
+                    stk[3 * top + 2] = (int)d;
+                }
+                top++;
+            } else {
+                const unsigned j = cut + lane;
+                if (j < l) {
+                    LP[j] = cut;
+                    RP[j] = l;
+                }
+            }
+            l = cut;
+        }
+        if (l > f) {   /* at most 16 elements: left to the final insertion sort */
+            const unsigned j = f + lane;
+            if (j < l) {
+                LP[j] = f;
+                RP[j] = l;
+            }
+        }
+        if (top == 0)
+            break;
+        top--;
+        urf_wave_lds_sync();
+        f = (unsigned)stk[3 * top];
+        l = (unsigned)stk[3 * top + 1];
+        d = (unsigned)stk[3 * top + 2];
+    }
+    MEM::sync();
+}
+
+/* __final_insertion_sort: stable, and every element stays inside its segment -- its final place */
+template <class MEM>
+__device__ __forceinline__ unsigned urf_tie_final_rank(unsigned j, typename MEM::rptr R, typename MEM::iptr LP, typename MEM::iptr RP)
+{
+    const unsigned sa = LP[j], se = RP[j], v = R[j];
+    unsigned rank = sa;
+    for (unsigned i = sa; i < se; i++) {
+        const unsigned u = R[i];
+        rank += (u < v || (u == v && i < j)) ? 1u : 0u;
+    }
+    return rank;
+}
+
+template <class MEM, unsigned CAP>
+__device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const urf_dev_params& dp, unsigned sk, unsigned s, unsigned k, unsigned n,
+                                                    typename MEM::rptr R, typename MEM::iptr P, typename MEM::iptr LP, typename MEM::iptr RP, int* stk)
+{
     const unsigned lane = threadIdx.x, K = (unsigned)dp.p.sectors;
     const unsigned sb = urf_sbase(a, s), base = sb + a.sec_off[(size_t)s * (K + 1) + k];
     const urf_sec_run two = a.sec_run[sk];
     const bool simple = two.nruns <= 2;
-    /* the sector in the reference's order (ROI order = tiles in order, input order inside): range bits and the point's
-     * address in the sector-sorted arrays */
-    {
+    auto adr_of = [&](unsigned i) { return i < two.c0 ? two.a0 + i : two.a1 + (i - two.c0); };   /* (simple sectors) */
+    /* the sector in the reference's order (ROI order = tiles in order, input order inside): range bits and the point --
+     * its position inside the sector (small instance) or its address in the sector-sorted arrays */
+    if constexpr (MEM::POS) {
+        for (unsigned i = lane; i < n; i += 64) {
+            R[i] = urf_fbits(a.sr[sb + adr_of(i)]);
+            P[i] = (uint16_t)i;
+        }
+    } else {
         unsigned nruns = 0;
         if (!simple) {
             unsigned off, len;
@@ -2434,7 +2586,7 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
         }
         unsigned r = 0;
         for (unsigned i = lane; i < n; i += 64) {
-            unsigned adr = i < two.c0 ? two.a0 + i : two.a1 + (i - two.c0);
+            unsigned adr = adr_of(i);
             if (!simple) {
                 while (r + 1 < nruns && i >= LP[r + 1])
                     r++;
@@ -2443,141 +2595,49 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
             R[i] = urf_fbits(a.sr[sb + adr]);
             P[i] = adr;
         }
-        MEM::sync();
     }
-    /* ---- __introsort_loop ---- */
-    {
-        const unsigned limit = 2u * (31u - (unsigned)__clz((int)n));
-        int top = 0;
-        unsigned f = 0, l = n, d = 0;
-        for (;;) {
-            while (l - f > 16u) {
-                if (d == limit) {
-                    if (lane == 0)
-                        urf_tie_heap_sort<PTR>(R, P, f, l);
-                    for (unsigned j = f + lane; j < l; j += 64) {   /* sorted: every element a segment of its own */
-                        LP[j] = j;
-                        RP[j] = j + 1;
-                    }
-                    MEM::sync();
-                    f = l;
-                    break;
-                }
-                d++;
-                {   /* __move_median_to_first(first, first + 1, mid, last - 1) */
-                    const unsigned mid = f + (l - f) / 2;
-                    const unsigned va = R[f + 1], vb = R[mid], vc = R[l - 1];
-                    unsigned m;
-                    if (va < vb)
-                        m = vb < vc ? mid : (va < vc ? l - 1 : f + 1);
-                    else if (va < vc)
-                        m = f + 1;
-                    else if (vb < vc)
-                        m = l - 1;
-                    else
-                        m = mid;
-                    if (lane == 0) {
-                        const unsigned r0 = R[f], p0 = P[f];
-                        R[f] = R[m];
-                        P[f] = P[m];
-                        R[m] = r0;
-                        P[m] = p0;
-                    }
-                    MEM::sync();
-                }
-                const unsigned pv = R[f];
-                /* __unguarded_partition(first + 1, last, first): where the left pointer can stop (>= pivot), where the right one (<= pivot) */
-                unsigned tL = 0, tR = 0;
-                for (unsigned c0 = f + 1; c0 < l; c0 += 64) {
-                    const unsigned p = c0 + lane;
-                    const bool in = p < l;
-                    const unsigned v = in ? R[p] : 0u;
-                    const bool isL = in && v >= pv, isR = in && v <= pv;
-                    const unsigned long long mL = __ballot(isL), mR = __ballot(isR);
-                    if (isL)
-                        LP[f + 1 + tL + urf_popc_below(mL)] = p;
-                    if (isR)
-                        RP[f + 1 + tR + urf_popc_below(mR)] = p;   /* ascending; the k-th from the right is entry tR - 1 - k */
-                    tL += (unsigned)__popcll(mL);
-                    tR += (unsigned)__popcll(mR);
-                }
-                MEM::sync();
-                const unsigned mn = tL < tR ? tL : tR;
-                unsigned ks = 0;
-                for (unsigned k0 = 0; k0 < mn; k0 += 64) {
-                    const unsigned kk = k0 + lane;
-                    const bool in = kk < mn;
-                    const unsigned lp = in ? LP[f + 1 + kk] : 0u, rp = in ? RP[f + tR - kk] : 0u;
-                    const bool ok = in && lp < rp;
-                    const unsigned long long mo = __ballot(ok), mi = __ballot(in);
-                    if (ok) {   /* iter_swap: the positions of all pairs are distinct */
-                        const unsigned r0 = R[lp], p0 = P[lp], r1 = R[rp], p1 = P[rp];
-                        R[lp] = r1;
-                        P[lp] = p1;
-                        R[rp] = r0;
-                        P[rp] = p0;
-                    }
-                    ks += (unsigned)__popcll(mo);
-                    if (mo != mi)
-                        break;
-                }
-                MEM::sync();
-                const unsigned Lk = ks < tL ? LP[f + 1 + ks] : 0xffffffffu;
-                const unsigned Rk = ks > 0 ? RP[f + 1 + tR - ks] : 0xffffffffu;
-                const unsigned cut = Lk < Rk ? Lk : Rk;
-                if (l - cut > 16u) {   /* __introsort_loop(cut, last, depth_limit): later */
-                    if (lane == 0) {
-                        stk[3 * top] = (int)cut;
-                        stk[3 * top + 1] = (int)l;
-                        stk[3 * top + 2] = (int)d;
-                    }
-                    top++;
-                } else {
-                    const unsigned j = cut + lane;
-                    if (j < l) {
-                        LP[j] = cut;
-                        RP[j] = l;
-                    }
-                }
-                l = cut;
+    MEM::sync();
+    urf_tie_introsort_loop<MEM>(n, R, P, LP, RP, stk);
+    /* sorted: R = range bits, P = points, Z = heights */
+    typename MEM::rptr Z;
+    if constexpr (MEM::POS) {
+        /* in place through registers (at most CAP / 64 elements per lane); the heights go where LP / RP were */
+        constexpr unsigned EPL = CAP / 64;
+        unsigned rk[EPL], rv[EPL], pv[EPL];
+#pragma unroll
+        for (unsigned q = 0; q < EPL; q++) {
+            const unsigned j = q * 64 + lane;
+            rk[q] = rv[q] = pv[q] = 0;
+            if (j < n) {
+                rk[q] = urf_tie_final_rank<MEM>(j, R, LP, RP);
+                rv[q] = R[j];
+                pv[q] = P[j];
             }
-            if (l > f) {   /* at most 16 elements: left to the final insertion sort */
-                const unsigned j = f + lane;
-                if (j < l) {
-                    LP[j] = f;
-                    RP[j] = l;
-                }
-            }
-            if (top == 0)
-                break;
-            top--;
-            urf_wave_lds_sync();
-            f = (unsigned)stk[3 * top];
-            l = (unsigned)stk[3 * top + 1];
-            d = (unsigned)stk[3 * top + 2];
         }
         MEM::sync();
+        Z = (unsigned*)LP;   /* (LP and RP are one stretch of 2 * CAP 16-bit entries) */
+#pragma unroll
+        for (unsigned q = 0; q < EPL; q++)
+            if (q * 64 + lane < n) {
+                R[rk[q]] = rv[q];
+                P[rk[q]] = (uint16_t)pv[q];
+                Z[rk[q]] = __float_as_uint(a.sz[sb + adr_of(pv[q])]);
+            }
+        MEM::sync();
+    } else {
+        for (unsigned j = lane; j < n; j += 64)
+            LP[j] = urf_tie_final_rank<MEM>(j, R, LP, RP);
+        MEM::sync();
+        for (unsigned j = lane; j < n; j += 64)
+            RP[LP[j]] = P[j];            /* address of the i-th point in sorted order */
+        MEM::sync();
+        for (unsigned j = lane; j < n; j += 64)
+            P[LP[j]] = R[j];             /* its range bits */
+        MEM::sync();
+        for (unsigned i = lane; i < n; i += 64)
+            R[i] = __float_as_uint(a.sz[sb + RP[i]]);   /* its height */
+        MEM::sync();
     }
-    /* ---- __final_insertion_sort: stable, and every element stays inside its segment ---- */
-    for (unsigned j = lane; j < n; j += 64) {
-        const unsigned sa = LP[j], se = RP[j], v = R[j];
-        unsigned rank = sa;
-        for (unsigned i = sa; i < se; i++) {
-            const unsigned u = R[i];
-            rank += (u < v || (u == v && i < j)) ? 1u : 0u;
-        }
-        LP[j] = rank;
-    }
-    MEM::sync();
-    for (unsigned j = lane; j < n; j += 64)
-        RP[LP[j]] = P[j];            /* address of the i-th point in sorted order */
-    MEM::sync();
-    for (unsigned j = lane; j < n; j += 64)
-        P[LP[j]] = R[j];             /* its range bits */
-    MEM::sync();
-    for (unsigned i = lane; i < n; i += 64)
-        R[i] = __float_as_uint(a.sz[sb + RP[i]]);   /* its height */
-    MEM::sync();
     /* ---- what the sort kernels publish: slopes, distance terms, the point's position / ring-sorted index ---- */
     const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
     const bool fmt16 = simple && n <= URF_STAR_MID_CAP_;   /* (urf_walk_report) */
@@ -2586,19 +2646,29 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
         const unsigned i = i0 + lane;
         bool hit = false;
         if (i < n) {
-            float slp = 0.f, g = 0.f;
+            float slp = 0.f, g = 0.f, ax, bx, az, bz;
+            if constexpr (MEM::POS) {
+                ax = __uint_as_float(R[i >= 1 ? i - 1 : 0]); bx = __uint_as_float(R[i]);
+                az = __uint_as_float(Z[i >= 1 ? i - 1 : 0]); bz = __uint_as_float(Z[i]);
+            } else {
+                ax = __uint_as_float(P[i >= 1 ? i - 1 : 0]); bx = __uint_as_float(P[i]);
+                az = __uint_as_float(R[i >= 1 ? i - 1 : 0]); bz = __uint_as_float(R[i]);
+            }
             if (i >= 1) {
-                const float ax = __uint_as_float(P[i - 1]), bx = __uint_as_float(P[i]);
-                slp = (__uint_as_float(R[i]) - __uint_as_float(R[i - 1])) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
+                slp = (bz - az) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
                 g = (bx - ax) * kdist;
                 hit = slp > slope_param;
             }
-            const unsigned adr = RP[i];
-            if (fmt16) {
-                a.ssrt16[base + i] = (uint16_t)((two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0);
+            if constexpr (MEM::POS) {
+                a.ssrt16[base + i] = P[i];
             } else {
-                const unsigned sl = a.sslot[sb + adr];
-                a.ssrt[base + i] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;   /* (RP may BE this stretch of ssrt: own element) */
+                const unsigned adr = RP[i];
+                if (fmt16) {
+                    a.ssrt16[base + i] = (uint16_t)((two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0);
+                } else {
+                    const unsigned sl = a.sslot[sb + adr];
+                    a.ssrt[base + i] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;   /* (RP may BE this stretch of ssrt: own element) */
+                }
             }
             a.wsg[base + i] = urf_sg{ slp, g };
         }
@@ -2613,14 +2683,16 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
     MEM::sync();
 }
 
-template <unsigned CAP>
+/* BIG = false: sectors of at most two runs and URF_TIE_SMALL_CAP points (every sector of an organised 64-ring sweep), 5 KB of LDS
+ * per wave; BIG = true: all others.  Persistent over blocks of `per_block` consecutive (scan, sector) entries of star_first. */
+template <bool BIG>
 __global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp, unsigned per_block)
 {
-    __shared__ unsigned W[4 * CAP];
+    constexpr unsigned CAP = BIG ? URF_TIE_BIG_CAP : URF_TIE_SMALL_CAP;
+    __shared__ unsigned W[BIG ? 4 * CAP : CAP + (3 * CAP) / 2];   /* R; P, LP, RP (32 / 16 bits) */
     __shared__ int stk[3 * 64];
-    constexpr bool BIG = CAP > URF_TIE_SMALL_CAP;
     if (a.star_count[4 + (BIG ? 1 : 0)] == 0u)
-        return;   /* (uniform) no sector of this instance's sizes is flagged */
+        return;   /* (uniform) no sector of this instance's kind is flagged */
     const unsigned K = (unsigned)dp.p.sectors, total = a.n_scans * K, lane = threadIdx.x;
     const unsigned nblk = (total + per_block - 1) / per_block;
     for (unsigned blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -2634,14 +2706,17 @@ __global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp
             if (a.info[s].status != URF_OK)
                 continue;   /* (a void scan's entries are leftovers of an earlier call) */
             const unsigned n = a.sec_cnt[sk];
-            if ((n > URF_TIE_SMALL_CAP) != BIG || n < 2)
+            if (urf_tie_big(n, a.sec_run[sk].nruns) != BIG || n < 2)
                 continue;
-            if (n <= CAP) {
-                urf_tie_sector_body<urf_tie_lds>(a, dp, sk, s, k, n, W, W + CAP, W + 2 * CAP, W + 3 * CAP, stk);
-            } else if (BIG) {
+            if constexpr (!BIG) {
+                uint16_t* I = (uint16_t*)(W + CAP);
+                urf_tie_sector_body<urf_tie_small, CAP>(a, dp, sk, s, k, n, W, I, I + CAP, I + 2 * CAP, stk);
+            } else if (n <= CAP) {
+                urf_tie_sector_body<urf_tie_lds, CAP>(a, dp, sk, s, k, n, W, W + CAP, W + 2 * CAP, W + 3 * CAP, stk);
+            } else {
                 const unsigned base = urf_sbase(a, s) + a.sec_off[(size_t)s * (K + 1) + k];
-                urf_tie_sector_body<urf_tie_glb>(a, dp, sk, s, k, n, (unsigned*)a.big_r + base, a.big_i + base, (unsigned*)a.big_z + base,
-                                                 a.ssrt + base, stk);
+                urf_tie_sector_body<urf_tie_glb, CAP>(a, dp, sk, s, k, n, (unsigned*)a.big_r + base, a.big_i + base, (unsigned*)a.big_z + base,
+                                                      a.ssrt + base, stk);
             }
         }
     }
