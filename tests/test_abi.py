@@ -116,3 +116,33 @@ def test_cpp_clients_build_against_the_product_library(tmp_path, client):
         r = subprocess.run([exe, str(cloud), str(tmp_path / "out.bin"), "1"], capture_output=True, text=True)
         assert r.returncode != 0 and "no usable HIP device" in (r.stderr + r.stdout)
         assert not os.path.exists(tmp_path / "out.bin")
+
+
+def test_rccl_shard_client_builds(tmp_path):
+    """tests/cpp/shard_demo.cpp (one context + one RCCL communicator per device, ncclAllReduce of the counters through rccl.h)
+    compiles and links against the product library and librccl without a GPU; tests/test_gpu_detector.py runs it on one.
+    Without a device it reports that and writes nothing."""
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) or not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no hipcc / rccl.h")
+    u.lib()
+    pkg = os.path.join(ROOT, "urban_road_filter_amd")
+    exe = str(tmp_path / "shard_demo")
+    subprocess.check_call([hipcc, "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shard_demo.cpp"), "-o", exe, "-L" + pkg, "-l:liburf_hip.so", "-lrccl",
+                           "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    undefined = subprocess.run(["nm", "-u", exe], capture_output=True, text=True).stdout
+    assert "ncclAllReduce" in undefined and "ncclCommInitAll" in undefined and "urf_classify_pc2_async" in undefined
+    from conftest import gpu_available
+    if not gpu_available():
+        import struct
+        import numpy as np
+        cloud = tmp_path / "cloud.bin"
+        with open(cloud, "wb") as f:
+            f.write(struct.pack("<I", 4096))
+            for _ in range(3):
+                f.write(np.zeros(4096, np.float32).tobytes())
+        r = subprocess.run([exe, str(tmp_path / "out.bin"), "0", str(cloud)], capture_output=True, text=True)
+        assert r.returncode != 0 and "no usable HIP device" in (r.stderr + r.stdout)
+        assert not os.path.exists(tmp_path / "out.bin")

@@ -154,3 +154,36 @@ def test_one_context_per_thread_from_cpp(tmp_path):
         road += ib["n_road"]
         curb += ib["n_curb"]
     assert "contexts 2 sweeps 5 + 5 road %d curb %d" % (road, curb) in r.stdout
+
+
+@pytest.mark.gpu
+def test_shards_and_rccl_counters_from_cpp(tmp_path):
+    """tests/cpp/shard_demo.cpp: the multi-GPU pattern with its collective, from C++ -- one context, one host thread and one
+    RCCL communicator per device (ncclCommInitAll), scan s on device s mod G, ncclAllReduce(sum) of the six counters and
+    ncclAllReduce(max) of the elapsed time through rccl.h.  The test box has one GPU: G = 1, the collectives run over a
+    communicator of one rank.  Labels equal oracle B, the reduced counters equal the sums over the sweeps."""
+    exe = str(tmp_path / "shard_demo")
+    pkg = os.path.join(ROOT, "urban_road_filter_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shard_demo.cpp"), "-o", exe, "-L" + pkg, "-l:liburf_hip.so", "-lrccl",
+                           "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    clouds = [u.synth_cloud(64, 2048, 1 + k % 2, 300 + k) for k in range(6)]
+    files = []
+    for k, (x, y, z) in enumerate(clouds):
+        files.append(str(tmp_path / ("c%d.bin" % k)))
+        with open(files[-1], "wb") as f:
+            f.write(struct.pack("<I", len(x)) + x.tobytes() + y.tobytes() + z.tobytes())
+    out = str(tmp_path / "labels.bin")
+    r = subprocess.run([exe, out, "0"] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    blob = np.fromfile(out, np.uint8).reshape(len(clouds), -1)
+    p = O.cfg_params("cfg2")
+    tot = {"n_roi": 0, "n_road": 0, "n_curb": 0}
+    for k, (x, y, z) in enumerate(clouds):
+        lb, ib, _ = O.run_b(x, y, z, p)
+        assert np.array_equal(blob[k], lb), k
+        for key in tot:
+            tot[key] += ib[key]
+    want = "scans %d points_in %d roi_points %d road %d curb %d ok_scans %d" % (len(clouds), len(clouds) * 64 * 2048, tot["n_roi"], tot["n_road"],
+                                                                                 tot["n_curb"], len(clouds))
+    assert want in r.stdout, r.stdout

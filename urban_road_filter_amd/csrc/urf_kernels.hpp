@@ -3711,8 +3711,46 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
      * 16-byte aligned (an organised sweep: always) that is one 16-byte load per array, otherwise
      * four mapped ones. */
     constexpr int NSQ = (CH + 2 * PAD + 4 * URF_RING_THREADS - 1) / (4 * URF_RING_THREADS);
-    float4 fx[NSQ], fy[NSQ], fz[NSQ];
-    auto fetch = [&](int cs) {
+    /* (the four-points-per-thread instance works on z alone and needs five points in front of a chunk and ten behind it:
+     * ONE quad per thread -- its own four points -- plus one halo value in each of 16 lanes, five registers per chunk in
+     * flight instead of eight: 0.42 -> 0.40 ms, r5) */
+    struct zbuf {
+        float4 q;
+        float h;
+    };
+    constexpr int QH = 8;   /* halo values on either side */
+    auto fetchq = [&](int cs, zbuf& b) {
+        const int j = cs + 4 * (int)tid;
+        b.q = make_float4(0.f, 0.f, 0.f, 0.f);
+        b.h = 0.f;
+        if (j < n) {
+            bool wide = false;
+            if (j + 3 < n) {
+                const unsigned t = map.tile((unsigned)j);
+                const unsigned idx = mapA[t] + (unsigned)j;
+                if ((unsigned)j + 3 < mapP[t + 1] && (idx & 3u) == 0) {
+                    wide = true;
+                    b.q = *(const float4*)(a.rz + idx);
+                }
+            }
+            if (!wide) {
+                float ez[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int e4 = 0; e4 < 4; e4++)
+                    if (j + e4 < n)
+                        ez[e4] = a.rz[map.at((unsigned)(j + e4))];
+                b.q = make_float4(ez[0], ez[1], ez[2], ez[3]);
+            }
+        }
+        if (tid < 2 * QH) {
+            const int hp = (int)tid < QH ? cs - QH + (int)tid : cs + CH + ((int)tid - QH);
+            if (hp >= 0 && hp < n)
+                b.h = a.rz[map.at((unsigned)hp)];
+        }
+    };
+    float4 fx[NSQ], fy[NSQ], fzA[NSQ];
+    [[maybe_unused]] zbuf zA;
+    auto fetch = [&](int cs, float4 (&fz)[NSQ]) {
 #pragma unroll
         for (int m = 0; m < NSQ; m++) {
             const int j = cs - PAD + 4 * ((int)tid + m * URF_RING_THREADS);
@@ -3750,13 +3788,23 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
             }
         }
     };
-    fetch(cs0);
-    for (int cs = cs0; cs < n; cs += CH, buf ^= 1u, hbi = hbi == 2u ? 0u : hbi + 1u) {
+    /* one chunk: `fz` / `zq` hold its z values (requested while the chunk before was evaluated); parked, then the buffer is
+     * refilled with chunk `cs_next` */
+    auto chunk = [&](const int cs, float4 (&fz)[NSQ], zbuf& zq, const int cs_next) {
         /* park [cs - PAD, cs + CH + PAD) (positions outside the ring hold zeros nobody reads), mark
          * the star hits of the chunk, clear the other bitmap */
         {
+            if constexpr (QUADS) {
+                float* const zw = S.zsb[buf] + zpad;   /* slot of position cs */
+                zw[4 * tid] = zq.q.x;                  /* (zpad = PAD + 1: the evaluation's 16-byte reads, one slot lower, are the aligned ones) */
+                zw[4 * tid + 1] = zq.q.y;
+                zw[4 * tid + 2] = zq.q.z;
+                zw[4 * tid + 3] = zq.q.w;
+                if (tid < 2 * QH)
+                    zw[(int)tid < QH ? (int)tid - QH : CH + ((int)tid - QH)] = zq.h;
+            }
 #pragma unroll
-            for (int m = 0; m < NSQ; m++) {
+            for (int m = 0; m < (QUADS ? 0 : NSQ); m++) {
                 const int li = 4 * ((int)tid + m * URF_RING_THREADS);   /* slot of position cs - PAD + li */
                 if (li < CH + 2 * PAD) {
                     if (!quads) {
@@ -3788,8 +3836,12 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
         }
         __syncthreads();
         URF_PHASE_ACC(2);
-        if (cs + CH < n)
-            fetch(cs + CH);
+        if (cs_next < n) {
+            if constexpr (QUADS)
+                fetchq(cs_next, zq);
+            else
+                fetch(cs_next, fz);
+        }
         if (quads) {
             /* ---- four consecutive points per thread, curbPoints == 5 ----
              * Cheap tests and the float azimuth for every point, stored at once; the points that
@@ -3862,6 +3914,8 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                     const unsigned ip = map.at((unsigned)p);
                     const float px = a.rx[ip], py = a.ry[ip];
                     unsigned flag = (t & URF_CAND_STAR) ? 1u : 0u;
+                    /* (r5, measured: the two angle tests as separate work items -- more lanes, one f64 chain per lane -- cost a barrier,
+                     * an atomic per hit and the gathers twice: 0.40 -> 0.44 ms, profiles/r5_ring_ab.txt) */
                     if (t & URF_CAND_XZERO) {   /* j = p - 2 and j + cp = p + 3 exist (height tests passed) */
                         const unsigned ij = map.at((unsigned)(p - 2)), i3 = map.at((unsigned)(p + 3));
                         if (urf_x_zero_angle(a.newY, dp.p.angleFilter1, a.rx[ij], a.ry[ij], a.rx[i3], a.ry[i3], p - 2, p, 5, a.rz[ij],
@@ -3945,6 +3999,19 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
         if (!QUADS)   /* (two z windows: the next chunk is parked into the other one; n_cand / the hit bitmaps are ordered by the barrier after the parking) */
             __syncthreads();
         URF_PHASE_ACC(5);
+        buf ^= 1u;
+        hbi = hbi == 2u ? 0u : hbi + 1u;
+    };
+    if constexpr (QUADS) {
+        /* (two chunks of lead, two register buffers in rotation: 0.402 ms against 0.399 -- the parking does not wait for data,
+         * profiles/r5_ring_ab.txt) */
+        fetchq(cs0, zA);
+        for (int cs = cs0; cs < n; cs += CH)
+            chunk(cs, fzA, zA, cs + CH);
+    } else {
+        fetch(cs0, fzA);
+        for (int cs = cs0; cs < n; cs += CH)
+            chunk(cs, fzA, zA, cs + CH);
     }
 
 #ifdef URF_EXP_SKIP_EPILOGUE
