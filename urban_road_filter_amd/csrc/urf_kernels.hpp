@@ -495,8 +495,16 @@ __global__ __launch_bounds__(URF_TABLE_THREADS) void k_table_repair(urf_kargs a,
  * tile is therefore transposed through LDS (slot = position in the tile's ring-sorted order,
  * row-padded against bank conflicts) and written out slot by slot, 2048 consecutive elements per
  * array.  Sector-sorted stores go out directly (a firing shares one sector: consecutive ranks). */
+/* (one pad word per 32 slots: the lanes of a step of an organised 64-ring tile write slots 32 apart -- lane * 33 + c are 32
+ * different banks per half wave; with one pad word per 64 slots, r2-r4, lanes 2k and 2k + 1 shared a bank: every staging
+ * store took twice its cycles) */
+#ifdef URF_EXP_SLOT_PAD64
 #define URF_SLOT(lp) ((lp) + ((lp) >> 6))
 #define URF_SLOTS (URF_TILE + URF_TILE / 64)
+#else
+#define URF_SLOT(lp) ((lp) + ((lp) >> 5))
+#define URF_SLOTS (URF_TILE + URF_TILE / 32)
+#endif
 #define URF_TILE_WAVES (URF_TILE_THREADS / 64)
 #define URF_WAVE_PTS (URF_TILE / URF_TILE_WAVES)   /* consecutive points of the tile a wave owns */
 
@@ -1546,6 +1554,10 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
                                                      unsigned* sh_first, uint32_t* star_first_out)
 {
     constexpr unsigned NB = URF_STAR_NB, PL = NB / 64;
+    /* (r5, measured: one pad word per PL counters -- a lane scans PL consecutive counters, lanes PL words apart meet in 32 / PL
+     * banks -- takes the kernel's SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE from 0.38 to 0.33 and makes it 4 % SLOWER: the index
+     * arithmetic costs more vector instructions than the conflicts cost cycles, profiles/r5_lds_ab.txt) */
+    auto CI = [](unsigned c) { return c; };
     const unsigned lane = threadIdx.x;
     const unsigned B = (n + 63) >> 6;
     URF_PHASE_ACC_DECL;
@@ -1605,7 +1617,7 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
         wq[q] = 0;
         if (q < B && key[q] != ~0ull) {
             bkt[q] = ((unsigned)(key[q] >> 32) - rmin) >> sh;
-            wq[q] = atomicAdd(&cnt[bkt[q]], 1u);   /* arrival order inside the bucket: resolved below */
+            wq[q] = atomicAdd(&cnt[CI(bkt[q])], 1u);   /* arrival order inside the bucket: resolved below */
         }
     }
     __syncthreads();
@@ -1616,7 +1628,7 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
         unsigned c8[PL], sum = 0;
 #pragma unroll
         for (unsigned e = 0; e < PL; e++) {
-            c8[e] = cnt[lane * PL + e];
+            c8[e] = cnt[CI(lane * PL + e)];
             sum += c8[e];
             maxc = c8[e] > maxc ? c8[e] : maxc;
         }
@@ -1629,11 +1641,11 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
         unsigned run = inc - sum;
 #pragma unroll
         for (unsigned e = 0; e < PL; e++) {
-            cnt[lane * PL + e] = run;
+            cnt[CI(lane * PL + e)] = run;
             run += c8[e];
         }
         if (lane == 63)
-            cnt[NB] = run;   /* == n */
+            cnt[CI(NB)] = run;   /* == n */
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned w = __shfl_xor(maxc, o);
             maxc = w > maxc ? w : maxc;
@@ -1672,8 +1684,8 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
         for (unsigned q = 0; q < MAXB; q++) {
             bb[q] = 0;
             if (q < B && key[q] != ~0ull) {
-                const unsigned b0 = cnt[bkt[q]];
-                bb[q] = b0 | ((cnt[bkt[q] + 1] - b0) << 16);
+                const unsigned b0 = cnt[CI(bkt[q])];
+                bb[q] = b0 | ((cnt[CI(bkt[q] + 1)] - b0) << 16);
                 need = need || (bb[q] >> 16) != (ol[q] & 0xffu);
             }
             rank[q] = (bb[q] & 0xffffu) + (ol[q] >> 8);
@@ -1703,7 +1715,7 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
                 if (q < B && pos < n && RK[pos] == 0xffffu) {
                     const unsigned long long kk = A[pos];
                     const unsigned bk = ((unsigned)(kk >> 32) - rmin) >> sh;
-                    const unsigned b0 = cnt[bk], b1 = cnt[bk + 1];
+                    const unsigned b0 = cnt[CI(bk)], b1 = cnt[CI(bk + 1)];
                     unsigned r = b0, t = b0;
                     for (; t + 3 < b1; t += 4) {   /* four bucket-mates per trip */
                         const unsigned long long k0 = A[t], k1 = A[t + 1], k2 = A[t + 2], k3 = A[t + 3];
@@ -1891,6 +1903,7 @@ struct urf_sort_shared {
     unsigned rmin, rmax, maxc;
     unsigned w[8];
 };
+#define URF_BLOCK_CNT(NB, NT) ((NB) + 1)   /* words of the counter array */
 /* rank[e] = number of keys of the workgroup smaller than key[e] (keys are distinct).  The keys come
  * back PERMUTED among the threads (every key exactly once, each with its rank). */
 template <int NT, int EPT, int NB>
@@ -1898,6 +1911,7 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
                                                     unsigned* cnt, urf_sort_shared* sh, bool force_general, unsigned (&rank)[EPT] URF_PH_PARAMS)
 {
     static_assert(NB % NT == 0 && NT / 64 <= 8, "bucket scan layout");
+    auto CI = [](unsigned c) { return c; };   /* (padded counters: measured slower, see urf_star_sort_sector) */
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
         /* (materialised here: hoisted out of the persistent loop of k_star_sort_mid, these three constants sat in registers
@@ -1940,7 +1954,7 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
         wq[e] = 0;
         if (key[e] != ~0ull) {
             bkt[e] = ((unsigned)(key[e] >> 32) - rmin) >> shf;
-            wq[e] = atomicAdd(&cnt[bkt[e]], 1u);
+            wq[e] = atomicAdd(&cnt[CI(bkt[e])], 1u);
         }
     }
     __syncthreads();
@@ -1949,7 +1963,7 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
         unsigned c8[NB / NT], sum = 0, maxc = 0;
 #pragma unroll
         for (int e = 0; e < NB / NT; e++) {
-            c8[e] = cnt[tid * (NB / NT) + e];
+            c8[e] = cnt[CI(tid * (NB / NT) + e)];
             sum += c8[e];
             maxc = c8[e] > maxc ? c8[e] : maxc;
         }
@@ -1965,11 +1979,11 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
             run += sh->w[v];
 #pragma unroll
         for (int e = 0; e < NB / NT; e++) {
-            cnt[tid * (NB / NT) + e] = run;
+            cnt[CI(tid * (NB / NT) + e)] = run;
             run += c8[e];
         }
         if (tid == NT - 1)
-            cnt[NB] = run;
+            cnt[CI(NB)] = run;
     }
     __syncthreads();
     URF_PHASE_ACC(7);
@@ -1979,7 +1993,7 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
 #pragma unroll
         for (int e = 0; e < EPT; e++)
             if (key[e] != ~0ull)
-                A[cnt[bkt[e]] + wq[e]] = key[e];
+                A[cnt[CI(bkt[e])] + wq[e]] = key[e];
         __syncthreads();
         URF_PHASE_ACC(8);
         /* From here on a thread owns the keys at POSITIONS tid + e * NT of the bucket-ordered array
@@ -1997,7 +2011,7 @@ __device__ __forceinline__ void urf_block_rank_keys(unsigned long long (&key)[EP
             rank[e] = 0;
             if (key[e] != ~0ull) {
                 const unsigned b = ((unsigned)(key[e] >> 32) - rmin) >> shf;
-                const unsigned b0 = cnt[b], b1 = cnt[b + 1];
+                const unsigned b0 = cnt[CI(b)], b1 = cnt[CI(b + 1)];
                 unsigned r = b0, t = b0;
                 for (; t + 1 < b1; t += 2) {   /* two bucket-mates per trip */
                     const unsigned long long k0 = A[t], k1 = A[t + 1];
@@ -2063,7 +2077,7 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
 {
     constexpr unsigned NT = URF_STAR_MID_THREADS, NB = 2048, EPT = URF_STAR_MID_CAP / NT;
     __shared__ unsigned long long A[URF_STAR_MID_CAP];
-    __shared__ unsigned cnt[NB + 1];
+    __shared__ unsigned cnt[URF_BLOCK_CNT(NB, NT)];
     __shared__ urf_sort_shared ssh;
     __shared__ unsigned sh_first, sh_nruns, sh_tie;
     const unsigned K = (unsigned)dp.p.sectors;
@@ -4992,7 +5006,7 @@ __global__ __launch_bounds__(256) void k_ring_order(urf_kargs a, urf_dev_params 
 {
     constexpr unsigned NT = 256, NB = 2048, EPT = 8, CAP = NT * EPT;
     __shared__ unsigned long long A[CAP];
-    __shared__ unsigned cnt[NB + 1];
+    __shared__ unsigned cnt[URF_BLOCK_CNT(NB, NT)];
     __shared__ urf_sort_shared ssh;
     __shared__ unsigned ncls[2], sh_tie;
     __shared__ int lom_stk[2 * 64];
