@@ -368,13 +368,15 @@ def test_mid_size_sector_scattered_over_many_tiles(ctx_big):
     assert np.array_equal(lg, lb) and info_equal(ig, ib)
 
 
+@pytest.mark.parametrize("twins", [False, True], ids=["other_height", "twins"])
 @pytest.mark.parametrize("n_pts", [300, 1500, 6000])
-def test_equal_ranges_follow_std_sort(ctx_big, n_pts):
+def test_equal_ranges_follow_std_sort(ctx_big, n_pts, twins):
     """Exact planar-range ties inside a sector are ordered as libstdc++'s std::sort orders them
     (star_shaped_search.cpp:109; oracle/urf_stdsort.h pins the algorithm against the real one, k_star_ties follows it
     on the device).  Duplicated (x, y) with another height -- the slope between the two is +-inf, the sign depends on
     the order -- on all three sizes: one wave's LDS (<= 512 points per sector), the big instance's LDS (<= 2048) and
-    global memory."""
+    global memory.  twins: the duplicates keep their height too -- the walk's arithmetic is then the same in any order and only
+    WHICH of the twins stands where the walk stops depends on it: k_star_ties' second pass, behind the walk."""
     p = O.cfg_params("cfg2")
     p.interval = 1.0
     x, y, z = crowded_cloud(n_pts, seed=9)
@@ -382,7 +384,7 @@ def test_equal_ranges_follow_std_sort(ctx_big, n_pts):
     dup = rng.integers(0, len(x), len(x) // 3)
     x = np.concatenate([x, x[dup]])
     y = np.concatenate([y, y[dup]])
-    z = np.concatenate([z, (z[dup] + 0.2 * rng.random(len(dup))).astype(np.float32)])   # same range, other height
+    z = np.concatenate([z, z[dup] if twins else (z[dup] + 0.2 * rng.random(len(dup))).astype(np.float32)])   # same range; other height or the same
     perm = rng.permutation(len(x))
     x, y, z = x[perm], y[perm], z[perm]
     lb, ib, st = O.run_b(x, y, z, p, debug=True)
@@ -449,7 +451,7 @@ def test_sensor_like_batch_and_callback_sequence():
         for k in range(6):
             lg, ig = ctx.classify_xyz(*clouds[k])
             assert np.array_equal(lg, ref[k][0]) and info_equal(ig, ref[k][1])
-            assert ctx.callback_path_state() == (1, 1 | 8 | 16)
+        assert ctx.callback_path_state() == (1, 1 | 8 | 16)   # (the first sweep that needed either pass of k_star_ties)
         lg, ig = ctx.classify_xyz(*free)
         assert np.array_equal(lg, O.run_b(*free, p)[0])
 

@@ -60,10 +60,23 @@
 #define URF_STATUS_REDO_NAN 0x7f000003
 #define URF_STATUS_REDO_HINT 0x7f000004   /* the table was incomplete because the walk stopped at the previous call's ring count */
 #define URF_STATUS_REDO_TIES 0x7f000005   /* a star sector holds equal planar ranges where the walk looks: needs k_star_ties */
-/* star_first[]: set by the sort kernels when the sector's sorted prefix (up to the walk's last index + 1) holds two equal
- * planar ranges -- their order is the one libstdc++'s std::sort leaves (star_shaped_search.cpp:109), which k_star_ties
- * reproduces; it rewrites the sector's outputs and clears the bit before the walk runs */
+/* star_first[] carries flags above the index (a scan holds at most 2^23 points).  Equal planar ranges of a sector are ordered
+ * as libstdc++'s std::sort orders them (star_shaped_search.cpp:109), which only k_star_ties knows how to do; the sort kernels
+ * order them by position and say what they saw:
+ *   URF_TIE_FLAG  the sorted prefix the walk may look at holds two equal ranges with DIFFERENT heights: the slopes around them
+ *                 depend on their order -- k_star_ties sorts the sector again before the walk and clears the bit;
+ *   URF_TIE_NEXT  the point behind the walk's last one has its range (and height): see URF_TIE_POST;
+ *   URF_TIE_DONE  k_star_ties has put the sector into std::sort's order.
+ * Equal ranges with EQUAL heights (what a sensor's neighbouring firings of one ring on flat ground produce: ~30 per sector)
+ * leave the sequence of (range, height) pairs -- all the walk computes with -- the same in any order; only WHICH point stands
+ * at the index the walk stops at depends on it, and only if that point has a twin behind it:
+ *   URF_TIE_POST  set by the walk kernels together with that index: k_star_ties' second pass (behind the walk) sorts the
+ *                 sector as std::sort does and reports the point at that index instead. */
 #define URF_TIE_FLAG 0x80000000u
+#define URF_TIE_NEXT 0x40000000u
+#define URF_TIE_DONE 0x20000000u
+#define URF_TIE_POST 0x10000000u
+#define URF_TIE_INDEX 0x00ffffffu
 #define URF_TIE_SMALL_CAP 512u   /* sectors of up to this many points: the small instance of k_star_ties (8 KB of LDS) */
 #define URF_TIE_BIG_CAP 2048u    /* ... up to this many: the big instance's LDS; beyond: in global memory */
 #define URF_AZ_UNKNOWN      -1.0f     /* decoded value of URF_REC_AZ_UNKNOWN */
@@ -200,7 +213,7 @@ struct urf_kargs {
     uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 385..2048 points */
     uint32_t* star_list_big;    /* [S*sectors] ... with more than 2048 points */
     uint32_t* star_count;       /* [8] lengths of the two lists, [2] = length of redo_list, [3] = length of nan_list, [4] / [5] != 0: some
-                                 * sector of at most / more than URF_TIE_SMALL_CAP points carries URF_TIE_FLAG (zeroed per call) */
+                                 * small / big sector (urf_tie_big) carries URF_TIE_FLAG, [6] / [7] != 0: ... URF_TIE_POST (zeroed per call) */
     uint32_t* table_upto;       /* [S] first point a speculative k_ring_table did not look at (0xffffffff: none) */
     uint32_t* table_redo;       /* [S] k_split: the speculative table of the scan is incomplete */
     uint32_t* redo_list;        /* [S] such scans (k_table_repair) */

@@ -1790,7 +1790,7 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
                 const float ax = __uint_as_float(pa.x), bx = __uint_as_float(pb.x);
                 slp = (__uint_as_float(pb.y) - __uint_as_float(pa.y)) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
                 g = (bx - ax) * kdist;
-                tie = tie || pa.x == pb.x;
+                tie = tie || (pa.x == pb.x && pa.y != pb.y);   /* equal ranges, different heights: the order decides slopes */
                 if (slp > slope_param)
                     atomicMin(sh_first, i);
             }
@@ -1802,12 +1802,17 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
             break;
     }
     const unsigned first = *sh_first;
-    /* (the point behind the walk's last one may take its place if the two are equal) */
-    if (lane == 0 && first + 1 < n && RZ[first + 1].x == RZ[first].x)
-        tie = true;
+    /* (the points behind the walk's last one that share its range may take its place: one of another height changes the
+     * slope there; twins only the identity of the point, URF_TIE_NEXT) */
+    unsigned next = 0;
+    if (lane == 0 && first < n)
+        for (unsigned j = first + 1; j < n && RZ[j].x == RZ[first].x; j++) {
+            next = URF_TIE_NEXT;
+            tie = tie || RZ[j].y != RZ[first].y;
+        }
     const bool any_tie = __any(tie);
     if (lane == 0)
-        *star_first_out = (first < n - 1 ? first : n - 1) | (any_tie ? URF_TIE_FLAG : 0u);   /* last index the walk may visit */
+        *star_first_out = (first < n - 1 ? first : n - 1) | (any_tie ? URF_TIE_FLAG : 0u) | next;   /* last index the walk may visit */
     URF_PHASE_ACC(5);
 #ifdef URF_EXP_PHASE_CLOCK
     if (threadIdx.x == 0 && blockIdx.y == gridDim.y / 2 && blockIdx.x >= 100 && blockIdx.x < 104)
@@ -2193,8 +2198,8 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
                     const float ax = __uint_as_float(R[i - 1]), bx = __uint_as_float(R[i]);
                     slp = (Z[i] - Z[i - 1]) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
                     g = (bx - ax) * kdist;
-                    if (R[i - 1] == R[i])
-                        sh_tie = 1u;   /* equal planar ranges where the walk may look: k_star_ties */
+                    if (R[i - 1] == R[i] && __float_as_uint(Z[i - 1]) != __float_as_uint(Z[i]))
+                        sh_tie = 1u;   /* equal planar ranges of different heights where the walk may look: k_star_ties */
                     if (slp > slope_param)
                         atomicMin(&sh_first, i);
                 }
@@ -2210,8 +2215,14 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
         }
         const unsigned first = sh_first;
         if (tid == 0) {
-            const bool tie = sh_tie != 0u || (first + 1 < n && R[first + 1] == R[first]);
-            a.star_first[sk] = (first < n - 1 ? first : n - 1) | (tie ? URF_TIE_FLAG : 0u);
+            bool tie = sh_tie != 0u;
+            unsigned next = 0;
+            if (first < n)
+                for (unsigned j = first + 1; j < n && R[j] == R[first]; j++) {
+                    next = URF_TIE_NEXT;
+                    tie = tie || __float_as_uint(Z[j]) != __float_as_uint(Z[first]);
+                }
+            a.star_first[sk] = (first < n - 1 ? first : n - 1) | (tie ? URF_TIE_FLAG : 0u) | next;
             if (tie)
                 urf_tie_found(a, s, n, simple ? 2u : 3u);
         }
@@ -2365,6 +2376,8 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
  * The arrays (range bits, the points, two work arrays of positions) live in LDS -- two instances: sectors of at most two runs
  * and URF_TIE_SMALL_CAP points, 5 KB per wave; anything else up to URF_TIE_BIG_CAP points, 32 KB -- and beyond that in the
  * sector's stretch of big_r / big_i / big_z / ssrt. */
+__device__ __forceinline__ int urf_walk_report(const urf_kargs& a, unsigned s, unsigned K, unsigned C, unsigned k, unsigned n, unsigned base,
+                                               unsigned hit_i);
 /* three memory policies: the small instance (sectors of at most two runs and URF_TIE_SMALL_CAP points: the index arrays hold
  * positions inside the sector, 16 bits), the big instance's LDS and global memory (the index arrays hold addresses) */
 struct urf_tie_small {
@@ -2693,28 +2706,33 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
         }
     }
     if (lane == 0)
-        a.star_first[sk] = first < n - 1 ? first : n - 1;   /* (without the flag) */
+        a.star_first[sk] = (first < n - 1 ? first : n - 1) | URF_TIE_DONE;   /* (the walk need not ask for the second pass) */
     MEM::sync();
 }
 
 /* BIG = false: sectors of at most two runs and URF_TIE_SMALL_CAP points (every sector of an organised 64-ring sweep), 5 KB of LDS
  * per wave; BIG = true: all others.  Persistent over blocks of `per_block` consecutive (scan, sector) entries of star_first. */
-template <bool BIG>
+/* POST = false: in front of the walk, the sectors the sort kernels flagged (URF_TIE_FLAG); POST = true: behind it, the sectors
+ * in which the walk stopped at a point with a twin behind it (URF_TIE_POST | index): sorted as std::sort does, the point that
+ * stands at that index is reported instead (the walk itself does not change: the twins have one range and one height). */
+template <bool BIG, bool POST>
 __global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp, unsigned per_block)
 {
     constexpr unsigned CAP = BIG ? URF_TIE_BIG_CAP : URF_TIE_SMALL_CAP;
     __shared__ unsigned W[BIG ? 4 * CAP : CAP + (3 * CAP) / 2];   /* R; P, LP, RP (32 / 16 bits) */
     __shared__ int stk[3 * 64];
-    if (a.star_count[4 + (BIG ? 1 : 0)] == 0u)
+    if (a.star_count[(POST ? 6 : 4) + (BIG ? 1 : 0)] == 0u)
         return;   /* (uniform) no sector of this instance's kind is flagged */
     const unsigned K = (unsigned)dp.p.sectors, total = a.n_scans * K, lane = threadIdx.x;
     const unsigned nblk = (total + per_block - 1) / per_block;
     for (unsigned blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const unsigned e = blk * per_block + lane;
         const unsigned sf = (lane < per_block && e < total) ? a.star_first[e] : 0u;
-        unsigned long long m = __ballot((sf & URF_TIE_FLAG) != 0u);
+        unsigned long long m = __ballot((sf & (POST ? URF_TIE_POST : URF_TIE_FLAG)) != 0u);
         while (m) {
-            const unsigned sk = blk * per_block + (unsigned)__ffsll((long long)m) - 1u;
+            const unsigned src = (unsigned)__ffsll((long long)m) - 1u;
+            const unsigned sk = blk * per_block + src;
+            const unsigned hit_i = (unsigned)__shfl((int)sf, (int)src) & URF_TIE_INDEX;   /* (POST) */
             m &= m - 1ull;
             const unsigned s = sk / K, k = sk % K;
             if (a.info[s].status != URF_OK)
@@ -2731,6 +2749,13 @@ __global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp
                 const unsigned base = urf_sbase(a, s) + a.sec_off[(size_t)s * (K + 1) + k];
                 urf_tie_sector_body<urf_tie_glb, CAP>(a, dp, sk, s, k, n, (unsigned*)a.big_r + base, a.big_i + base, (unsigned*)a.big_z + base,
                                                       a.ssrt + base, stk);
+            }
+            if constexpr (POST) {
+                /* (the body's stores are complete: it ends with a fence; ssrt16 / ssrt now hold std::sort's order up to the walk's last index) */
+                __threadfence();
+                const int hit = urf_walk_report(a, s, K, (unsigned)dp.p.channels, k, n, urf_sbase(a, s) + a.sec_off[(size_t)s * (K + 1) + k], hit_i);
+                if (lane == 0)
+                    a.star_hit[sk] = hit;
             }
         }
     }
@@ -2984,9 +3009,27 @@ __device__ __forceinline__ void urf_walk_sequential(urf_walk_state& W, unsigned 
 
 /* what every wave of a walk kernel starts with: its 64 sectors' places (sbase / slast in LDS, by wave 0) and the longest walk among them */
 struct urf_walk_sectors {
-    unsigned k, n, base, last, maxlast;
+    unsigned k, n, base, last, maxlast, sf;   /* sf: star_first with its URF_TIE_* flags */
     bool have;
 };
+/* The walk stopped at sorted index hit_i.  If the point there has a twin behind it (same range, same height: the sort kernels
+ * let such pairs pass, URF_TIE_*), WHICH of them stands at that index is a matter of std::sort's order: the sector goes to
+ * k_star_ties' second pass.  "The next point has the same range" = its distance term is zero (wsg holds it up to the sort's
+ * last index; for the last index itself the sort kernel left URF_TIE_NEXT).  (A distance term that is zero for another reason
+ * -- kdist == 0, underflow -- only costs the second pass a sector it did not have to look at.) */
+__device__ __forceinline__ void urf_walk_twins(const urf_kargs& a, unsigned s, unsigned K, unsigned k, unsigned n, unsigned base, unsigned sf,
+                                               unsigned hit_i)
+{
+    if (hit_i == 0 || (sf & URF_TIE_DONE) || hit_i + 1 >= n)
+        return;
+    const bool twin = hit_i == (sf & URF_TIE_INDEX) ? (sf & URF_TIE_NEXT) != 0u : a.wsg[base + hit_i + 1].g == 0.0f;
+    if (!twin)
+        return;
+    a.star_first[(size_t)s * K + k] = URF_TIE_POST | hit_i;
+    a.star_count[6 + (urf_tie_big(n, a.sec_run[(size_t)s * K + k].nruns) ? 1 : 0)] = 1u;
+    if (a.optimistic & URF_OPT_NO_TIES)
+        a.info[s].status = URF_STATUS_REDO_TIES;   /* nobody runs the second pass in this launch sequence: once more, with it */
+}
 __device__ __forceinline__ urf_walk_sectors urf_walk_prologue(const urf_kargs& a, unsigned s, unsigned K, unsigned lane, bool publish)
 {
     unsigned* sbase = walk_sbase;
@@ -2997,7 +3040,8 @@ __device__ __forceinline__ urf_walk_sectors urf_walk_prologue(const urf_kargs& a
     q.n = q.have ? a.sec_cnt[(size_t)s * K + q.k] : 0;
     const unsigned rel = q.have ? a.sec_off[(size_t)s * (K + 1) + q.k] : 0;
     q.base = urf_sbase(a, s) + rel;
-    q.last = q.n >= 2 ? a.star_first[(size_t)s * K + q.k] : 0;
+    q.sf = q.n >= 2 ? a.star_first[(size_t)s * K + q.k] : 0;
+    q.last = q.sf & URF_TIE_INDEX;
     if (publish) {
         sbase[lane] = q.last ? rel : 0u;   /* a sector without a walk reads the scan's first pair, whatever it is */
         slast[lane] = q.last;
@@ -3026,7 +3070,8 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
     const unsigned n = have ? a.sec_cnt[(size_t)s * K + k] : 0;
     const unsigned rel = have ? a.sec_off[(size_t)s * (K + 1) + k] : 0;
     const unsigned base = urf_sbase(a, s) + rel;
-    const unsigned last = n >= 2 ? a.star_first[(size_t)s * K + k] : 0;
+    const unsigned sf = n >= 2 ? a.star_first[(size_t)s * K + k] : 0;
+    const unsigned last = sf & URF_TIE_INDEX;
     sbase[lane] = last ? rel : 0u;   /* a sector without a walk reads the scan's first pair, whatever it is */
     slast[lane] = last;
     unsigned maxlast = last;
@@ -3097,8 +3142,10 @@ __global__ __launch_bounds__(64) void k_star_walk(urf_kargs a, urf_dev_params dp
         __syncthreads();
     }
     const int hit = urf_walk_report(a, s, K, C, k, n, base, W.hit_i);
-    if (have)
+    if (have) {
         a.star_hit[(size_t)s * K + k] = hit;
+        urf_walk_twins(a, s, K, k, n, base, sf, W.hit_i);
+    }
 }
 
 /* The same walk for a handful of sweeps (the callback path: one), where the device is empty and the time is the
@@ -3331,8 +3378,10 @@ __global__ __launch_bounds__(URF_WALK_FEW_THREADS) void k_star_walk_few(urf_karg
     if (stop != 0xffffffffu && __any(W.lim != 0))
         urf_walk_sequential(W, stop * URF_WALK_CHUNK, last, q.maxlast, wsg, a.walk_tab, lane, kdev, slope_param, dmin);
     const int hit = urf_walk_report(a, s, K, (unsigned)dp.p.channels, q.k, q.n, q.base, W.hit_i);
-    if (q.have)
+    if (q.have) {
         a.star_hit[(size_t)s * K + q.k] = hit;
+        urf_walk_twins(a, s, K, q.k, q.n, q.base, q.sf, W.hit_i);
+    }
 }
 
 /* ------------------------------------------------------------------------- */
