@@ -175,7 +175,13 @@ typedef struct urf_scan_info {
  * (urf_ordered_indices) equal the reference's.  (Up to round 3 this was "deviation D5": such a point simply never became
  * road and never cut a beam short.)  n_nan_azimuth counts these points (0 on every real sweep: a return at the sensor's
  * own axis).  One residue: two points of such a ring with bit-identical azimuths on either side of a NaN's place are told
- * apart by position in the reference and by value here. */
+ * apart by position in the reference and by value here.
+ * COST: the quicksort is the reference's own -- Lomuto, pivot = last element, O(n^2) on the nearly sorted rings of an
+ * organised sweep (56 % of the reference's CPU time goes there) -- run by ONE wave per such ring: about 1 ms for a ring of
+ * 2 048 points, several ms for a ring beyond 6 144 points (sorted in global memory), against ~0.13 ms for the whole sweep
+ * otherwise; on the callback path the first such sweep is additionally run twice (urf_callback_path_state).  A region of
+ * interest that excludes the sensor's own axis (the reference's "x + y + z != 0" filter already drops (0, 0, 0) filler
+ * points) never gets here. */
 
 typedef struct urf_ctx urf_ctx;
 

@@ -649,6 +649,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     /* k_star_ties: as many one-wave workgroups as are resident (LDS: 5 KB / 32 KB), each over blocks of `tie_per` consecutive sectors */
     const unsigned tie_total = K * n_scans, tie_per = tie_total <= 16384u ? 1u : 4u, tie_nblk = (tie_total + tie_per - 1) / tie_per;
     const unsigned tie_g_small = tie_nblk < c->n_cus * 24u ? tie_nblk : c->n_cus * 24u, tie_g_big = tie_nblk < c->n_cus * 4u ? tie_nblk : c->n_cus * 4u;
+    const bool tie_one_launch = n_scans <= URF_WALK_FEW_SCANS;   /* a handful of sweeps: the big instance takes every sector (one launch less per pass) */
     if (star) {
         const dim3 g_sec(K, n_scans);
         hipLaunchKernelGGL(k_star_sort_small, g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
@@ -662,8 +663,9 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
          * leaves them in.  Benchmark clouds hold none (both kernels return at once); a real sensor's sweep holds equal ranges in
          * every sector, but nearly all of them between twins (one height), which only the second pass below cares about. */
         if (!(a.optimistic & URF_OPT_NO_TIES)) {
-            hipLaunchKernelGGL((k_star_ties<false, false>), dim3(tie_g_small), dim3(64), 0, st, a, dp, tie_per);
-            hipLaunchKernelGGL((k_star_ties<true, false>), dim3(tie_g_big), dim3(64), 0, st, a, dp, tie_per);
+            if (!tie_one_launch)
+                hipLaunchKernelGGL((k_star_ties<false, false>), dim3(tie_g_small), dim3(64), 0, st, a, dp, tie_per, 0u);
+            hipLaunchKernelGGL((k_star_ties<true, false>), dim3(tie_g_big), dim3(64), 0, st, a, dp, tie_per, tie_one_launch ? 1u : 0u);
         }
     }
     mark();   /* "k_star_sort" = the three sort kernels (mid / big run over normally empty work lists) */
@@ -674,8 +676,9 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
             hipLaunchKernelGGL(k_star_walk, dim3((K + 63) / 64, n_scans), dim3(64), 0, st, a, dp);
         /* second pass of k_star_ties: the sectors in which the walk stopped at a point with a twin behind it (URF_TIE_POST) */
         if (!(a.optimistic & URF_OPT_NO_TIES)) {
-            hipLaunchKernelGGL((k_star_ties<false, true>), dim3(tie_g_small), dim3(64), 0, st, a, dp, tie_per);
-            hipLaunchKernelGGL((k_star_ties<true, true>), dim3(tie_g_big), dim3(64), 0, st, a, dp, tie_per);
+            if (!tie_one_launch)
+                hipLaunchKernelGGL((k_star_ties<false, true>), dim3(tie_g_small), dim3(64), 0, st, a, dp, tie_per, 0u);
+            hipLaunchKernelGGL((k_star_ties<true, true>), dim3(tie_g_big), dim3(64), 0, st, a, dp, tie_per, tie_one_launch ? 1u : 0u);
         }
     }
     mark();

@@ -2716,12 +2716,14 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
  * in which the walk stopped at a point with a twin behind it (URF_TIE_POST | index): sorted as std::sort does, the point that
  * stands at that index is reported instead (the walk itself does not change: the twins have one range and one height). */
 template <bool BIG, bool POST>
-__global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp, unsigned per_block)
+__global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp, unsigned per_block, unsigned all_kinds)
 {
+    /* all_kinds (the big instance, a handful of sweeps: one launch instead of two on the chain of a single sweep): small
+     * sectors too, through the 32-bit arrays */
     constexpr unsigned CAP = BIG ? URF_TIE_BIG_CAP : URF_TIE_SMALL_CAP;
     __shared__ unsigned W[BIG ? 4 * CAP : CAP + (3 * CAP) / 2];   /* R; P, LP, RP (32 / 16 bits) */
     __shared__ int stk[3 * 64];
-    if (a.star_count[(POST ? 6 : 4) + (BIG ? 1 : 0)] == 0u)
+    if (a.star_count[(POST ? 6 : 4) + (BIG ? 1 : 0)] == 0u && !(all_kinds && a.star_count[POST ? 6 : 4] != 0u))
         return;   /* (uniform) no sector of this instance's kind is flagged */
     const unsigned K = (unsigned)dp.p.sectors, total = a.n_scans * K, lane = threadIdx.x;
     const unsigned nblk = (total + per_block - 1) / per_block;
@@ -2738,7 +2740,7 @@ __global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp
             if (a.info[s].status != URF_OK)
                 continue;   /* (a void scan's entries are leftovers of an earlier call) */
             const unsigned n = a.sec_cnt[sk];
-            if (urf_tie_big(n, a.sec_run[sk].nruns) != BIG || n < 2)
+            if ((urf_tie_big(n, a.sec_run[sk].nruns) != BIG && !all_kinds) || n < 2)
                 continue;
             if constexpr (!BIG) {
                 uint16_t* I = (uint16_t*)(W + CAP);
@@ -4273,7 +4275,7 @@ __global__ __launch_bounds__(256) void k_nan_rings(urf_kargs a, urf_dev_params d
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sh_pairs[];
     __shared__ int stk[2 * 64];
-    __shared__ unsigned n_nan, first_nan, last_nan;
+    __shared__ unsigned n_nan, first_nan, last_nan, claimed;
     const unsigned n_list = a.star_count[3];
     if (n_list == 0)
         return;
@@ -4289,12 +4291,22 @@ __global__ __launch_bounds__(256) void k_nan_rings(urf_kargs a, urf_dev_params d
         const unsigned sb = urf_sbase(a, s);
         const unsigned n = a.ring_cnt[(size_t)s * C + c], ro = a.ring_off[(size_t)s * (C + 1) + c];
         volatile unsigned long long* const A = n <= URF_NAN_LDS ? sh_pairs : (unsigned long long*)(a.wsg + sb + ro);
+        /* A ring can stand on the list twice (k_split listed it, k_table_repair cleared the mask, k_split_repair listed it
+         * again): the first workgroup to get here claims it -- k_ring left vis = (+inf, -inf), the claim turns f_hi into a NaN
+         * pattern until the real value is written below -- and the other one leaves: two workgroups sorting one ring's stretch
+         * of global memory in place (rings beyond URF_NAN_LDS points) would race. */
         if (tid == 0) {
+            unsigned* const claim = (unsigned*)&a.vis[(size_t)s * C + c].f_hi;
+            claimed = atomicCAS(claim, 0x7f800000u, 0x7fc00001u) == 0x7f800000u ? 1u : 0u;
             n_nan = 0;
             first_nan = 0xffffffffu;
             last_nan = 0;
         }
         __syncthreads();
+        if (!claimed) {   /* (uniform) */
+            __syncthreads();
+            continue;
+        }
         /* the ring in bucket order (input order: what the reference sorts), exact azimuths */
         unsigned mine = 0;
         for (unsigned j = tid; j < n; j += 256) {
@@ -4309,8 +4321,10 @@ __global__ __launch_bounds__(256) void k_nan_rings(urf_kargs a, urf_dev_params d
         __threadfence_block();
         __syncthreads();
         if (n_nan == 0) {   /* (uniform) a bit set against a ring table that was rebuilt afterwards */
-            if (tid == 0)
+            if (tid == 0) {
                 atomicAnd(&a.nan_mask[(size_t)s * 4 + (c >> 5)], ~(1u << (c & 31u)));
+                a.vis[(size_t)s * C + c] = urf_vis{ __builtin_inff(), -__builtin_inff() };   /* (the claim above) */
+            }
             __syncthreads();
             continue;
         }
