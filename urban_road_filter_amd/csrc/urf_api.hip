@@ -646,10 +646,11 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     mark();
     hipLaunchKernelGGL(k_index, g_scan, dim3(256), 0, st, a, dp);
     mark();
-    /* k_star_ties: as many one-wave workgroups as are resident (LDS: 5 KB / 32 KB), each over blocks of `tie_per` consecutive sectors */
-    const unsigned tie_total = K * n_scans, tie_per = tie_total <= 16384u ? 1u : 4u, tie_nblk = (tie_total + tie_per - 1) / tie_per;
-    const unsigned tie_g_small = tie_nblk < c->n_cus * 24u ? tie_nblk : c->n_cus * 24u, tie_g_big = tie_nblk < c->n_cus * 4u ? tie_nblk : c->n_cus * 4u;
-    const bool tie_one_launch = n_scans <= URF_WALK_FEW_SCANS;   /* a handful of sweeps: the big instance takes every sector (one launch less per pass) */
+    /* k_star_ties: one-wave workgroups (32 KB of LDS: four per CU), each over blocks of `tie_per` consecutive sectors */
+    /* (a batch: 64 entries per wave and load -- one sector in a hundred carries a flag, and with four entries per block the waves
+     * spent their time reading flags one dependent load after the other; a handful of sweeps: one workgroup per sector) */
+    const unsigned tie_total = K * n_scans, tie_per = tie_total <= 16384u ? 1u : 64u, tie_nblk = (tie_total + tie_per - 1) / tie_per;
+    const unsigned tie_grid = tie_nblk < c->n_cus * 4u ? tie_nblk : c->n_cus * 4u;
     if (star) {
         const dim3 g_sec(K, n_scans);
         hipLaunchKernelGGL(k_star_sort_small, g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
@@ -660,13 +661,10 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
             hipLaunchKernelGGL(k_star_sort_big, dim3(c->n_cus * 2), dim3(256), 0, st, a, dp);
         }
         /* sectors whose sorted prefix holds equal planar ranges of different heights (URF_TIE_FLAG): the order libstdc++'s std::sort
-         * leaves them in.  Benchmark clouds hold none (both kernels return at once); a real sensor's sweep holds equal ranges in
+         * leaves them in.  Benchmark clouds hold none (the kernel returns at once); a real sensor's sweep holds equal ranges in
          * every sector, but nearly all of them between twins (one height), which only the second pass below cares about. */
-        if (!(a.optimistic & URF_OPT_NO_TIES)) {
-            if (!tie_one_launch)
-                hipLaunchKernelGGL((k_star_ties<false, false>), dim3(tie_g_small), dim3(64), 0, st, a, dp, tie_per, 0u);
-            hipLaunchKernelGGL((k_star_ties<true, false>), dim3(tie_g_big), dim3(64), 0, st, a, dp, tie_per, tie_one_launch ? 1u : 0u);
-        }
+        if (!(a.optimistic & URF_OPT_NO_TIES))
+            hipLaunchKernelGGL(k_star_ties<false>, dim3(tie_grid), dim3(64), 0, st, a, dp, tie_per);
     }
     mark();   /* "k_star_sort" = the three sort kernels (mid / big run over normally empty work lists) */
     if (star) {
@@ -675,11 +673,8 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         else
             hipLaunchKernelGGL(k_star_walk, dim3((K + 63) / 64, n_scans), dim3(64), 0, st, a, dp);
         /* second pass of k_star_ties: the sectors in which the walk stopped at a point with a twin behind it (URF_TIE_POST) */
-        if (!(a.optimistic & URF_OPT_NO_TIES)) {
-            if (!tie_one_launch)
-                hipLaunchKernelGGL((k_star_ties<false, true>), dim3(tie_g_small), dim3(64), 0, st, a, dp, tie_per, 0u);
-            hipLaunchKernelGGL((k_star_ties<true, true>), dim3(tie_g_big), dim3(64), 0, st, a, dp, tie_per, tie_one_launch ? 1u : 0u);
-        }
+        if (!(a.optimistic & URF_OPT_NO_TIES))
+            hipLaunchKernelGGL(k_star_ties<true>, dim3(tie_grid), dim3(64), 0, st, a, dp, tie_per);
     }
     mark();
     const dim3 g_ring(C, n_scans);

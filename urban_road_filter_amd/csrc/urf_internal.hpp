@@ -77,8 +77,7 @@
 #define URF_TIE_DONE 0x20000000u
 #define URF_TIE_POST 0x10000000u
 #define URF_TIE_INDEX 0x00ffffffu
-#define URF_TIE_SMALL_CAP 512u   /* sectors of up to this many points: the small instance of k_star_ties (8 KB of LDS) */
-#define URF_TIE_BIG_CAP 2048u    /* ... up to this many: the big instance's LDS; beyond: in global memory */
+#define URF_TIE_CAP 2048u    /* k_star_ties: sectors of up to this many points in LDS; beyond: in global memory */
 #define URF_AZ_UNKNOWN      -1.0f     /* decoded value of URF_REC_AZ_UNKNOWN */
 #define URF_RING_NONE       0xFFu
 #define URF_SEC_NONE        0x3FFu
@@ -212,8 +211,8 @@ struct urf_kargs {
     uint32_t* star_first;       /* [S][sectors] last sorted index the walk may visit */
     uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 385..2048 points */
     uint32_t* star_list_big;    /* [S*sectors] ... with more than 2048 points */
-    uint32_t* star_count;       /* [8] lengths of the two lists, [2] = length of redo_list, [3] = length of nan_list, [4] / [5] != 0: some
-                                 * small / big sector (urf_tie_big) carries URF_TIE_FLAG, [6] / [7] != 0: ... URF_TIE_POST (zeroed per call) */
+    uint32_t* star_count;       /* [8] lengths of the two lists, [2] = length of redo_list, [3] = length of nan_list, [4] != 0: some
+                                 * sector carries URF_TIE_FLAG, [5] != 0: ... URF_TIE_POST (zeroed per call) */
     uint32_t* table_upto;       /* [S] first point a speculative k_ring_table did not look at (0xffffffff: none) */
     uint32_t* table_redo;       /* [S] k_split: the speculative table of the scan is incomplete */
     uint32_t* redo_list;        /* [S] such scans (k_table_repair) */

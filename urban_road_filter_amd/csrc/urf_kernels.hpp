@@ -1824,10 +1824,9 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
 /* a sector was flagged with URF_TIE_FLAG: tell k_star_ties' instance for its size that there is work -- or, in a launch
  * sequence without it (callback path), void the sweep: urf_classify_pc2_wait() runs it again with the kernel (every writer
  * writes the same value) */
-__device__ __forceinline__ bool urf_tie_big(unsigned n, unsigned nruns) { return n > URF_TIE_SMALL_CAP || nruns > 2u; }
-__device__ __forceinline__ void urf_tie_found(const urf_kargs& a, unsigned s, unsigned n, unsigned nruns)
+__device__ __forceinline__ void urf_tie_found(const urf_kargs& a, unsigned s)
 {
-    a.star_count[4 + (urf_tie_big(n, nruns) ? 1 : 0)] = 1u;
+    a.star_count[4] = 1u;
     if (a.optimistic & URF_OPT_NO_TIES)
         a.info[s].status = URF_STATUS_REDO_TIES;
 }
@@ -1871,7 +1870,7 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
      * its 80 registers; such sectors take the workgroup path now.) */
     const bool tie = urf_star_sort_sector<URF_STAR_SMALL_CAP / 64>(a, dp, sb, obase, n, two, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
     if (tie && lane == 0)
-        urf_tie_found(a, s, n, two.nruns);
+        urf_tie_found(a, s);
 }
 
 template <int NT>
@@ -2224,7 +2223,7 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
                 }
             a.star_first[sk] = (first < n - 1 ? first : n - 1) | (tie ? URF_TIE_FLAG : 0u) | next;
             if (tie)
-                urf_tie_found(a, s, n, simple ? 2u : 3u);
+                urf_tie_found(a, s);
         }
         __syncthreads();
         URF_PHASE_ACC(3);
@@ -2343,7 +2342,7 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
         if (threadIdx.x == 0) {
             a.star_first[sk] = (sh_first < n - 1 ? sh_first : n - 1) | (sh_tie ? URF_TIE_FLAG : 0u);
             if (sh_tie)
-                urf_tie_found(a, s, n, 3u);
+                urf_tie_found(a, s);
         }
         __syncthreads();
     }
@@ -2373,29 +2372,20 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
  * each <= the next: every element's final place is its segment's start + the smaller elements of the segment + the equal
  * ones in front of it.  tests/test_stdsort.py pins the same formulation on the CPU against the real std::sort.
  *
- * The arrays (range bits, the points, two work arrays of positions) live in LDS -- two instances: sectors of at most two runs
- * and URF_TIE_SMALL_CAP points, 5 KB per wave; anything else up to URF_TIE_BIG_CAP points, 32 KB -- and beyond that in the
- * sector's stretch of big_r / big_i / big_z / ssrt. */
+ * The arrays (range bits, the points, two work arrays of positions) live in LDS for sectors of up to URF_TIE_CAP points
+ * (32 KB) and beyond that in the sector's stretch of big_r / big_i / big_z / ssrt. */
 __device__ __forceinline__ int urf_walk_report(const urf_kargs& a, unsigned s, unsigned K, unsigned C, unsigned k, unsigned n, unsigned base,
                                                unsigned hit_i);
-/* three memory policies: the small instance (sectors of at most two runs and URF_TIE_SMALL_CAP points: the index arrays hold
- * positions inside the sector, 16 bits), the big instance's LDS and global memory (the index arrays hold addresses) */
-struct urf_tie_small {
-    typedef unsigned* rptr;
-    typedef uint16_t* iptr;
-    static constexpr bool POS = true;
-    static __device__ __forceinline__ void sync() { urf_wave_lds_sync(); }
-};
+/* two memory policies: LDS (sectors of up to URF_TIE_CAP points) and global memory; the index arrays hold the points'
+ * addresses in the sector-sorted arrays */
 struct urf_tie_lds {
     typedef unsigned* rptr;
     typedef unsigned* iptr;
-    static constexpr bool POS = false;
     static __device__ __forceinline__ void sync() { urf_wave_lds_sync(); }
 };
 struct urf_tie_glb {
     typedef volatile unsigned* rptr;   /* (volatile: one lane writes what the others read next) */
     typedef volatile unsigned* iptr;
-    static constexpr bool POS = false;
     static __device__ __forceinline__ void sync()
     {
         __threadfence_block();
@@ -2587,7 +2577,7 @@ __device__ __forceinline__ unsigned urf_tie_final_rank(unsigned j, typename MEM:
     return rank;
 }
 
-template <class MEM, unsigned CAP>
+template <class MEM>
 __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const urf_dev_params& dp, unsigned sk, unsigned s, unsigned k, unsigned n,
                                                     typename MEM::rptr R, typename MEM::iptr P, typename MEM::iptr LP, typename MEM::iptr RP, int* stk)
 {
@@ -2595,15 +2585,9 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
     const unsigned sb = urf_sbase(a, s), base = sb + a.sec_off[(size_t)s * (K + 1) + k];
     const urf_sec_run two = a.sec_run[sk];
     const bool simple = two.nruns <= 2;
-    auto adr_of = [&](unsigned i) { return i < two.c0 ? two.a0 + i : two.a1 + (i - two.c0); };   /* (simple sectors) */
-    /* the sector in the reference's order (ROI order = tiles in order, input order inside): range bits and the point --
-     * its position inside the sector (small instance) or its address in the sector-sorted arrays */
-    if constexpr (MEM::POS) {
-        for (unsigned i = lane; i < n; i += 64) {
-            R[i] = urf_fbits(a.sr[sb + adr_of(i)]);
-            P[i] = (uint16_t)i;
-        }
-    } else {
+    /* the sector in the reference's order (ROI order = tiles in order, input order inside): range bits and the point's
+     * address in the sector-sorted arrays */
+    {
         unsigned nruns = 0;
         if (!simple) {
             unsigned off, len;
@@ -2613,7 +2597,7 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
         }
         unsigned r = 0;
         for (unsigned i = lane; i < n; i += 64) {
-            unsigned adr = adr_of(i);
+            unsigned adr = i < two.c0 ? two.a0 + i : two.a1 + (i - two.c0);
             if (!simple) {
                 while (r + 1 < nruns && i >= LP[r + 1])
                     r++;
@@ -2625,46 +2609,19 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
     }
     MEM::sync();
     urf_tie_introsort_loop<MEM>(n, R, P, LP, RP, stk);
-    /* sorted: R = range bits, P = points, Z = heights */
-    typename MEM::rptr Z;
-    if constexpr (MEM::POS) {
-        /* in place through registers (at most CAP / 64 elements per lane); the heights go where LP / RP were */
-        constexpr unsigned EPL = CAP / 64;
-        unsigned rk[EPL], rv[EPL], pv[EPL];
-#pragma unroll
-        for (unsigned q = 0; q < EPL; q++) {
-            const unsigned j = q * 64 + lane;
-            rk[q] = rv[q] = pv[q] = 0;
-            if (j < n) {
-                rk[q] = urf_tie_final_rank<MEM>(j, R, LP, RP);
-                rv[q] = R[j];
-                pv[q] = P[j];
-            }
-        }
-        MEM::sync();
-        Z = (unsigned*)LP;   /* (LP and RP are one stretch of 2 * CAP 16-bit entries) */
-#pragma unroll
-        for (unsigned q = 0; q < EPL; q++)
-            if (q * 64 + lane < n) {
-                R[rk[q]] = rv[q];
-                P[rk[q]] = (uint16_t)pv[q];
-                Z[rk[q]] = __float_as_uint(a.sz[sb + adr_of(pv[q])]);
-            }
-        MEM::sync();
-    } else {
-        for (unsigned j = lane; j < n; j += 64)
-            LP[j] = urf_tie_final_rank<MEM>(j, R, LP, RP);
-        MEM::sync();
-        for (unsigned j = lane; j < n; j += 64)
-            RP[LP[j]] = P[j];            /* address of the i-th point in sorted order */
-        MEM::sync();
-        for (unsigned j = lane; j < n; j += 64)
-            P[LP[j]] = R[j];             /* its range bits */
-        MEM::sync();
-        for (unsigned i = lane; i < n; i += 64)
-            R[i] = __float_as_uint(a.sz[sb + RP[i]]);   /* its height */
-        MEM::sync();
-    }
+    /* sorted: RP = addresses, P = range bits, R = heights */
+    for (unsigned j = lane; j < n; j += 64)
+        LP[j] = urf_tie_final_rank<MEM>(j, R, LP, RP);
+    MEM::sync();
+    for (unsigned j = lane; j < n; j += 64)
+        RP[LP[j]] = P[j];            /* address of the i-th point in sorted order */
+    MEM::sync();
+    for (unsigned j = lane; j < n; j += 64)
+        P[LP[j]] = R[j];             /* its range bits */
+    MEM::sync();
+    for (unsigned i = lane; i < n; i += 64)
+        R[i] = __float_as_uint(a.sz[sb + RP[i]]);   /* its height */
+    MEM::sync();
     /* ---- what the sort kernels publish: slopes, distance terms, the point's position / ring-sorted index ---- */
     const float slope_param = dp.slope_param, kdist = dp.p.kdist_param;
     const bool fmt16 = simple && n <= URF_STAR_MID_CAP_;   /* (urf_walk_report) */
@@ -2673,29 +2630,19 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
         const unsigned i = i0 + lane;
         bool hit = false;
         if (i < n) {
-            float slp = 0.f, g = 0.f, ax, bx, az, bz;
-            if constexpr (MEM::POS) {
-                ax = __uint_as_float(R[i >= 1 ? i - 1 : 0]); bx = __uint_as_float(R[i]);
-                az = __uint_as_float(Z[i >= 1 ? i - 1 : 0]); bz = __uint_as_float(Z[i]);
-            } else {
-                ax = __uint_as_float(P[i >= 1 ? i - 1 : 0]); bx = __uint_as_float(P[i]);
-                az = __uint_as_float(R[i >= 1 ? i - 1 : 0]); bz = __uint_as_float(R[i]);
-            }
+            float slp = 0.f, g = 0.f;
             if (i >= 1) {
-                slp = (bz - az) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
+                const float ax = __uint_as_float(P[i - 1]), bx = __uint_as_float(P[i]);
+                slp = (__uint_as_float(R[i]) - __uint_as_float(R[i - 1])) / (bx - ax);   /* star_shaped_search.cpp:27-30 */
                 g = (bx - ax) * kdist;
                 hit = slp > slope_param;
             }
-            if constexpr (MEM::POS) {
-                a.ssrt16[base + i] = P[i];
+            const unsigned adr = RP[i];
+            if (fmt16) {
+                a.ssrt16[base + i] = (uint16_t)((two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0);
             } else {
-                const unsigned adr = RP[i];
-                if (fmt16) {
-                    a.ssrt16[base + i] = (uint16_t)((two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0);
-                } else {
-                    const unsigned sl = a.sslot[sb + adr];
-                    a.ssrt[base + i] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;   /* (RP may BE this stretch of ssrt: own element) */
-                }
+                const unsigned sl = a.sslot[sb + adr];
+                a.ssrt[base + i] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;   /* (RP may BE this stretch of ssrt: own element) */
             }
             a.wsg[base + i] = urf_sg{ slp, g };
         }
@@ -2710,21 +2657,21 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
     MEM::sync();
 }
 
-/* BIG = false: sectors of at most two runs and URF_TIE_SMALL_CAP points (every sector of an organised 64-ring sweep), 5 KB of LDS
- * per wave; BIG = true: all others.  Persistent over blocks of `per_block` consecutive (scan, sector) entries of star_first. */
 /* POST = false: in front of the walk, the sectors the sort kernels flagged (URF_TIE_FLAG); POST = true: behind it, the sectors
  * in which the walk stopped at a point with a twin behind it (URF_TIE_POST | index): sorted as std::sort does, the point that
- * stands at that index is reported instead (the walk itself does not change: the twins have one range and one height). */
-template <bool BIG, bool POST>
-__global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp, unsigned per_block, unsigned all_kinds)
+ * stands at that index is reported instead (the walk itself does not change: the twins have one range and one height).
+ * One wave per sector, persistent over blocks of `per_block` consecutive (scan, sector) entries of star_first.  (Until the
+ * twins were told apart, EVERY sector of a sensor's sweep came through here and a second instance with 16-bit index arrays
+ * -- 5 KB of LDS, six waves per SIMD -- carried the load: 65 k -> 135 k sweeps/s; with one sector in a hundred left, one
+ * instance with 32 KB does: the time is the latency of one wave's chain.) */
+template <bool POST>
+__global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp, unsigned per_block)
 {
-    /* all_kinds (the big instance, a handful of sweeps: one launch instead of two on the chain of a single sweep): small
-     * sectors too, through the 32-bit arrays */
-    constexpr unsigned CAP = BIG ? URF_TIE_BIG_CAP : URF_TIE_SMALL_CAP;
-    __shared__ unsigned W[BIG ? 4 * CAP : CAP + (3 * CAP) / 2];   /* R; P, LP, RP (32 / 16 bits) */
+    constexpr unsigned CAP = URF_TIE_CAP;
+    __shared__ unsigned W[4 * CAP];   /* R, P, LP, RP */
     __shared__ int stk[3 * 64];
-    if (a.star_count[(POST ? 6 : 4) + (BIG ? 1 : 0)] == 0u && !(all_kinds && a.star_count[POST ? 6 : 4] != 0u))
-        return;   /* (uniform) no sector of this instance's kind is flagged */
+    if (a.star_count[POST ? 5 : 4] == 0u)
+        return;   /* (uniform) no sector is flagged */
     const unsigned K = (unsigned)dp.p.sectors, total = a.n_scans * K, lane = threadIdx.x;
     const unsigned nblk = (total + per_block - 1) / per_block;
     for (unsigned blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -2740,20 +2687,17 @@ __global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp
             if (a.info[s].status != URF_OK)
                 continue;   /* (a void scan's entries are leftovers of an earlier call) */
             const unsigned n = a.sec_cnt[sk];
-            if ((urf_tie_big(n, a.sec_run[sk].nruns) != BIG && !all_kinds) || n < 2)
+            if (n < 2)
                 continue;
-            if constexpr (!BIG) {
-                uint16_t* I = (uint16_t*)(W + CAP);
-                urf_tie_sector_body<urf_tie_small, CAP>(a, dp, sk, s, k, n, W, I, I + CAP, I + 2 * CAP, stk);
-            } else if (n <= CAP) {
-                urf_tie_sector_body<urf_tie_lds, CAP>(a, dp, sk, s, k, n, W, W + CAP, W + 2 * CAP, W + 3 * CAP, stk);
+            if (n <= CAP) {
+                urf_tie_sector_body<urf_tie_lds>(a, dp, sk, s, k, n, W, W + CAP, W + 2 * CAP, W + 3 * CAP, stk);
             } else {
                 const unsigned base = urf_sbase(a, s) + a.sec_off[(size_t)s * (K + 1) + k];
-                urf_tie_sector_body<urf_tie_glb, CAP>(a, dp, sk, s, k, n, (unsigned*)a.big_r + base, a.big_i + base, (unsigned*)a.big_z + base,
-                                                      a.ssrt + base, stk);
+                urf_tie_sector_body<urf_tie_glb>(a, dp, sk, s, k, n, (unsigned*)a.big_r + base, a.big_i + base, (unsigned*)a.big_z + base,
+                                                 a.ssrt + base, stk);
             }
             if constexpr (POST) {
-                /* (the body's stores are complete: it ends with a fence; ssrt16 / ssrt now hold std::sort's order up to the walk's last index) */
+                /* (ssrt16 / ssrt now hold std::sort's order up to the walk's last index) */
                 __threadfence();
                 const int hit = urf_walk_report(a, s, K, (unsigned)dp.p.channels, k, n, urf_sbase(a, s) + a.sec_off[(size_t)s * (K + 1) + k], hit_i);
                 if (lane == 0)
@@ -3028,7 +2972,7 @@ __device__ __forceinline__ void urf_walk_twins(const urf_kargs& a, unsigned s, u
     if (!twin)
         return;
     a.star_first[(size_t)s * K + k] = URF_TIE_POST | hit_i;
-    a.star_count[6 + (urf_tie_big(n, a.sec_run[(size_t)s * K + k].nruns) ? 1 : 0)] = 1u;
+    a.star_count[5] = 1u;
     if (a.optimistic & URF_OPT_NO_TIES)
         a.info[s].status = URF_STATUS_REDO_TIES;   /* nobody runs the second pass in this launch sequence: once more, with it */
 }
