@@ -248,6 +248,22 @@ def e2e_callback_path(u, O, params, n_sweeps=8, reps=40, stream_reps=160):
         hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, 16, IN_FLIGHT)
         sec = min(hctx.bench_callback_stream(recs, n, 32, 0, 4, 8, stream_reps, IN_FLIGHT)[0] for _ in range(2))
         out["e2e_overlapped_scans_per_s_default_roi"] = round(stream_reps / sec, 1)
+        # a sweep as a sensor's driver delivers it (planar-range ties in every star sector): both passes of k_star_ties are part of
+        # the launch sequence after the first such sweep (urf_callback_path_state bit 4)
+        xs, ys, zs = u.synth_cloud(RINGS, COLS, 3, 9000)
+        bufs = np.zeros((n, 32), np.uint8)
+        bufs[:, 0:4] = xs.view(np.uint8).reshape(-1, 4)
+        bufs[:, 4:8] = ys.view(np.uint8).reshape(-1, 4)
+        bufs[:, 8:12] = zs.view(np.uint8).reshape(-1, 4)
+        recs_s = [bufs.reshape(-1)]
+        lbs, _, _ = O.run_b(xs, ys, zs, params)
+        ctx.set_params(params)
+        lgs, _ = ctx.classify_pc2(recs_s[0], n, 32, 0, 4, 8)
+        if not np.array_equal(lgs, lbs):
+            raise SystemExit("parity failure on the callback path (sensor-like sweep)")
+        recs, keep = recs_s * n_sweeps, recs
+        out["e2e_latency_ms_sensor_like"] = round(latency(ctx), 4)
+        recs = keep
     out["e2e_method"] = ("every e2e_overlapped_* figure: one untimed pass, then the better of two timed passes of %d sweeps; e2e_latency_ms*: median of %d "
                          "synchronous calls after 4 untimed ones (e2e_latency_ms_native_mean: mean of %d).  Library: e2e_latency_ms, *_default_roi latency and the "
                          "*_python_client streams run in liburf_hip.so (the product); the native-loop streams, e2e_latency_ms_native_mean and "

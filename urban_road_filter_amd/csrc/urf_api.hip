@@ -260,7 +260,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles)
     A(k.angle, S * C) A(k.ring_thr, S * C * 4) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_run, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
-    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_count, 8 * URF_ASYNC_SLOTS)   /* eight counters per scratch row in use at once */
+    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.tie_list, S * K) A(k.tie_post, S * K) A(k.star_count, 8 * URF_ASYNC_SLOTS)   /* eight counters per scratch row in use at once */
     A(k.table_upto, S) A(k.table_redo, S) A(k.redo_list, S) A(k.table_cause, S) A(k.ring_hint, URF_ASYNC_SLOTS)
     A(k.nan_mask, S * 4) A(k.nan_list, 2 * S * C) A(k.vis, S * C)
     A(k.maxdist, S * C) A(k.quad, S * 4)
@@ -511,7 +511,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     k.rpre += r * C * (tiles + 1); k.rstart += r * C * tiles;
     k.angle += r * C; k.ring_thr += r * C * 4; k.ring_lut += r * URF_LUT_CELLS; k.ring_cnt += r * C; k.ring_off += r * (C + 1);
     k.sec_cnt += r * K; k.sec_run += r * K; k.sec_off += r * (K + 1); k.star_hit += r * K;
-    k.star_first += r * K; k.star_list_mid += r * K; k.star_list_big += r * K; k.star_count += 8 * r;
+    k.star_first += r * K; k.star_list_mid += r * K; k.star_list_big += r * K; k.tie_list += r * K; k.tie_post += r * K; k.star_count += 8 * r;
     k.table_upto += r; k.table_redo += r; k.redo_list += r; k.table_cause += r; k.ring_hint += r;
     k.nan_mask += r * 4; k.nan_list += 2 * r * C; k.vis += r * C;
     k.maxdist += r * C; k.quad += r * 4;
@@ -646,11 +646,9 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     mark();
     hipLaunchKernelGGL(k_index, g_scan, dim3(256), 0, st, a, dp);
     mark();
-    /* k_star_ties: one-wave workgroups (32 KB of LDS: four per CU), each over blocks of `tie_per` consecutive sectors */
-    /* (a batch: 64 entries per wave and load -- one sector in a hundred carries a flag, and with four entries per block the waves
-     * spent their time reading flags one dependent load after the other; a handful of sweeps: one workgroup per sector) */
-    const unsigned tie_total = K * n_scans, tie_per = tie_total <= 16384u ? 1u : 64u, tie_nblk = (tie_total + tie_per - 1) / tie_per;
-    const unsigned tie_grid = tie_nblk < c->n_cus * 4u ? tie_nblk : c->n_cus * 4u;
+    /* k_star_ties: persistent one-wave workgroups (32 KB of LDS: four per CU) over a list that holds one sector in a hundred of
+     * a sensor's sweep and nothing of a benchmark cloud */
+    const unsigned tie_grid = K * n_scans < c->n_cus * 4u ? K * n_scans : c->n_cus * 4u;
     if (star) {
         const dim3 g_sec(K, n_scans);
         hipLaunchKernelGGL(k_star_sort_small, g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
@@ -664,7 +662,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
          * leaves them in.  Benchmark clouds hold none (the kernel returns at once); a real sensor's sweep holds equal ranges in
          * every sector, but nearly all of them between twins (one height), which only the second pass below cares about. */
         if (!(a.optimistic & URF_OPT_NO_TIES))
-            hipLaunchKernelGGL(k_star_ties<false>, dim3(tie_grid), dim3(64), 0, st, a, dp, tie_per);
+            hipLaunchKernelGGL(k_star_ties<false>, dim3(tie_grid), dim3(64), 0, st, a, dp);
     }
     mark();   /* "k_star_sort" = the three sort kernels (mid / big run over normally empty work lists) */
     if (star) {
@@ -674,7 +672,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
             hipLaunchKernelGGL(k_star_walk, dim3((K + 63) / 64, n_scans), dim3(64), 0, st, a, dp);
         /* second pass of k_star_ties: the sectors in which the walk stopped at a point with a twin behind it (URF_TIE_POST) */
         if (!(a.optimistic & URF_OPT_NO_TIES))
-            hipLaunchKernelGGL(k_star_ties<true>, dim3(tie_grid), dim3(64), 0, st, a, dp, tie_per);
+            hipLaunchKernelGGL(k_star_ties<true>, dim3(tie_grid), dim3(64), 0, st, a, dp);
     }
     mark();
     const dim3 g_ring(C, n_scans);

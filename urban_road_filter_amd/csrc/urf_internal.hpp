@@ -211,8 +211,10 @@ struct urf_kargs {
     uint32_t* star_first;       /* [S][sectors] last sorted index the walk may visit */
     uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 385..2048 points */
     uint32_t* star_list_big;    /* [S*sectors] ... with more than 2048 points */
-    uint32_t* star_count;       /* [8] lengths of the two lists, [2] = length of redo_list, [3] = length of nan_list, [4] != 0: some
-                                 * sector carries URF_TIE_FLAG, [5] != 0: ... URF_TIE_POST (zeroed per call) */
+    uint32_t* tie_list;         /* [S*sectors] scan*sectors+sector of the sectors that carry URF_TIE_FLAG (sort kernels -> k_star_ties, first pass) */
+    uint32_t* tie_post;         /* [S*sectors] ... URF_TIE_POST (walk kernels -> second pass) */
+    uint32_t* star_count;       /* [8] lengths of the two lists, [2] = length of redo_list, [3] = length of nan_list, [4] = length of
+                                 * tie_list, [5] = of tie_post (zeroed per call) */
     uint32_t* table_upto;       /* [S] first point a speculative k_ring_table did not look at (0xffffffff: none) */
     uint32_t* table_redo;       /* [S] k_split: the speculative table of the scan is incomplete */
     uint32_t* redo_list;        /* [S] such scans (k_table_repair) */

@@ -1824,9 +1824,9 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
 /* a sector was flagged with URF_TIE_FLAG: tell k_star_ties' instance for its size that there is work -- or, in a launch
  * sequence without it (callback path), void the sweep: urf_classify_pc2_wait() runs it again with the kernel (every writer
  * writes the same value) */
-__device__ __forceinline__ void urf_tie_found(const urf_kargs& a, unsigned s)
+__device__ __forceinline__ void urf_tie_found(const urf_kargs& a, unsigned s, unsigned sk)
 {
-    a.star_count[4] = 1u;
+    a.tie_list[atomicAdd(&a.star_count[4], 1u)] = sk;   /* (one sector in a hundred of a sensor's sweep; none of a benchmark cloud) */
     if (a.optimistic & URF_OPT_NO_TIES)
         a.info[s].status = URF_STATUS_REDO_TIES;
 }
@@ -1870,7 +1870,7 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
      * its 80 registers; such sectors take the workgroup path now.) */
     const bool tie = urf_star_sort_sector<URF_STAR_SMALL_CAP / 64>(a, dp, sb, obase, n, two, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
     if (tie && lane == 0)
-        urf_tie_found(a, s);
+        urf_tie_found(a, s, s * K + k);
 }
 
 template <int NT>
@@ -2223,7 +2223,7 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
                 }
             a.star_first[sk] = (first < n - 1 ? first : n - 1) | (tie ? URF_TIE_FLAG : 0u) | next;
             if (tie)
-                urf_tie_found(a, s);
+                urf_tie_found(a, s, sk);
         }
         __syncthreads();
         URF_PHASE_ACC(3);
@@ -2342,7 +2342,7 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
         if (threadIdx.x == 0) {
             a.star_first[sk] = (sh_first < n - 1 ? sh_first : n - 1) | (sh_tie ? URF_TIE_FLAG : 0u);
             if (sh_tie)
-                urf_tie_found(a, s);
+                urf_tie_found(a, s, sk);
         }
         __syncthreads();
     }
@@ -2374,8 +2374,7 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
  *
  * The arrays (range bits, the points, two work arrays of positions) live in LDS for sectors of up to URF_TIE_CAP points
  * (32 KB) and beyond that in the sector's stretch of big_r / big_i / big_z / ssrt. */
-__device__ __forceinline__ int urf_walk_report(const urf_kargs& a, unsigned s, unsigned K, unsigned C, unsigned k, unsigned n, unsigned base,
-                                               unsigned hit_i);
+__device__ __forceinline__ int urf_walk_slot_to_ring_pos(const urf_kargs& a, unsigned s, unsigned C, unsigned v);
 /* two memory policies: LDS (sectors of up to URF_TIE_CAP points) and global memory; the index arrays hold the points'
  * addresses in the sector-sorted arrays */
 struct urf_tie_lds {
@@ -2445,6 +2444,76 @@ __device__ __noinline__ void urf_tie_heap_sort(RP_ R, IP_ P, unsigned f, unsigne
     }
 }
 
+/* __unguarded_partition_pivot(first, last) on [f, l), l - f > 16, by one wave: returns the cut.  R = range bits, P = the
+ * points (moved along), LP / RP: work arrays (the stretch [f + 1, l) of each is used). */
+template <class MEM>
+__device__ __forceinline__ unsigned urf_tie_partition(typename MEM::rptr R, typename MEM::iptr P, typename MEM::iptr LP, typename MEM::iptr RP,
+                                                      unsigned f, unsigned l)
+{
+    const unsigned lane = threadIdx.x;
+    {   /* __move_median_to_first(first, first + 1, mid, last - 1) */
+        const unsigned mid = f + (l - f) / 2;
+        const unsigned va = R[f + 1], vb = R[mid], vc = R[l - 1];
+        unsigned m;
+        if (va < vb)
+            m = vb < vc ? mid : (va < vc ? l - 1 : f + 1);
+        else if (va < vc)
+            m = f + 1;
+        else if (vb < vc)
+            m = l - 1;
+        else
+            m = mid;
+        if (lane == 0) {
+            const unsigned r0 = R[f], p0 = P[f];
+            R[f] = R[m];
+            P[f] = P[m];
+            R[m] = r0;
+            P[m] = p0;
+        }
+        MEM::sync();
+    }
+    const unsigned pv = R[f];
+    /* __unguarded_partition(first + 1, last, first): where the left pointer can stop (>= pivot), where the right one (<= pivot) */
+    unsigned tL = 0, tR = 0;
+    for (unsigned c0 = f + 1; c0 < l; c0 += 64) {
+        const unsigned p = c0 + lane;
+        const bool in = p < l;
+        const unsigned v = in ? R[p] : 0u;
+        const bool isL = in && v >= pv, isR = in && v <= pv;
+        const unsigned long long mL = __ballot(isL), mR = __ballot(isR);
+        if (isL)
+            LP[f + 1 + tL + urf_popc_below(mL)] = p;
+        if (isR)
+            RP[f + 1 + tR + urf_popc_below(mR)] = p;   /* ascending; the k-th from the right is entry tR - 1 - k */
+        tL += (unsigned)__popcll(mL);
+        tR += (unsigned)__popcll(mR);
+    }
+    MEM::sync();
+    const unsigned mn = tL < tR ? tL : tR;
+    unsigned ks = 0;
+    for (unsigned k0 = 0; k0 < mn; k0 += 64) {
+        const unsigned kk = k0 + lane;
+        const bool in = kk < mn;
+        const unsigned lp = in ? LP[f + 1 + kk] : 0u, rp = in ? RP[f + tR - kk] : 0u;
+        const bool ok = in && lp < rp;
+        const unsigned long long mo = __ballot(ok), mi = __ballot(in);
+        if (ok) {   /* iter_swap: the positions of all pairs are distinct */
+            const unsigned r0 = R[lp], p0 = P[lp], r1 = R[rp], p1 = P[rp];
+            R[lp] = r1;
+            P[lp] = p1;
+            R[rp] = r0;
+            P[rp] = p0;
+        }
+        ks += (unsigned)__popcll(mo);
+        if (mo != mi)
+            break;
+    }
+    MEM::sync();
+    const unsigned Lk = ks < tL ? LP[f + 1 + ks] : 0xffffffffu;
+    const unsigned Rk = ks > 0 ? RP[f + 1 + tR - ks] : 0xffffffffu;
+    return Lk < Rk ? Lk : Rk;
+}
+
 /* __introsort_loop on R (range bits) with P (the points) moved along; LP / RP: work arrays of n entries each.  Leaves, for
  * every element j, the segment [LP[j], RP[j]) the final insertion sort will keep it in. */
 template <class MEM>
@@ -2469,67 +2538,7 @@ __device__ __forceinline__ void urf_tie_introsort_loop(unsigned n, typename MEM:
                 break;
             }
             d++;
-            {   /* __move_median_to_first(first, first + 1, mid, last - 1) */
-                const unsigned mid = f + (l - f) / 2;
-                const unsigned va = R[f + 1], vb = R[mid], vc = R[l - 1];
-                unsigned m;
-                if (va < vb)
-                    m = vb < vc ? mid : (va < vc ? l - 1 : f + 1);
-                else if (va < vc)
-                    m = f + 1;
-                else if (vb < vc)
-                    m = l - 1;
-                else
-                    m = mid;
-                if (lane == 0) {
-                    const unsigned r0 = R[f], p0 = P[f];
-                    R[f] = R[m];
-                    P[f] = P[m];
-                    R[m] = r0;
-                    P[m] = p0;
-                }
-                MEM::sync();
-            }
-            const unsigned pv = R[f];
-            /* __unguarded_partition(first + 1, last, first): where the left pointer can stop (>= pivot), where the right one (<= pivot) */
-            unsigned tL = 0, tR = 0;
-            for (unsigned c0 = f + 1; c0 < l; c0 += 64) {
-                const unsigned p = c0 + lane;
-                const bool in = p < l;
-                const unsigned v = in ? R[p] : 0u;
-                const bool isL = in && v >= pv, isR = in && v <= pv;
-                const unsigned long long mL = __ballot(isL), mR = __ballot(isR);
-                if (isL)
-                    LP[f + 1 + tL + urf_popc_below(mL)] = p;
-                if (isR)
-                    RP[f + 1 + tR + urf_popc_below(mR)] = p;   /* ascending; the k-th from the right is entry tR - 1 - k */
-                tL += (unsigned)__popcll(mL);
-                tR += (unsigned)__popcll(mR);
-            }
-            MEM::sync();
-            const unsigned mn = tL < tR ? tL : tR;
-            unsigned ks = 0;
-            for (unsigned k0 = 0; k0 < mn; k0 += 64) {
-                const unsigned kk = k0 + lane;
-                const bool in = kk < mn;
-                const unsigned lp = in ? LP[f + 1 + kk] : 0u, rp = in ? RP[f + tR - kk] : 0u;
-                const bool ok = in && lp < rp;
-                const unsigned long long mo = __ballot(ok), mi = __ballot(in);
-                if (ok) {   /* iter_swap: the positions of all pairs are distinct */
-                    const unsigned r0 = R[lp], p0 = P[lp], r1 = R[rp], p1 = P[rp];
-                    R[lp] = r1;
-                    P[lp] = p1;
-                    R[rp] = r0;
-                    P[rp] = p0;
-                }
-                ks += (unsigned)__popcll(mo);
-                if (mo != mi)
-                    break;
-            }
-            MEM::sync();
-            const unsigned Lk = ks < tL ? LP[f + 1 + ks] : 0xffffffffu;
-            const unsigned Rk = ks > 0 ? RP[f + 1 + tR - ks] : 0xffffffffu;
-            const unsigned cut = Lk < Rk ? Lk : Rk;
+            const unsigned cut = urf_tie_partition<MEM>(R, P, LP, RP, f, l);
             if (l - cut > 16u) {   /* __introsort_loop(cut, last, depth_limit): later */
                 if (lane == 0) {
                     stk[3 * top] = (int)cut;
@@ -2564,6 +2573,45 @@ __device__ __forceinline__ void urf_tie_introsort_loop(unsigned n, typename MEM:
     MEM::sync();
 }
 
+/* WHICH point std::sort leaves at sorted index `target`: the partitions of the segment that holds that index, and only
+ * those -- what the introsort loop does to the other side of a cut never reaches it (the second pass of k_star_ties needs one
+ * point, not the order: n + n / 2 + n / 4 ... elements looked at instead of n log n).  Returns the point (P's entry). */
+template <class MEM>
+__device__ __forceinline__ unsigned urf_tie_select(unsigned n, unsigned target, typename MEM::rptr R, typename MEM::iptr P, typename MEM::iptr LP,
+                                                   typename MEM::iptr RP)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned limit = 2u * (31u - (unsigned)__clz((int)n));
+    unsigned f = 0, l = n, d = 0;
+    while (l - f > 16u) {
+        if (d == limit) {   /* __partial_sort: the segment is sorted when it returns */
+            if (lane == 0)
+                urf_tie_heap_sort<typename MEM::rptr, typename MEM::iptr>(R, P, f, l);
+            MEM::sync();
+            return P[target];
+        }
+        d++;
+        const unsigned cut = urf_tie_partition<MEM>(R, P, LP, RP, f, l);
+        if (target < cut)
+            l = cut;
+        else
+            f = cut;
+    }
+    /* __final_insertion_sort keeps the segment's elements inside it, stably: the one whose place is `target` */
+    const unsigned j = f + lane;
+    unsigned rank = 0xffffffffu;
+    if (j < l) {
+        const unsigned v = R[j];
+        rank = f;
+        for (unsigned i = f; i < l; i++) {
+            const unsigned u = R[i];
+            rank += (u < v || (u == v && i < j)) ? 1u : 0u;
+        }
+    }
+    const unsigned long long m = __ballot(rank == target);   /* exactly one lane */
+    return P[f + (unsigned)__ffsll((long long)m) - 1u];
+}
+
 /* __final_insertion_sort: stable, and every element stays inside its segment -- its final place */
 template <class MEM>
 __device__ __forceinline__ unsigned urf_tie_final_rank(unsigned j, typename MEM::rptr R, typename MEM::iptr LP, typename MEM::iptr RP)
@@ -2577,9 +2625,10 @@ __device__ __forceinline__ unsigned urf_tie_final_rank(unsigned j, typename MEM:
     return rank;
 }
 
-template <class MEM>
+template <class MEM, bool POST>
 __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const urf_dev_params& dp, unsigned sk, unsigned s, unsigned k, unsigned n,
-                                                    typename MEM::rptr R, typename MEM::iptr P, typename MEM::iptr LP, typename MEM::iptr RP, int* stk)
+                                                    unsigned hit_i, typename MEM::rptr R, typename MEM::iptr P, typename MEM::iptr LP,
+                                                    typename MEM::iptr RP, int* stk)
 {
     const unsigned lane = threadIdx.x, K = (unsigned)dp.p.sectors;
     const unsigned sb = urf_sbase(a, s), base = sb + a.sec_off[(size_t)s * (K + 1) + k];
@@ -2608,6 +2657,20 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
         }
     }
     MEM::sync();
+    if constexpr (POST) {
+        /* behind the walk: the point std::sort leaves at the index the walk stopped at (urf_walk_report's conversion of a
+         * point's address in the sector-sorted arrays into its place in the ring-major ones) */
+        const unsigned adr = urf_tie_select<MEM>(n, hit_i, R, P, LP, RP);
+        const unsigned sl = a.sslot[sb + adr];
+        const unsigned v = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+        const int hit = urf_walk_slot_to_ring_pos(a, s, (unsigned)dp.p.channels, v);
+        if (lane == 0) {
+            a.star_hit[sk] = hit;
+            a.star_first[sk] = 0;   /* (the flag is consumed) */
+        }
+        MEM::sync();
+        return;
+    }
     urf_tie_introsort_loop<MEM>(n, R, P, LP, RP, stk);
     /* sorted: RP = addresses, P = range bits, R = heights */
     for (unsigned j = lane; j < n; j += 64)
@@ -2660,29 +2723,27 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
 /* POST = false: in front of the walk, the sectors the sort kernels flagged (URF_TIE_FLAG); POST = true: behind it, the sectors
  * in which the walk stopped at a point with a twin behind it (URF_TIE_POST | index): sorted as std::sort does, the point that
  * stands at that index is reported instead (the walk itself does not change: the twins have one range and one height).
- * One wave per sector, persistent over blocks of `per_block` consecutive (scan, sector) entries of star_first.  (Until the
- * twins were told apart, EVERY sector of a sensor's sweep came through here and a second instance with 16-bit index arrays
- * -- 5 KB of LDS, six waves per SIMD -- carried the load: 65 k -> 135 k sweeps/s; with one sector in a hundred left, one
- * instance with 32 KB does: the time is the latency of one wave's chain.) */
+ * One wave per sector, persistent over the list the sort / walk kernels appended the sector to.  (Until the twins were told
+ * apart, EVERY sector of a sensor's sweep came through here -- flags scanned instead of a list appended to by 368 000 atomics
+ * on one counter -- and a second instance with 16-bit index arrays, 5 KB of LDS and six waves per SIMD carried the load:
+ * 65 k -> 135 k sweeps/s; with one sector in a hundred left, one instance with 32 KB does: the time is the latency of one
+ * wave's chain.) */
 template <bool POST>
-__global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp, unsigned per_block)
+__global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp)
 {
     constexpr unsigned CAP = URF_TIE_CAP;
     __shared__ unsigned W[4 * CAP];   /* R, P, LP, RP */
     __shared__ int stk[3 * 64];
-    if (a.star_count[POST ? 5 : 4] == 0u)
-        return;   /* (uniform) no sector is flagged */
-    const unsigned K = (unsigned)dp.p.sectors, total = a.n_scans * K, lane = threadIdx.x;
-    const unsigned nblk = (total + per_block - 1) / per_block;
-    for (unsigned blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const unsigned e = blk * per_block + lane;
-        const unsigned sf = (lane < per_block && e < total) ? a.star_first[e] : 0u;
-        unsigned long long m = __ballot((sf & (POST ? URF_TIE_POST : URF_TIE_FLAG)) != 0u);
-        while (m) {
-            const unsigned src = (unsigned)__ffsll((long long)m) - 1u;
-            const unsigned sk = blk * per_block + src;
-            const unsigned hit_i = (unsigned)__shfl((int)sf, (int)src) & URF_TIE_INDEX;   /* (POST) */
-            m &= m - 1ull;
+    const unsigned count = a.star_count[POST ? 5 : 4];   /* (uniform; 0 for every tie-free sweep: the kernel returns at once) */
+    const unsigned K = (unsigned)dp.p.sectors;
+    const uint32_t* const list = POST ? a.tie_post : a.tie_list;
+    for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
+        {
+            const unsigned sk = list[w];
+            const unsigned sf = a.star_first[sk];
+            if (!(sf & (POST ? URF_TIE_POST : URF_TIE_FLAG)))
+                continue;
+            const unsigned hit_i = sf & URF_TIE_INDEX;   /* (POST) */
             const unsigned s = sk / K, k = sk % K;
             if (a.info[s].status != URF_OK)
                 continue;   /* (a void scan's entries are leftovers of an earlier call) */
@@ -2690,18 +2751,11 @@ __global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp
             if (n < 2)
                 continue;
             if (n <= CAP) {
-                urf_tie_sector_body<urf_tie_lds>(a, dp, sk, s, k, n, W, W + CAP, W + 2 * CAP, W + 3 * CAP, stk);
+                urf_tie_sector_body<urf_tie_lds, POST>(a, dp, sk, s, k, n, hit_i, W, W + CAP, W + 2 * CAP, W + 3 * CAP, stk);
             } else {
                 const unsigned base = urf_sbase(a, s) + a.sec_off[(size_t)s * (K + 1) + k];
-                urf_tie_sector_body<urf_tie_glb>(a, dp, sk, s, k, n, (unsigned*)a.big_r + base, a.big_i + base, (unsigned*)a.big_z + base,
-                                                 a.ssrt + base, stk);
-            }
-            if constexpr (POST) {
-                /* (ssrt16 / ssrt now hold std::sort's order up to the walk's last index) */
-                __threadfence();
-                const int hit = urf_walk_report(a, s, K, (unsigned)dp.p.channels, k, n, urf_sbase(a, s) + a.sec_off[(size_t)s * (K + 1) + k], hit_i);
-                if (lane == 0)
-                    a.star_hit[sk] = hit;
+                urf_tie_sector_body<urf_tie_glb, POST>(a, dp, sk, s, k, n, hit_i, (unsigned*)a.big_r + base, a.big_i + base,
+                                                       (unsigned*)a.big_z + base, a.ssrt + base, stk);
             }
         }
     }
@@ -2841,6 +2895,26 @@ __device__ __forceinline__ void urf_walk_chunk_general(urf_walk_state& w_, unsig
  * sector of at most two runs the sort left the point's position inside the sector (ssrt16), which sec_run turns
  * into its place in the sector-sorted arrays, where its slot stands; other sectors hold the index itself (ssrt).
  * The ring is the run of tile t that contains the slot (bisection in the tile's run table). */
+/* tile-local ring-sorted index v = t * URF_TILE + slot (0xffffffff: on no ring) -> the point's position in the ring-major arrays, -1: none */
+__device__ __forceinline__ int urf_walk_slot_to_ring_pos(const urf_kargs& a, unsigned s, unsigned C, unsigned v)
+{
+    int hit = -1;
+    if (v != 0xffffffffu) {
+        const unsigned t = v / URF_TILE, j = v % URF_TILE;
+        const uint16_t* row = a.troff + ((size_t)s * a.tiles + t) * (C + 1);
+        unsigned lo = 0, hi = C;   /* largest c with row[c] <= j (its run is not empty) */
+        while (hi - lo > 1) {
+            const unsigned mid = (lo + hi) >> 1;
+            if ((unsigned)row[mid] <= j)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const unsigned p = a.rpre[((size_t)s * C + lo) * (a.tiles + 1) + t] + (j - (unsigned)row[lo]);
+        hit = (int)(a.ring_off[(size_t)s * (C + 1) + lo] + p);   /* relative to the scan's scratch base */
+    }
+    return hit;
+}
 __device__ __forceinline__ int urf_walk_report(const urf_kargs& a, unsigned s, unsigned K, unsigned C, unsigned k, unsigned n, unsigned base,
                                                unsigned hit_i)
 {
@@ -2857,20 +2931,7 @@ __device__ __forceinline__ int urf_walk_report(const urf_kargs& a, unsigned s, u
             v = a.ssrt[base + hit_i];
         }
     }
-    if (v != 0xffffffffu) {
-        const unsigned t = v / URF_TILE, j = v % URF_TILE;
-        const uint16_t* row = a.troff + ((size_t)s * a.tiles + t) * (C + 1);
-        unsigned lo = 0, hi = C;   /* largest c with row[c] <= j (its run is not empty) */
-        while (hi - lo > 1) {
-            const unsigned mid = (lo + hi) >> 1;
-            if ((unsigned)row[mid] <= j)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const unsigned p = a.rpre[((size_t)s * C + lo) * (a.tiles + 1) + t] + (j - (unsigned)row[lo]);
-        hit = (int)(a.ring_off[(size_t)s * (C + 1) + lo] + p);   /* relative to the scan's scratch base */
-    }
+    hit = urf_walk_slot_to_ring_pos(a, s, C, v);
     return hit;
 }
 
@@ -2972,7 +3033,7 @@ __device__ __forceinline__ void urf_walk_twins(const urf_kargs& a, unsigned s, u
     if (!twin)
         return;
     a.star_first[(size_t)s * K + k] = URF_TIE_POST | hit_i;
-    a.star_count[5] = 1u;
+    a.tie_post[atomicAdd(&a.star_count[5], 1u)] = s * K + k;
     if (a.optimistic & URF_OPT_NO_TIES)
         a.info[s].status = URF_STATUS_REDO_TIES;   /* nobody runs the second pass in this launch sequence: once more, with it */
 }
