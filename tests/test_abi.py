@@ -146,3 +146,11 @@ def test_rccl_shard_client_builds(tmp_path):
         r = subprocess.run([exe, str(tmp_path / "out.bin"), "0", str(cloud)], capture_output=True, text=True)
         assert r.returncode != 0 and "no usable HIP device" in (r.stderr + r.stdout)
         assert not os.path.exists(tmp_path / "out.bin")
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() -- the driver's "does it build" check -- compiles what is stale and asserts the ABI version it expects."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    g = importlib.import_module("__graft_entry__")
+    g.build()
