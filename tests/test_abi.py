@@ -1,6 +1,7 @@
 """The C-ABI library loads without a GPU and exports every function include/urf.h declares."""
 import ctypes
 import os
+import sys
 import re
 
 import pytest
