@@ -4794,12 +4794,21 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         cnt_curb = 0;
         n_unsure = 0;
     }
-    __syncthreads();
+    /* An ORGANISED tile (k_split: every ring holds 2048 / C consecutive slots; every tile of a sweep in firing order) needs no
+     * table of its slots' rings: slot j lies on ring j / (2048 / C).  Decided from the run table itself; such a tile skips the
+     * marks, the prefix maximum and two of the three barriers (r5). */
+    const unsigned logP = 11u - (31u - (unsigned)__clz((int)C));   /* log2(2048 / C) for a power of two */
+#ifdef URF_EXP_LABEL_NO_ORG
+    const bool organised = (__syncthreads_or(1) != 0) && false;
+#else
+    const bool organised = __syncthreads_or(((C & (C - 1u)) != 0u) || (tid <= C && v_koff != (tid << logP))) == 0;
+#endif
     const unsigned npts = koff[C];
     /* Ring of every slot of the tile's ring-sorted order: each non-empty run marks its first slot
      * with ring + 1, a prefix maximum over the slots spreads the marks (runs are in ring order).
      * Eight consecutive slots per thread, shuffles across the wave, LDS across the four waves --
      * a seventh of the instructions of a bisection in koff per point. */
+    if (!organised) {   /* (uniform) */
     if (tid < C && koff[tid + 1] > koff[tid])
         ring_of[koff[tid]] = (uint8_t)(tid + 1);
     __syncthreads();
@@ -4839,6 +4848,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         w32[2 * tid + 1] = o1;
     }
     __syncthreads();
+    }
     unsigned my_road = 0, my_curb = 0;
     if (npts != 0) {   /* uniform; 0: no point of the tile lies on a ring */
     /* Straight-line per point: slots past the tile's last one read whatever the scratch holds there
@@ -4859,7 +4869,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     for (unsigned qq = 0; qq < QB; qq++) {
         const unsigned q = q0 + qq;
         const unsigned j = tid + q * URF_LABEL_TILE_THREADS;
-        cc[qq] = (unsigned)ring_of[j] - 1u;   /* (past the last slot: the last ring, from the prefix maximum) */
+        cc[qq] = organised ? j >> logP : (unsigned)ring_of[j] - 1u;   /* (past the last slot: the last ring, from the prefix maximum) */
         const float az = urf_az_decode(rec[q] >> URF_REC_AZ_SHIFT);
         const bool num = az == az;
         int cf = num ? (int)__builtin_floorf(az) : 0, cb = num ? (int)__builtin_ceilf(az) : 0;
