@@ -2355,10 +2355,12 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
  * the two points comes second decides the sign), so the reference's labels depend on that order.  The benchmark clouds
  * are tie-free by construction; a real sensor's sweep -- ranges quantised to millimetres,
  * neighbouring firings of a ring on flat ground -- holds such pairs in every sector.  The sort kernels above order equal
- * ranges by position (the stable order) and flag a sector whose sorted prefix, as far as the walk may look plus one, holds
- * equal neighbours (URF_TIE_FLAG in star_first); this kernel then sorts the flagged sector AGAIN, as libstdc++ does
- * (bits/stl_algo.h of GCC 5 .. 13: __sort -> __introsort_loop -> __unguarded_partition_pivot / __partial_sort,
- * __final_insertion_sort), and rewrites everything the sort kernels wrote for it.
+ * ranges by position (the stable order) and list a sector whose sorted prefix, as far as the walk may look plus one, holds
+ * equal neighbours of DIFFERENT heights (URF_TIE_FLAG in star_first, tie_list); this kernel then sorts the listed sector
+ * AGAIN, as libstdc++ does (bits/stl_algo.h of GCC 5 .. 13: __sort -> __introsort_loop -> __unguarded_partition_pivot /
+ * __partial_sort, __final_insertion_sort), and rewrites everything the sort kernels wrote for it.  Equal neighbours of one
+ * height (twins: nearly all of a sensor's) do not change what the walk computes, only which of them stands where it stops:
+ * the walk kernels list such a sector (URF_TIE_POST, tie_post) and the second pass picks that one point (urf_tie_select).
  *
  * One wave per sector.  What has to be followed literally is the introsort loop: only it moves equal elements past each
  * other.  (a) __move_median_to_first on (first + 1, mid, last - 1).  (b) __unguarded_partition against the pivot now at
