@@ -2093,22 +2093,36 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
      * has long arrived.  (Fetched on the spot, with the run list built from the per-tile tables by
      * one wave, this cost 7 000 of the 32 000 cycles a sector took.) */
     auto list_entry = [&](unsigned w) -> unsigned { return w < count ? a.star_list_mid[w] : 0u; };
-    unsigned sk_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)list_entry(blockIdx.x));
-    unsigned n_cur = a.sec_cnt[sk_cur], so_cur = a.sec_off[(size_t)(sk_cur / K) * (K + 1) + sk_cur % K];
-    urf_sec_run two_cur = a.sec_run[sk_cur];
+    auto rfl = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    /* (r5) The list entry is fetched TWO iterations ahead and the description one, and both are taken into scalar registers
+     * in front of the tail's stores: loads and stores share one in-order counter on this chip, so a load still pending when
+     * the tail's barrier comes makes the workgroup wait for the acknowledgement of every store issued before it -- 6 100 of a
+     * sector's 20 300 cycles went there, and another round trip into the list entry at the top of every iteration. */
+    struct urf_mid_desc {
+        unsigned sk, n, so, a0, c0, a1, nruns;
+    };
+    urf_mid_desc cur;
+    cur.sk = rfl(list_entry(blockIdx.x));
+    {
+        const urf_sec_run t = a.sec_run[cur.sk];
+        cur.n = rfl(a.sec_cnt[cur.sk]);
+        cur.so = rfl(a.sec_off[(size_t)(cur.sk / K) * (K + 1) + cur.sk % K]);
+        cur.a0 = rfl(t.a0);
+        cur.c0 = rfl(t.c0);
+        cur.a1 = rfl(t.a1);
+        cur.nruns = rfl(t.nruns);
+    }
+    unsigned sk_next = rfl(list_entry(blockIdx.x + gridDim.x));
     for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
-        const unsigned sk_next = (unsigned)__builtin_amdgcn_readfirstlane((int)list_entry(w + gridDim.x));
-        const unsigned sk = sk_cur;
+        const unsigned sk = cur.sk;
         const unsigned s = sk / K, k = sk % K;
         unsigned off, len;
         urf_scan_range(a, s, off, len);
-        const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)n_cur);
+        const unsigned n = cur.n;
         const unsigned sb = urf_sbase(a, s);
-        const unsigned obase = sb + (unsigned)__builtin_amdgcn_readfirstlane((int)so_cur);
-        const unsigned two_a0 = (unsigned)__builtin_amdgcn_readfirstlane((int)two_cur.a0);
-        const unsigned two_c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)two_cur.c0);
-        const unsigned two_a1 = (unsigned)__builtin_amdgcn_readfirstlane((int)two_cur.a1);
-        const bool simple = (unsigned)__builtin_amdgcn_readfirstlane((int)two_cur.nruns) <= 2u;
+        const unsigned obase = sb + cur.so;
+        const unsigned two_a0 = cur.a0, two_c0 = cur.c0, two_a1 = cur.a1;
+        const bool simple = cur.nruns <= 2u;
         /* a sector scattered over more than two tiles: its runs (<= n <= 2048 of them) are listed in A's
          * memory until the keys are in registers */
         unsigned* runP = (unsigned*)A;
@@ -2145,11 +2159,11 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
                 key[e] = ((unsigned long long)urf_fbits(a.sr[sb + adr]) << 32) | adr;
             }
         }
-        /* the next sector's description: requested now, used at the top of the next iteration */
-        sk_cur = sk_next;
-        n_cur = a.sec_cnt[sk_next];
-        so_cur = a.sec_off[(size_t)(sk_next / K) * (K + 1) + sk_next % K];
-        two_cur = a.sec_run[sk_next];
+        /* the next sector's description and the list entry behind it: requested now, taken in front of the tail */
+        const unsigned n_nx = a.sec_cnt[sk_next];
+        const unsigned so_nx = a.sec_off[(size_t)(sk_next / K) * (K + 1) + sk_next % K];
+        const urf_sec_run two_nx = a.sec_run[sk_next];
+        const unsigned sk_nx2 = list_entry(w + 2 * gridDim.x);
         __syncthreads();   /* the run list has been read: A is free */
         URF_PHASE_ACC(1);
         unsigned rank[EPT];
@@ -2182,6 +2196,18 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
                 Z[rank[e]] = zreg[e];
                 S[rank[e]] = sreg[e];
             }
+        {   /* every load of the iteration has arrived by now: none is pending when the tail's stores go out */
+            urf_mid_desc nx;
+            nx.sk = sk_next;
+            nx.n = rfl(n_nx);
+            nx.so = rfl(so_nx);
+            nx.a0 = rfl(two_nx.a0);
+            nx.c0 = rfl(two_nx.c0);
+            nx.a1 = rfl(two_nx.a1);
+            nx.nruns = rfl(two_nx.nruns);
+            sk_next = rfl(sk_nx2);
+            cur = nx;
+        }
         __syncthreads();
         /* tail: slopes / distance terms / ring-sorted indices in sorted order; the walk can never pass the
          * first "static" hit (slope > slope_param), so stop after the chunk of NT elements that holds it */
