@@ -1,10 +1,14 @@
 """include/urf_libm.h (the shared acosf/asinf/atan2f) through oracle B's exports:
 correctly rounded w.r.t. a binary64 evaluation and within 1 ulp of the host libm."""
 import ctypes
+import os
 
 import numpy as np
+import pytest
 
 import oracles as O
+
+ROOT = O.ROOT
 
 
 def _vec(fn, *args):
@@ -91,3 +95,19 @@ def test_ring_threshold_cotangent():
     # strictly decreasing: what turns "the angle lies in a window" into "u lies between two thresholds"
     assert np.all(np.diff(got[:20001]) < 0)
 
+
+
+def test_angle_filter_as_a_threshold_on_the_cosine(tmp_path):
+    """x_zero / z_zero test "alpha <= angleFilter", alpha = acosf(b) in degrees; the kernels test "b >= T" with T found by bisection
+    when the parameters are set (urf_api.hip: urf_angle_threshold).  Valid because alpha falls as b grows: tools/check_acos_threshold.c
+    checks that, and the bisection, against include/urf_libm.h (full run: every float of [-1, 1]; here its quick mode)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "check_acos")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "check_acos_threshold.c"), "-o", exe, "-lm"])
+    r = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    assert "alpha(b) rises somewhere: 0 of" in r.stdout

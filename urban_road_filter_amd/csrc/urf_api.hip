@@ -172,6 +172,34 @@ static void beam_init(std::vector<urf_beam>& beams, int rep, float width)
     }
 }
 
+/* x_zero_method.cpp:58-61 / z_zero_method.cpp:63-66 test "alpha <= angleFilter" with alpha = (float)((double)(acosf(b) * 180.0f) /
+ * M_PI), b the clamped cosine.  alpha falls (weakly) as b grows -- checked for EVERY float of [-1, 1] against include/urf_libm.h's
+ * acosf by tools/check_acos_threshold.c, together with the bisection below for fourteen filter angles -- so the test is "b >= T" with
+ * T = the smallest float of [-1, 1] whose alpha passes: no arc cosine on the device (a fifth of the candidate chain of k_ring).  A NaN
+ * cosine fails either form.  Returns 2 when no b passes. */
+static float urf_angle_threshold(float angle_filter)
+{
+    auto alpha_of = [](float b) { return (float)((double)(urf_acosf(b) * 180.0f) / M_PI); };   /* (IEEE division: what urf_div_pi equals) */
+    auto from_key = [](uint32_t k) {   /* the floats of [-1, 1] in ascending order */
+        const uint32_t one = 0x3f800000u;
+        const uint32_t u = k <= one ? 0x80000000u | (one - k) : k - one - 1u;
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
+    if (!(alpha_of(1.0f) <= angle_filter))
+        return 2.0f;
+    uint32_t lo = 0, hi = 2u * 0x3f800000u + 1u;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (alpha_of(from_key(mid)) <= angle_filter)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return from_key(lo);
+}
+
 static int upload_params(urf_ctx* c)
 {
     const urf_params& p = c->params;
@@ -182,6 +210,8 @@ static int upload_params(urf_ctx* c)
     dp.fwd_limit = 360.0f - p.beamZone;                                /* blind_spots.cpp:68 */
     dp.bwd_limit = 0.0f + p.beamZone;                                  /* blind_spots.cpp:177 */
     dp.inv_cp = 1.0f / (float)p.curbPoints;                            /* z_zero_method.cpp:52 */
+    dp.x_angle_thr = urf_angle_threshold(p.angleFilter1);
+    dp.z_angle_thr = urf_angle_threshold(p.angleFilter2);
     /* keys 0..K-1 plus "none" (mapped to K) must be distinguishable */
     dp.sec_keybits = 1;
     while ((1u << dp.sec_keybits) <= (unsigned)p.sectors)

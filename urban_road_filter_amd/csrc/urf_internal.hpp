@@ -102,6 +102,8 @@ struct urf_dev_params {
     float    fwd_limit;     /* 360 - beamZone  (blind_spots.cpp:68)  */
     float    bwd_limit;     /* 0 + beamZone    (blind_spots.cpp:177) */
     float    inv_cp;        /* 1 / (float)curbPoints (z_zero_method.cpp:52) */
+    float    x_angle_thr;   /* "alpha <= angleFilter1" (x_zero_method.cpp:58-61) as a threshold on the cosine: bracket >= x_angle_thr */
+    float    z_angle_thr;   /* ... angleFilter2 (z_zero_method.cpp:63-66); urf_api.hip: urf_angle_threshold */
     uint32_t sec_keybits;   /* bits needed for sector keys incl. "none" */
     uint32_t ring_keybits;
     uint32_t exp_flags;     /* test hook (urf_set_debug_flags): bit 2 forces the general star sort path; 0 in production */

@@ -3518,7 +3518,7 @@ struct urf_ring_map {
 /* (The angle tests and the exact azimuth are NOT inlined: only the few points that pass the cheap
  * height tests get here, and inlined their f64 code dictates the kernel's register allocation --
  * k_ring spilled 52..80 bytes per lane with them inside.) */
-__device__ __noinline__ bool urf_x_zero_angle(const float* newY, float angleFilter1, float xj, float yj, float x3, float y3,
+__device__ __noinline__ bool urf_x_zero_angle(const float* newY, float angleFilter1, float x_angle_thr, float xj, float yj, float x3, float y3,
                                               int j, int p, int cp, float zj, float pz, float z3)
 {
     const double dx = (double)(x3 - xj), dy = (double)(y3 - yj);
@@ -3539,14 +3539,18 @@ __device__ __noinline__ bool urf_x_zero_angle(const float* newY, float angleFilt
         br = -1.0f;
     else if (br > 1.0f)
         br = 1.0f;
+#ifdef URF_EXP_ACOS
     const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));   /* :58 */
     return alpha <= angleFilter1;                                               /* :61 */
+#else
+    return br >= x_angle_thr;   /* :58-61 "alpha <= angleFilter1", alpha = acos(br) in degrees: urf_api.hip urf_angle_threshold */
+#endif
 }
 
 /* z_zero_method.cpp:21-66 for the centre p, given the height tests passed.  xy(r, x, y) delivers the
  * planar coordinates of ring position r (an LDS window or a gather from the ring-sorted arrays). */
 template <class FXY>
-__device__ __forceinline__ bool urf_z_zero_angle(float inv_cp, float angleFilter2, FXY xy, int p, int cp, float px, float py)
+__device__ __forceinline__ bool urf_z_zero_angle(float inv_cp, float angleFilter2, float z_angle_thr, FXY xy, int p, int cp, float px, float py)
 {
     float xa, ya, xb, yb;
     xy(p + cp, xb, yb);
@@ -3579,30 +3583,34 @@ __device__ __forceinline__ bool urf_z_zero_angle(float inv_cp, float angleFilter
         br = -1.0f;
     else if (br > 1.0f)
         br = 1.0f;
+#ifdef URF_EXP_ACOS
     const float alpha = (float)urf_div_pi((double)(urf_acosf(br) * 180.0f));   /* :63 */
     return alpha <= angleFilter2;                                               /* :66 */
+#else
+    return br >= z_angle_thr;   /* :63-66, as in urf_x_zero_angle */
+#endif
 }
 
 /* the two instances k_ring uses: operands gathered from the ring-sorted arrays through the ring's
  * map (quad mapping), or read from an LDS window whose element 0 is ring position `origin` */
 __device__ __noinline__ bool urf_z_zero_angle_gather(const float* rx, const float* ry, const urf_ring_map map, float inv_cp,
-                                                     float angleFilter2, int p, int cp, float px, float py)
+                                                     float angleFilter2, float z_angle_thr, int p, int cp, float px, float py)
 {
     auto gxy = [&](int r, float& x, float& y) {
         const unsigned idx = map.at((unsigned)r);
         x = rx[idx];
         y = ry[idx];
     };
-    return urf_z_zero_angle(inv_cp, angleFilter2, gxy, p, cp, px, py);
+    return urf_z_zero_angle(inv_cp, angleFilter2, z_angle_thr, gxy, p, cp, px, py);
 }
 __device__ __noinline__ bool urf_z_zero_angle_window(const float* xs, const float* ys, int origin, float inv_cp, float angleFilter2,
-                                                     int p, int cp, float px, float py)
+                                                     float z_angle_thr, int p, int cp, float px, float py)
 {
     auto lxy = [&](int r, float& x, float& y) {
         x = xs[r - origin];
         y = ys[r - origin];
     };
-    return urf_z_zero_angle(inv_cp, angleFilter2, lxy, p, cp, px, py);
+    return urf_z_zero_angle(inv_cp, angleFilter2, z_angle_thr, lxy, p, cp, px, py);
 }
 
 /* exact azimuth (and planar range when captured) of one point and its entry in the curb tables
@@ -4016,12 +4024,12 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                      * an atomic per hit and the gathers twice: 0.40 -> 0.44 ms, profiles/r5_ring_ab.txt) */
                     if (t & URF_CAND_XZERO) {   /* j = p - 2 and j + cp = p + 3 exist (height tests passed) */
                         const unsigned ij = map.at((unsigned)(p - 2)), i3 = map.at((unsigned)(p + 3));
-                        if (urf_x_zero_angle(a.newY, dp.p.angleFilter1, a.rx[ij], a.ry[ij], a.rx[i3], a.ry[i3], p - 2, p, 5, a.rz[ij],
+                        if (urf_x_zero_angle(a.newY, dp.p.angleFilter1, dp.x_angle_thr, a.rx[ij], a.ry[ij], a.rx[i3], a.ry[i3], p - 2, p, 5, a.rz[ij],
                                              a.rz[ip], a.rz[i3]))
                             flag |= 2u;
                     }
                     if ((t & URF_CAND_ZZERO) &&   /* operands come from the ring-sorted arrays (L2) */
-                        urf_z_zero_angle_gather(a.rx, a.ry, map, dp.inv_cp, dp.p.angleFilter2, p, 5, px, py))
+                        urf_z_zero_angle_gather(a.rx, a.ry, map, dp.inv_cp, dp.p.angleFilter2, dp.z_angle_thr, p, 5, px, py))
                         flag |= 4u;
                     if (flag || (t & URF_CAND_EXACT)) {
                         const float az = urf_ring_point(a.rd2, a.caz, S, ip, px, py, flag, want_quad);
@@ -4059,7 +4067,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                         const bool heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight ||
                                               __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
                                              (double)__builtin_fabsf(zj - z3) >= 0.05;          /* :62-64 */
-                        if (heights && urf_x_zero_angle(a.newY, dp.p.angleFilter1, S.xs[j - cs + PAD], S.ys[j - cs + PAD],
+                        if (heights && urf_x_zero_angle(a.newY, dp.p.angleFilter1, dp.x_angle_thr, S.xs[j - cs + PAD], S.ys[j - cs + PAD],
                                                         S.xs[j + cp - cs + PAD], S.ys[j + cp - cs + PAD], j, p, cp, zj, pz, z3))
                             flag |= 2u;
                     }
@@ -4077,7 +4085,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                         }
                         const bool heights = (max1 - az >= dp.p.curbHeight || max2 - az >= dp.p.curbHeight) &&
                                              (double)__builtin_fabsf(max1 - max2) >= 0.05;      /* :67-69 */
-                        if (heights && urf_z_zero_angle_window(S.xs, S.ys, cs - PAD, dp.inv_cp, dp.p.angleFilter2, p, cp, px, py))
+                        if (heights && urf_z_zero_angle_window(S.xs, S.ys, cs - PAD, dp.inv_cp, dp.p.angleFilter2, dp.z_angle_thr, p, cp, px, py))
                             flag |= 4u;
                     }
                 }
