@@ -4035,7 +4035,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
                         const float az = urf_ring_point(a.rd2, a.caz, S, ip, px, py, flag, want_quad);
                         if (flag) {
                             atomicOr(&a.rec[ip], flag << URF_REC_FLAG_SHIFT);
-                            if (!(az == az))   /* x == y == 0: deviation D5 (include/urf.h), counted per scan (the others: k_label) */
+                            if (!(az == az))   /* x == y == 0: a NaN azimuth (include/urf.h: n_nan_azimuth), counted per scan (the others: k_label) */
                                 atomicAdd(&a.info[s].n_nan_azimuth, 1u);
                         }
                     }
@@ -4736,7 +4736,7 @@ __device__ __forceinline__ bool urf_road_test(const urf_win* __restrict__ win, f
 }
 
 /* the same decision on the exact azimuth of the point in ring-sorted slot `slot`: bit 0 = road, bit 1 =
- * the azimuth is NaN (x == y == 0: deviation D5, counted by the caller) */
+ * the azimuth is NaN (x == y == 0: counted by the caller, urf_scan_info::n_nan_azimuth) */
 __device__ __noinline__ unsigned urf_road_exact(const urf_kargs& a, const urf_win* win, unsigned slot)
 {
     float d2;
@@ -4990,7 +4990,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
             a.labels[off + tbase + li] = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0) | URF_LABEL_ROAD;
             my_road++;
         }
-        if (!(az == az))   /* x == y == 0: deviation D5 (include/urf.h), counted per scan */
+        if (!(az == az))   /* x == y == 0: a NaN azimuth (include/urf.h: n_nan_azimuth), counted per scan */
             atomicAdd(&a.info[s].n_nan_azimuth, 1u);
     }
     if (my_road)
