@@ -2,7 +2,8 @@
 own sources built with the shared libm (oracle/_ref/urf_ref_libm) on further random clouds / parameter sets of tests/fuzz.py --
 labels, summaries and the three published orders.  Needs /root/reference at build time only (oracle/Makefile).
     python tools/fuzz_cpu_more.py [first_seed last_seed]
-Last run: seeds 2000..105999 (round 4): 0 mismatches (profiles/README.md)."""
+Last runs: seeds 2000..105999 (round 4); 5000000..5031999 and 5100000..5299999 (round 5: two fifths of the clouds with planar-range ties, oracle B
+sorting with the restated std::sort): 0 mismatches (profiles/README.md)."""
 import os
 import sys
 
