@@ -57,12 +57,15 @@ WORKLOADS = {
                  text="cfg2: %d single 64x2048 street sweep, all three detectors + blind_spots, ROI +-200 m, resident in HBM (latency)"),
     "cfg5": dict(rings=128, cols=4096, scans=256, params="cfg5",
                  text="cfg5: batch of %d 128x4096 street sweeps, channels=128, interval=0.05, star at 360 sectors, ROI +-200 m"),
+    "sensor": dict(rings=64, cols=2048, scans=1024, params="cfg2", scene=3,
+                   text="batch of %d 64x2048 street sweeps as a sensor's driver delivers them (range noise sigma 1 cm, 2 mm range steps, 1.5 %% drop-outs, "
+                        "~10 000 planar-range ties per sweep left in), all three detectors + blind_spots, ROI +-200 m"),
     "default_roi": dict(rings=64, cols=2048, scans=1024, params="default_roi",
                         text="batch of %d 64x2048 street sweeps with the reference's DEFAULT ROI (x 0..30, y -10..10: ~40 %% of the points survive)"),
 }
 
 
-def gen_batch(n_scans, seed0, world=1):
+def gen_batch(n_scans, seed0, world=1, scene=1):
     """n_scans distinct street sweeps (seeds seed0..), generated on a thread pool
     (urf_synth_cloud releases the GIL); the ranks of a node share its cores."""
     import urban_road_filter_amd as u
@@ -71,7 +74,7 @@ def gen_batch(n_scans, seed0, world=1):
     Z = np.empty_like(X)
 
     def one(s):
-        x, y, z = u.synth_cloud(RINGS, COLS, 1, seed0 + s)
+        x, y, z = u.synth_cloud(RINGS, COLS, scene, seed0 + s)
         X[s], Y[s], Z[s] = x, y, z
 
     with cf.ThreadPoolExecutor(max_workers=max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))) as ex:
@@ -478,7 +481,7 @@ def main():
     S = args.scans or wl["scans"]
     params = O.cfg_params(wl["params"])   # cfg3: reference defaults, ROI widened to +-200 m
     t_gen = time.perf_counter()
-    X, Y, Z = gen_batch(S, sharding.shard_seeds(S, rank)[0], world)   # seeds 1..S on rank 0, S+1..2S on rank 1, ...
+    X, Y, Z = gen_batch(S, sharding.shard_seeds(S, rank)[0], world, wl.get("scene", 1))   # seeds 1..S on rank 0, S+1..2S on rank 1, ...
     t_gen = time.perf_counter() - t_gen
 
     stream = torch.cuda.Stream(device=dev)   # the library launches on this stream (urf_set_stream), so events on it see the kernels

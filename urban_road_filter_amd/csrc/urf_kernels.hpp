@@ -3820,6 +3820,13 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
     /* (the four-points-per-thread instance works on z alone and needs five points in front of a chunk and ten behind it:
      * ONE quad per thread -- its own four points -- plus one halo value in each of 16 lanes, five registers per chunk in
      * flight instead of eight: 0.42 -> 0.40 ms, r5) */
+    /* (a sweep with drop-outs -- every real one -- has runs of uneven length, and a quad of ring positions then starts at any
+     * slot of its tile's run: global memory takes a 16-byte load at any 4-byte boundary, so only a quad that straddles two runs
+     * falls back to four mapped loads.  With the loads restricted to 16-byte boundaries, r2-r4, three quads in four fell back on
+     * such a sweep: k_ring 0.59 ms per 1024 sensor-like sweeps against 0.39 on the drop-out-free benchmark clouds.) */
+    struct __attribute__((packed, aligned(4))) urf_f4u {
+        float x, y, z, w;
+    };
     struct zbuf {
         float4 q;
         float h;
@@ -3834,9 +3841,10 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
             if (j + 3 < n) {
                 const unsigned t = map.tile((unsigned)j);
                 const unsigned idx = mapA[t] + (unsigned)j;
-                if ((unsigned)j + 3 < mapP[t + 1] && (idx & 3u) == 0) {
+                if ((unsigned)j + 3 < mapP[t + 1]) {   /* four consecutive slots of one run: one 16-byte load, aligned or not */
                     wide = true;
-                    b.q = *(const float4*)(a.rz + idx);
+                    const urf_f4u v = *(const urf_f4u*)(a.rz + idx);
+                    b.q = make_float4(v.x, v.y, v.z, v.w);
                 }
             }
             if (!wide) {
@@ -3867,13 +3875,15 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
             if (j >= 0 && j + 3 < n) {
                 const unsigned t = map.tile((unsigned)j);
                 const unsigned idx = mapA[t] + (unsigned)j;
-                if ((unsigned)j + 3 < mapP[t + 1] && (idx & 3u) == 0) {
+                if ((unsigned)j + 3 < mapP[t + 1]) {   /* (one run: a 16-byte load at any 4-byte boundary, see fetchq) */
                     wide = true;
                     if (!quads) {   /* (uniform) the four-points-per-thread path works on z alone */
-                        fx[m] = *(const float4*)(a.rx + idx);
-                        fy[m] = *(const float4*)(a.ry + idx);
+                        const urf_f4u vx = *(const urf_f4u*)(a.rx + idx), vy = *(const urf_f4u*)(a.ry + idx);
+                        fx[m] = make_float4(vx.x, vx.y, vx.z, vx.w);
+                        fy[m] = make_float4(vy.x, vy.y, vy.z, vy.w);
                     }
-                    fz[m] = *(const float4*)(a.rz + idx);
+                    const urf_f4u vz = *(const urf_f4u*)(a.rz + idx);
+                    fz[m] = make_float4(vz.x, vz.y, vz.z, vz.w);
                 }
             }
             if (!wide) {
