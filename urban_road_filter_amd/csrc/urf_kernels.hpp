@@ -3837,22 +3837,28 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
         b.q = make_float4(0.f, 0.f, 0.f, 0.f);
         b.h = 0.f;
         if (j < n) {
-            bool wide = false;
-            if (j + 3 < n) {
-                const unsigned t = map.tile((unsigned)j);
-                const unsigned idx = mapA[t] + (unsigned)j;
-                if ((unsigned)j + 3 < mapP[t + 1]) {   /* four consecutive slots of one run: one 16-byte load, aligned or not */
-                    wide = true;
-                    const urf_f4u v = *(const urf_f4u*)(a.rz + idx);
-                    b.q = make_float4(v.x, v.y, v.z, v.w);
-                }
-            }
-            if (!wide) {
+            const unsigned t = map.tile((unsigned)j);
+            const unsigned end = mapP[t + 1], idx = mapA[t] + (unsigned)j;
+            if ((unsigned)j + 3 < end) {   /* four consecutive slots of one run: one 16-byte load, aligned or not */
+                const urf_f4u v = *(const urf_f4u*)(a.rz + idx);
+                b.q = make_float4(v.x, v.y, v.z, v.w);
+            } else {
+                /* the quad straddles the end of its run (a sweep with drop-outs: one quad in eight; a wave takes both branches, so
+                 * this one must be short): the rest lies at the start of the next run -- or, runs of fewer than three points,
+                 * wherever the map says */
+                const unsigned t1 = t + 1 < nruns ? t + 1 : t;
+                const unsigned end1 = mapP[t1 + 1], base1 = mapA[t1];
                 float ez[4] = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-                for (int e4 = 0; e4 < 4; e4++)
-                    if (j + e4 < n)
-                        ez[e4] = a.rz[map.at((unsigned)(j + e4))];
+                for (int e4 = 0; e4 < 4; e4++) {
+                    const unsigned pos = (unsigned)(j + e4);
+                    if (pos < (unsigned)n) {
+                        unsigned ie = pos < end ? idx + (unsigned)e4 : base1 + pos;
+                        if (pos >= end && pos >= end1)
+                            ie = map.at(pos);
+                        ez[e4] = a.rz[ie];
+                    }
+                }
                 b.q = make_float4(ez[0], ez[1], ez[2], ez[3]);
             }
         }
