@@ -513,11 +513,17 @@ __host__ __device__ inline unsigned urf_align16(unsigned v) { return (v + 15u) &
 /* LDS carve of k_split: tab | ul | thr | lut | koff[C+1] | soff[Ks+1] | misc[64] | tmax[C] u64 |
  * union { keyr[T] u8, keys[T] u16, pending[T] u16, wcnt_r[W][C] u16, wcnt_s[W][Ks] u16 ;
  *         staging x y z record [URF_SLOTS] u32 } */
+/* k_split's small words: [0] ROI points, [1] pending, [2 + wave] wave sums, [30] "not organised with holes", [31] "not organised",
+ * [32 + step] step keys, [64 + step] points of the step that take part in the star-shaped search, [96 + step] ... in the steps
+ * before it ([128]: in the tile), [130 + step] step keys with the empty steps filled in (key + 1; 0: none yet), [162 + step] the
+ * step keys of a tile with holes (sector of the step's first lane that has one), [200 ...) one byte per (ring, wave): points of the
+ * ring among the wave's four firings */
+#define URF_SPLIT_MISC_WORDS 336
 __host__ __device__ inline size_t urf_split_lds_bytes(unsigned C, unsigned K, bool star)
 {
     const unsigned Ks = star ? K : 0;
     const size_t fixed = URF_MAX_CHANNELS * (4 + 4 + 16) + urf_align16(URF_LUT_CELLS) + urf_align16((C + 1) * 4) +
-                         urf_align16((Ks + 1) * 4) + 256 + urf_align16(C * 8);
+                         urf_align16((Ks + 1) * 4) + URF_SPLIT_MISC_WORDS * 4 + urf_align16(C * 8);
     const size_t phase_a = 5 * (size_t)URF_TILE + urf_align16(2 * URF_TILE_WAVES * (C + Ks));
     const size_t phase_b = 4 * (size_t)URF_SLOTS * 4;
     return fixed + (phase_a > phase_b ? phase_a : phase_b);
@@ -593,6 +599,100 @@ __device__ URF_EXACT_INLINE urf_exact_key urf_exact_keys(const float* tab, unsig
 #ifndef URF_SPLIT_WAVES_PER_EU
 #define URF_SPLIT_WAVES_PER_EU 6   /* 73 VGPRs without spills; A/B on one box: 4 -> 1.39 ms, 6 -> 1.04 ms, 8 (32 B of scratch) -> 1.12 ms */
 #endif
+/* ORGANISED WITH HOLES (r5; 64 rings): an organised tile with points MISSING -- a real sensor's drop-outs, rings a region of
+ * interest cuts off -- every point that is there sits on its expected ring (C == 64: ring = lane), the points of a step that take
+ * part in the star-shaped search share one sector, the sectors of the steps that have one do not fall.  The slots are then counts
+ * of the points that are there: ring c starts behind the rings in front of it and holds its points in firing order (per ring and
+ * wave one byte of counts, read back as one 8-byte word per ring); the sector-sorted order is the input order of the points that
+ * take part (per step a count, one scan over the 32 of them).  Two ballots per step, one scan per family, no match_any, no counter
+ * matrix, one barrier instead of three.  Called by every thread of the workgroup for a tile that failed the first test; NOT inlined:
+ * inside k_split its few registers tipped the kernel over its 80 (the general path spilled 16 bytes).  misc: URF_SPLIT_MISC_WORDS
+ * of LDS (k_split's layout), koff: the ring run table.  Returns ok = 0 when the tile does not have the shape. */
+struct urf_holey_slots {
+    unsigned lp[4], sp[4], ok;
+};
+__device__ __noinline__ urf_holey_slots urf_split_holey(unsigned r0, unsigned r1, unsigned r2, unsigned r3, unsigned s0, unsigned s1, unsigned s2,
+                                                        unsigned s3, unsigned wave, unsigned lane, bool star, unsigned* misc, unsigned* koff)
+{
+    unsigned* const stepcnt = misc + 64;
+    unsigned* const stepbase = misc + 96;
+    unsigned* const stepfk = misc + 130;
+    unsigned* const stepkh = misc + 162;
+    uint8_t* const ringcnt = (uint8_t*)(misc + 200);
+    const unsigned rk[4] = { r0, r1, r2, r3 }, sk[4] = { s0, s1, s2, s3 };
+    urf_holey_slots out;
+    bool mine_h = true;
+    unsigned own = 0;   /* points of this lane's ring among the wave's four firings */
+#pragma unroll
+    for (unsigned q = 0; q < 4; q++) {
+        const bool onr = rk[q] != URF_RING_NONE, ons = sk[q] != URF_SEC_NONE;
+        mine_h = mine_h & (!onr | (rk[q] == lane));
+        own += onr ? 1u : 0u;
+        if (star) {
+            const unsigned long long psm = __ballot(ons);   /* lanes of the step that take part in the star-shaped search */
+            const unsigned src = psm ? (unsigned)__ffsll((long long)psm) - 1u : 0u;
+            const unsigned f = psm ? (unsigned)__builtin_amdgcn_readlane((int)sk[q], (int)src) : URF_SEC_NONE;   /* the step's sector */
+            mine_h = mine_h & (!ons | (sk[q] == f));
+            if (lane == 0) {
+                stepkh[wave * 4 + q] = f;
+                stepcnt[wave * 4 + q] = (unsigned)__popcll(psm);
+            }
+        }
+    }
+    ringcnt[lane * URF_TILE_WAVES + wave] = (uint8_t)own;
+    if (__ballot(!mine_h) != 0ull && lane == 0)
+        misc[30] = 1u;   /* (every writer writes the same value) */
+    __syncthreads();
+    out.ok = 0;
+#pragma unroll
+    for (unsigned q = 0; q < 4; q++)
+        out.lp[q] = out.sp[q] = 0xffffffffu;
+    if (misc[30] != 0u)
+        return out;   /* (uniform) */
+    /* the steps' keys must not fall, steps without a key skipped: key + 1 against the largest in front of it */
+    const unsigned k1 = (star && lane < URF_TILE_GROUPS && stepkh[lane & 31u] != URF_SEC_NONE) ? stepkh[lane & 31u] + 1u : 0u;
+    const unsigned fk = urf_wave_scan_max(k1);
+    unsigned exc = (unsigned)__shfl_up((int)fk, 1);
+    exc = lane == 0 ? 0u : exc;
+    if (__ballot(k1 != 0u && k1 < exc) != 0ull)
+        return out;   /* (uniform) */
+    out.ok = 1;
+    /* ring `lane`: its points in the waves in front of this one, in the whole tile; first slot = the rings in front of it */
+    const unsigned long long w8 = ((const unsigned long long*)ringcnt)[lane];
+    unsigned before = 0, total = 0;
+#pragma unroll
+    for (unsigned w = 0; w < URF_TILE_WAVES; w++) {
+        const unsigned b = (unsigned)(w8 >> (8u * w)) & 0xffu;
+        total += b;
+        before += w < wave ? b : 0u;
+    }
+    const unsigned kinc = urf_wave_scan_add(total);
+    unsigned run = kinc - total + before;
+    /* the points of the steps in front of each of the wave's four that take part in the star-shaped search */
+    const unsigned sc = (star && lane < URF_TILE_GROUPS) ? stepcnt[lane & 31u] : 0u;
+    const unsigned sinc = urf_wave_scan_add(sc);
+#pragma unroll
+    for (unsigned q = 0; q < 4; q++) {
+        const bool onr = rk[q] != URF_RING_NONE, ons = sk[q] != URF_SEC_NONE;
+        out.lp[q] = onr ? run : 0xffffffffu;
+        run += onr ? 1u : 0u;
+        const unsigned sb0 = (unsigned)__shfl((int)(sinc - sc), (int)(wave * 4 + q));
+        out.sp[q] = ons ? sb0 + urf_popc_below(__ballot(ons)) : 0xffffffffu;
+    }
+    if (wave == 0) {   /* the run tables (the sector table: k_split, once stepbase / stepfk can be read) */
+        koff[lane] = kinc - total;
+        if (lane == 63)
+            koff[64] = kinc;
+        if (lane < URF_TILE_GROUPS) {
+            stepbase[lane] = sinc - sc;
+            stepfk[lane] = fk;   /* the step keys with the empty steps filled in from the left (key + 1; 0: none yet) */
+        }
+        if (lane == URF_TILE_GROUPS - 1u)
+            stepbase[URF_TILE_GROUPS] = sinc;
+    }
+    return out;
+}
+
 __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev_params& dp, unsigned s, unsigned t, unsigned char* sh_raw,
                                                const unsigned tid)
 {
@@ -621,9 +721,11 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     unsigned* koff = (unsigned*)(lut + urf_align16(URF_LUT_CELLS));
     unsigned* soff = koff + urf_align16((C + 1) * 4) / 4;
     unsigned* misc = soff + urf_align16((Ks + 1) * 4) / 4;   /* [0] ROI points, [1] pending, [2 + wave] wave sums, [31] "not organised", [32 + step] step keys */
-    static_assert(2 + URF_TILE_WAVES <= 31 && URF_TILE_GROUPS <= 32, "misc[2 + wave], misc[32 + step]");
+    static_assert(2 + URF_TILE_WAVES <= 30 && URF_TILE_GROUPS <= 32 && 200 + URF_TILE_WAVES * 64 / 4 <= URF_SPLIT_MISC_WORDS, "misc[2 + wave], misc[32 + step], ringcnt");
     unsigned* const stepkey = misc + 32;
-    unsigned long long* tmax = (unsigned long long*)(misc + 64);   /* largest x*x + y*y per ring (binary64 bits: non-negative doubles order like integers) */
+    unsigned* const stepbase = misc + 96;
+    unsigned* const stepfk = misc + 130;
+    unsigned long long* tmax = (unsigned long long*)(misc + URF_SPLIT_MISC_WORDS);   /* largest x*x + y*y per ring (binary64 bits: non-negative doubles order like integers) */
     unsigned char* un = (unsigned char*)(tmax + urf_align16(C * 8) / 8);
     uint8_t* keyr = un;
     uint16_t* keys = (uint16_t*)(un + URF_TILE);
@@ -907,7 +1009,8 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
      * and the whole ranking machinery below -- match_any per step, per-wave counters, the scans over waves and
      * keys, three barriers -- has nothing to compute.  Decided per tile from the keys themselves (one ballot per step
      * and family, the step keys compared across the tile), so any other tile simply takes the general path. */
-    bool organised = false;
+    unsigned mode = 0;   /* 0: the general path, 1: organised tile, 2: organised with holes */
+    unsigned hlp[Q] = { 0, 0, 0, 0 }, hsp[Q] = { 0, 0, 0, 0 };
 #ifndef URF_EXP_NO_ORGANISED
     {
         const bool shape = (C & (C - 1u)) == 0u && tbase + URF_TILE <= len;   /* (uniform) */
@@ -928,12 +1031,28 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
         __syncthreads();
         static_assert(URF_TILE_GROUPS == 32, "one lane per step of the tile compares it with the next");
         const bool falls = star && lane < URF_TILE_GROUPS - 1u && stepkey[lane] > stepkey[lane + 1];
-        organised = misc[31] == 0u && __ballot(falls) == 0ull;   /* (uniform over the workgroup) */
+        mode = (misc[31] == 0u && __ballot(falls) == 0ull) ? 1u : 0u;   /* (uniform over the workgroup) */
+#ifndef URF_EXP_NO_HOLEY
+        /* (a second look only at a tile that failed the first: the fully organised tile pays nothing for it, the tile with
+         * holes one barrier and a call) */
+        if (mode == 0u && shape && C == 64u) {   /* (uniform) */
+            const urf_holey_slots hs = urf_split_holey(rkey[0], rkey[1], rkey[2], rkey[3], skey[0], skey[1], skey[2], skey[3], wave, lane, star,
+                                                       misc, koff);
+            if (hs.ok) {
+                mode = 2u;
+#pragma unroll
+                for (unsigned q = 0; q < Q; q++) {
+                    hlp[q] = hs.lp[q];
+                    hsp[q] = hs.sp[q];
+                }
+            }
+        }
+#endif
     }
 #endif
     unsigned lp[Q], sp[Q];
     const unsigned logC = 31u - (unsigned)__clz((int)C);
-    if (organised) {
+    if (mode == 1u) {
         const unsigned P = URF_TILE >> logC;
         /* (the slots are computed where they are used, below; so is the rings' largest range) */
 #pragma unroll
@@ -952,6 +1071,12 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
                 lo += (lo == URF_TILE_GROUPS - 1u && stepkey[lo] < k) ? 1u : 0u;
                 soff[k] = lo * 64u;
             }
+    } else if (mode == 2u) {
+#pragma unroll
+        for (unsigned q = 0; q < Q; q++) {
+            lp[q] = hlp[q];
+            sp[q] = hsp[q];
+        }
     } else {
     /* step 1: ranks inside the wave's own 256 points.  The lanes of a step that share a key read
      * the key's running count (one LDS address: a broadcast), the first of them adds the group's
@@ -1063,6 +1188,15 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     }   /* (general path) */
     __syncthreads();   /* keys and wcnt are dead: their memory becomes the staging buffers */
     URF_PHASE_MARK;
+    if (mode == 2u && star)   /* (uniform) sector k starts with the first step whose key is >= k: its points in front of it */
+        for (unsigned k = tid; k <= K; k += URF_TILE_THREADS) {
+            unsigned lo = 0;   /* number of steps whose (filled-in) key + 1 is < k + 1 */
+#pragma unroll
+            for (unsigned step = URF_TILE_GROUPS / 2; step > 0; step >>= 1)
+                lo += stepfk[lo + step - 1] < k + 1u ? step : 0u;
+            lo += (lo == URF_TILE_GROUPS - 1u && stepfk[lo] < k + 1u) ? 1u : 0u;
+            soff[k] = stepbase[lo];
+        }
     unsigned* stx = (unsigned*)un;
     unsigned* sty = stx + URF_SLOTS;
     unsigned* stz = sty + URF_SLOTS;
@@ -1075,11 +1209,15 @@ __device__ __forceinline__ void urf_split_tile(const urf_kargs& a, const urf_dev
     for (unsigned q = 0; q < Q; q++) {
         const unsigned li = wave * URF_WAVE_PTS + q * 64 + lane;
         const float x = px[q], y = py[q], z = pz[q];
-        if (organised) {   /* (uniform) closed-form slots; maxDistance as on the general path (lidar_segmentation.cpp:271-274) */
+        if (mode == 1u) {   /* (uniform) closed-form slots; maxDistance as on the general path (lidar_segmentation.cpp:271-274) */
             lp[q] = (li & (C - 1u)) * (URF_TILE >> logC) + (li >> logC);
             sp[q] = star ? li : 0xffffffffu;
             const double s2 = (double)x * (double)x + (double)y * (double)y;
             atomicMax(&tmax[li & (C - 1u)], (unsigned long long)__double_as_longlong(s2));
+        }
+        if (mode == 2u && lp[q] != 0xffffffffu) {   /* (uniform) maxDistance as on the other paths; C == 64: the ring is the lane */
+            const double s2 = (double)x * (double)x + (double)y * (double)y;
+            atomicMax(&tmax[lane], (unsigned long long)__double_as_longlong(s2));
         }
         if (lp[q] != 0xffffffffu) {
             const unsigned sl = URF_SLOT(lp[q]);
