@@ -330,7 +330,8 @@ def other_configs(u, O, torch, ctx, stream, dev, dx, dy, dz, dl, di, X, Y, Z, S)
         return {"scans_per_s": round(sps, 2), "ms_per_step": round(ms, 4), "scans_per_step": n_scans, "points_per_scan": n_pts,
                 "frac": round(13.0 * n_pts * sps / (HBM_PEAK_GBS * 1e9), 5),
                 "kernel_ms": {k: round(v / max(kcalls, 1), 4) for k, v in kms.items()},
-                "parity_checked_scans": picked, "workload": note}
+                "front_scans_per_gpu": front_scans,
+            "parity_checked_scans": picked, "workload": note}
 
     def run(c, fn, n_pts, n_scans, steps, warmup, note, picked):
         ms = _timed_steps(torch, stream, fn, steps, warmup)
@@ -435,6 +436,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-outputs", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--front", type=int, default=-1, help="urf_set_front_mode: 0 legacy kernels only, 1 / 2 the fused front end (default: the library's)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (backend as given) even with one rank and run its barrier / all-reduces")
     args = ap.parse_args()
@@ -496,6 +498,8 @@ def main():
 
     ctx = u.Context(N_PTS, S, device=dev_index, params=params)
     ctx.set_stream(stream.cuda_stream)
+    if args.front >= 0:
+        ctx.set_front_mode(args.front)
 
     def step():
         ctx.classify_batch_soa(dx, dy, dz, N_PTS, S, dl, di)
@@ -503,6 +507,7 @@ def main():
     # parity gate: no number is reported for a batch whose labels differ from the CPU oracle
     step()
     torch.cuda.synchronize()
+    front_scans = ctx.front_scans()   # scans of the batch that took the fused front end (urf_front.hpp)
     picked = sorted(np.random.default_rng(20260925 + rank).choice(S, min(args.parity_scans, S), replace=False).tolist())
     for s in picked:   # a seeded random sample of the batch, not its first scans
         lb, _, _ = O.run_b(X[s], Y[s], Z[s], params)
@@ -605,6 +610,7 @@ def main():
             "kernel_ms": {k: round(v / max(kcalls, 1), 4) for k, v in kms.items()},
             "outputs_ms_per_batch": outputs_ms,
             "counters": dict(zip(sharding.COUNTER_NAMES, [int(v) for v in counters])),
+            "front_scans_per_gpu": front_scans,
             "parity_checked_scans": picked,
             "backend": dist.get_backend() if use_dist else None,
             "seeds_rank0": [int(sharding.shard_seeds(S, 0)[0]), int(sharding.shard_seeds(S, 0)[-1])],

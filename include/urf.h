@@ -60,8 +60,10 @@ extern "C" {
  * 4 (round 5): equal planar ranges inside a star sector are ordered as libstdc++'s std::sort orders them
  * (star_shaped_search.cpp:109) and equal azimuths inside a ring as the reference's Lomuto quicksort does
  * (lidar_segmentation.cpp:70-93): "deviation D2" of earlier versions is gone, labels on real sensor data (range ties in
- * every sector) and the published order equal the reference's; urf_callback_path_state reports sequence bit 4. */
-#define URF_ABI_VERSION 4
+ * every sector) and the published order equal the reference's; urf_callback_path_state reports sequence bit 4.
+ * 5 (round 6): urf_set_front_mode / urf_front_scans (the fused front end for batches of sweeps in firing order); the
+ * entry points that read ring-sorted intermediate results may run the last batch call again, see there. */
+#define URF_ABI_VERSION 5
 
 /* ---- label byte --------------------------------------------------------- */
 #define URF_LABEL_MASK   0x03u
@@ -377,6 +379,22 @@ int urf_read_stage(urf_ctx* ctx, urf_stage what, uint32_t scan, void* host_dst, 
  * urf_marker_points look at the LAST classify call of the context with the parameters that call
  * ran with; the label buffer handed to that call must still be alive (see LIFETIME above). */
 int urf_enable_stage_capture(urf_ctx* ctx, int mode);
+
+/* ---- the fused front end for batches of sweeps in firing order (round 6) -------
+ * A batch call (urf_classify_batch_*) whose scans arrive as a spinning LiDAR's driver delivers them -- firing after
+ * firing, the 64 lasers of a firing in one fixed order (any order), returns missing where there were none -- is classified
+ * by a front end that keeps no ring-sorted copy of the sweep (urban_road_filter_amd/csrc/urf_front.hpp: one lane per
+ * laser, the detectors' windows of lidar_segmentation.cpp:280-283 / x_zero_method.cpp:30-67 / z_zero_method.cpp:21-72
+ * in registers).  Decided per scan on the device; a scan without that shape takes the general kernels in the same
+ * call; labels and summaries are identical either way.  Applies with channels == 64, curbPoints == 5, no stage
+ * capture, at most 128 x 2048 points per scan.  mode 0: never; 1 (default): batch calls of at least 32 scans; 2: every
+ * batch call it applies to.  urf_read_stage / urf_ordered_indices* / urf_marker_points* read ring-sorted intermediate
+ * results: after a call that took the fused front end they first run that call again through the general kernels
+ * (the call's INPUT arrays must then still be alive, like its label buffer), and the context stays with the general
+ * kernels afterwards (until mode 2 is set again).  urf_front_scans: how many scans of the last batch call took the
+ * fused front end (synchronises). */
+int urf_set_front_mode(urf_ctx* ctx, int mode);
+int urf_front_scans(urf_ctx* ctx, uint32_t* n_fused);
 
 /* ---- per-kernel timing (benchmark) ------------------------------------------
  * With timing on, every classify call brackets each kernel of the pipeline

@@ -37,7 +37,7 @@ def test_test_hooks_live_in_their_own_library():
 
 
 def test_abi_version_and_struct_size():
-    assert u.lib().urf_abi_version() == 4   # include/urf.h: URF_ABI_VERSION
+    assert u.lib().urf_abi_version() == 5   # include/urf.h: URF_ABI_VERSION
     p = u.default_params()
     assert p.size == ctypes.sizeof(u.Params) == 104
     assert ctypes.sizeof(u.ScanInfo) == 32

@@ -147,6 +147,8 @@ def lib(hooks=False):
         "urf_bench_callback_stream": [vp, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.c_uint32, C.c_int, u8p, C.POINTER(C.c_double)],
         "urf_abi_version": [],
+        "urf_set_front_mode": [vp, C.c_int],
+        "urf_front_scans": [vp, C.c_void_p],
     }
     for name, args in sig.items():
         if name in HOOK_SYMBOLS and not has_hooks:
@@ -335,6 +337,16 @@ class Context:
         self._need_hooks("urf_selftest")
         n = C.c_uint64(0)
         self._check(self._lib.urf_selftest(self._h, C.byref(n)), "urf_selftest")
+        return n.value
+
+    def set_front_mode(self, mode):
+        """The fused front end for batches of sweeps in firing order (include/urf.h): 0 never, 1 batches of >= 32 scans, 2 always."""
+        self._check(self._lib.urf_set_front_mode(self._h, int(mode)), "urf_set_front_mode")
+
+    def front_scans(self):
+        """Scans of the last batch call that took the fused front end."""
+        n = C.c_uint32(0)
+        self._check(self._lib.urf_front_scans(self._h, C.addressof(n)), "urf_front_scans")
         return n.value
 
     def enable_kernel_timing(self, on=True):

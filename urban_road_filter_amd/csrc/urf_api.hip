@@ -23,6 +23,7 @@
 #endif
 #include "urf_internal.hpp"
 #include "urf_kernels.hpp"
+#include "urf_front.hpp"
 
 #define URF_ASYNC_SLOTS 4
 static_assert(URF_ASYNC_SLOTS == URF_MAX_IN_FLIGHT, "include/urf.h documents the number of sweeps in flight");
@@ -118,6 +119,13 @@ struct urf_ctx {
      * a scan that proves it wrong is repaired in the same call and raises this host-visible flag,
      * after which the context builds its tables the long way */
     uint32_t* h_spec_failed = nullptr;  /* pinned, device-mapped: [0] look-ahead, [1] ring-count hint */
+    /* the fused front end (urf_front.hpp, urf_set_front_mode): 0 never, 1 batches of at least URF_FRONT_MIN_SCANS scans (default),
+     * 2 every batch call it applies to.  The entry points that read ring-sorted intermediate results (urf_read_stage,
+     * urf_ordered_indices*, urf_marker_points*) run the last call again through the legacy kernels when it took the fused ones,
+     * and the context keeps to the legacy kernels from then on (want_ring_sorted). */
+    int front_mode = 1;
+    uint32_t front_tpb = 4;
+    bool want_ring_sorted = false;
     bool speculate = true;
     bool use_hint = true;           /* k_ring_table also stops at the ring count of the row's previous call (until that fails once) */
     /* last call, for the entry points that read its intermediate results (urf_read_stage,
@@ -299,6 +307,9 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.stop_f, S * URF_DEG_CELLS) A(k.stop_b, S * URF_DEG_CELLS)
     A(k.win, S * C * URF_DEG_CELLS)
     A(k.info, S)
+    k.front_cand_cap = max_points / 8 > 4096 ? max_points / 8 : 4096;
+    A(k.front_ok, S) A(k.front_pres, S * tiles * 64) A(k.front_maxs, S * tiles * 64) A(k.front_lane_ring, S * 64) A(k.front_ring_lane, S * C)
+    A(k.front_cand, S * k.front_cand_cap) A(k.front_all, S * k.front_cand_cap) A(k.front_ncand, S)
     A(c->offsets_copy, S + 1)
     A(c->compact_cnt, S * tiles * 4)
     A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
@@ -312,6 +323,8 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
         k.walk_tab = tab;
     }
     k.sstride = c->sstride;
+    if (const char* e = std::getenv("URF_FRONT_TPB"))   /* tuning experiments: tiles per block of k_front */
+        c->front_tpb = (uint32_t)std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : c->front_tpb;
     {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess)
@@ -482,6 +495,32 @@ extern "C" double urf_ring_threshold_cot(double angle_deg)
     return urf_cot_deg(angle_deg);
 }
 
+extern "C" int urf_set_front_mode(urf_ctx* c, int mode)
+{
+    if (!c || mode < 0 || mode > 2)
+        return URF_ERR_INVALID_ARG;
+    c->front_mode = mode;
+    if (mode == 2)
+        c->want_ring_sorted = false;
+    return URF_OK;
+}
+
+extern "C" int urf_front_scans(urf_ctx* c, uint32_t* n_fused)
+{
+    if (!c || !n_fused)
+        return URF_ERR_INVALID_ARG;
+    *n_fused = 0;
+    if (c->last_is_slot || !c->last_a.front || c->last_scans == 0)
+        return URF_OK;
+    URF_HIP(c, hipSetDevice(c->device));
+    URF_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> ok(c->last_scans);
+    URF_HIP(c, hipMemcpy(ok.data(), c->last_a.front_ok, ok.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t v : ok)
+        *n_fused += v ? 1u : 0u;
+    return URF_OK;
+}
+
 extern "C" int urf_enable_kernel_timing(urf_ctx* c, int on)
 {
     if (!c)
@@ -550,6 +589,8 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     k.stop_f += r * URF_DEG_CELLS; k.stop_b += r * URF_DEG_CELLS;
     k.win += r * C * URF_DEG_CELLS;
     k.info += r;
+    k.front_ok += r; k.front_pres += r * tiles * 64; k.front_maxs += r * tiles * 64; k.front_lane_ring += r * 64; k.front_ring_lane += r * C;
+    k.front_cand += r * (size_t)k.front_cand_cap; k.front_all += r * (size_t)k.front_cand_cap; k.front_ncand += r;
     return k;
 }
 
@@ -587,7 +628,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
                         const uint32_t* d_offsets, uint32_t n_per_scan, uint32_t max_len, uint32_t n_scans,
                         uint8_t* d_labels, urf_scan_info* d_info, uint32_t row = 0, hipStream_t on_stream = nullptr,
                         urf_kargs* a_out = nullptr, urf_dev_params* dp_out = nullptr, const urf_dev_params* dp_in = nullptr,
-                        int capture_in = -1)
+                        int capture_in = -1, bool legacy_only = false)
 {
     /* dp_in / capture_in: the parameters and capture mode a sweep was SUBMITTED with (urf_classify_pc2_wait runs a voided
      * sweep again: "a sweep in flight keeps its parameters", include/urf.h) */
@@ -613,7 +654,8 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         /* the context keeps its own copy: the entry points that look at this call's results later
          * (urf_read_stage, urf_ordered_indices, urf_marker_points) must not depend on the caller
          * keeping d_offsets alive.  Scratch memory is indexed by scan, never by these offsets. */
-        URF_HIP(c, hipMemcpyAsync(c->offsets_copy, d_offsets, ((size_t)n_scans + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        if (d_offsets != c->offsets_copy)   /* (last_row_intact runs the last call again with the copy itself) */
+            URF_HIP(c, hipMemcpyAsync(c->offsets_copy, d_offsets, ((size_t)n_scans + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
         a.offsets = c->offsets_copy;
     }
     a.n_per_scan = n_per_scan;
@@ -649,6 +691,13 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
     const dim3 g_tiles(a.tiles, n_scans), g_scan(n_scans);
+    /* The fused front end (urf_front.hpp) for batches of sweeps in firing order: k_front tries every scan, the legacy kernels
+     * skip the scans it kept.  64 lasers = 64 lanes, the detectors' window of curbPoints == 5 in registers, no stage capture
+     * (its values are the legacy kernels'), not for the single sweeps of the callback path (sixteen waves on the whole device). */
+    a.front = (c->front_mode != 0 && !legacy_only && !c->want_ring_sorted && !on_stream && a.capture == 0 && C == URF_FRONT_LANES &&
+               dp.p.curbPoints == 5 && a.tiles <= URF_FRONT_MAX_TILES && (c->front_mode == 2 || n_scans >= URF_FRONT_MIN_SCANS))
+                  ? 1u : 0u;
+    a.front_tpb = c->front_tpb;
 
     std::vector<hipEvent_t>* ev = nullptr;
     if (c->timing) {
@@ -668,6 +717,8 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     mark();
     hipLaunchKernelGGL(k_ring_table, g_scan, dim3(URF_TABLE_THREADS), 0, st, a, dp);
     mark();
+    if (a.front)
+        hipLaunchKernelGGL(k_front, dim3((a.tiles + a.front_tpb - 1) / a.front_tpb, n_scans), dim3(64), 0, st, a, dp);
     hipLaunchKernelGGL(k_split, g_tiles, dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
     if (a.table_lookahead && !(a.optimistic & URF_OPT_NO_REPAIR)) {   /* normally both find nothing to do */
         hipLaunchKernelGGL(k_table_repair, g_scan, dim3(URF_TABLE_THREADS), 0, st, a, dp);
@@ -710,6 +761,8 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         hipLaunchKernelGGL(k_ring, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
     else
         hipLaunchKernelGGL(k_ring_general, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
+    if (a.front)
+        hipLaunchKernelGGL(k_front_finish, g_scan, dim3(URF_FINISH_THREADS), (size_t)a.tiles * 128 * sizeof(unsigned), st, a, dp);
     /* the rings that hold a point with a NaN azimuth (k_split listed them: normally none, the kernel returns at once) */
     if (!(a.optimistic & URF_OPT_NO_NAN))
         hipLaunchKernelGGL(k_nan_rings, dim3(32), dim3(256), URF_NAN_LDS * sizeof(unsigned long long), st, a, dp);
@@ -717,6 +770,8 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_BEAM_THREADS), (size_t)C * (24 * sizeof(unsigned) + URF_CURB_LIST * sizeof(float)), st, a, dp);
     mark();
     hipLaunchKernelGGL(k_label, g_tiles, dim3(URF_LABEL_TILE_THREADS), 0, st, a, dp);
+    if (a.front)
+        hipLaunchKernelGGL(k_label_front, g_tiles, dim3(URF_LABEL_TILE_THREADS), 0, st, a, dp);
     mark();
     URF_HIP(c, hipGetLastError());
     if (d_info)
@@ -1193,6 +1248,16 @@ static int last_row_intact(urf_ctx* c)
         c->last_error = "the scratch row of the sweep waited for last has been resubmitted (create the context with max_batch >= "
                         "the number of sweeps in flight, or read its intermediate results before submitting on its row again)";
         return URF_ERR_BUSY;
+    }
+    if (!c->last_is_slot && c->last_a.front) {
+        /* the last batch call went through the fused front end (urf_front.hpp), which keeps no ring-sorted copies: once more through
+         * the legacy kernels (same inputs -- the caller's arrays must still be alive --, same parameters, same labels), and the
+         * context stays with them: a caller that reads ring-sorted results pays for them once, not per call */
+        c->want_ring_sorted = true;
+        const urf_kargs a = c->last_a;
+        const urf_dev_params dp = c->last_dp;
+        return run_pipeline(c, a.x, a.y, a.z, a.offsets, a.n_per_scan, a.max_len, a.n_scans, a.labels, nullptr, 0, nullptr, nullptr, nullptr, &dp,
+                            (int)a.capture, true);
     }
     return URF_OK;
 }

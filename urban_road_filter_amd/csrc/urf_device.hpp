@@ -461,6 +461,20 @@ __device__ __forceinline__ bool urf_in_beam(const urf_beam& b, float x, float y)
     return (c - b.o) < y && y < (c + b.o);
 }
 
+/* The correctly rounded square root of a float in [2^-90, 2^126] (what the compiler's own expansion of sqrtf does between its
+ * scaling of tiny arguments and its test for zero / infinity: the hardware's root is within one ulp, the two neighbours are
+ * tried with one fma each).  k_front's planar range (star_shaped_search.cpp:164) for the points of the fast path: seven
+ * instructions instead of eighteen; anything outside the interval takes __builtin_sqrtf. */
+__device__ __forceinline__ float urf_sqrt_rn_normal(float x)
+{
+    float r = __builtin_amdgcn_sqrtf(x);
+    const float rd = __uint_as_float(__float_as_uint(r) - 1u), ru = __uint_as_float(__float_as_uint(r) + 1u);
+    const float ed = __builtin_fmaf(-rd, r, x), eu = __builtin_fmaf(-ru, r, x);
+    r = ed <= 0.0f ? rd : r;
+    r = eu > 0.0f ? ru : r;
+    return r;
+}
+
 /* non-negative floats order like their bit patterns */
 __device__ __forceinline__ unsigned urf_fbits(float f) { return __float_as_uint(f); }
 

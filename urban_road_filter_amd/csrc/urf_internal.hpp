@@ -142,6 +142,9 @@ struct alignas(8) urf_wu { float w, u; };   /* (float)(i - 1), 1 / (float)i: the
  * behind the last one -- the largest, from b_lo.  A ring without such a point: (+inf, -inf). */
 struct alignas(8) urf_vis { float f_hi, b_lo; };
 
+/* k_front -> k_front_finish: (index of the point inside its scan, URF_FC_*); k_front_finish's list of curb points: (azimuth bits, ring) */
+struct alignas(8) urf_u2 { uint32_t x, y; };
+
 /* k_beams -> k_label, per (ring, integer degree) */
 struct urf_win { float hi, lo; };
 
@@ -162,6 +165,10 @@ struct urf_kargs {
                                    needed it into URF_STATUS_REDO_*, which urf_classify_pc2_wait() answers with the full sequence */
     uint32_t capture;           /* 0 production; 1 every point takes the exact sequence, values recorded;
                                    2 production decisions, ring / sector keys recorded */
+    uint32_t  front;            /* this call launches it (urf_api.hip decides: 64 channels, curbPoints 5, no stage capture, a batch) */
+    uint32_t  front_tpb;        /* tiles per block of k_front */
+    uint32_t  front_cand_cap;   /* entries per scan of front_cand / front_all */
+    uint32_t  front_pad_;
     /* output */
     uint8_t* labels;
     urf_scan_info* info;        /* context copy, [n_scans] */
@@ -247,6 +254,16 @@ struct urf_kargs {
     /* tables */
     const float*    newY;       /* [max_points] x_zero_method.cpp:24-27 */
     const urf_beam* beams;      /* [sectors] */
+    /* the fused front end (urf_front.hpp): scans that arrive firing by firing skip k_split / k_ring / k_label */
+    uint32_t* front_ok;         /* [S] 1: the scan has the shape so far (k_ring_table sets it, k_front / k_table_repair clear it); the legacy
+                                 * kernels skip a scan whose flag is set, the fused ones a scan whose flag is clear */
+    uint32_t* front_pres;       /* [S][tiles][64] bit j of word (t, l): lane l of firing j of tile t is a ring point */
+    unsigned long long* front_maxs; /* [S][tiles][64] per block and lane the largest x*x + y*y of its ring points (binary64 bits) */
+    uint32_t* front_lane_ring;  /* [S][64] the ring of lane l (0xffffffff: none yet) */
+    uint32_t* front_ring_lane;  /* [S][channels] the lane of ring r */
+    urf_u2*   front_cand;       /* [S][front_cand_cap] (input index, URF_FC_*): points whose detector decision is pending (k_front -> k_front_finish) */
+    urf_u2*   front_all;        /* [S][front_cand_cap] (azimuth bits, ring) of every curb point (k_front_finish: rings whose list overflowed) */
+    uint32_t* front_ncand;      /* [S] */
 };
 
 #endif /* URF_INTERNAL_HPP */

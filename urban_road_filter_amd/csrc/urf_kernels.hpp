@@ -457,6 +457,19 @@ __global__ __launch_bounds__(URF_TABLE_THREADS) void k_ring_table(urf_kargs a, u
     __shared__ urf_table_shared T;
     if (blockIdx.x == 0 && threadIdx.x < 8)
         a.star_count[threadIdx.x] = 0;   /* the call's work-list lengths (k_table_repair, k_index): first kernel of the sequence */
+    {   /* the fused front end's per-scan state (urf_front.hpp): every scan is a candidate until k_front finds otherwise */
+        const unsigned s = blockIdx.x, tid = threadIdx.x;
+        if (tid == 0) {
+            a.front_ok[s] = a.front;
+            a.front_ncand[s] = 0;
+        }
+        if (a.front) {
+            if (tid < 64)
+                a.front_lane_ring[(size_t)s * 64 + tid] = 0xffffffffu;
+            if (tid < (unsigned)dp.p.channels)
+                a.front_ring_lane[(size_t)s * dp.p.channels + tid] = 0xffffffffu;
+        }
+    }
     urf_ring_table_scan(a, dp, blockIdx.x, a.table_lookahead, T);
 }
 
@@ -467,6 +480,8 @@ __global__ __launch_bounds__(URF_TABLE_THREADS) void k_table_repair(urf_kargs a,
     const unsigned s = blockIdx.x;
     if (!a.table_redo[s])
         return;
+    if (a.front && threadIdx.x == 0)
+        a.front_ok[s] = 0u;   /* k_split_repair splits the scan the legacy way: the legacy kernels take it from here (urf_front.hpp) */
     const unsigned cause = a.table_cause[s];   /* (before the walk below overwrites it) */
     urf_ring_table_scan(a, dp, s, 0, T);
     if (threadIdx.x == 0) {
@@ -545,8 +560,8 @@ struct urf_exact_key {
 #else
 #define URF_EXACT_INLINE __noinline__
 #endif
-__device__ URF_EXACT_INLINE urf_exact_key urf_exact_keys(const float* tab, unsigned nR, float interval, float x, float y, float z,
-                                                     unsigned sectors, float Kfi)
+__device__ __forceinline__ urf_exact_key urf_exact_keys_body(const float* tab, unsigned nR, float interval, float x, float y, float z,
+                                                            unsigned sectors, float Kfi)
 {
     urf_exact_key r;
     r.valpha = urf_vertical_angle(x, y, z);
@@ -565,6 +580,17 @@ __device__ URF_EXACT_INLINE urf_exact_key urf_exact_keys(const float* tab, unsig
     if (sectors)
         r.sector = urf_sector(x, y, Kfi, sectors);
     return r;
+}
+__device__ URF_EXACT_INLINE urf_exact_key urf_exact_keys(const float* tab, unsigned nR, float interval, float x, float y, float z,
+                                                     unsigned sectors, float Kfi)
+{
+    return urf_exact_keys_body(tab, nR, interval, x, y, z, sectors, Kfi);
+}
+/* (k_front's own instance: a function shared with k_split takes its register budget from both callers) */
+__device__ __noinline__ urf_exact_key urf_exact_keys_front(const float* tab, unsigned nR, float interval, float x, float y, float z,
+                                                           unsigned sectors, float Kfi)
+{
+    return urf_exact_keys_body(tab, nR, interval, x, y, z, sectors, Kfi);
 }
 
 /* timing experiment (tools/ab_noparity.sh): wave 0 of a few workgroups in the middle of the grid prints
@@ -1271,6 +1297,8 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_split[];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         *a.ring_hint = 0;   /* k_ring_table has read the previous call's ring count; k_index collects this call's */
+    if (a.front && __builtin_amdgcn_readfirstlane((int)((const uint32_t* __restrict__)a.front_ok)[blockIdx.y]))
+        return;   /* (uniform) a scan of the fused front end (urf_front.hpp) */
     urf_split_tile(a, dp, blockIdx.y, blockIdx.x, sh_split, threadIdx.x);
 }
 
@@ -1509,11 +1537,16 @@ __device__ __forceinline__ void urf_index_body(const urf_kargs& a, const urf_dev
          * 0.0180 vs 0.0183 ms) */
         urf_index_sectors<1u>(a, s, K, ntiles);
     }
+    const bool fused = a.front && a.front_ok[s];   /* (uniform) urf_front.hpp: no ring-sorted copies, k_front_finish counts the rings' points */
+    if (fused && tid == 0)
+        atomicMax(a.ring_hint, a.info[s].n_rings);
+    if (!fused) {
     for (unsigned k0 = 0; k0 < C; k0 += 64)
         urf_index_family(L, a.troff + (size_t)s * a.tiles * (C + 1), C, k0, ntiles, a.tiles, a.rpre + (size_t)s * C * (a.tiles + 1),
                          a.rstart + (size_t)s * C * a.tiles, a.ring_cnt + (size_t)s * C);
     urf_scan_keys_256(&a.ring_cnt[(size_t)s * C], &a.ring_off[(size_t)s * (C + 1)], C, sh);
-    {   /* lidar_segmentation.cpp:605-608: road_probably = every point of sorted ring 10 */
+    }
+    if (!fused) {   /* lidar_segmentation.cpp:605-608: road_probably = every point of sorted ring 10 */
         unsigned tot = 0;
         for (unsigned k = tid; k < C; k += 256)
             tot += a.ring_cnt[(size_t)s * C + k];
@@ -1531,6 +1564,7 @@ __device__ __forceinline__ void urf_index_body(const urf_kargs& a, const urf_dev
     }
     if (!dp.p.star_shaped_method)
         return;
+    __syncthreads();   /* sec_cnt / sec_run are other threads' stores (a fused scan has passed no barrier since urf_index_sectors) */
     urf_scan_keys_256(&a.sec_cnt[(size_t)s * K], &a.sec_off[(size_t)s * (K + 1)], K, sh);
     /* sectors too large for one wave's LDS tile go on the work lists of k_star_mid / k_star_big
      * (one atomic per wave, not per sector) */
@@ -3065,6 +3099,8 @@ __device__ __forceinline__ void urf_walk_chunk_general(urf_walk_state& w_, unsig
 __device__ __forceinline__ int urf_walk_slot_to_ring_pos(const urf_kargs& a, unsigned s, unsigned C, unsigned v)
 {
     int hit = -1;
+    if (a.front && a.front_ok[s])   /* a scan of the fused front end (urf_front.hpp): sslot holds the index inside the input tile, k_front_finish wants the input index */
+        return (int)v;
     if (v != 0xffffffffu) {
         const unsigned t = v / URF_TILE, j = v % URF_TILE;
         const uint16_t* row = a.troff + ((size_t)s * a.tiles + t) * (C + 1);
@@ -3850,6 +3886,8 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
     urf_scan_range(a, s, off, len);
     if (in.status != URF_OK || c >= in.n_rings)
         return;
+    if (a.front && a.front_ok[s])
+        return;   /* (uniform) a scan of the fused front end (urf_front.hpp: k_front_finish) */
     const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
     const unsigned sb = urf_sbase(a, s);
     const int cp = dp.p.curbPoints;
@@ -4929,6 +4967,8 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         }
     }
     const unsigned tid = threadIdx.x;
+    if (a.front && a.front_ok[s])
+        return;   /* (uniform) a scan of the fused front end (urf_front.hpp: k_label_front) */
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned tbase = t * URF_TILE;
@@ -5826,6 +5866,13 @@ __global__ __launch_bounds__(256) void k_selftest_div_pi(unsigned long long* mis
          b += (unsigned long long)gridDim.x * blockDim.x) {
         const double a = (double)__uint_as_float((unsigned)b);
         if (urf_div_pi(a) != a / URF_PI_D)
+            bad++;
+    }
+    /* urf_sqrt_rn_normal(x) == sqrtf(x) for every float of [2^-90, 2^126] (k_front's planar range) */
+    for (unsigned long long b = 0x12800000ull + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= 0x7e800000ull;
+         b += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((unsigned)b);
+        if (__float_as_uint(urf_sqrt_rn_normal(x)) != __float_as_uint(__builtin_sqrtf(x)))
             bad++;
     }
     if (bad)
