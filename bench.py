@@ -325,13 +325,13 @@ def other_configs(u, O, torch, ctx, stream, dev, dx, dy, dz, dl, di, X, Y, Z, S)
     `frac` = 13 B/point x points/s / 8 TB/s, the whole pipeline."""
     res = {}
 
-    def entry(n_pts, n_scans, ms, kms, kcalls, picked, note):
+    def entry(n_pts, n_scans, ms, kms, kcalls, picked, note, fused=None):
         sps = n_scans / (ms * 1e-3)
         return {"scans_per_s": round(sps, 2), "ms_per_step": round(ms, 4), "scans_per_step": n_scans, "points_per_scan": n_pts,
                 "frac": round(13.0 * n_pts * sps / (HBM_PEAK_GBS * 1e9), 5),
                 "kernel_ms": {k: round(v / max(kcalls, 1), 4) for k, v in kms.items()},
-                "front_scans_per_gpu": front_scans,
-            "parity_checked_scans": picked, "workload": note}
+                "front_scans": fused,   # scans of a step that took the fused front end (urf_front.hpp)
+                "parity_checked_scans": picked, "workload": note}
 
     def run(c, fn, n_pts, n_scans, steps, warmup, note, picked):
         ms = _timed_steps(torch, stream, fn, steps, warmup)
@@ -342,7 +342,7 @@ def other_configs(u, O, torch, ctx, stream, dev, dx, dy, dz, dl, di, X, Y, Z, S)
             fn()
         kms, kcalls = c.kernel_timing()
         c.enable_kernel_timing(False)
-        return entry(n_pts, n_scans, ms, kms, kcalls, picked, note)
+        return entry(n_pts, n_scans, ms, kms, kcalls, picked, note, c.front_scans())
 
     def gate(labels_of, clouds, params, picked, what):
         for s in picked:

@@ -43,21 +43,23 @@ def run_batch(ctx, sweeps, mode):
     return lab, info, nf
 
 
-def check(name, sweeps, params, ctxs, verbose=True):
+def check(name, sweeps, params, ctxs, verbose=True, fresh=False):
+    """fresh: a context of its own -- its first call with a scan the fused front end hands back goes through the LIST-driven
+    legacy kernels (a context that has seen one launches them as full grids from then on)."""
     n = len(sweeps[0][0])
-    key = (n, len(sweeps))
+    key = (n, len(sweeps), name if fresh else "")
     if key not in ctxs:
         ctxs[key] = u.Context(n, len(sweeps))
     ctx = ctxs[key]
     ctx.set_params(params)
     bad = 0
     res = {}
-    for mode in (2, 0):
-        lab, info, nf = run_batch(ctx, sweeps, mode)
+    for mode in (2, 3, 0):   # 3 = mode 2 once more: a context that has handed a scan back launches the legacy kernels as full grids
+        lab, info, nf = run_batch(ctx, sweeps, min(mode, 2))
         res[mode] = (lab, info, nf)
     for si, (x, y, z) in enumerate(sweeps):
         lb, ib, _ = oracles.run_b(x, y, z, params)
-        for mode in (2, 0):
+        for mode in (2, 3, 0):
             lab, info, nf = res[mode]
             d = int(np.count_nonzero(lab[si] != lb))
             iv = dict(zip(INFO_KEYS, [int(v) for v in info[si]]))
@@ -96,7 +98,7 @@ def basic(ctxs):
     rng = np.random.default_rng(5)
     perm = rng.permutation(64)
     bad += check("laser order (lanes permuted) x3", [permute_lanes(oracles.cfg_cloud("sensor", s), perm) for s in (1, 2, 3)], P("sensor"), ctxs)
-    bad += check("rotated start column x3", [rotate_cols(oracles.cfg_cloud("cfg2", s), k) for s, k in ((1, 5), (2, 700), (3, 1999))], P("cfg2"), ctxs)
+    bad += check("rotated start column x3", [rotate_cols(oracles.cfg_cloud("cfg2", s), k) for s, k in ((1, 5), (2, 700), (3, 1999))], P("cfg2"), ctxs, fresh=True)
     p = P("cfg2")
     for xd in (1, 2):
         p.xDirection = xd
@@ -115,10 +117,15 @@ def basic(ctxs):
     x, y, z = oracles.cfg_cloud("cfg2", 3)
     pm = np.random.default_rng(1).permutation(len(x))
     sw.insert(1, (x[pm], y[pm], z[pm]))
-    bad += check("mixed batch (scan 1 shuffled)", sw, P("cfg2"), ctxs)
+    bad += check("mixed batch (scan 1 shuffled), lists", sw, P("cfg2"), ctxs, fresh=True)
+    bad += check("mixed batch (scan 1 shuffled), grids", sw, P("cfg2"), ctxs)
     # short sweeps: 64 x 96 (one and a half tiles ... partial last tile), 64 x 40
     for cols in (96, 40, 33):
-        bad += check("short sweep 64 x %d" % cols, [u.synth_cloud(64, cols, 1, 7)], P("cfg2"), ctxs)
+        bad += check("short sweep 64 x %d" % cols, [u.synth_cloud(64, cols, 1, 7)], P("cfg2"), ctxs, fresh=True)
+    # the reference's default region of interest on a sweep stored from another column: the speculative ring table fails
+    sw = [rotate_cols(oracles.cfg_cloud("default_roi", s), 1024) for s in (1, 2)] + [oracles.cfg_cloud("default_roi", 3)]
+    bad += check("default roi, rear-stored (table repair), lists", sw, P("default_roi"), ctxs, fresh=True)
+    bad += check("default roi, rear-stored (table repair), again", sw, P("default_roi"), ctxs, fresh=True)
     return bad
 
 

@@ -126,6 +126,11 @@ struct urf_ctx {
     int front_mode = 1;
     uint32_t front_tpb = 4;
     bool want_ring_sorted = false;
+    /* k_front hands a scan without the shape back to the legacy kernels.  As long as no call has done so, those are launched
+     * list-driven (a few persistent workgroups that find an empty list) instead of as full grids of workgroups that look at the
+     * scan's flag and leave; after the first such scan (h_spec_failed[2]) they come as full grids, and once a whole batch has been
+     * handed back (h_spec_failed[3]: unorganised clouds) the context stops trying.  urf_set_params / urf_set_front_mode start over. */
+    bool front_direct = false, front_off = false;
     bool speculate = true;
     bool use_hint = true;           /* k_ring_table also stops at the ring count of the row's previous call (until that fails once) */
     /* last call, for the entry points that read its intermediate results (urf_read_stage,
@@ -309,7 +314,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.info, S)
     k.front_cand_cap = max_points / 8 > 4096 ? max_points / 8 : 4096;
     A(k.front_ok, S) A(k.front_pres, S * tiles * 64) A(k.front_maxs, S * tiles * 64) A(k.front_lane_ring, S * 64) A(k.front_ring_lane, S * C)
-    A(k.front_cand, S * k.front_cand_cap) A(k.front_all, S * k.front_cand_cap) A(k.front_ncand, S)
+    A(k.front_cand, S * k.front_cand_cap) A(k.front_all, S * k.front_cand_cap) A(k.front_ncand, S) A(k.front_list, S)
     A(c->offsets_copy, S + 1)
     A(c->compact_cnt, S * tiles * 4)
     A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
@@ -327,16 +332,17 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
         c->front_tpb = (uint32_t)std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : c->front_tpb;
     {
         void* hp = nullptr;
-        if (hipHostMalloc(&hp, 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess)
+        if (hipHostMalloc(&hp, 4 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess)
             return fail(URF_ERR_HIP);
-        c->h_spec_failed = (uint32_t*)hp;
-        c->h_spec_failed[0] = c->h_spec_failed[1] = 0;
+        c->h_spec_failed = (uint32_t*)hp;   /* [2], [3]: the fused front end's two flags (front_direct, front_off) */
+        c->h_spec_failed[0] = c->h_spec_failed[1] = c->h_spec_failed[2] = c->h_spec_failed[3] = 0;
         if (hipMemset(k.ring_hint, 0, URF_ASYNC_SLOTS * sizeof(uint32_t)) != hipSuccess)
             return fail(URF_ERR_HIP);
         void* dp_ = nullptr;
         if (hipHostGetDevicePointer(&dp_, hp, 0) != hipSuccess)
             return fail(URF_ERR_HIP);
         k.spec_failed = (uint32_t*)dp_;
+        k.front_state = k.spec_failed + 2;
     }
     /* x_zero_method.cpp:24-27: newY[j] = newY[j-1] + 0.0100 (float += double), a
      * data-independent table shared by all rings */
@@ -428,8 +434,11 @@ extern "C" int urf_set_params(urf_ctx* c, const urf_params* p)
         if (st)
             URF_HIP(c, hipStreamSynchronize(st));   /* a sweep in flight on another row keeps its parameters */
     /* the ring counts of earlier calls say nothing about sweeps classified with OTHER parameters (region of interest, interval) */
-    if (std::memcmp(&c->params, p, sizeof(*p)) != 0)
+    if (std::memcmp(&c->params, p, sizeof(*p)) != 0) {
         URF_HIP(c, hipMemsetAsync(c->k.ring_hint, 0, URF_ASYNC_SLOTS * sizeof(uint32_t), c->stream));
+        c->front_direct = c->front_off = false;   /* ... nor does what the fused front end made of them */
+        c->h_spec_failed[2] = c->h_spec_failed[3] = 0;
+    }
     c->params = *p;
     c->epoch++;
     return upload_params(c);
@@ -499,6 +508,10 @@ extern "C" int urf_set_front_mode(urf_ctx* c, int mode)
 {
     if (!c || mode < 0 || mode > 2)
         return URF_ERR_INVALID_ARG;
+    if (mode != c->front_mode && mode != 0) {   /* (a new start: what earlier calls made of the fused front end is forgotten) */
+        c->front_direct = c->front_off = false;
+        c->h_spec_failed[2] = c->h_spec_failed[3] = 0;
+    }
     c->front_mode = mode;
     if (mode == 2)
         c->want_ring_sorted = false;
@@ -590,7 +603,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     k.win += r * C * URF_DEG_CELLS;
     k.info += r;
     k.front_ok += r; k.front_pres += r * tiles * 64; k.front_maxs += r * tiles * 64; k.front_lane_ring += r * 64; k.front_ring_lane += r * C;
-    k.front_cand += r * (size_t)k.front_cand_cap; k.front_all += r * (size_t)k.front_cand_cap; k.front_ncand += r;
+    k.front_cand += r * (size_t)k.front_cand_cap; k.front_all += r * (size_t)k.front_cand_cap; k.front_ncand += r; k.front_list += r;
     return k;
 }
 
@@ -694,10 +707,15 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     /* The fused front end (urf_front.hpp) for batches of sweeps in firing order: k_front tries every scan, the legacy kernels
      * skip the scans it kept.  64 lasers = 64 lanes, the detectors' window of curbPoints == 5 in registers, no stage capture
      * (its values are the legacy kernels'), not for the single sweeps of the callback path (sixteen waves on the whole device). */
-    a.front = (c->front_mode != 0 && !legacy_only && !c->want_ring_sorted && !on_stream && a.capture == 0 && C == URF_FRONT_LANES &&
+    if (c->h_spec_failed[2])
+        c->front_direct = true;
+    if (c->h_spec_failed[3] && c->front_mode != 2)
+        c->front_off = true;
+    a.front = (c->front_mode != 0 && !c->front_off && !legacy_only && !c->want_ring_sorted && !on_stream && a.capture == 0 && C == URF_FRONT_LANES &&
                dp.p.curbPoints == 5 && a.tiles <= URF_FRONT_MAX_TILES && (c->front_mode == 2 || n_scans >= URF_FRONT_MIN_SCANS))
                   ? 1u : 0u;
     a.front_tpb = c->front_tpb;
+    a.front_lists = (a.front && !c->front_direct) ? 1u : 0u;
 
     std::vector<hipEvent_t>* ev = nullptr;
     if (c->timing) {
@@ -719,9 +737,14 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     mark();
     if (a.front)
         hipLaunchKernelGGL(k_front, dim3((a.tiles + a.front_tpb - 1) / a.front_tpb, n_scans), dim3(64), 0, st, a, dp);
-    hipLaunchKernelGGL(k_split, g_tiles, dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
+    if (a.front_lists) {   /* what k_front handed back (normally nothing) */
+        hipLaunchKernelGGL(k_table_repair, g_scan, dim3(URF_TABLE_THREADS), 0, st, a, dp, 1u);
+        hipLaunchKernelGGL(k_split_list, dim3(c->n_cus * 2), dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
+    } else {
+        hipLaunchKernelGGL(k_split, g_tiles, dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
+    }
     if (a.table_lookahead && !(a.optimistic & URF_OPT_NO_REPAIR)) {   /* normally both find nothing to do */
-        hipLaunchKernelGGL(k_table_repair, g_scan, dim3(URF_TABLE_THREADS), 0, st, a, dp);
+        hipLaunchKernelGGL(k_table_repair, g_scan, dim3(URF_TABLE_THREADS), 0, st, a, dp, 0u);
         hipLaunchKernelGGL(k_split_repair, dim3(c->n_cus), dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
     }
     mark();
@@ -757,19 +780,24 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     }
     mark();
     const dim3 g_ring(C, n_scans);
-    if (dp.p.curbPoints == 5)   /* the reference's default: four points per thread, z only */
+    if (a.front_lists)
+        hipLaunchKernelGGL(k_ring_list, dim3(c->n_cus * 8), dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
+    else if (dp.p.curbPoints == 5)   /* the reference's default: four points per thread, z only */
         hipLaunchKernelGGL(k_ring, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
     else
         hipLaunchKernelGGL(k_ring_general, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
     if (a.front)
-        hipLaunchKernelGGL(k_front_finish, g_scan, dim3(URF_FINISH_THREADS), (size_t)a.tiles * 128 * sizeof(unsigned), st, a, dp);
+        hipLaunchKernelGGL(k_front_finish, g_scan, dim3(URF_FINISH_THREADS), (size_t)a.tiles * 384 > 4096 ? (size_t)a.tiles * 384 : 4096, st, a, dp);
     /* the rings that hold a point with a NaN azimuth (k_split listed them: normally none, the kernel returns at once) */
     if (!(a.optimistic & URF_OPT_NO_NAN))
         hipLaunchKernelGGL(k_nan_rings, dim3(32), dim3(256), URF_NAN_LDS * sizeof(unsigned long long), st, a, dp);
     mark();
     hipLaunchKernelGGL(k_beams, g_scan, dim3(URF_BEAM_THREADS), (size_t)C * (24 * sizeof(unsigned) + URF_CURB_LIST * sizeof(float)), st, a, dp);
     mark();
-    hipLaunchKernelGGL(k_label, g_tiles, dim3(URF_LABEL_TILE_THREADS), 0, st, a, dp);
+    if (a.front_lists)
+        hipLaunchKernelGGL(k_label_list, dim3(c->n_cus * 4), dim3(URF_LABEL_TILE_THREADS), 0, st, a, dp);
+    else
+        hipLaunchKernelGGL(k_label, g_tiles, dim3(URF_LABEL_TILE_THREADS), 0, st, a, dp);
     if (a.front)
         hipLaunchKernelGGL(k_label_front, g_tiles, dim3(URF_LABEL_TILE_THREADS), 0, st, a, dp);
     mark();

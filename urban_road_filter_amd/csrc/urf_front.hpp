@@ -406,16 +406,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(URF_FRONT_WA
 /* ------------------------------------------------------------------------- */
 /* k_front_finish                                                              */
 /* ------------------------------------------------------------------------- */
-#define URF_FINISH_THREADS 1024   /* the candidates' chains of dependent round trips (point, neighbours, newY, the record's atomic) are what the kernel
-                                     * waits for: sixteen waves per scan keep four times as many in flight as four did (0.25 -> ms, r6) */
+#ifndef URF_FINISH_THREADS
+#define URF_FINISH_THREADS 256   /* four waves and <= 40 KB of LDS per scan: four workgroups per CU, a batch of 1024 scans in one round (A/B 256 / 512 /
+                                    * 1024 threads: cfg3 0.186 / 0.184 / 0.206 ms, the reference's default region of interest 0.210 / 0.241 / 0.264) */
+#endif
 struct urf_finish_shared {
     unsigned n[64];              /* ring points of lane l */
     unsigned ring[64];           /* its ring (0xffffffff: the lane holds no ring point) */
     unsigned ncurb[URF_FRONT_LANES];   /* (the fused front end runs with 64 channels) */
     float curb[URF_FRONT_LANES][URF_CURB_LIST];
     int q[4];
-    unsigned n_all;              /* entries of the scan's list of all curb points (the candidate list's memory, rewritten) */
-    int cmin[URF_DEG_CELLS], cmax[URF_DEG_CELLS];
+    unsigned n_all;              /* entries of the scan's list of all curb points */
+    unsigned qsum[URF_FINISH_THREADS / 64][64];
 };
 
 /* firing of the ring point in front of / behind firing f in lane l; 0xffffffff: none */
@@ -447,7 +449,7 @@ __device__ __forceinline__ unsigned urf_front_next(const unsigned* P, unsigned n
 __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a, urf_dev_params dp)
 {
     __shared__ urf_finish_shared S;
-    extern __shared__ unsigned sh_finish[];   /* P[tiles][64] presence words | B[tiles][64] ring points of the lane in the tiles before */
+    extern __shared__ unsigned sh_finish[];   /* P[tiles][64] presence words | B[tiles][64] (u16) ring points of the lane in the tiles before */
     const unsigned s = blockIdx.x, tid = threadIdx.x;
     if (!a.front_ok[s])
         return;
@@ -459,11 +461,15 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
     if (in.status != URF_OK)
         return;
     unsigned* const P = sh_finish;
-    unsigned* const B = sh_finish + a.tiles * 64u;
+    uint16_t* const B = (uint16_t*)(sh_finish + a.tiles * 64u);
     const unsigned sb = urf_sbase(a, s);
     const float* __restrict__ const gx = a.x + off;
     const float* __restrict__ const gy = a.y + off;
     const float* __restrict__ const gz = a.z + off;
+    const urf_u2* const cand = a.front_cand + (size_t)s * a.front_cand_cap;
+    const unsigned nc_raw = a.front_ncand[s];
+    const unsigned nc = nc_raw < a.front_cand_cap ? nc_raw : a.front_cand_cap;
+    urf_u2 cd_next = tid < nc ? cand[tid] : urf_u2{ 0u, 0u };   /* (requested with everything else the workgroup needs first) */
     for (unsigned k = tid; k < ntiles * 64u; k += URF_FINISH_THREADS)
         P[k] = a.front_pres[(size_t)s * a.tiles * 64u + k];
     if (tid < URF_FRONT_LANES)
@@ -484,24 +490,22 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
         const unsigned l = tid & 63u, part = tid >> 6;
         const unsigned tq = (ntiles + NP - 1u) / NP, ta = part * tq < ntiles ? part * tq : ntiles, tb = ta + tq < ntiles ? ta + tq : ntiles;
         unsigned run = 0;
-        for (unsigned t = ta; t < tb; t++) {
-            B[t * 64u + l] = run;
+        for (unsigned t = ta; t < tb; t++)
             run += (unsigned)__popc(P[t * 64u + l]);
-        }
-        __shared__ unsigned qsum[NP][64];
-        qsum[part][l] = run;
+        S.qsum[part][l] = run;
         __syncthreads();
         unsigned add = 0, all = 0;
         for (unsigned p = 0; p < NP; p++) {
-            add += p < part ? qsum[p][l] : 0u;
-            all += qsum[p][l];
+            add += p < part ? S.qsum[p][l] : 0u;
+            all += S.qsum[p][l];
         }
-        for (unsigned t = ta; t < tb; t++)
-            B[t * 64u + l] += add;
+        for (unsigned t = ta; t < tb; t++) {
+            B[t * 64u + l] = (uint16_t)add;
+            add += (unsigned)__popc(P[t * 64u + l]);
+        }
         if (part == 0)
             S.n[l] = all;
     }
-    __syncthreads();
     /* ring sizes, the scan's summary, the rings' largest ranges */
     if (tid < C)
         a.ring_cnt[(size_t)s * C + tid] = 0;
@@ -515,9 +519,14 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
             a.ring_cnt[(size_t)s * C + r] = n;
             unsigned long long m = 0;
             const unsigned nblk = (ntiles + a.front_tpb - 1u) / a.front_tpb;
-            for (unsigned b = 0; b < nblk; b++) {
-                const unsigned long long v = a.front_maxs[((size_t)s * a.tiles + b) * 64u + tid];
-                m = v > m ? v : m;
+            for (unsigned b0 = 0; b0 < nblk; b0 += 8u) {   /* (eight blocks' values in flight: one after the other this lane's chain was sixteen round trips) */
+                unsigned long long v[8];
+#pragma unroll
+                for (unsigned b = 0; b < 8; b++)
+                    v[b] = a.front_maxs[((size_t)s * a.tiles + (b0 + b < nblk ? b0 + b : b0)) * 64u + tid];
+#pragma unroll
+                for (unsigned b = 0; b < 8; b++)
+                    m = v[b] > m ? v[b] : m;
             }
             a.maxdist[(size_t)s * C + r] = (float)__builtin_sqrt(__longlong_as_double((long long)m));
             a.vis[(size_t)s * C + r] = urf_vis{ __builtin_inff(), -__builtin_inff() };
@@ -527,15 +536,15 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
         if (tid == 0)
             a.info[s].n_ring_pts = tot;
     }
-    /* one ring point that has a detector's mark: the reference's azimuth, its ring's list, ring 1's quadrants
-     * (urf_ring_point: lidar_segmentation.cpp:245-269, blind_spots.cpp:19-56) */
-    urf_u2* const cand = a.front_cand + (size_t)s * a.front_cand_cap;
+    /* A ring point that has a detector's mark: its record's flag (whoever sets the first one lists the point), the reference's
+     * azimuth, its ring's list, ring 1's quadrants (urf_ring_point: lidar_segmentation.cpp:245-269, blind_spots.cpp:19-56).  The
+     * atomic is on its way while the azimuth is worked out. */
     auto mark = [&](unsigned idx, unsigned flag, unsigned r, float px, float py) {
         const unsigned old = atomicOr(&a.rec[sb + idx], flag << URF_REC_FLAG_SHIFT);
-        if ((old >> URF_REC_FLAG_SHIFT) & 7u)
-            return;   /* already a curb point: listed by whoever marked it first */
         float d2;
         const float az = urf_azimuth(px, py, &d2);
+        if ((old >> URF_REC_FLAG_SHIFT) & 7u)
+            return;   /* already a curb point: listed by whoever marked it first */
         const unsigned e = atomicAdd(&S.ncurb[r], 1u);
         if (e < URF_CURB_LIST)
             S.curb[r][e] = az;
@@ -554,67 +563,84 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
                 atomicMin(&S.q[3], ab);
         }
     };
-    const unsigned nc_raw = a.front_ncand[s];
-    const unsigned nc = nc_raw < a.front_cand_cap ? nc_raw : a.front_cand_cap;
+    /* The candidates.  What the kernel waits for is memory round trips, so every candidate makes ONE for its data: the next
+     * record is requested an iteration ahead; the neighbours' firings come from the presence words in LDS; then the point, its
+     * ten neighbours (x, y, z) and the three table values of x_zero are requested together, unconditionally -- a lane that does
+     * not need a neighbour asks for its own point again, the same cache line. */
     for (unsigned e = tid; e < nc; e += URF_FINISH_THREADS) {
-        const urf_u2 cd = cand[e];
+        const urf_u2 cd = cd_next;
+        if (e + URF_FINISH_THREADS < nc)
+            cd_next = cand[e + URF_FINISH_THREADS];
         const unsigned idx = cd.x, what = cd.y;
         const unsigned l = idx & 63u, f = idx >> 6;
         const unsigned r = S.ring[l];
         const unsigned n = S.n[l];
-        const unsigned p = B[(f >> 5) * 64u + l] + (unsigned)__popc(P[(f >> 5) * 64u + l] & ((1u << (f & 31u)) - 1u));
-        const float px = gx[idx], py = gy[idx], pz = gz[idx];
-        unsigned flag = 0;
-        if ((what & (URF_FC_XZ | URF_FC_EDGE_X)) && dp.p.x_zero_method && p >= 7u && p + 3u < n) {
-            /* x_zero_method.cpp:30-68, j = p - 2 in [curbPoints, n - 1 - curbPoints], marks p = j + 2 */
-            unsigned fj = urf_front_prev(P, l, f);
-            fj = urf_front_prev(P, l, fj);
-            unsigned f3 = urf_front_next(P, ntiles, l, f);
-            f3 = urf_front_next(P, ntiles, l, f3);
-            f3 = urf_front_next(P, ntiles, l, f3);
-            const unsigned ij = fj * 64u + l, i3 = f3 * 64u + l;
-            const float zj = gz[ij], z3 = gz[i3];
-            bool heights = true;
-            if (what & URF_FC_EDGE_X)
-                heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight || __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
-                          (double)__builtin_fabsf(zj - z3) >= 0.05;
-            if (heights && urf_x_zero_angle(a.newY, dp.p.angleFilter1, dp.x_angle_thr, gx[ij], gy[ij], gx[i3], gy[i3], (int)p - 2, (int)p, 5, zj, pz, z3))
-                flag |= 2u;
-        }
-        if ((what & (URF_FC_ZZ | URF_FC_EDGE_Z)) && dp.p.z_zero_method && p >= 5u && p + 5u < n) {
-            /* z_zero_method.cpp:21-72 for the centre p */
-            unsigned fm[5], fp[5];
+        const unsigned p = (unsigned)B[(f >> 5) * 64u + l] + (unsigned)__popc(P[(f >> 5) * 64u + l] & ((1u << (f & 31u)) - 1u));
+        /* x_zero_method.cpp:30-68 marks p = j + 2 for j = p - 2 in [curbPoints, n - 1 - curbPoints]; z_zero_method.cpp:21-72 for the centre p */
+        const bool doX = (what & (URF_FC_XZ | URF_FC_EDGE_X)) && dp.p.x_zero_method && p >= 7u && p + 3u < n;
+        const bool doZ = (what & (URF_FC_ZZ | URF_FC_EDGE_Z)) && dp.p.z_zero_method && p >= 5u && p + 5u < n;
+        const unsigned nprev = doZ ? 5u : (doX ? 2u : 0u), nnext = doZ ? 5u : (doX ? 3u : 0u);
+        unsigned im[5], ip[5];   /* input indices of the neighbours (own index: not needed) */
+        {
             unsigned g = f;
 #pragma unroll
             for (unsigned k = 0; k < 5; k++) {
-                g = urf_front_prev(P, l, g);
-                fm[k] = g;
+                if (k < nprev)
+                    g = urf_front_prev(P, l, g);
+                im[k] = k < nprev ? g * 64u + l : idx;
             }
             g = f;
 #pragma unroll
             for (unsigned k = 0; k < 5; k++) {
-                g = urf_front_next(P, ntiles, l, g);
-                fp[k] = g;
+                if (k < nnext)
+                    g = urf_front_next(P, ntiles, l, g);
+                ip[k] = k < nnext ? g * 64u + l : idx;
             }
+        }
+        const bool needz = (what & (URF_FC_EDGE_X | URF_FC_EDGE_Z)) != 0u;   /* the march has not looked at the heights */
+        float xm[5], ym[5], zm[5], xp[5], yp[5], zp[5];
+        const float px = gx[idx], py = gy[idx], pz = gz[idx];
+#pragma unroll
+        for (unsigned k = 0; k < 5; k++) {
+            xm[k] = gx[im[k]];
+            ym[k] = gy[im[k]];
+            xp[k] = gx[ip[k]];
+            yp[k] = gy[ip[k]];
+            /* (heights: x_zero reads j = p - 2 and j + 5 = p + 3 in any case, the rest only what the march left undecided) */
+            zm[k] = gz[(needz || k == 1u) ? im[k] : idx];
+            zp[k] = gz[(needz || k == 2u) ? ip[k] : idx];
+        }
+        const unsigned pj = doX ? p - 2u : 0u;
+        const float nyj = a.newY[pj], ny2 = a.newY[doX ? p : 0u], ny3 = a.newY[pj + (doX ? 5u : 0u)];
+        unsigned flag = 0;
+        if (doX) {
+            const float zj = zm[1], z3 = zp[2];
+            bool heights = true;
+            if (what & URF_FC_EDGE_X)
+                heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight || __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
+                          (double)__builtin_fabsf(zj - z3) >= 0.05;
+            if (heights && urf_x_zero_angle_vals(nyj, ny2, ny3, dp.p.angleFilter1, dp.x_angle_thr, xm[1], ym[1], xp[2], yp[2], zj, pz, z3))
+                flag |= 2u;
+        }
+        if (doZ) {
             bool heights = true;
             if (what & URF_FC_EDGE_Z) {
                 const float azp = __builtin_fabsf(pz);
                 float max1 = azp, max2 = azp;
 #pragma unroll
                 for (unsigned k = 0; k < 5; k++) {
-                    const float za = __builtin_fabsf(gz[fm[k] * 64u + l]), zb = __builtin_fabsf(gz[fp[k] * 64u + l]);
+                    const float za = __builtin_fabsf(zm[k]), zb = __builtin_fabsf(zp[k]);
                     max1 = za > max1 ? za : max1;
                     max2 = zb > max2 ? zb : max2;
                 }
                 heights = (max1 - azp >= dp.p.curbHeight || max2 - azp >= dp.p.curbHeight) && (double)__builtin_fabsf(max1 - max2) >= 0.05;
             }
             if (heights) {
-                auto gxy = [&](int rel, float& xx, float& yy) {   /* rel: position relative to the centre */
-                    const unsigned ff = rel < 0 ? fm[-rel - 1] : fp[rel - 1];
-                    xx = gx[ff * 64u + l];
-                    yy = gy[ff * 64u + l];
+                auto xy = [&](int pos, float& xx, float& yy) {   /* pos: ring position; the centre's is p */
+                    const int rel = pos - (int)p;
+                    xx = rel < 0 ? xm[-rel - 1] : xp[rel - 1];
+                    yy = rel < 0 ? ym[-rel - 1] : yp[rel - 1];
                 };
-                auto xy = [&](int pos, float& xx, float& yy) { gxy(pos - (int)p, xx, yy); };
                 if (urf_z_zero_angle(dp.inv_cp, dp.p.angleFilter2, dp.z_angle_thr, xy, (int)p, 5, px, py))
                     flag |= 4u;
             }
@@ -643,15 +669,18 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
             a.curb_az[((size_t)s * C + r) * URF_CURB_LIST + e] = S.curb[r][e];
     }
     /* a ring with more curb points than its list holds (rough ground): the per-degree tables instead, from the scan's
-     * list of all curb points -- sufmin[i] = smallest curb azimuth >= i, premax[i] = largest <= i, NaN = none */
+     * list of all curb points -- sufmin[i] = smallest curb azimuth >= i, premax[i] = largest <= i, NaN = none.  (The presence
+     * words are no longer needed: their memory holds the two tables of the ring at hand.) */
     const unsigned n_all = S.n_all < a.front_cand_cap ? S.n_all : a.front_cand_cap;
+    int* const cmin = (int*)sh_finish;
+    int* const cmax = cmin + URF_DEG_CELLS;
     for (unsigned r = 0; r < in.n_rings; r++) {
         if (S.ncurb[r] <= URF_CURB_LIST)
             continue;   /* (uniform) */
         __syncthreads();
         for (unsigned i = tid; i < URF_DEG_CELLS; i += URF_FINISH_THREADS) {
-            S.cmin[i] = URF_INT_NONE_MIN;
-            S.cmax[i] = -1;
+            cmin[i] = URF_INT_NONE_MIN;
+            cmax[i] = -1;
         }
         __syncthreads();
         for (unsigned e = tid; e < n_all; e += URF_FINISH_THREADS) {
@@ -662,8 +691,8 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
             int cl = (int)__builtin_floorf(az), ch = (int)__builtin_ceilf(az);
             cl = cl < 0 ? 0 : (cl > 360 ? 360 : cl);
             ch = ch < 0 ? 0 : (ch > 360 ? 360 : ch);
-            atomicMin(&S.cmin[cl], (int)v.x);
-            atomicMax(&S.cmax[ch], (int)v.x);
+            atomicMin(&cmin[cl], (int)v.x);
+            atomicMax(&cmax[ch], (int)v.x);
         }
         __syncthreads();
         if (tid < 64) {   /* one wave: running maximum upwards, running minimum downwards */
@@ -674,8 +703,8 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
 #pragma unroll
             for (unsigned e = 0; e < 6; e++) {
                 const unsigned i = 6u * tid + e;
-                up[e] = i < URF_DEG_CELLS ? (unsigned)(S.cmax[i] + 1) : 0u;
-                dn[e] = i < URF_DEG_CELLS ? ~(unsigned)S.cmin[URF_DEG_CELLS - 1 - i] : 0u;
+                up[e] = i < URF_DEG_CELLS ? (unsigned)(cmax[i] + 1) : 0u;
+                dn[e] = i < URF_DEG_CELLS ? ~(unsigned)cmin[URF_DEG_CELLS - 1 - i] : 0u;
                 if (e) {
                     up[e] = up[e] > up[e - 1] ? up[e] : up[e - 1];
                     dn[e] = dn[e] > dn[e - 1] ? dn[e] : dn[e - 1];

@@ -223,7 +223,7 @@ struct urf_kargs {
     uint32_t* tie_list;         /* [S*sectors] scan*sectors+sector of the sectors that carry URF_TIE_FLAG (sort kernels -> k_star_ties, first pass) */
     uint32_t* tie_post;         /* [S*sectors] ... URF_TIE_POST (walk kernels -> second pass) */
     uint32_t* star_count;       /* [8] lengths of the two lists, [2] = length of redo_list, [3] = length of nan_list, [4] = length of
-                                 * tie_list, [5] = of tie_post (zeroed per call) */
+                                 * tie_list, [5] = of tie_post, [6] = of front_list (zeroed per call) */
     uint32_t* table_upto;       /* [S] first point a speculative k_ring_table did not look at (0xffffffff: none) */
     uint32_t* table_redo;       /* [S] k_split: the speculative table of the scan is incomplete */
     uint32_t* redo_list;        /* [S] such scans (k_table_repair) */
@@ -264,6 +264,9 @@ struct urf_kargs {
     urf_u2*   front_cand;       /* [S][front_cand_cap] (input index, URF_FC_*): points whose detector decision is pending (k_front -> k_front_finish) */
     urf_u2*   front_all;        /* [S][front_cand_cap] (azimuth bits, ring) of every curb point (k_front_finish: rings whose list overflowed) */
     uint32_t* front_ncand;      /* [S] */
+    uint32_t* front_list;       /* [S] the scans whose flag is clear (k_front_collect; star_count[6] = how many): the list-driven legacy kernels' work */
+    uint32_t* front_state;      /* host-mapped: [0] some scan of some call was handed back, [1] every scan of some call was */
+    uint32_t  front_lists;      /* this call launches the legacy kernels list-driven (k_split_list, k_ring_list, k_label_list) */
 };
 
 #endif /* URF_INTERNAL_HPP */

@@ -474,18 +474,30 @@ __global__ __launch_bounds__(URF_TABLE_THREADS) void k_ring_table(urf_kargs a, u
 }
 
 /* the scans whose speculative table k_split found incomplete: the whole walk, listed for k_split_repair */
-__global__ __launch_bounds__(URF_TABLE_THREADS) void k_table_repair(urf_kargs a, urf_dev_params dp)
+__global__ __launch_bounds__(URF_TABLE_THREADS) void k_table_repair(urf_kargs a, urf_dev_params dp, unsigned collect)
 {
     __shared__ urf_table_shared T;
     const unsigned s = blockIdx.x;
-    if (!a.table_redo[s])
+    const bool redo = a.table_redo[s] != 0u;
+    /* collect (the launch behind k_front, urf_front.hpp): the scans the fused front end handed back -- or whose speculative table it
+     * found incomplete -- are listed for the list-driven legacy kernels; host-visible: was there one, were they all */
+    if (collect && threadIdx.x == 0 && (redo || a.front_ok[s] == 0u)) {
+        a.front_ok[s] = 0u;
+        const unsigned e = atomicAdd(&a.star_count[6], 1u);
+        a.front_list[e] = s;
+        a.front_state[0] = 1u;
+        if (e + 1u == a.n_scans)
+            a.front_state[1] = 1u;
+    }
+    if (!redo)
         return;
     if (a.front && threadIdx.x == 0)
         a.front_ok[s] = 0u;   /* k_split_repair splits the scan the legacy way: the legacy kernels take it from here (urf_front.hpp) */
     const unsigned cause = a.table_cause[s];   /* (before the walk below overwrites it) */
     urf_ring_table_scan(a, dp, s, 0, T);
     if (threadIdx.x == 0) {
-        a.redo_list[atomicAdd(&a.star_count[2], 1u)] = s;
+        if (!collect)   /* (a collected scan is split by k_split_list) */
+            a.redo_list[atomicAdd(&a.star_count[2], 1u)] = s;
         a.spec_failed[cause == 2u ? 1 : 0] = 1u;   /* host-visible: the context stops using the rule that failed */
     }
 }
@@ -1313,6 +1325,22 @@ __global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_e
         asm volatile("" : "+v"(tid_i));
         urf_split_tile(a, dp, a.redo_list[w / a.tiles], w % a.tiles, sh_split, tid_i);
         __syncthreads();   /* the LDS carve is reused by the next tile */
+    }
+}
+
+/* the scans the fused front end handed back (urf_front.hpp: front_list; normally none), and -- that list holds them too -- the
+ * scans whose speculative ring table k_table_repair has rebuilt: split the legacy way */
+__global__ __launch_bounds__(URF_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_SPLIT_WAVES_PER_EU, URF_SPLIT_WAVES_PER_EU))) void k_split_list(urf_kargs a, urf_dev_params dp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_split[];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *a.ring_hint = 0;   /* (k_split's duty) */
+    const unsigned n = a.star_count[6];
+    for (unsigned w = blockIdx.x; w < n * a.tiles; w += gridDim.x) {
+        unsigned tid_i = threadIdx.x;
+        asm volatile("" : "+v"(tid_i));
+        urf_split_tile(a, dp, a.front_list[w / a.tiles], w % a.tiles, sh_split, tid_i);
+        __syncthreads();
     }
 }
 
@@ -3692,13 +3720,12 @@ struct urf_ring_map {
 /* (The angle tests and the exact azimuth are NOT inlined: only the few points that pass the cheap
  * height tests get here, and inlined their f64 code dictates the kernel's register allocation --
  * k_ring spilled 52..80 bytes per lane with them inside.) */
-__device__ __noinline__ bool urf_x_zero_angle(const float* newY, float angleFilter1, float x_angle_thr, float xj, float yj, float x3, float y3,
-                                              int j, int p, int cp, float zj, float pz, float z3)
+__device__ __forceinline__ bool urf_x_zero_angle_body(float nyj, float ny2, float ny3, float angleFilter1, float x_angle_thr, float xj, float yj, float x3, float y3,
+                                                      float zj, float pz, float z3)
 {
     const double dx = (double)(x3 - xj), dy = (double)(y3 - yj);
     if (!(dx * dx + dy * dy < URF_DIST5_SQ))                                    /* :35-40 */
         return false;
-    const float nyj = newY[j], ny2 = newY[p], ny3 = newY[j + cp];
     double u, v;
     u = (double)(ny2 - nyj); v = (double)(pz - zj);
     const float x1 = (float)__builtin_sqrt(u * u + v * v);
@@ -3719,6 +3746,18 @@ __device__ __noinline__ bool urf_x_zero_angle(const float* newY, float angleFilt
 #else
     return br >= x_angle_thr;   /* :58-61 "alpha <= angleFilter1", alpha = acos(br) in degrees: urf_api.hip urf_angle_threshold */
 #endif
+}
+
+__device__ __noinline__ bool urf_x_zero_angle(const float* newY, float angleFilter1, float x_angle_thr, float xj, float yj, float x3, float y3,
+                                              int j, int p, int cp, float zj, float pz, float z3)
+{
+    return urf_x_zero_angle_body(newY[j], newY[p], newY[j + cp], angleFilter1, x_angle_thr, xj, yj, x3, y3, zj, pz, z3);
+}
+/* (k_front_finish requests the three table values together with the points: its own instance) */
+__device__ __noinline__ bool urf_x_zero_angle_vals(float nyj, float ny2, float ny3, float angleFilter1, float x_angle_thr, float xj, float yj, float x3,
+                                                   float y3, float zj, float pz, float z3)
+{
+    return urf_x_zero_angle_body(nyj, ny2, ny3, angleFilter1, x_angle_thr, xj, yj, x3, y3, zj, pz, z3);
 }
 
 /* z_zero_method.cpp:21-66 for the centre p, given the height tests passed.  xy(r, x, y) delivers the
@@ -3854,7 +3893,7 @@ __device__ __forceinline__ double urf_arc_ratio(const urf_dev_params& dp, float 
  * otherwise the general path with x / y / z windows.  Two instances, so that the common one does not
  * carry the other's registers. */
 template <bool QUADS>
-__device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_params& dp)
+__device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_params& dp, const unsigned c, const unsigned s)
 {
     constexpr int CH = URF_RING_CHUNK, PAD = URF_RING_PAD;
     __shared__ urf_ring_shared_t<QUADS> S;
@@ -3862,7 +3901,7 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
     int* const cmin = S.cmin;
     int* const cmax = S.cmax;
     int* const sh_q = S.q;
-    const unsigned c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    const unsigned tid = threadIdx.x;
     const unsigned C = (unsigned)dp.p.channels, K = (unsigned)dp.p.sectors;
     const bool star = dp.p.star_shaped_method != 0;
     /* Everything the workgroup needs before it can start is requested at once (scan summary, the
@@ -4397,11 +4436,26 @@ __device__ __forceinline__ void urf_ring_body(const urf_kargs& a, const urf_dev_
 #endif
 __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_eu(URF_RING_WAVES, URF_RING_WAVES))) void k_ring(urf_kargs a, urf_dev_params dp)
 {
-    urf_ring_body<true>(a, dp);
+    urf_ring_body<true>(a, dp, blockIdx.x, blockIdx.y);
 }
 __global__ __launch_bounds__(URF_RING_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ring_general(urf_kargs a, urf_dev_params dp)
 {
-    urf_ring_body<false>(a, dp);
+    urf_ring_body<false>(a, dp, blockIdx.x, blockIdx.y);
+}
+/* The scans the fused front end handed back (urf_front.hpp: front_list, normally none -- the kernels return at once): persistent
+ * workgroups over list x rings, so that a batch whose scans all took the fused front end does not pay for 65 536 workgroups
+ * that look at a flag and leave. */
+__global__ __launch_bounds__(URF_RING_THREADS) void k_ring_list(urf_kargs a, urf_dev_params dp)
+{
+    const unsigned n = a.star_count[6], C = (unsigned)dp.p.channels;
+    for (unsigned w = blockIdx.x; w < n * C; w += gridDim.x) {
+        const unsigned s = a.front_list[w / C], c = w % C;
+        if (dp.p.curbPoints == 5)
+            urf_ring_body<true>(a, dp, c, s);
+        else
+            urf_ring_body<false>(a, dp, c, s);
+        __syncthreads();   /* the LDS is reused by the next ring */
+    }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -4945,7 +4999,8 @@ __device__ __noinline__ unsigned urf_road_exact(const urf_kargs& a, const urf_wi
 #ifndef URF_LABEL_WAVES
 #define URF_LABEL_WAVES 8
 #endif
-__global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_LABEL_WAVES, URF_LABEL_WAVES))) void k_label(urf_kargs a, urf_dev_params dp)
+__global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_LABEL_WAVES, URF_LABEL_WAVES))) void k_label(urf_kargs a, urf_dev_params dp);   /* (below: the tile's body first) */
+__device__ __forceinline__ void urf_label_tile(const urf_kargs& a, const urf_dev_params& dp, const unsigned s, const unsigned t)
 {
     __shared__ unsigned koff[URF_MAX_CHANNELS + 1];
     __shared__ uint8_t img[URF_TILE + URF_TILE / 16 + 4] __attribute__((aligned(8)));   /* + a spare byte for the slots past the tile's last */
@@ -4953,19 +5008,6 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     __shared__ unsigned wave_max[URF_LABEL_TILE_THREADS / 64];
     __shared__ unsigned cnt_road, cnt_curb, n_unsure;
     __shared__ unsigned un_pos[URF_LABEL_UNSURE], un_key[URF_LABEL_UNSURE];   /* points to decide on the exact azimuth */
-    /* Workgroups are handed to the eight XCDs round robin, each XCD with its own L2.  The tiles of a
-     * scan all read the scan's window table (185 KB): spread over the XCDs every L2 fetched most of it
-     * (5.9 B per point of this kernel's 13.9); with the mapping below the tiles of one scan run on ONE
-     * XCD (eight scans at a time, one per XCD) and the table comes from memory once. */
-    unsigned s = blockIdx.y, t = blockIdx.x;
-    {
-        const unsigned T = gridDim.x, lin = blockIdx.y * T + blockIdx.x;
-        const unsigned grp = lin / (8u * T), r = lin - grp * (8u * T);
-        if ((grp + 1u) * 8u <= gridDim.y) {   /* a complete group of eight scans */
-            s = grp * 8u + (r & 7u);
-            t = r >> 3;
-        }
-    }
     const unsigned tid = threadIdx.x;
     if (a.front && a.front_ok[s])
         return;   /* (uniform) a scan of the fused front end (urf_front.hpp: k_label_front) */
@@ -5198,6 +5240,33 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
             atomicAdd(&o->n_road, cnt_road);
         if (cnt_curb)
             atomicAdd(&o->n_curb, cnt_curb);
+    }
+}
+
+__global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(URF_LABEL_WAVES, URF_LABEL_WAVES))) void k_label(urf_kargs a, urf_dev_params dp)
+{
+    /* Workgroups are handed to the eight XCDs round robin, each XCD with its own L2.  The tiles of a
+     * scan all read the scan's window table (185 KB): spread over the XCDs every L2 fetched most of it
+     * (5.9 B per point of this kernel's 13.9); with the mapping below the tiles of one scan run on ONE
+     * XCD (eight scans at a time, one per XCD) and the table comes from memory once. */
+    unsigned s = blockIdx.y, t = blockIdx.x;
+    {
+        const unsigned T = gridDim.x, lin = blockIdx.y * T + blockIdx.x;
+        const unsigned grp = lin / (8u * T), r = lin - grp * (8u * T);
+        if ((grp + 1u) * 8u <= gridDim.y) {   /* a complete group of eight scans */
+            s = grp * 8u + (r & 7u);
+            t = r >> 3;
+        }
+    }
+    urf_label_tile(a, dp, s, t);
+}
+/* the scans the fused front end handed back (k_ring_list): persistent workgroups over list x tiles */
+__global__ __launch_bounds__(URF_LABEL_TILE_THREADS) void k_label_list(urf_kargs a, urf_dev_params dp)
+{
+    const unsigned n = a.star_count[6];
+    for (unsigned w = blockIdx.x; w < n * a.tiles; w += gridDim.x) {
+        urf_label_tile(a, dp, a.front_list[w / a.tiles], w % a.tiles);
+        __syncthreads();   /* the LDS is reused by the next tile */
     }
 }
 
