@@ -399,7 +399,7 @@ def other_configs(u, O, torch, ctx, stream, dev, dx, dy, dz, dl, di, X, Y, Z, S)
     # ---- sensor-like sweeps: what a driver delivers (range noise, 2 mm range steps, drop-outs) -- ~10 000 exact planar-range
     # ties per sweep, in EVERY star sector, whose order is libstdc++'s std::sort's (star_shaped_search.cpp:109): every sector
     # is sorted a second time by k_star_ties.  The headline's clouds are tie-free by SURVEY.md 8d's rule.
-    Ss = 256 if S >= 256 else S
+    Ss = S   # (r6: as many as the headline's step, so that the two rates compare)
     Xs = np.empty((Ss, N_PTS), np.float32)
     Ys = np.empty_like(Xs)
     Zs = np.empty_like(Xs)
@@ -420,6 +420,58 @@ def other_configs(u, O, torch, ctx, stream, dev, dx, dy, dz, dl, di, X, Y, Z, S)
                              "(sigma 1 cm), 2 mm range steps, 1.5 %% drop-outs, ~10 000 planar-range ties per sweep left in (every star sector "
                              "is sorted again in std::sort's order by k_star_ties), ROI +-200 m" % Ss, pickeds)
     del sx, sy, sz
+    # ---- the SAME cfg3 sweeps in the storage orders other drivers deliver (r6; the reference makes no assumption about the order,
+    # lidar_segmentation.cpp:100-117, 221-278).  laser_order: firing by firing, the 64 lasers of a firing in a fixed non-monotone
+    # order (a Velodyne's laser numbering) -- the fused front end learns the lane -> ring map; ring_major: row-major H x W, one ring
+    # after the other (an Ouster's organised cloud) and shuffled: neither is a sequence of firings, the general kernels take them.
+    # Equal input sets: labels are those of the firing-order sweep permuted, gated against oracle B on the permuted input.
+    def layout(name, index_of, note):
+        idx = torch.from_numpy(index_of.astype(np.int64)).to(dev)
+        lx, ly, lz = (t.index_select(1, idx).contiguous() for t in (dx, dy, dz))
+        torch.cuda.synchronize()   # (torch's own stream has written them; the library launches on `stream`)
+        ctx.set_params(p2)
+        fnl = lambda: ctx.classify_batch_soa(lx, ly, lz, N_PTS, S, dl, di)   # noqa: E731
+        fnl()
+        torch.cuda.synchronize()
+        pk = sorted(np.random.default_rng(17).choice(S, min(2, S), replace=False).tolist())
+        gate(lambda s: dl[s].cpu().numpy(), lambda s: (X[s][index_of], Y[s][index_of], Z[s][index_of]), p2, pk, name)
+        res[name] = run(ctx, fnl, N_PTS, S, 10, 2, note % S, pk)
+
+    rng_l = np.random.default_rng(23)
+    perm64 = rng_l.permutation(RINGS)
+    fir = np.arange(N_PTS).reshape(COLS, RINGS)
+    layout("laser_order", fir[:, perm64].reshape(-1), "the %d cfg3 sweeps with the 64 lasers of every firing in a fixed random order (laser-number order)")
+    layout("ring_major", fir.T.reshape(-1), "the %d cfg3 sweeps stored ring by ring (row-major 64 x 2048: an organised cloud as an Ouster's driver delivers it)")
+    layout("shuffled", rng_l.permutation(N_PTS), "the %d cfg3 sweeps with their points in one random order (an unorganised cloud)")
+    # ---- a batch in which every 8th sweep defeats the speculative ring table (r6): the reference's default region of interest, every
+    # 8th sweep stored from the rear -- no point of its first 8192 lies in the region, k_ring_table gives up with an empty table,
+    # the scan is repaired and split again inside the call (and handed back by the fused front end).  first_call_ms: the call that
+    # pays for the failed speculation; ms_per_step: the calls after it (the context has stopped speculating).
+    with u.Context(N_PTS, S, device=dev.index, params=p_roi) as ch:
+        ch.set_stream(stream.cuda_stream)
+        rear = torch.arange(0, S, 8, device=dev)
+        roll = torch.from_numpy(np.roll(fir, COLS // 2, axis=0).reshape(-1).astype(np.int64)).to(dev)
+        hx, hy, hz = (t.clone() for t in (dx, dy, dz))
+        for t in (hx, hy, hz):
+            t[rear] = t[rear].index_select(1, roll)
+        torch.cuda.synchronize()
+        fnh = lambda: ch.classify_batch_soa(hx, hy, hz, N_PTS, S, dl, di)   # noqa: E731
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        fnh()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        first_ms = e0.elapsed_time(e1)
+        fused_first = ch.front_scans()
+        roll_np = np.roll(fir, COLS // 2, axis=0).reshape(-1)
+        pk = [0, 8, 5] if S > 8 else [0]
+        gate(lambda s: dl[s].cpu().numpy(), lambda s: ((X[s][roll_np], Y[s][roll_np], Z[s][roll_np]) if s % 8 == 0 else (X[s], Y[s], Z[s])),
+             p_roi, pk, "heterogeneous")
+        res["heterogeneous"] = run(ch, fnh, N_PTS, S, 10, 2, "batch of %d default-ROI sweeps, every 8th stored from the rear: the speculative ring table "
+                                   "of those fails (repaired in the call; the fused front end hands them back)" % S, pk)
+        res["heterogeneous"]["first_call_ms"] = round(first_ms, 4)
+        res["heterogeneous"]["front_scans_first_call"] = fused_first
+        del hx, hy, hz
     return res
 
 
@@ -596,7 +648,8 @@ def main():
             "dtype": "f32+f64",
             "data": "synthetic",
             "config": {"workload": wl["text"] % S,
-                       "scans_per_gpu": S, "points_per_scan": N_PTS, "sharding": "one batch per GPU, no data-path collective"},
+                       "scans_per_gpu": S, "points_per_scan": N_PTS,
+                       "sharding": "one batch per GPU (rank r classifies the contiguous seed block r*S+1 .. (r+1)*S), no data-path collective"},
             "hbm_roofline_frac_whole_pipeline": round(whole / HBM_PEAK_GBS, 5),   # 13 B/point x points/s over the WHOLE step / 8 TB/s: the honest figure
             "roofline": {"bound": "hbm", "whole_pipeline_frac": round(whole / HBM_PEAK_GBS, 5), "whole_pipeline_achieved": round(whole, 2),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -646,6 +699,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         if world == 1 and args.workload == "cfg3" and not args.no_other_configs:
+            # (the outputs above read ring-sorted intermediate results: the context ran the batch again through the general kernels and
+            # would stay with them -- include/urf.h; the configurations below are timed as a caller without those outputs sees them)
+            ctx.set_front_mode(args.front if args.front >= 0 else 1)
             out["other_configs"] = other_configs(u, O, torch, ctx, stream, dev, dx, dy, dz, dl, di, X, Y, Z, S)
         if world == 1 and not args.no_e2e and args.workload == "cfg3":
             ctx.close()   # the batch context's scratch is not needed any more

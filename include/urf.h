@@ -391,7 +391,10 @@ int urf_enable_stage_capture(urf_ctx* ctx, int mode);
  * batch call it applies to.  urf_read_stage / urf_ordered_indices* / urf_marker_points* read ring-sorted intermediate
  * results: after a call that took the fused front end they first run that call again through the general kernels
  * (the call's INPUT arrays must then still be alive, like its label buffer), and the context stays with the general
- * kernels afterwards (until mode 2 is set again).  urf_front_scans: how many scans of the last batch call took the
+ * kernels afterwards (until urf_set_front_mode is called again with a mode other than 0).  A context that has handed a
+ * scan back launches the general kernels as full grids next to the fused ones from then on, and one that has handed a
+ * whole batch back (unorganised clouds) stops trying in mode 1; urf_set_params with other parameters and
+ * urf_set_front_mode with another mode forget both.  urf_front_scans: how many scans of the last batch call took the
  * fused front end (synchronises). */
 int urf_set_front_mode(urf_ctx* ctx, int mode);
 int urf_front_scans(urf_ctx* ctx, uint32_t* n_fused);

@@ -1,0 +1,239 @@
+"""The fused front end for batches of sweeps in firing order (urban_road_filter_amd/csrc/urf_front.hpp: k_front, k_front_finish,
+k_label_front) through the C ABI: labels and summaries against oracle B -- on sweeps that take it (analytic and sensor-like, with
+drop-outs, cut by the reference's default region of interest, lasers in any fixed order inside a firing, partial last tiles), on
+sweeps that must NOT take it (stored from another column, shuffled, points on the sensor's axis) next to ones that do, through the
+list-driven and the full-grid legacy kernels; what the context does around it (urf_set_front_mode, urf_front_scans, the entry
+points that read ring-sorted intermediate results)."""
+import numpy as np
+import pytest
+
+import oracles as O
+import urban_road_filter_amd as u
+from fuzz_organised import case
+from hipmem import DevBuf
+from test_gpu_parity import check_against_b, run_batch
+
+pytestmark = pytest.mark.gpu
+N = 64 * 2048
+
+
+def fused_batch(ctx, scans, p, mode=2, ragged=False):
+    ctx.set_front_mode(mode)
+    labels, infos = run_batch(ctx, scans, p, ragged=ragged)
+    return labels, infos, ctx.front_scans()
+
+
+def permuted(cloud, perm):
+    """The lasers of every firing in another (fixed) order: what a driver that reports in laser-number order delivers."""
+    return tuple(np.ascontiguousarray(a.reshape(-1, 64)[:, perm].reshape(-1)) for a in cloud)
+
+
+def rolled(cloud, cols):
+    return tuple(np.ascontiguousarray(np.roll(a.reshape(-1, 64), cols, axis=0).reshape(-1)) for a in cloud)
+
+
+@pytest.mark.parametrize("name,seeds", [("cfg2", (1, 2, 3, 4)), ("narrow", (1, 2, 3)), ("sensor", (1, 2, 3, 4)), ("sensor_narrow", (1, 2)),
+                                        ("default_roi", (1, 2, 3)), ("sensor_default_roi", (1, 2))])
+def test_sweeps_in_firing_order_take_the_fused_front_end(name, seeds):
+    p = O.cfg_params(name)
+    scans = [O.cfg_cloud(name, s) for s in seeds]
+    with u.Context(N, len(scans)) as ctx:
+        labels, infos, nf = fused_batch(ctx, scans, p)
+        assert nf == len(scans)
+        check_against_b(labels, infos, scans, p)
+        labels, infos, nf = fused_batch(ctx, scans[::-1], p)   # other batch positions, the row's previous ring count as a hint
+        assert nf == len(scans)
+        check_against_b(labels, infos, scans[::-1], p)
+
+
+def test_lasers_in_any_fixed_order():
+    """Lane l of a firing is laser l, whatever table entry that laser sits on: learned from the lane's first point."""
+    p = O.cfg_params("sensor")
+    perm = np.random.default_rng(5).permutation(64)
+    scans = [permuted(O.cfg_cloud("sensor", s), perm) for s in (1, 2)] + [permuted(O.cfg_cloud("cfg2", 3), perm[::-1].copy())]
+    with u.Context(N, len(scans)) as ctx:
+        labels, infos, nf = fused_batch(ctx, scans, p)
+        assert nf == len(scans)
+        check_against_b(labels, infos, scans, p)
+
+
+@pytest.mark.parametrize("tweak", [{"xDirection": 1}, {"xDirection": 2}, {"starbeam_filter": 1}, {"star_shaped_method": 0},
+                                   {"x_zero_method": 0}, {"z_zero_method": 0}, {"blind_spots": 0}, {"curbHeight": 0.01},
+                                   {"interval": 0.1, "angleFilter1": 120.0, "angleFilter2": 100.0}])
+def test_parameters(tweak):
+    """(curbHeight 0.01: rings with more curb points than their list holds -- the per-degree tables of k_front_finish)"""
+    p = O.cfg_params("cfg2")
+    for k, v in tweak.items():
+        setattr(p, k, v)
+    scans = [O.cfg_cloud("narrow", 1), O.cfg_cloud("sensor", 2), O.cfg_cloud("cfg2", 3)]
+    with u.Context(N, len(scans)) as ctx:
+        labels, infos, nf = fused_batch(ctx, scans, p)
+        assert nf == len(scans)
+        check_against_b(labels, infos, scans, p)
+
+
+def test_scans_without_the_shape_are_handed_back():
+    """A shuffled sweep and one stored from another column (its sectors fall inside a tile) between organised ones: the legacy
+    kernels take them in the same call -- list-driven on a context that has not seen such a scan, as full grids afterwards."""
+    p = O.cfg_params("cfg2")
+    x, y, z = O.cfg_cloud("cfg2", 3)
+    pm = np.random.default_rng(1).permutation(len(x))
+    scans = [O.cfg_cloud("cfg2", 1), (x[pm], y[pm], z[pm]), O.cfg_cloud("sensor", 2), rolled(O.cfg_cloud("narrow", 4), 700)]
+    with u.Context(N, len(scans)) as ctx:
+        for _ in range(3):   # first call: lists; then grids
+            labels, infos, nf = fused_batch(ctx, scans, p)
+            assert nf == 2
+            check_against_b(labels, infos, scans, p)
+        labels, infos, nf = fused_batch(ctx, scans, p, mode=0)
+        assert nf == 0
+        check_against_b(labels, infos, scans, p)
+
+
+def test_a_batch_of_unorganised_clouds_switches_it_off():
+    """Every scan handed back: the context stops trying (mode 1), urf_set_front_mode starts over."""
+    p = O.cfg_params("cfg2")
+    rng = np.random.default_rng(3)
+    scans = []
+    for s in range(3):
+        x, y, z = O.cfg_cloud("cfg2", 10 + s)
+        pm = rng.permutation(len(x))
+        scans.append((x[pm], y[pm], z[pm]))
+    good = [O.cfg_cloud("cfg2", 20 + s) for s in range(3)]
+    with u.Context(N, 3) as ctx:
+        ctx.set_front_mode(2)
+        labels, infos, nf = fused_batch(ctx, scans, p)
+        assert nf == 0
+        check_against_b(labels, infos, scans, p)
+        ctx.set_front_mode(1)
+        labels, infos = run_batch(ctx, good, p)          # (mode 1: fewer than 32 scans never take it anyway)
+        assert ctx.front_scans() == 0
+        check_against_b(labels, infos, good, p)
+        labels, infos, nf = fused_batch(ctx, good, p)    # mode 2 again: a new start
+        assert nf == 3
+        check_against_b(labels, infos, good, p)
+
+
+def test_rear_stored_default_roi_sweeps_repair_their_ring_table():
+    """The speculative ring table of a sweep stored from the rear is incomplete; k_front notices like k_split does, the scan is
+    repaired and split the legacy way in the same call."""
+    p = O.cfg_params("default_roi")
+    scans = [rolled(O.cfg_cloud("default_roi", s), 1024) for s in (1, 2)] + [O.cfg_cloud("default_roi", 3)]
+    for _ in range(2):
+        with u.Context(N, len(scans)) as ctx:
+            labels, infos, nf = fused_batch(ctx, scans, p)
+            assert nf == 1
+            check_against_b(labels, infos, scans, p)
+            labels, infos, nf = fused_batch(ctx, scans, p)   # (the context has stopped speculating on the ring table)
+            check_against_b(labels, infos, scans, p)
+
+
+@pytest.mark.parametrize("cols", [96, 40, 33, 2047])
+def test_partial_last_tile_and_ragged_batches(cols):
+    p = O.cfg_params("cfg2")
+    a = u.synth_cloud(64, cols, 1, 7)
+    b = u.synth_cloud(64, 512, 3, 8)
+    scans = [a, b, tuple(v[:64 * 300 + 17].copy() for v in b)]   # (the last one ends inside a firing)
+    with u.Context(64 * 2048, len(scans)) as ctx:
+        labels, infos, nf = fused_batch(ctx, scans, p, ragged=True)
+        assert nf >= 2
+        check_against_b(labels, infos, scans, p)
+
+
+def test_points_on_the_axis_and_too_few_points():
+    """A ring point with x == y == 0 (NaN azimuth: k_nan_rings, legacy kernels) and a scan below the 30-point threshold."""
+    p = O.cfg_params("cfg2")
+    a = tuple(v.copy() for v in O.cfg_cloud("cfg2", 5))
+    a[0][64 * 100 + 7] = 0.0
+    a[1][64 * 100 + 7] = 0.0
+    few = tuple(v.copy() for v in O.cfg_cloud("cfg2", 6))
+    few[0][29:] = 1.0e6
+    scans = [a, few, O.cfg_cloud("sensor", 7)]
+    with u.Context(N, len(scans)) as ctx:
+        ctx.set_front_mode(2)
+        labels, infos = run_batch(ctx, scans, p)
+        for k, (x, y, z) in enumerate(scans):
+            lb, ib, _ = O.run_b(x, y, z, p)
+            assert np.array_equal(labels[k], lb), k
+            assert int(np.int32(infos[k][0])) == ib["status"] and all(int(infos[k][j]) == ib[f] for j, f in
+                                                                       ((1, "n_roi"), (4, "n_road"), (5, "n_curb"), (7, "n_nan_azimuth"))), k
+        assert ctx.front_scans() == 2   # (the too-few scan keeps its flag: nothing is published for it either way)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_organised_sweeps_with_holes(seed):
+    """tests/fuzz_organised.py through the fused front end (curbPoints != 5 takes the legacy kernels)."""
+    (x, y, z), p = case(7_300_000 + seed)
+    lb, ib, _ = O.run_b(x, y, z, p)
+    with u.Context(len(x), 1) as ctx:
+        labels, infos, nf = fused_batch(ctx, [(x, y, z)], p)
+    assert np.array_equal(labels[0], lb), "%d labels differ (fused %d)" % (int((labels[0] != lb).sum()), nf)
+    keys = ("status", "n_roi", "n_rings", "n_ring_pts", "n_road", "n_curb", "n_ring10")
+    assert {f: int(v) for f, v in zip(keys, infos[0][:7])} == {f: ib[f] for f in keys}
+    assert p.curbPoints == 5 or nf == 0
+
+
+def test_ring_sorted_results_after_a_fused_call():
+    """urf_ordered_indices / urf_marker_points / urf_read_stage read ring-sorted intermediate results: the call is run again
+    through the legacy kernels, the context stays with them."""
+    p = O.cfg_params("cfg2")
+    scans = [O.cfg_cloud("sensor", 1), O.cfg_cloud("narrow", 2)]
+    with u.Context(N, 2) as ctx:
+        X, Y, Z = (np.concatenate([s[k] for s in scans]) for k in range(3))
+        dx, dy, dz = DevBuf.from_numpy(X), DevBuf.from_numpy(Y), DevBuf.from_numpy(Z)
+        dl = DevBuf(2 * N)
+        ctx.set_params(p)
+        ctx.set_front_mode(2)
+        ctx.classify_batch_soa(dx, dy, dz, N, 2, dl, None)
+        assert ctx.front_scans() == 2
+        for k, (x, y, z) in enumerate(scans):
+            lb, ib, st = O.run_b(x, y, z, p, debug=True)
+            road, curb, prob = ctx.ordered_indices(N, scan=k)
+            assert np.array_equal(road, st["road_order"]) and np.array_equal(curb, st["curb_order"]) and np.array_equal(prob, st["ring10_order"])
+            assert np.array_equal(ctx.marker_points(scan=k), st["marker_pts"])
+            assert np.array_equal(ctx.read_stage(u.STAGE_DETECT, N, scan=k), st["detect"])
+            assert np.array_equal(dl.to_numpy(np.uint8).reshape(2, N)[k], lb)
+        assert ctx.front_scans() == 0                      # (the call was run again through the legacy kernels)
+        ctx.set_front_mode(1)
+        ctx.classify_batch_soa(dx, dy, dz, N, 2, dl, None)
+        assert ctx.front_scans() == 0                      # ... and the context stays with them
+        ctx.set_front_mode(2)
+        ctx.classify_batch_soa(dx, dy, dz, N, 2, dl, None)
+        assert ctx.front_scans() == 2
+
+
+def test_stage_capture_and_other_shapes_keep_the_legacy_kernels():
+    p = O.cfg_params("cfg2")
+    scans = [O.cfg_cloud("cfg2", 1)]
+    with u.Context(N, 1) as ctx:
+        ctx.enable_stage_capture(2)
+        labels, infos, nf = fused_batch(ctx, scans, p)
+        assert nf == 0
+        check_against_b(labels, infos, scans, p)
+        ctx.enable_stage_capture(0)
+        p9 = O.cfg_params("cfg2")
+        p9.curbPoints = 9
+        labels, infos, nf = fused_batch(ctx, scans, p9)
+        assert nf == 0
+        check_against_b(labels, infos, scans, p9)
+    p5 = O.cfg_params("cfg5")
+    with u.Context(128 * 1024, 1) as ctx:
+        c5 = u.synth_cloud(128, 1024, 1, 3)
+        labels, infos, nf = fused_batch(ctx, [c5], p5)
+        assert nf == 0
+        check_against_b(labels, infos, [c5], p5)
+
+
+def test_mode_one_takes_batches_of_32_scans():
+    p = O.cfg_params("cfg2")
+    base = [u.synth_cloud(64, 256, 1 + (s % 2) * 2, 50 + s) for s in range(8)]
+    scans = [base[s % 8] for s in range(40)]
+    with u.Context(64 * 256, 40) as ctx:
+        ctx.set_front_mode(1)
+        labels, infos = run_batch(ctx, scans, p)
+        assert ctx.front_scans() == 40
+        check_against_b(labels[:8], infos[:8], scans[:8], p)
+        for s in range(8, 40):
+            assert np.array_equal(labels[s], labels[s % 8]) and np.array_equal(infos[s], infos[s % 8])
+        labels, infos = run_batch(ctx, scans[:31], p)
+        assert ctx.front_scans() == 0
+        check_against_b(labels[:8], infos[:8], scans[:8], p)

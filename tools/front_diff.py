@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--scene", type=int, default=1)
     ap.add_argument("--params", default="cfg2")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--perm", type=int, default=-1, help="seed of a fixed permutation of the 64 lasers inside every firing")
+    ap.add_argument("--oracle", default="", help="comma-separated scans to compare with oracle B as well")
     ap.add_argument("--fresh", type=int, default=0, help="this many fresh contexts whose FIRST call takes the fused front end")
     a = ap.parse_args()
     S, n = a.scans, 64 * 2048
@@ -34,6 +36,9 @@ def main():
 
     with cf.ThreadPoolExecutor(max_workers=32) as ex:
         list(ex.map(one, range(S)))
+    if a.perm >= 0:
+        pm = np.random.default_rng(a.perm).permutation(64)
+        X, Y, Z = (np.ascontiguousarray(v.reshape(S, 2048, 64)[:, :, pm].reshape(S, n)) for v in (X, Y, Z))
     p = oracles.cfg_params(a.params)
     ctx = u.Context(n, S, params=p)
     dx, dy, dz = DevBuf.from_numpy(X), DevBuf.from_numpy(Y), DevBuf.from_numpy(Z)
@@ -44,6 +49,11 @@ def main():
     L0 = dl.to_numpy(np.uint8).reshape(S, n).copy()
     I0 = di.to_numpy(np.uint32).reshape(S, 8).copy()
     total_bad = 0
+    for sc in [int(v) for v in a.oracle.split(",") if v]:
+        lb, ib, _ = oracles.run_b(X[sc], Y[sc], Z[sc], p)
+        d = np.nonzero(L0[sc] != lb)[0]
+        print("oracle vs legacy scan %d: %d labels differ %s legacy %s oracle %s" % (sc, len(d), d[:10], L0[sc][d[:10]], lb[d[:10]]), flush=True)
+        total_bad += len(d) > 0
     for rep in range(a.reps):
         dl.fill(0xEE)
         ctx.set_front_mode(2)

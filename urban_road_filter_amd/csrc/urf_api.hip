@@ -513,8 +513,8 @@ extern "C" int urf_set_front_mode(urf_ctx* c, int mode)
         c->h_spec_failed[2] = c->h_spec_failed[3] = 0;
     }
     c->front_mode = mode;
-    if (mode == 2)
-        c->want_ring_sorted = false;
+    if (mode != 0)
+        c->want_ring_sorted = false;   /* (a caller that asks for ring-sorted results again pays for them again) */
     return URF_OK;
 }
 

@@ -78,6 +78,34 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t urf_buf(const void* p, unsigne
 }
 #define URF_OOB 0xffffffffu
 
+/* What the fast decisions of a firing leave open -- a point that is not SURELY on its lane's table entry, whose sector is within
+ * the margin of a border, or that the approximations refuse: the reference's exact sequence (urf_exact_keys).  Returns bit 0: on
+ * the lane's ring; bits 1-11: sector + 1 (0: none wanted); bits 12-18 + URF_FO_ADOPT: the lane has no confirmed entry yet and the
+ * point lies on this one; URF_FO_NONE: on no ring; URF_FO_FAIL: the scan does not have the shape (one lane, two rings; a ring point
+ * on the sensor's axis, whose azimuth is NaN: k_nan_rings, legacy path).  NOT inlined: a call under a branch that is rarely
+ * taken, and nothing the hot path keeps in registers depends on what happens in here. */
+#define URF_FO_ADOPT 0x20000000u
+#define URF_FO_NONE 0x40000000u
+#define URF_FO_FAIL 0x80000000u
+__device__ __noinline__ unsigned urf_front_open(const float* tab, unsigned nR, float interval, float x, float y, float z, unsigned sectors, float Kfi,
+                                                unsigned E, unsigned econf)
+{
+    const urf_exact_key ek = urf_exact_keys_body(tab, nR, interval, x, y, z, sectors, Kfi);
+    unsigned r = sectors ? ((ek.sector + 1u) & 0x7ffu) << 1 : 0u;
+    if (ek.ring == URF_RING_NONE)
+        r |= URF_FO_NONE;
+    else if (x == 0.0f && y == 0.0f)
+        r |= URF_FO_FAIL;
+    else if (ek.ring == E)
+        r |= 1u;
+    else if (!econf)
+        r |= 1u | URF_FO_ADOPT | (ek.ring << 12);
+    else
+        r |= URF_FO_FAIL;
+    return r;
+}
+__device__ __noinline__ float urf_sqrtf_generic(float x) { return __builtin_sqrtf(x); }
+
 /* the wave's candidate buffer (LDS; the workgroup IS the wave) and its flush into the scan's list: one atomic per ~150 candidates */
 #define URF_FRONT_CBUF 256u
 __device__ __forceinline__ void urf_front_flush(const urf_kargs& a, unsigned s, urf_u2* cbuf, unsigned& ncb, bool& overflow)
@@ -173,7 +201,7 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
         const float rho2 = x * x + y * y;
         const float u = -z * __builtin_amdgcn_rsqf(rho2);   /* urf_fast_cot */
         const bool fast = (rho2 >= URF_FAST_MIN2) & (rho2 <= URF_FAST_MAX2) & (__builtin_fabsf(u) <= URF_LUT_UMAX) & roi;
-        bool on = fast & (u >= th.y) & (u <= th.z) & (u < th.below);
+        const bool on_f = fast & (u >= th.y) & (u <= th.z) & (u < th.below);
         float fi = 0.f;
         int fs = -1;
         if (PH == 1u) {
@@ -181,25 +209,21 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
             if (STAR)
                 fs = fast ? urf_fast_sector_ranged(fi, dp.Kfi, K, dp.sector_margin) : -1;
         }
-        const bool open = roi & (!on | (PH == 1u && STAR && fs < 0));
+        bool on = on_f;
+        const bool open = roi & !(on_f & (PH != 1u || !STAR || fs >= 0));
         if (__ballot(open) != 0ull) {   /* (uniform) rare: the reference's exact sequence for the lanes that need it */
-            if (open) {
-                const urf_exact_key ek = urf_exact_keys_front(tab, nR, dp.p.interval, x, y, z, (PH == 1u && STAR) ? K : 0u, dp.Kfi);
-                fs = (int)ek.sector;
-                if (ek.ring == URF_RING_NONE) {
-                    on = false;
-                    if (PH == 1u && i >= upto)
-                        a.table_redo[s] = 1u;   /* the speculative ring table is incomplete (k_table_repair, legacy path) */
-                } else if (x == 0.0f && y == 0.0f) {
-                    failed = true;              /* a ring point on the sensor's axis: NaN azimuth (k_nan_rings, legacy path) */
-                } else if (ek.ring == E) {
-                    on = true;
-                } else if (!econf) {
-                    E = ek.ring;                /* this lane's laser sits on another table entry: learned from its first point */
+            unsigned r = 0;
+            if (open)
+                r = urf_front_open(tab, nR, dp.p.interval, x, y, z, (PH == 1u && STAR) ? K : 0u, dp.Kfi, E, econf ? 1u : 0u);
+            on = open ? (r & 1u) != 0u : on;
+            fs = open ? (int)((r >> 1) & 0x7ffu) - 1 : fs;
+            failed = failed | (open & ((r & URF_FO_FAIL) != 0u));
+            if (PH == 1u && open && (r & URF_FO_NONE) && i >= upto)
+                a.table_redo[s] = 1u;   /* the speculative ring table is incomplete (k_table_repair, legacy path) */
+            if (__ballot(open && (r & URF_FO_ADOPT)) != 0ull) {   /* (uniform) this lane's laser sits on another table entry: learned from its first point */
+                if (open && (r & URF_FO_ADOPT)) {
+                    E = (r >> 12) & 0x7fu;
                     th = urf_front_load_thr(a, s, C, E, nR);
-                    on = true;
-                } else {
-                    failed = true;              /* one lane, two rings */
                 }
             }
         }
@@ -223,7 +247,7 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
                 const unsigned o4 = ons ? so * 4u : URF_OOB;
                 float pr = urf_sqrt_rn_normal(rho2);   /* star_shaped_search.cpp:164: sqrtf(x * x + y * y) */
                 if (__ballot(ons & !((rho2 >= 0x1p-90f) & (rho2 <= 0x1p126f))) != 0ull)   /* (uniform; practically never) */
-                    pr = __builtin_sqrtf(rho2);
+                    pr = urf_sqrtf_generic(rho2);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pr), bsr, o4, 0, 2);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), bsz, o4, 0, 2);
                 __builtin_amdgcn_raw_buffer_store_b16((short)(on ? stp * 64u + lane : URF_SLOT_NONE), bss, ons ? so * 2u : URF_OOB, 0, 2);

@@ -598,12 +598,6 @@ __device__ URF_EXACT_INLINE urf_exact_key urf_exact_keys(const float* tab, unsig
 {
     return urf_exact_keys_body(tab, nR, interval, x, y, z, sectors, Kfi);
 }
-/* (k_front's own instance: a function shared with k_split takes its register budget from both callers) */
-__device__ __noinline__ urf_exact_key urf_exact_keys_front(const float* tab, unsigned nR, float interval, float x, float y, float z,
-                                                           unsigned sectors, float Kfi)
-{
-    return urf_exact_keys_body(tab, nR, interval, x, y, z, sectors, Kfi);
-}
 
 /* timing experiment (tools/ab_noparity.sh): wave 0 of a few workgroups in the middle of the grid prints
  * the shader-clock cycles between the kernel's barriers */
@@ -3150,7 +3144,7 @@ __device__ __forceinline__ int urf_walk_report(const urf_kargs& a, unsigned s, u
 {
     int hit = -1;
     unsigned v = 0xffffffffu;
-    if (hit_i) {
+    if (hit_i && hit_i < n) {   /* (an index behind the sector would read behind its stretch of the arrays) */
         const urf_sec_run two = a.sec_run[(size_t)s * K + k];
         if (two.nruns <= 2 && n <= URF_STAR_MID_CAP_) {
             const unsigned i0 = a.ssrt16[base + hit_i];
@@ -3259,7 +3253,9 @@ __device__ __forceinline__ void urf_walk_twins(const urf_kargs& a, unsigned s, u
 {
     if (hit_i == 0 || (sf & URF_TIE_DONE) || hit_i + 1 >= n)
         return;
-    const bool twin = hit_i == (sf & URF_TIE_INDEX) ? (sf & URF_TIE_NEXT) != 0u : a.wsg[base + hit_i + 1].g == 0.0f;
+    const float gn = a.wsg[base + hit_i + 1].g;
+    /* (not greater, not smaller: a NaN -- 0 * inf with a non-finite kdist_param -- counts as a twin and costs one sector of the second pass) */
+    const bool twin = hit_i == (sf & URF_TIE_INDEX) ? (sf & URF_TIE_NEXT) != 0u : !(gn > 0.0f || gn < 0.0f);
     if (!twin)
         return;
     a.star_first[(size_t)s * K + k] = URF_TIE_POST | hit_i;
@@ -3450,7 +3446,9 @@ __global__ __launch_bounds__(URF_WALK_FEW_THREADS) void k_star_walk_few(urf_karg
     __shared__ unsigned ctl[2], nan_at, fin_hit[64], fin_lim[64];
     const unsigned K = (unsigned)dp.p.sectors;
     const unsigned s = blockIdx.y, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    if (a.info[s].status != URF_OK)
+    /* (ONE decision for the workgroup: another workgroup of the scan may void it -- urf_walk_twins, URF_STATUS_REDO_TIES -- between the
+     * loads of this one's five waves, and a wave that carried on alone would read what nobody wrote) */
+    if (__syncthreads_or(a.info[s].status != URF_OK))
         return;
     const urf_walk_sectors q = urf_walk_prologue(a, s, K, lane, wave == 0);
     if (threadIdx.x == 0) {
