@@ -787,7 +787,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     else
         hipLaunchKernelGGL(k_ring_general, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
     if (a.front)
-        hipLaunchKernelGGL(k_front_finish, g_scan, dim3(URF_FINISH_THREADS), (size_t)a.tiles * 384 > 4096 ? (size_t)a.tiles * 384 : 4096, st, a, dp);
+        hipLaunchKernelGGL(k_front_finish, g_scan, dim3(URF_FINISH_THREADS), (size_t)a.tiles * 384 + 2 * URF_FINISH_CHUNK * sizeof(urf_u2), st, a, dp);
     /* the rings that hold a point with a NaN azimuth (k_split listed them: normally none, the kernel returns at once) */
     if (!(a.optimistic & URF_OPT_NO_NAN))
         hipLaunchKernelGGL(k_nan_rings, dim3(32), dim3(256), URF_NAN_LDS * sizeof(unsigned long long), st, a, dp);

@@ -48,6 +48,11 @@
 #define URF_FC_ZZ 2u       /* passed z_zero's as the centre */
 #define URF_FC_EDGE_X 4u   /* x_zero not evaluated by the march (window incomplete at a block border): everything pending */
 #define URF_FC_EDGE_Z 8u
+#ifndef URF_FRONT_NT
+#define URF_FRONT_NT 0   /* cache policy of k_front's stores (2 = non-temporal).  A sweep with drop-outs compacts its star records, a step's 64 stores then straddle
+                          * cache lines that the next step completes: non-temporal, such half-written lines left the L2 at once (the address queue in
+                          * front of it full 18 x as often as on a sweep without holes, k_front 1.50 ms per 1024 sensor-like sweeps against 0.98) */
+#endif
 #ifndef URF_FRONT_WAVES
 #define URF_FRONT_WAVES 5   /* 88 registers; at 6 (80) the kernel reloads a spilled constant in every step, behind an s_waitcnt vmcnt(0) that drains its prefetch */
 #endif
@@ -104,7 +109,6 @@ __device__ __noinline__ unsigned urf_front_open(const float* tab, unsigned nR, f
         r |= URF_FO_FAIL;
     return r;
 }
-__device__ __noinline__ float urf_sqrtf_generic(float x) { return __builtin_sqrtf(x); }
 
 /* the wave's candidate buffer (LDS; the workgroup IS the wave) and its flush into the scan's list: one atomic per ~150 candidates */
 #define URF_FRONT_CBUF 256u
@@ -232,7 +236,7 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
             /* the record, input order: ring | azimuth code (URF_REC_*; detector hits are OR-ed in by k_front_finish) */
             const unsigned azc_v = urf_az_code(urf_fast_azimuth_of(fi));   /* (unconditionally, then a select: a branch around eight instructions costs more) */
             const unsigned azc = urf_fast_az_ok(x, y) ? azc_v : URF_REC_AZ_UNKNOWN;
-            __builtin_amdgcn_raw_buffer_store_b32((azc << URF_REC_AZ_SHIFT) | (on ? E : URF_FRONT_RING_NONE), brec, i * 4u, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b32((azc << URF_REC_AZ_SHIFT) | (on ? E : URF_FRONT_RING_NONE), brec, i * 4u, 0, URF_FRONT_NT);
             if (STAR) {
                 /* star-shaped search: the firing's participants share one sector */
                 unsigned sk = (unsigned)fs;
@@ -245,12 +249,11 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
                 failed = failed | (ons & (sk != f0));
                 const unsigned so = (f / URF_FRONT_STEPS) * URF_TILE + tstar + urf_popc_below(psm);
                 const unsigned o4 = ons ? so * 4u : URF_OOB;
-                float pr = urf_sqrt_rn_normal(rho2);   /* star_shaped_search.cpp:164: sqrtf(x * x + y * y) */
-                if (__ballot(ons & !((rho2 >= 0x1p-90f) & (rho2 <= 0x1p126f))) != 0ull)   /* (uniform; practically never) */
-                    pr = urf_sqrtf_generic(rho2);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pr), bsr, o4, 0, 2);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), bsz, o4, 0, 2);
-                __builtin_amdgcn_raw_buffer_store_b16((short)(on ? stp * 64u + lane : URF_SLOT_NONE), bss, ons ? so * 2u : URF_OOB, 0, 2);
+                const float pr = urf_sqrt_rn_normal(rho2);   /* star_shaped_search.cpp:164: sqrtf(x * x + y * y) */
+                failed = failed | (ons & !((rho2 >= 0x1p-90f) & (rho2 <= 0x1p126f)));   /* (outside the shortcut's interval: the legacy kernels) */
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pr), bsr, o4, 0, URF_FRONT_NT);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), bsz, o4, 0, URF_FRONT_NT);
+                __builtin_amdgcn_raw_buffer_store_b16((short)(on ? stp * 64u + lane : URF_SLOT_NONE), bss, ons ? so * 2u : URF_OOB, 0, URF_FRONT_NT);
                 stepkey_v = lane == stp ? (int)f0 : stepkey_v;
                 stepcnt_v = lane == stp ? (int)__popcll(psm) : stepcnt_v;
                 tstar += (unsigned)__popcll(psm);
@@ -430,6 +433,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(URF_FRONT_WA
 /* ------------------------------------------------------------------------- */
 /* k_front_finish                                                              */
 /* ------------------------------------------------------------------------- */
+#define URF_FINISH_CHUNK 768u   /* candidates per chunk (each may be listed twice): 12 KB of LDS */
 #ifndef URF_FINISH_THREADS
 #define URF_FINISH_THREADS 256   /* four waves and <= 40 KB of LDS per scan: four workgroups per CU, a batch of 1024 scans in one round (A/B 256 / 512 /
                                     * 1024 threads: cfg3 0.186 / 0.184 / 0.206 ms, the reference's default region of interest 0.210 / 0.241 / 0.264) */
@@ -437,10 +441,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(URF_FRONT_WA
 struct urf_finish_shared {
     unsigned n[64];              /* ring points of lane l */
     unsigned ring[64];           /* its ring (0xffffffff: the lane holds no ring point) */
-    unsigned ncurb[URF_FRONT_LANES];   /* (the fused front end runs with 64 channels) */
-    float curb[URF_FRONT_LANES][URF_CURB_LIST];
+    unsigned ncurb[URF_FRONT_LANES];   /* curb points of ring r (the fused front end runs with 64 channels) */
     int q[4];
-    unsigned n_all;              /* entries of the scan's list of all curb points */
+    unsigned n_pend;             /* entries of the scan's list of points to mark */
+    unsigned nx, nz;             /* x_zero / z_zero items of the chunk at hand */
     unsigned qsum[URF_FINISH_THREADS / 64][64];
 };
 
@@ -486,6 +490,7 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
         return;
     unsigned* const P = sh_finish;
     uint16_t* const B = (uint16_t*)(sh_finish + a.tiles * 64u);
+    urf_u2* const chunk = (urf_u2*)(sh_finish + a.tiles * 96u);   /* [2 * URF_FINISH_CHUNK] a chunk of the candidate list, by kind */
     const unsigned sb = urf_sbase(a, s);
     const float* __restrict__ const gx = a.x + off;
     const float* __restrict__ const gy = a.y + off;
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
     const urf_u2* const cand = a.front_cand + (size_t)s * a.front_cand_cap;
     const unsigned nc_raw = a.front_ncand[s];
     const unsigned nc = nc_raw < a.front_cand_cap ? nc_raw : a.front_cand_cap;
-    urf_u2 cd_next = tid < nc ? cand[tid] : urf_u2{ 0u, 0u };   /* (requested with everything else the workgroup needs first) */
+    URF_PHASE_DECL;
     for (unsigned k = tid; k < ntiles * 64u; k += URF_FINISH_THREADS)
         P[k] = a.front_pres[(size_t)s * a.tiles * 64u + k];
     if (tid < URF_FRONT_LANES)
@@ -505,9 +510,10 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
         S.q[1] = (int)urf_fbits(180.f);
         S.q[2] = (int)urf_fbits(180.f);
         S.q[3] = (int)urf_fbits(360.f);
-        S.n_all = 0;
+        S.n_pend = 0;
     }
     __syncthreads();
+    URF_PHASE_MARK;
     /* positions: the tiles in as many stretches as the workgroup has waves, per lane; then the stretches' sums */
     {
         constexpr unsigned NP = URF_FINISH_THREADS / 64u;
@@ -534,6 +540,7 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
     if (tid < C)
         a.ring_cnt[(size_t)s * C + tid] = 0;
     __syncthreads();
+    URF_PHASE_MARK;
     if (tid < 64) {
         const unsigned r = S.ring[tid], n = r != 0xffffffffu ? S.n[tid] : 0u;
         unsigned tot = n;
@@ -560,142 +567,192 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
         if (tid == 0)
             a.info[s].n_ring_pts = tot;
     }
-    /* A ring point that has a detector's mark: its record's flag (whoever sets the first one lists the point), the reference's
-     * azimuth, its ring's list, ring 1's quadrants (urf_ring_point: lidar_segmentation.cpp:245-269, blind_spots.cpp:19-56).  The
-     * atomic is on its way while the azimuth is worked out. */
-    auto mark = [&](unsigned idx, unsigned flag, unsigned r, float px, float py) {
-        const unsigned old = atomicOr(&a.rec[sb + idx], flag << URF_REC_FLAG_SHIFT);
-        float d2;
-        const float az = urf_azimuth(px, py, &d2);
-        if ((old >> URF_REC_FLAG_SHIFT) & 7u)
-            return;   /* already a curb point: listed by whoever marked it first */
-        const unsigned e = atomicAdd(&S.ncurb[r], 1u);
-        if (e < URF_CURB_LIST)
-            S.curb[r][e] = az;
-        const unsigned ea = atomicAdd(&S.n_all, 1u);
-        if (ea < a.front_cand_cap)
-            a.front_all[(size_t)s * a.front_cand_cap + ea] = urf_u2{ __float_as_uint(az), r };
-        if (r == 1u && dp.p.blind_spots) {
-            const int ab = (int)urf_fbits(az);
-            if (az >= 0.f && az < 90.f)
-                atomicMax(&S.q[0], ab);
-            else if (az >= 90.f && az < 180.f)
-                atomicMin(&S.q[1], ab);
-            else if (az >= 180.f && az < 270.f)
-                atomicMax(&S.q[2], ab);
-            else if (az < 360.f)
-                atomicMin(&S.q[3], ab);
-        }
+    /* The candidates.  One wave-instruction costs the same with one busy lane as with sixty-four, and every kind of candidate has
+     * its own expensive chain (x_zero: three f64 roots and a division; z_zero: ten differences, two roots, a division; a passed
+     * test: the reference's azimuth -- a root, a division, an arc sine).  A wave that met all kinds in one iteration ran all
+     * chains with a few lanes each: 1 200 instructions per iteration, 0.18 ms per 1024 scans.  So the list is worked off in
+     * chunks, a chunk PARTITIONED by kind in LDS, each kind by whole waves, what passed collected and marked by whole waves:
+     *   phase X   x_zero items    (XZ, EDGE_X)
+     *   phase Z   z_zero items    (ZZ, EDGE_Z)
+     *   phase M   the points that got a mark, and the star-shaped hits: record flag, azimuth, ring list, quadrants.
+     * An item makes ONE memory round trip for its data: neighbours' firings from the presence words in LDS, then the point, the
+     * neighbours and x_zero's table values requested together. */
+    urf_u2* const pend = a.front_all + (size_t)s * a.front_cand_cap;   /* (index, flags) of what phase M has to mark; later the list of all curb points */
+    auto passed = [&](unsigned idx, unsigned flag) {
+        const unsigned e = atomicAdd(&S.n_pend, 1u);
+        if (e < a.front_cand_cap)
+            pend[e] = urf_u2{ idx, flag };
     };
-    /* The candidates.  What the kernel waits for is memory round trips, so every candidate makes ONE for its data: the next
-     * record is requested an iteration ahead; the neighbours' firings come from the presence words in LDS; then the point, its
-     * ten neighbours (x, y, z) and the three table values of x_zero are requested together, unconditionally -- a lane that does
-     * not need a neighbour asks for its own point again, the same cache line. */
-    for (unsigned e = tid; e < nc; e += URF_FINISH_THREADS) {
-        const urf_u2 cd = cd_next;
-        if (e + URF_FINISH_THREADS < nc)
-            cd_next = cand[e + URF_FINISH_THREADS];
-        const unsigned idx = cd.x, what = cd.y;
-        const unsigned l = idx & 63u, f = idx >> 6;
-        const unsigned r = S.ring[l];
-        const unsigned n = S.n[l];
-        const unsigned p = (unsigned)B[(f >> 5) * 64u + l] + (unsigned)__popc(P[(f >> 5) * 64u + l] & ((1u << (f & 31u)) - 1u));
-        /* x_zero_method.cpp:30-68 marks p = j + 2 for j = p - 2 in [curbPoints, n - 1 - curbPoints]; z_zero_method.cpp:21-72 for the centre p */
-        const bool doX = (what & (URF_FC_XZ | URF_FC_EDGE_X)) && dp.p.x_zero_method && p >= 7u && p + 3u < n;
-        const bool doZ = (what & (URF_FC_ZZ | URF_FC_EDGE_Z)) && dp.p.z_zero_method && p >= 5u && p + 5u < n;
-        const unsigned nprev = doZ ? 5u : (doX ? 2u : 0u), nnext = doZ ? 5u : (doX ? 3u : 0u);
-        unsigned im[5], ip[5];   /* input indices of the neighbours (own index: not needed) */
-        {
-            unsigned g = f;
-#pragma unroll
-            for (unsigned k = 0; k < 5; k++) {
-                if (k < nprev)
-                    g = urf_front_prev(P, l, g);
-                im[k] = k < nprev ? g * 64u + l : idx;
+    constexpr unsigned CH = URF_FINISH_CHUNK;
+    for (unsigned c0 = 0; c0 < nc; c0 += CH) {
+        const unsigned cn = nc - c0 < CH ? nc - c0 : CH;
+        if (tid == 0) {
+            S.nx = 0;
+            S.nz = 0;
+        }
+        __syncthreads();
+        /* partition: x_zero items from the front, z_zero items from the back (an item of a block's end may be both) */
+        for (unsigned e = tid; e < cn; e += URF_FINISH_THREADS) {
+            const urf_u2 cd = cand[c0 + e];
+            if (cd.y & (URF_FC_XZ | URF_FC_EDGE_X))
+                chunk[atomicAdd(&S.nx, 1u)] = cd;
+            if (cd.y & (URF_FC_ZZ | URF_FC_EDGE_Z))
+                chunk[2u * CH - 1u - atomicAdd(&S.nz, 1u)] = cd;
+        }
+        __syncthreads();
+        const unsigned nx = S.nx, nz = S.nz;
+        /* phase X: x_zero_method.cpp:30-68 marks p = j + 2 for j = p - 2 in [curbPoints, n - 1 - curbPoints] */
+        if (dp.p.x_zero_method)
+            for (unsigned e = tid; e < nx; e += URF_FINISH_THREADS) {
+                const urf_u2 cd = chunk[e];
+                const unsigned idx = cd.x, l = idx & 63u, f = idx >> 6;
+                const unsigned n = S.n[l];
+                const unsigned p = (unsigned)B[(f >> 5) * 64u + l] + (unsigned)__popc(P[(f >> 5) * 64u + l] & ((1u << (f & 31u)) - 1u));
+                if (!(p >= 7u && p + 3u < n))
+                    continue;
+                unsigned fj = urf_front_prev(P, l, f);
+                fj = urf_front_prev(P, l, fj);
+                unsigned f3 = urf_front_next(P, ntiles, l, f);
+                f3 = urf_front_next(P, ntiles, l, f3);
+                f3 = urf_front_next(P, ntiles, l, f3);
+                const unsigned ij = fj * 64u + l, i3 = f3 * 64u + l;
+                const float pz = gz[idx], xj = gx[ij], yj = gy[ij], zj = gz[ij], x3 = gx[i3], y3 = gy[i3], z3 = gz[i3];
+                const float nyj = a.newY[p - 2u], ny2 = a.newY[p], ny3 = a.newY[p + 3u];
+                bool heights = true;
+                if (cd.y & URF_FC_EDGE_X)   /* (the march has not looked at the heights) */
+                    heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight || __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
+                              (double)__builtin_fabsf(zj - z3) >= 0.05;
+                if (heights && urf_x_zero_angle_vals(nyj, ny2, ny3, dp.p.angleFilter1, dp.x_angle_thr, xj, yj, x3, y3, zj, pz, z3))
+                    passed(idx, 2u);
             }
-            g = f;
+        /* phase Z: z_zero_method.cpp:21-72 for the centre p */
+        if (dp.p.z_zero_method)
+            for (unsigned e = tid; e < nz; e += URF_FINISH_THREADS) {
+                const urf_u2 cd = chunk[2u * CH - 1u - e];
+                const unsigned idx = cd.x, l = idx & 63u, f = idx >> 6;
+                const unsigned n = S.n[l];
+                const unsigned p = (unsigned)B[(f >> 5) * 64u + l] + (unsigned)__popc(P[(f >> 5) * 64u + l] & ((1u << (f & 31u)) - 1u));
+                if (!(p >= 5u && p + 5u < n))
+                    continue;
+                unsigned im[5], ip[5];
+                {
+                    unsigned g = f;
 #pragma unroll
-            for (unsigned k = 0; k < 5; k++) {
-                if (k < nnext)
-                    g = urf_front_next(P, ntiles, l, g);
-                ip[k] = k < nnext ? g * 64u + l : idx;
-            }
-        }
-        const bool needz = (what & (URF_FC_EDGE_X | URF_FC_EDGE_Z)) != 0u;   /* the march has not looked at the heights */
-        float xm[5], ym[5], zm[5], xp[5], yp[5], zp[5];
-        const float px = gx[idx], py = gy[idx], pz = gz[idx];
+                    for (unsigned k = 0; k < 5; k++) {
+                        g = urf_front_prev(P, l, g);
+                        im[k] = g * 64u + l;
+                    }
+                    g = f;
 #pragma unroll
-        for (unsigned k = 0; k < 5; k++) {
-            xm[k] = gx[im[k]];
-            ym[k] = gy[im[k]];
-            xp[k] = gx[ip[k]];
-            yp[k] = gy[ip[k]];
-            /* (heights: x_zero reads j = p - 2 and j + 5 = p + 3 in any case, the rest only what the march left undecided) */
-            zm[k] = gz[(needz || k == 1u) ? im[k] : idx];
-            zp[k] = gz[(needz || k == 2u) ? ip[k] : idx];
-        }
-        const unsigned pj = doX ? p - 2u : 0u;
-        const float nyj = a.newY[pj], ny2 = a.newY[doX ? p : 0u], ny3 = a.newY[pj + (doX ? 5u : 0u)];
-        unsigned flag = 0;
-        if (doX) {
-            const float zj = zm[1], z3 = zp[2];
-            bool heights = true;
-            if (what & URF_FC_EDGE_X)
-                heights = (__builtin_fabsf(zj - pz) >= dp.p.curbHeight || __builtin_fabsf(z3 - pz) >= dp.p.curbHeight) &&
-                          (double)__builtin_fabsf(zj - z3) >= 0.05;
-            if (heights && urf_x_zero_angle_vals(nyj, ny2, ny3, dp.p.angleFilter1, dp.x_angle_thr, xm[1], ym[1], xp[2], yp[2], zj, pz, z3))
-                flag |= 2u;
-        }
-        if (doZ) {
-            bool heights = true;
-            if (what & URF_FC_EDGE_Z) {
-                const float azp = __builtin_fabsf(pz);
-                float max1 = azp, max2 = azp;
+                    for (unsigned k = 0; k < 5; k++) {
+                        g = urf_front_next(P, ntiles, l, g);
+                        ip[k] = g * 64u + l;
+                    }
+                }
+                const bool needz = (cd.y & URF_FC_EDGE_Z) != 0u;   /* (the march has not looked at the heights) */
+                float xm[5], ym[5], zm[5] = { 0.f, 0.f, 0.f, 0.f, 0.f }, xp[5], yp[5], zp[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
+                const float px = gx[idx], py = gy[idx], pz = gz[idx];
 #pragma unroll
                 for (unsigned k = 0; k < 5; k++) {
-                    const float za = __builtin_fabsf(zm[k]), zb = __builtin_fabsf(zp[k]);
-                    max1 = za > max1 ? za : max1;
-                    max2 = zb > max2 ? zb : max2;
+                    xm[k] = gx[im[k]];
+                    ym[k] = gy[im[k]];
+                    xp[k] = gx[ip[k]];
+                    yp[k] = gy[ip[k]];
                 }
-                heights = (max1 - azp >= dp.p.curbHeight || max2 - azp >= dp.p.curbHeight) && (double)__builtin_fabsf(max1 - max2) >= 0.05;
+                /* (what bounds this kernel is the rate at which a CU takes scattered 4-byte loads -- one cache line per lane and
+                 * instruction: the heights are only asked for by a wave that holds such an item) */
+                if (__ballot(needz) != 0ull) {
+#pragma unroll
+                    for (unsigned k = 0; k < 5; k++) {
+                        zm[k] = gz[needz ? im[k] : idx];
+                        zp[k] = gz[needz ? ip[k] : idx];
+                    }
+                }
+                bool heights = true;
+                if (needz) {
+                    const float azp = __builtin_fabsf(pz);
+                    float max1 = azp, max2 = azp;
+#pragma unroll
+                    for (unsigned k = 0; k < 5; k++) {
+                        const float za = __builtin_fabsf(zm[k]), zb = __builtin_fabsf(zp[k]);
+                        max1 = za > max1 ? za : max1;
+                        max2 = zb > max2 ? zb : max2;
+                    }
+                    heights = (max1 - azp >= dp.p.curbHeight || max2 - azp >= dp.p.curbHeight) && (double)__builtin_fabsf(max1 - max2) >= 0.05;
+                }
+                if (heights) {
+                    auto xy = [&](int pos, float& xx, float& yy) {   /* pos: ring position; the centre's is p */
+                        const int rel = pos - (int)p;
+                        xx = rel < 0 ? xm[-rel - 1] : xp[rel - 1];
+                        yy = rel < 0 ? ym[-rel - 1] : yp[rel - 1];
+                    };
+                    if (urf_z_zero_angle(dp.inv_cp, dp.p.angleFilter2, dp.z_angle_thr, xy, (int)p, 5, px, py))
+                        passed(idx, 4u);
+                }
             }
-            if (heights) {
-                auto xy = [&](int pos, float& xx, float& yy) {   /* pos: ring position; the centre's is p */
-                    const int rel = pos - (int)p;
-                    xx = rel < 0 ? xm[-rel - 1] : xp[rel - 1];
-                    yy = rel < 0 ? ym[-rel - 1] : yp[rel - 1];
-                };
-                if (urf_z_zero_angle(dp.inv_cp, dp.p.angleFilter2, dp.z_angle_thr, xy, (int)p, 5, px, py))
-                    flag |= 4u;
-            }
-        }
-        if (flag)
-            mark(idx, flag, r, px, py);
+        __syncthreads();   /* the chunk's buffer is free for the next one */
     }
+    URF_PHASE_MARK;
     /* lidar_segmentation.cpp:235-242: the star-shaped hits (the walk reported them as input indices; -1: none or on no ring) */
     if (dp.p.star_shaped_method)
         for (unsigned k = tid; k < K; k += URF_FINISH_THREADS) {
             const int h = a.star_hit[(size_t)s * K + k];
-            if (h >= 0) {
-                const unsigned idx = (unsigned)h, r = S.ring[idx & 63u];
-                mark(idx, 1u, r, gx[idx], gy[idx]);
-            }
+            if (h >= 0)
+                passed((unsigned)h, 1u);
         }
     __syncthreads();
+    URF_PHASE_MARK;
+    /* phase M.  A ring point that has a detector's mark: its record's flag (whoever sets the first one lists the point), the
+     * reference's azimuth, its ring's list, ring 1's quadrants (urf_ring_point: lidar_segmentation.cpp:245-269, blind_spots.cpp:
+     * 19-56).  The atomic is on its way while the azimuth is worked out.  The list of all curb points (the rings whose own list
+     * overflows) takes the places of the entries already read: entry e is rewritten by the thread that read it. */
+    const unsigned n_pend = S.n_pend < a.front_cand_cap ? S.n_pend : a.front_cand_cap;
+    for (unsigned e = tid; e < n_pend; e += URF_FINISH_THREADS) {
+        const urf_u2 pd = pend[e];
+        const unsigned idx = pd.x, r = S.ring[idx & 63u];
+        const float px = gx[idx], py = gy[idx];
+        const unsigned old = atomicOr(&a.rec[sb + idx], pd.y << URF_REC_FLAG_SHIFT);
+        float d2;
+        const float az = urf_azimuth(px, py, &d2);
+        urf_u2 out = urf_u2{ 0u, 0xffffffffu };   /* (ring 0xffffffff: not a list entry) */
+        if (((old >> URF_REC_FLAG_SHIFT) & 7u) == 0u) {   /* otherwise: already a curb point, listed by whoever marked it first */
+            const unsigned ec = atomicAdd(&S.ncurb[r], 1u);
+            if (ec < URF_CURB_LIST)
+                a.curb_az[((size_t)s * C + r) * URF_CURB_LIST + ec] = az;
+            out = urf_u2{ __float_as_uint(az), r };
+            if (r == 1u && dp.p.blind_spots) {
+                const int ab = (int)urf_fbits(az);
+                if (az >= 0.f && az < 90.f)
+                    atomicMax(&S.q[0], ab);
+                else if (az >= 90.f && az < 180.f)
+                    atomicMin(&S.q[1], ab);
+                else if (az >= 180.f && az < 270.f)
+                    atomicMax(&S.q[2], ab);
+                else if (az < 360.f)
+                    atomicMin(&S.q[3], ab);
+            }
+        }
+        pend[e] = out;
+    }
+    URF_PHASE_MARK;
+    __syncthreads();
+    URF_PHASE_MARK;
+#ifdef URF_EXP_PHASE_CLOCK
+    if (threadIdx.x == 0 && blockIdx.x >= 500 && blockIdx.x < 504) {
+        printf("k_front_finish wg %u candidates %u marked %u\n", blockIdx.x, nc, n_pend);
+        for (unsigned ph_i = 1; ph_i < ph_n; ph_i++)
+            printf("k_front_finish wg %u phase %u: %llu cycles\n", blockIdx.x, ph_i, ph_t[ph_i] - ph_t[ph_i - 1]);
+    }
+#endif
     /* what k_beams reads (k_ring's epilogue) */
     if (tid < 4 && dp.p.blind_spots && in.n_rings > 1)
         a.quad[(size_t)s * 4 + tid] = __uint_as_float((unsigned)S.q[tid]);
     for (unsigned r = tid; r < in.n_rings; r += URF_FINISH_THREADS)
         a.curb_cnt[(size_t)s * C + r] = S.ncurb[r] <= URF_CURB_LIST ? S.ncurb[r] : URF_CURB_DENSE;
-    for (unsigned k = tid; k < in.n_rings * URF_CURB_LIST; k += URF_FINISH_THREADS) {
-        const unsigned r = k / URF_CURB_LIST, e = k % URF_CURB_LIST;
-        if (e < S.ncurb[r] && S.ncurb[r] <= URF_CURB_LIST)
-            a.curb_az[((size_t)s * C + r) * URF_CURB_LIST + e] = S.curb[r][e];
-    }
     /* a ring with more curb points than its list holds (rough ground): the per-degree tables instead, from the scan's
      * list of all curb points -- sufmin[i] = smallest curb azimuth >= i, premax[i] = largest <= i, NaN = none.  (The presence
      * words are no longer needed: their memory holds the two tables of the ring at hand.) */
-    const unsigned n_all = S.n_all < a.front_cand_cap ? S.n_all : a.front_cand_cap;
+    const unsigned n_all = n_pend;
     int* const cmin = (int*)sh_finish;
     int* const cmax = cmin + URF_DEG_CELLS;
     for (unsigned r = 0; r < in.n_rings; r++) {
