@@ -44,7 +44,7 @@ def test_single_rank_line_has_the_contract_keys():
     assert d["backend"] is None
     # the other BASELINE configurations, each behind its own parity gate (bench.py: other_configs)
     oc = d["other_configs"]
-    assert set(oc) == {"cfg2", "cfg5", "default_roi", "sensor_like"}
+    assert set(oc) == {"cfg2", "cfg5", "default_roi", "sensor_like", "laser_order", "ring_major", "shuffled", "heterogeneous"}
     for name, e in oc.items():
         assert e["scans_per_s"] > 0 and 0 < e["frac"] < 1 and e["parity_checked_scans"], name
     assert oc["cfg5"]["points_per_scan"] == 128 * 4096 and oc["cfg2"]["scans_per_step"] == 1

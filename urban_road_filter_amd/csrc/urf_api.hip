@@ -753,6 +753,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     /* k_star_ties: persistent one-wave workgroups (32 KB of LDS: four per CU) over a list that holds one sector in a hundred of
      * a sensor's sweep and nothing of a benchmark cloud */
     const unsigned tie_grid = K * n_scans < c->n_cus * 4u ? K * n_scans : c->n_cus * 4u;
+    const unsigned tie_grid_small = K * n_scans < c->n_cus * 16u ? K * n_scans : c->n_cus * 16u;   /* (8 KB of LDS per wave) */
     if (star) {
         const dim3 g_sec(K, n_scans);
         hipLaunchKernelGGL(k_star_sort_small, g_sec, dim3(URF_STAR_THREADS), 0, st, a, dp);
@@ -765,8 +766,10 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         /* sectors whose sorted prefix holds equal planar ranges of different heights (URF_TIE_FLAG): the order libstdc++'s std::sort
          * leaves them in.  Benchmark clouds hold none (the kernel returns at once); a real sensor's sweep holds equal ranges in
          * every sector, but nearly all of them between twins (one height), which only the second pass below cares about. */
-        if (!(a.optimistic & URF_OPT_NO_TIES))
-            hipLaunchKernelGGL(k_star_ties<false>, dim3(tie_grid), dim3(64), 0, st, a, dp);
+        if (!(a.optimistic & URF_OPT_NO_TIES)) {
+            hipLaunchKernelGGL((k_star_ties<false, URF_TIE_SMALL>), dim3(tie_grid_small), dim3(64), 0, st, a, dp);
+            hipLaunchKernelGGL((k_star_ties<false, URF_TIE_CAP>), dim3(tie_grid), dim3(64), 0, st, a, dp);
+        }
     }
     mark();   /* "k_star_sort" = the three sort kernels (mid / big run over normally empty work lists) */
     if (star) {
@@ -775,8 +778,10 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         else
             hipLaunchKernelGGL(k_star_walk, dim3((K + 63) / 64, n_scans), dim3(64), 0, st, a, dp);
         /* second pass of k_star_ties: the sectors in which the walk stopped at a point with a twin behind it (URF_TIE_POST) */
-        if (!(a.optimistic & URF_OPT_NO_TIES))
-            hipLaunchKernelGGL(k_star_ties<true>, dim3(tie_grid), dim3(64), 0, st, a, dp);
+        if (!(a.optimistic & URF_OPT_NO_TIES)) {
+            hipLaunchKernelGGL((k_star_ties<true, URF_TIE_SMALL>), dim3(tie_grid_small), dim3(64), 0, st, a, dp);
+            hipLaunchKernelGGL((k_star_ties<true, URF_TIE_CAP>), dim3(tie_grid), dim3(64), 0, st, a, dp);
+        }
     }
     mark();
     const dim3 g_ring(C, n_scans);

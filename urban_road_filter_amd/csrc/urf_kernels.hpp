@@ -2950,10 +2950,14 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
  * on one counter -- and a second instance with 16-bit index arrays, 5 KB of LDS and six waves per SIMD carried the load:
  * 65 k -> 135 k sweeps/s; with one sector in a hundred left, one instance with 32 KB does: the time is the latency of one
  * wave's chain.) */
-template <bool POST>
+/* Two instances per pass (r6): sectors of at most URF_TIE_SMALL points -- every sector of a 64 x 2048 sweep -- in 8 KB of LDS per
+ * wave, as many waves resident as the list of a 1024-sweep batch has sectors (one round: a pass is the latency of ONE wave's
+ * chain, ~40 us per sector; with 32 KB per wave and four waves per CU such a batch took two or three rounds per pass); the larger
+ * ones as before. */
+#define URF_TIE_SMALL 512u
+template <bool POST, unsigned CAP>
 __global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp)
 {
-    constexpr unsigned CAP = URF_TIE_CAP;
     __shared__ unsigned W[4 * CAP];   /* R, P, LP, RP */
     __shared__ int stk[3 * 64];
     const unsigned count = a.star_count[POST ? 5 : 4];   /* (uniform; 0 for every tie-free sweep: the kernel returns at once) */
@@ -2972,6 +2976,8 @@ __global__ __launch_bounds__(64) void k_star_ties(urf_kargs a, urf_dev_params dp
             const unsigned n = a.sec_cnt[sk];
             if (n < 2)
                 continue;
+            if (CAP == URF_TIE_SMALL ? n > URF_TIE_SMALL : n <= URF_TIE_SMALL)
+                continue;   /* (the other instance's) */
             if (n <= CAP) {
                 urf_tie_sector_body<urf_tie_lds, POST>(a, dp, sk, s, k, n, hit_i, W, W + CAP, W + 2 * CAP, W + 3 * CAP, stk);
             } else {
