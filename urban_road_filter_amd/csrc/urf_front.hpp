@@ -266,7 +266,6 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
         /* the lane's window moves on by its new ring point; what has become decidable is decided */
         if (__ballot(on) == 0ull)
             return;   /* (uniform) */
-        bool zz = false, xz = false, ez = false, ex = false;
         if (on) {
             w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8; w8 = w9; w9 = w10;
             w10 = z;
@@ -281,29 +280,25 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
         }
         if (PH == 0u)
             return;
-        if (on) {
-            const bool full = wc == 11u;
-            /* the centre (five points back) and the point x_zero marks (three back): are they this block's */
-            const bool c_in = tot >= 6u && tot - 5u <= nin;
-            const bool p_in = tot >= 4u && tot - 3u <= nin;
-            if (full) {
-                /* z_zero_method.cpp:39-40, 48-49, 67-69 */
-                const float a5 = __builtin_fabsf(w5);
-                const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(w0), __builtin_fabsf(w1)), __builtin_fabsf(w2)),
-                                                 __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(w3), __builtin_fabsf(w4)), a5));
-                const float m2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a5, __builtin_fabsf(w6)), __builtin_fabsf(w7)),
-                                                 __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(w8), __builtin_fabsf(w9)), __builtin_fabsf(w10)));
-                zz = use_z & c_in & ((m1 - a5 >= curbH) | (m2 - a5 >= curbH)) & ((double)__builtin_fabsf(m1 - m2) >= 0.05);
-                /* x_zero_method.cpp:62-64 for the triple (w5, w7, w10) = (j, j + 2, j + 5) */
-                xz = use_x & p_in & ((__builtin_fabsf(w5 - w7) >= curbH) | (__builtin_fabsf(w10 - w7) >= curbH)) &
-                     ((double)__builtin_fabsf(w5 - w10) >= 0.05);
-            } else if (!from_start) {
-                /* the window began inside this march (a block border with a hole in the halo, a ring that has just
-                 * entered the region of interest): positions unknown here, k_front_finish decides */
-                ez = use_z & c_in;
-                ex = use_x & p_in;
-            }
-        }
+        /* (straight-line: every lane computes, the lanes without a new point are masked out at the end -- branches around the
+         * tests put the four results through registers and selects) */
+        const bool full = wc == 11u;
+        /* the centre (five points back) and the point x_zero marks (three back): are they this block's */
+        const bool c_in = on & (tot >= 6u) & (tot - 5u <= nin);
+        const bool p_in = on & (tot >= 4u) & (tot - 3u <= nin);
+        /* z_zero_method.cpp:39-40, 48-49, 67-69 */
+        const float a5 = __builtin_fabsf(w5);
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(w0), __builtin_fabsf(w1)), __builtin_fabsf(w2)),
+                                         __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(w3), __builtin_fabsf(w4)), a5));
+        const float m2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a5, __builtin_fabsf(w6)), __builtin_fabsf(w7)),
+                                         __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(w8), __builtin_fabsf(w9)), __builtin_fabsf(w10)));
+        const bool hz = ((m1 - a5 >= curbH) | (m2 - a5 >= curbH)) & (__builtin_fabsf(m1 - m2) >= 0.05f);   /* ((double)v >= 0.05 <=> v >= 0.05f: the float above 0.05) */
+        /* x_zero_method.cpp:62-64 for the triple (w5, w7, w10) = (j, j + 2, j + 5) */
+        const bool hx = ((__builtin_fabsf(w5 - w7) >= curbH) | (__builtin_fabsf(w10 - w7) >= curbH)) & (__builtin_fabsf(w5 - w10) >= 0.05f);
+        const bool zz = use_z & c_in & full & hz, xz = use_x & p_in & full & hx;
+        /* a window that began inside this march (a block border with a hole in the halo, a ring that has just entered the
+         * region of interest): positions unknown here, k_front_finish decides */
+        const bool ez = use_z & c_in & !full & !from_start, ex = use_x & p_in & !full & !from_start;
         if (__ballot(zz | xz | ez | ex) != 0ull) {   /* (uniform) */
             urf_front_push(cbuf, ncb, zz | ez, ((fwA & 0xffffu) + Fs) * 64u + lane, zz ? URF_FC_ZZ : URF_FC_EDGE_Z);
             urf_front_push(cbuf, ncb, xz | ex, ((fwB & 0xffffu) + Fs) * 64u + lane, xz ? URF_FC_XZ : URF_FC_EDGE_X);
