@@ -237,3 +237,34 @@ def test_mode_one_takes_batches_of_32_scans():
         labels, infos = run_batch(ctx, scans[:31], p)
         assert ctx.front_scans() == 0
         check_against_b(labels[:8], infos[:8], scans[:8], p)
+
+
+def ring_major(cloud):
+    """The same sweep stored ring by ring (row-major 64 x W: what an Ouster's driver delivers as an organised cloud)."""
+    return tuple(np.ascontiguousarray(a.reshape(-1, 64).T.reshape(-1)) for a in cloud)
+
+
+def shuffled(cloud, seed):
+    pm = np.random.default_rng(seed).permutation(len(cloud[0]))
+    return tuple(a[pm].copy() for a in cloud)
+
+
+@pytest.mark.parametrize("mode", [2, 0])
+def test_storage_orders_of_sensor_like_sweeps_against_the_oracle(mode):
+    """The reference makes no assumption about the order its input arrives in (lidar_segmentation.cpp:100-117, 221-278), and
+    with equal planar ranges in a star sector the labels DEPEND on it (std::sort's tie order): sensor-like sweeps -- ties in
+    every sector -- ring-major, in laser order and shuffled, each against oracle B on the same input.  Ring-major: every
+    sector is 64 runs of ~6 points (k_star_sort_runs)."""
+    p = O.cfg_params("sensor")
+    perm = np.random.default_rng(9).permutation(64)
+    scans = [ring_major(O.cfg_cloud("sensor", 1)), permuted(O.cfg_cloud("sensor", 2), perm), shuffled(O.cfg_cloud("sensor", 3), 4),
+             ring_major(O.cfg_cloud("sensor_narrow", 5)), O.cfg_cloud("sensor", 6)]
+    with u.Context(N, len(scans)) as ctx:
+        labels, infos, nf = fused_batch(ctx, scans, p, mode=mode)
+        assert nf == (2 if mode else 0)
+        check_against_b(labels, infos, scans, p)
+    pr = O.cfg_params("sensor_default_roi")
+    scans = [ring_major(O.cfg_cloud("sensor_default_roi", 7)), shuffled(O.cfg_cloud("sensor_default_roi", 8), 9)]
+    with u.Context(N, len(scans)) as ctx:
+        labels, infos, nf = fused_batch(ctx, scans, pr, mode=mode)
+        check_against_b(labels, infos, scans, pr)

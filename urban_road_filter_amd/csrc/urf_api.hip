@@ -303,7 +303,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.rpre, S * C * (tiles + 1)) A(k.rstart, S * C * tiles)
     A(k.angle, S * C) A(k.ring_thr, S * C * 4) A(k.ring_lut, S * URF_LUT_CELLS) A(k.ring_cnt, S * C) A(k.ring_off, S * (C + 1))
     A(k.sec_cnt, S * K) A(k.sec_run, S * K) A(k.sec_off, S * (K + 1)) A(k.star_hit, S * K)
-    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.tie_list, S * K) A(k.tie_post, S * K) A(k.star_count, 8 * URF_ASYNC_SLOTS)   /* eight counters per scratch row in use at once */
+    A(k.star_first, S * K) A(k.star_list_mid, S * K) A(k.star_list_big, S * K) A(k.star_list_runs, S * K) A(k.tie_list, S * K) A(k.tie_post, S * K) A(k.star_count, 8 * URF_ASYNC_SLOTS)   /* eight counters per scratch row in use at once */
     A(k.table_upto, S) A(k.table_redo, S) A(k.redo_list, S) A(k.table_cause, S) A(k.ring_hint, URF_ASYNC_SLOTS)
     A(k.nan_mask, S * 4) A(k.nan_list, 2 * S * C) A(k.vis, S * C)
     A(k.maxdist, S * C) A(k.quad, S * 4)
@@ -593,7 +593,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     k.rpre += r * C * (tiles + 1); k.rstart += r * C * tiles;
     k.angle += r * C; k.ring_thr += r * C * 4; k.ring_lut += r * URF_LUT_CELLS; k.ring_cnt += r * C; k.ring_off += r * (C + 1);
     k.sec_cnt += r * K; k.sec_run += r * K; k.sec_off += r * (K + 1); k.star_hit += r * K;
-    k.star_first += r * K; k.star_list_mid += r * K; k.star_list_big += r * K; k.tie_list += r * K; k.tie_post += r * K; k.star_count += 8 * r;
+    k.star_first += r * K; k.star_list_mid += r * K; k.star_list_big += r * K; k.star_list_runs += r * K; k.tie_list += r * K; k.tie_post += r * K; k.star_count += 8 * r;
     k.table_upto += r; k.table_redo += r; k.redo_list += r; k.table_cause += r; k.ring_hint += r;
     k.nan_mask += r * 4; k.nan_list += 2 * r * C; k.vis += r * C;
     k.maxdist += r * C; k.quad += r * 4;
@@ -762,6 +762,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
             hipLaunchKernelGGL(k_star_sort_mid, dim3(c->n_cus * (URF_MID_WAVES * 256 / URF_STAR_MID_THREADS)), dim3(URF_STAR_MID_THREADS), 0, st,
                                a, dp);   /* as many workgroups as are resident */
             hipLaunchKernelGGL(k_star_sort_big, dim3(c->n_cus * 2), dim3(256), 0, st, a, dp);
+            hipLaunchKernelGGL(k_star_sort_runs, dim3(c->n_cus * 20), dim3(URF_STAR_THREADS), 0, st, a, dp);   /* (five waves per SIMD) */
         }
         /* sectors whose sorted prefix holds equal planar ranges of different heights (URF_TIE_FLAG): the order libstdc++'s std::sort
          * leaves them in.  Benchmark clouds hold none (the kernel returns at once); a real sensor's sweep holds equal ranges in

@@ -130,6 +130,7 @@ struct urf_dev_params {
 /* A sector's points sit in one run per tile (k_split's sector-sorted order).  The first two non-empty
  * runs: point i of the sector is element a0 + i of the sector-sorted arrays for i < c0, a1 + (i - c0)
  * beyond (indices relative to the scan's scratch); nruns > 2: the sort walks the per-tile tables. */
+#define URF_RUNS_FLAG 0x40000000u   /* in nruns (k_index): more than two runs, but one short run per tile: k_star_sort_runs */
 struct urf_sec_run { uint32_t a0, c0, a1, nruns; };
 
 /* k_star_sort_* -> k_star_walk, per point of a sector in sorted order */
@@ -220,6 +221,7 @@ struct urf_kargs {
     uint32_t* star_first;       /* [S][sectors] last sorted index the walk may visit */
     uint32_t* star_list_mid;    /* [S*sectors] work list: scan*sectors+sector of sectors with 385..2048 points */
     uint32_t* star_list_big;    /* [S*sectors] ... with more than 2048 points */
+    uint32_t* star_list_runs;   /* [S*sectors] ... of many short runs (URF_RUNS_FLAG; star_count[7]) */
     uint32_t* tie_list;         /* [S*sectors] scan*sectors+sector of the sectors that carry URF_TIE_FLAG (sort kernels -> k_star_ties, first pass) */
     uint32_t* tie_post;         /* [S*sectors] ... URF_TIE_POST (walk kernels -> second pass) */
     uint32_t* star_count;       /* [8] lengths of the two lists, [2] = length of redo_list, [3] = length of nan_list, [4] = length of

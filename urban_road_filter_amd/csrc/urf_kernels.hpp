@@ -1463,11 +1463,12 @@ __device__ __forceinline__ void urf_index_sectors(const urf_kargs& a, unsigned s
     const unsigned tid = threadIdx.x;
     const uint16_t* toff = a.tsoff + (size_t)s * a.tiles * (K + 1);
     for (unsigned kp = 0; kp < K; kp += 256 * NK) {
-        unsigned run[NK];
+        unsigned run[NK], mx[NK];
         urf_sec_run sr[NK];
 #pragma unroll
         for (unsigned h = 0; h < NK; h++) {
             run[h] = 0;
+            mx[h] = 0;
             sr[h] = urf_sec_run{ 0u, 0u, 0u, 0u };
         }
         for (unsigned t0 = 0; t0 < ntiles; t0 += 16) {
@@ -1499,12 +1500,16 @@ __device__ __forceinline__ void urf_index_sectors(const urf_kargs& a, unsigned s
                     sr[h].a1 = second ? ad : sr[h].a1;
                     sr[h].nruns += c != 0u;
                     run[h] += c;
+                    mx[h] = c > mx[h] ? c : mx[h];
                 }
         }
 #pragma unroll
         for (unsigned h = 0; h < NK; h++) {
             const unsigned k = kp + h * 256 + tid;
             if (k < K) {
+                /* many short runs, one per tile of at most 64: k_star_sort_runs (one lane per run) instead of the workgroup kernel */
+                if (sr[h].nruns > 2u && ntiles <= 64u && mx[h] <= URF_STAR_SMALL_CAP / 64u)
+                    sr[h].nruns |= URF_RUNS_FLAG;
                 a.sec_cnt[(size_t)s * K + k] = run[h];
                 a.sec_run[(size_t)s * K + k] = sr[h];
             }
@@ -1596,19 +1601,25 @@ __device__ __forceinline__ void urf_index_body(const urf_kargs& a, const urf_dev
         /* (the wave-per-sector kernel takes sectors of at most two runs: one scattered over more tiles -- an
          * unorganised cloud -- goes the workgroup path whatever its size) */
         const unsigned nr = k < K ? a.sec_run[(size_t)s * K + k].nruns : 0;   /* (this thread's own store above) */
-        const bool mid = (c > URF_STAR_SMALL_CAP || (nr > 2 && c >= 2)) && c <= URF_STAR_MID_CAP_, big = c > URF_STAR_MID_CAP_;
-        const unsigned long long bm = __ballot(mid), bb = __ballot(big);
-        unsigned pm = 0, pb = 0;
-        if ((a.optimistic & URF_OPT_NO_LISTS) && (bm | bb) && urf_lane() == 0)
+        const bool runs = (nr & URF_RUNS_FLAG) != 0u && c >= 2 && c <= URF_STAR_SMALL_CAP;
+        const bool mid = (c > URF_STAR_SMALL_CAP || (nr > 2 && c >= 2 && !runs)) && c <= URF_STAR_MID_CAP_, big = c > URF_STAR_MID_CAP_;
+        const unsigned long long bm = __ballot(mid), bb = __ballot(big), br = __ballot(runs);
+        unsigned pm = 0, pb = 0, pr = 0;
+        if ((a.optimistic & URF_OPT_NO_LISTS) && (bm | bb | br) && urf_lane() == 0)
             a.info[s].status = URF_STATUS_REDO_LISTS;   /* nobody sorts the lists in this launch sequence (every writer writes the same value) */
         if (urf_lane() == 0) {
             if (bm)
                 pm = atomicAdd(&a.star_count[0], (unsigned)__popcll(bm));
             if (bb)
                 pb = atomicAdd(&a.star_count[1], (unsigned)__popcll(bb));
+            if (br)
+                pr = atomicAdd(&a.star_count[7], (unsigned)__popcll(br));
         }
         pm = __shfl(pm, 0);
         pb = __shfl(pb, 0);
+        pr = __shfl(pr, 0);
+        if (runs)
+            a.star_list_runs[pr + urf_popc_below(br)] = s * K + k;
         if (mid)
             a.star_list_mid[pm + urf_popc_below(bm)] = s * K + k;
         if (big)
@@ -1742,10 +1753,15 @@ __device__ __forceinline__ unsigned urf_sector_runs(const urf_kargs& a, unsigned
  * bucket collects more than 64 keys (heavily clustered ranges) the wave falls back to the
  * general path: every 64-key block is sorted in registers by an in-wave
  * bitonic network and the blocks are merged by ranking. */
-template <unsigned MAXB>
+/* RUNS (r6): a sector that meets MANY tiles with a few points in each -- every sector of a sweep stored ring by ring (row-major H x W:
+ * tile t = ring t, ~6 of its points per sector) -- used to go to the workgroup kernel of the oversized sectors (12 barriers per
+ * sector: 4.7 ms per 1024 such sweeps).  Here lane t takes the run of tile t (its address and length come from the caller): the
+ * points of one ring again sit in the registers of one lane, which is what the ranking below is built for.  Such a sector publishes
+ * tile-local ring-sorted indices (ssrt), as the workgroup kernels do for every sector of more than two runs. */
+template <unsigned MAXB, bool RUNS = false>
 __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const urf_dev_params& dp, unsigned sb, unsigned obase, unsigned n,
                                                      const urf_sec_run& two, unsigned long long* A, unsigned* cnt,
-                                                     unsigned* sh_first, uint32_t* star_first_out)
+                                                     unsigned* sh_first, uint32_t* star_first_out, unsigned run_adr = 0, unsigned run_cnt = 0)
 {
     constexpr unsigned NB = URF_STAR_NB, PL = NB / 64;
     /* (r5, measured: one pad word per PL counters -- a lane scans PL consecutive counters, lanes PL words apart meet in 32 / PL
@@ -1753,7 +1769,8 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
      * arithmetic costs more vector instructions than the conflicts cost cycles, profiles/r5_lds_ab.txt) */
     auto CI = [](unsigned c) { return c; };
     const unsigned lane = threadIdx.x;
-    const unsigned B = (n + 63) >> 6;
+    const unsigned Bn = (n + 63) >> 6;                           /* rounds over the sector's positions */
+    const unsigned B = RUNS ? urf_wave_max(run_cnt) : Bn;        /* rounds over the lanes' elements */
     URF_PHASE_ACC_DECL;
     unsigned long long key[MAXB];
     float zreg[MAXB];      /* the height travels with the key: the tail then needs no dependent gathers from memory */
@@ -1771,25 +1788,28 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
         const unsigned a1m = two.a1 - two.c0;
         /* straight-line: elements past the sector's end repeat its last one (valid addresses) and
          * are dropped afterwards; all loads of the lane are in flight together */
-        unsigned adr[MAXB], rbv[MAXB];
+        unsigned adr[MAXB], rbv[MAXB], slv[MAXB];
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
             const unsigned i = q * 64 + lane, ic = i < n ? i : n - 1u;
-            adr[q] = ic + (ic < two.c0 ? two.a0 : a1m);
+            adr[q] = RUNS ? run_adr + (q < run_cnt ? q : 0u) : ic + (ic < two.c0 ? two.a0 : a1m);
         }
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
             rbv[q] = 0;
             zreg[q] = 0.f;
+            slv[q] = 0;
             if (q < B) {   /* uniform */
                 rbv[q] = urf_fbits(a.sr[sb + adr[q]]);
                 zreg[q] = a.sz[sb + adr[q]];
+                if (RUNS)
+                    slv[q] = a.sslot[sb + adr[q]];
             }
         }
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
-            const bool valid = q * 64 + lane < n;
-            sreg[q] = q * 64 + lane;
+            const bool valid = RUNS ? q < run_cnt : q * 64 + lane < n;
+            sreg[q] = RUNS ? (slv[q] == URF_SLOT_NONE ? 0xffffffffu : (adr[q] & ~(URF_TILE - 1u)) + slv[q]) : q * 64 + lane;
             key[q] = valid ? ((unsigned long long)rbv[q] << 32) | adr[q] : ~0ull;
             rmin = valid && rbv[q] < rmin ? rbv[q] : rmin;
             rmax = valid && rbv[q] > rmax ? rbv[q] : rmax;
@@ -1906,7 +1926,7 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
 #pragma unroll
             for (unsigned q = 0; q < MAXB; q++) {
                 const unsigned pos = q * 64 + lane;
-                if (q < B && pos < n && RK[pos] == 0xffffu) {
+                if (q < Bn && pos < n && RK[pos] == 0xffffu) {
                     const unsigned long long kk = A[pos];
                     const unsigned bk = ((unsigned)(kk >> 32) - rmin) >> sh;
                     const unsigned b0 = cnt[CI(bk)], b1 = cnt[CI(bk + 1)];
@@ -1942,7 +1962,12 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
                     const unsigned adr = (unsigned)key[q];
                     zreg[q] = a.sz[sb + adr];
                     /* at most two runs: the position inside the sector from the address */
-                    sreg[q] = (two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0;
+                    if (RUNS) {
+                        const unsigned sl = a.sslot[sb + adr];
+                        sreg[q] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+                    } else {
+                        sreg[q] = (two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0;
+                    }
                 }
             }
         __syncthreads();
@@ -1988,7 +2013,10 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
                 if (slp > slope_param)
                     atomicMin(sh_first, i);
             }
-            a.ssrt16[obase + i] = (uint16_t)S[i];
+            if (RUNS)
+                a.ssrt[obase + i] = S[i];
+            else
+                a.ssrt16[obase + i] = (uint16_t)S[i];
             a.wsg[obase + i] = urf_sg{ slp, g };
         }
         __syncthreads();
@@ -2065,6 +2093,43 @@ __global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_e
     const bool tie = urf_star_sort_sector<URF_STAR_SMALL_CAP / 64>(a, dp, sb, obase, n, two, A, cnt, &sh_first, &a.star_first[(size_t)s * K + k]);
     if (tie && lane == 0)
         urf_tie_found(a, s, s * K + k);
+}
+
+/* the sectors k_index listed as "many short runs" (URF_RUNS_FLAG: more than two runs, at most 64 tiles, at most six points per
+ * run -- a sweep stored ring by ring; normally none): persistent waves over the list */
+__global__ __launch_bounds__(URF_STAR_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_star_sort_runs(urf_kargs a, urf_dev_params dp)
+{
+    constexpr unsigned NB = URF_STAR_NB;
+    __shared__ unsigned long long A[8 * 64];
+    __shared__ unsigned cnt[NB + 1];
+    __shared__ unsigned sh_first;
+    const unsigned count = a.star_count[7], lane = threadIdx.x;
+    const unsigned K = (unsigned)dp.p.sectors;
+    for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
+        const unsigned sk = a.star_list_runs[w], s = sk / K, k = sk % K;
+        if (a.info[s].status != URF_OK)
+            continue;
+        unsigned off, len;
+        urf_scan_range(a, s, off, len);
+        const unsigned ntiles = (len + URF_TILE - 1) / URF_TILE;
+        const unsigned so0 = a.sec_off[(size_t)s * (K + 1) + k], so1 = a.sec_off[(size_t)s * (K + 1) + k + 1];
+        const urf_sec_run two = a.sec_run[sk];
+        const unsigned n = so1 - so0;
+        unsigned c0 = 0, c1 = 0;
+        if (lane < ntiles) {   /* (ntiles <= 64: k_index) */
+            const uint16_t* row = a.tsoff + ((size_t)s * a.tiles + lane) * (K + 1) + k;
+            c0 = row[0];
+            c1 = row[1];
+        }
+        const unsigned sb = urf_sbase(a, s), obase = sb + so0;
+        if (lane == 0)
+            sh_first = n;
+        const bool tie = urf_star_sort_sector<URF_STAR_SMALL_CAP / 64, true>(a, dp, sb, obase, n, two, A, cnt, &sh_first, &a.star_first[sk],
+                                                                              c1 > c0 ? lane * URF_TILE + c0 : 0u, c1 - c0);   /* (a lane without a run reads the scan's first element, never a tile behind its last) */
+        if (tie && lane == 0)
+            urf_tie_found(a, s, sk);
+        __syncthreads();   /* the LDS is reused by the next sector */
+    }
 }
 
 template <int NT>
