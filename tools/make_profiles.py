@@ -53,7 +53,8 @@ def main(src, tag):
         v = vals.get((k, c), [0.0])
         return sum(v) / len(v)
     pipeline = ("k_ring_table", "k_split", "k_table_repair", "k_split_repair", "k_index", "k_star_sort_small", "k_star_sort_mid", "k_nan_rings",
-                "k_star_sort_big", "k_star_ties", "k_star_walk", "k_star_walk_few", "k_ring", "k_beams", "k_label")
+                "k_star_sort_big", "k_star_ties", "k_star_walk", "k_star_walk_few", "k_ring", "k_beams", "k_label",
+                "k_front", "k_front_finish", "k_label_front", "k_split_list", "k_ring_list", "k_label_list", "k_star_sort_runs")   # (r6: the fused front end)
     kernels = sorted({k for k, _ in vals if k in pipeline})
     per = {k: int(2 * avg(k, "FETCH_SIZE") * 1024 + avg(k, "WRITE_SIZE") * 1024) for k in kernels}
     # bench.py's timing slot "k_star_sort" spans k_star_sort_small/mid/big (the latter two run over
