@@ -131,6 +131,9 @@ struct urf_ctx {
      * scan's flag and leave; after the first such scan (h_spec_failed[2]) they come as full grids, and once a whole batch has been
      * handed back (h_spec_failed[3]: unorganised clouds) the context stops trying.  urf_set_params / urf_set_front_mode start over. */
     bool front_direct = false, front_off = false;
+    /* k_front_finish's first part runs on a stream of its own next to the star-shaped search (run_pipeline) */
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool speculate = true;
     bool use_hint = true;           /* k_ring_table also stops at the ring count of the row's previous call (until that fails once) */
     /* last call, for the entry points that read its intermediate results (urf_read_stage,
@@ -314,7 +317,7 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
     A(k.info, S)
     k.front_cand_cap = max_points / 8 > 4096 ? max_points / 8 : 4096;
     A(k.front_ok, S) A(k.front_pres, S * tiles * 64) A(k.front_maxs, S * tiles * 64) A(k.front_lane_ring, S * 64) A(k.front_ring_lane, S * C)
-    A(k.front_cand, S * k.front_cand_cap) A(k.front_all, S * k.front_cand_cap) A(k.front_ncand, S) A(k.front_list, S)
+    A(k.front_cand, S * k.front_cand_cap) A(k.front_all, S * k.front_cand_cap) A(k.front_ncand, S) A(k.front_list, S) A(k.front_st, S * 72)
     A(c->offsets_copy, S + 1)
     A(c->compact_cnt, S * tiles * 4)
     A(c->d_newY, (size_t)max_points) A(c->d_beams, K)
@@ -407,6 +410,14 @@ extern "C" int urf_destroy(urf_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->own_stream)
         (void)hipStreamSynchronize(c->own_stream);
+    if (c->side_stream) {
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipStreamDestroy(c->side_stream);
+        if (c->ev_fork)
+            (void)hipEventDestroy(c->ev_fork);
+        if (c->ev_join)
+            (void)hipEventDestroy(c->ev_join);
+    }
     for (hipStream_t st : c->row_stream)
         if (st)
             (void)hipStreamSynchronize(st);
@@ -603,7 +614,7 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     k.win += r * C * URF_DEG_CELLS;
     k.info += r;
     k.front_ok += r; k.front_pres += r * tiles * 64; k.front_maxs += r * tiles * 64; k.front_lane_ring += r * 64; k.front_ring_lane += r * C;
-    k.front_cand += r * (size_t)k.front_cand_cap; k.front_all += r * (size_t)k.front_cand_cap; k.front_ncand += r; k.front_list += r;
+    k.front_cand += r * (size_t)k.front_cand_cap; k.front_all += r * (size_t)k.front_cand_cap; k.front_ncand += r; k.front_list += r; k.front_st += r * 72;
     return k;
 }
 
@@ -748,6 +759,27 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         hipLaunchKernelGGL(k_split_repair, dim3(c->n_cus), dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
     }
     mark();
+    /* k_front_finish's first part (positions, the detectors' candidates and their marks) depends on nothing behind k_front: it goes to a
+     * stream of its own and runs NEXT TO k_index, the star-shaped search's sort and walk -- it waits for scattered loads (0.18 ms on its
+     * own), they are bound by vector issue.  With the per-kernel event brackets on (urf_enable_kernel_timing) everything stays on one
+     * stream, so that the brackets add up to the step. */
+    bool side = false, part1 = false;
+    const size_t finish_lds = (size_t)a.tiles * 384 + 2 * URF_FINISH_CHUNK * sizeof(urf_u2);
+    if (a.front && !ev) {
+        if (!c->side_stream) {
+            if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+                c->side_stream = nullptr;
+        }
+        if (c->side_stream && hipEventRecord(c->ev_fork, st) == hipSuccess && hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) == hipSuccess) {
+            hipLaunchKernelGGL(k_front_finish, g_scan, dim3(URF_FINISH_THREADS), finish_lds, c->side_stream, a, dp, 1u);
+            part1 = true;
+            side = hipEventRecord(c->ev_join, c->side_stream) == hipSuccess;
+            if (!side)   /* (cannot be joined by an event: wait for it here) */
+                (void)hipStreamSynchronize(c->side_stream);
+        }
+    }
     hipLaunchKernelGGL(k_index, g_scan, dim3(256), 0, st, a, dp);
     mark();
     /* k_star_ties: persistent one-wave workgroups (32 KB of LDS: four per CU) over a list that holds one sector in a hundred of
@@ -792,8 +824,11 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         hipLaunchKernelGGL(k_ring, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
     else
         hipLaunchKernelGGL(k_ring_general, g_ring, dim3(URF_RING_THREADS), (2 * (size_t)a.tiles + 1) * sizeof(unsigned), st, a, dp);
-    if (a.front)
-        hipLaunchKernelGGL(k_front_finish, g_scan, dim3(URF_FINISH_THREADS), (size_t)a.tiles * 384 + 2 * URF_FINISH_CHUNK * sizeof(urf_u2), st, a, dp);
+    if (a.front) {
+        if (side && hipStreamWaitEvent(st, c->ev_join, 0) != hipSuccess)
+            (void)hipStreamSynchronize(c->side_stream);
+        hipLaunchKernelGGL(k_front_finish, g_scan, dim3(URF_FINISH_THREADS), finish_lds, st, a, dp, part1 ? 2u : 0u);   /* (2: the star-shaped hits, the hand-over to k_beams) */
+    }
     /* the rings that hold a point with a NaN azimuth (k_split listed them: normally none, the kernel returns at once) */
     if (!(a.optimistic & URF_OPT_NO_NAN))
         hipLaunchKernelGGL(k_nan_rings, dim3(32), dim3(256), URF_NAN_LDS * sizeof(unsigned long long), st, a, dp);

@@ -428,6 +428,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(URF_FRONT_WA
 /* ------------------------------------------------------------------------- */
 /* k_front_finish                                                              */
 /* ------------------------------------------------------------------------- */
+#define URF_FRONT_ST_WORDS 72u   /* k_front_finish part 1 -> part 2: 64 list lengths, 4 quadrant values, the length of the list of marks */
 #define URF_FINISH_CHUNK 768u   /* candidates per chunk (each may be listed twice): 12 KB of LDS */
 #ifndef URF_FINISH_THREADS
 #define URF_FINISH_THREADS 256   /* four waves and <= 40 KB of LDS per scan: four workgroups per CU, a batch of 1024 scans in one round (A/B 256 / 512 /
@@ -469,7 +470,11 @@ __device__ __forceinline__ unsigned urf_front_next(const unsigned* P, unsigned n
     return t * 32u + (unsigned)__ffs((int)w) - 1u;
 }
 
-__global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a, urf_dev_params dp)
+/* part 0: everything.  Parts 1 and 2 (r6): what does not depend on the star-shaped search -- positions, ring sizes, the candidates of the
+ * two detectors and their marks -- as a launch of its own on a SECOND stream, next to k_index / k_star_sort_* / k_star_walk (it waits for
+ * scattered loads, they for vector issue: urf_api.hip), and the star-shaped hits, the lists' hand-over to k_beams and the overflow tables
+ * behind the walk.  The counters travel from part 1 to part 2 through front_st. */
+__global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a, urf_dev_params dp, unsigned part)
 {
     __shared__ urf_finish_shared S;
     extern __shared__ unsigned sh_finish[];   /* P[tiles][64] presence words | B[tiles][64] (u16) ring points of the lane in the tiles before */
@@ -486,14 +491,22 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
     unsigned* const P = sh_finish;
     uint16_t* const B = (uint16_t*)(sh_finish + a.tiles * 64u);
     urf_u2* const chunk = (urf_u2*)(sh_finish + a.tiles * 96u);   /* [2 * URF_FINISH_CHUNK] a chunk of the candidate list, by kind */
+    unsigned* const st = a.front_st + (size_t)s * URF_FRONT_ST_WORDS;   /* [0..63] ncurb, [64..67] quadrants, [68] list length: part 1 -> part 2 */
+    urf_u2* const pend = a.front_all + (size_t)s * a.front_cand_cap;   /* (index, flags) of what phase M has to mark; later the list of all curb points */
     const unsigned sb = urf_sbase(a, s);
     const float* __restrict__ const gx = a.x + off;
     const float* __restrict__ const gy = a.y + off;
     const float* __restrict__ const gz = a.z + off;
+    auto passed = [&](unsigned idx, unsigned flag) {
+        const unsigned e = atomicAdd(&S.n_pend, 1u);
+        if (e < a.front_cand_cap)
+            pend[e] = urf_u2{ idx, flag };
+    };
+    unsigned m_from = 0;   /* phase M starts here in the list */
+    if (part != 2u) {
     const urf_u2* const cand = a.front_cand + (size_t)s * a.front_cand_cap;
     const unsigned nc_raw = a.front_ncand[s];
     const unsigned nc = nc_raw < a.front_cand_cap ? nc_raw : a.front_cand_cap;
-    URF_PHASE_DECL;
     for (unsigned k = tid; k < ntiles * 64u; k += URF_FINISH_THREADS)
         P[k] = a.front_pres[(size_t)s * a.tiles * 64u + k];
     if (tid < URF_FRONT_LANES)
@@ -508,34 +521,32 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
         S.n_pend = 0;
     }
     __syncthreads();
-    URF_PHASE_MARK;
     /* positions: the tiles in as many stretches as the workgroup has waves, per lane; then the stretches' sums */
     {
         constexpr unsigned NP = URF_FINISH_THREADS / 64u;
-        const unsigned l = tid & 63u, part = tid >> 6;
-        const unsigned tq = (ntiles + NP - 1u) / NP, ta = part * tq < ntiles ? part * tq : ntiles, tb = ta + tq < ntiles ? ta + tq : ntiles;
+        const unsigned l = tid & 63u, prt = tid >> 6;
+        const unsigned tq = (ntiles + NP - 1u) / NP, ta = prt * tq < ntiles ? prt * tq : ntiles, tb = ta + tq < ntiles ? ta + tq : ntiles;
         unsigned run = 0;
         for (unsigned t = ta; t < tb; t++)
             run += (unsigned)__popc(P[t * 64u + l]);
-        S.qsum[part][l] = run;
+        S.qsum[prt][l] = run;
         __syncthreads();
         unsigned add = 0, all = 0;
         for (unsigned p = 0; p < NP; p++) {
-            add += p < part ? S.qsum[p][l] : 0u;
+            add += p < prt ? S.qsum[p][l] : 0u;
             all += S.qsum[p][l];
         }
         for (unsigned t = ta; t < tb; t++) {
             B[t * 64u + l] = (uint16_t)add;
             add += (unsigned)__popc(P[t * 64u + l]);
         }
-        if (part == 0)
+        if (prt == 0)
             S.n[l] = all;
     }
     /* ring sizes, the scan's summary, the rings' largest ranges */
     if (tid < C)
         a.ring_cnt[(size_t)s * C + tid] = 0;
     __syncthreads();
-    URF_PHASE_MARK;
     if (tid < 64) {
         const unsigned r = S.ring[tid], n = r != 0xffffffffu ? S.n[tid] : 0u;
         unsigned tot = n;
@@ -572,12 +583,6 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
      *   phase M   the points that got a mark, and the star-shaped hits: record flag, azimuth, ring list, quadrants.
      * An item makes ONE memory round trip for its data: neighbours' firings from the presence words in LDS, then the point, the
      * neighbours and x_zero's table values requested together. */
-    urf_u2* const pend = a.front_all + (size_t)s * a.front_cand_cap;   /* (index, flags) of what phase M has to mark; later the list of all curb points */
-    auto passed = [&](unsigned idx, unsigned flag) {
-        const unsigned e = atomicAdd(&S.n_pend, 1u);
-        if (e < a.front_cand_cap)
-            pend[e] = urf_u2{ idx, flag };
-    };
     constexpr unsigned CH = URF_FINISH_CHUNK;
     for (unsigned c0 = 0; c0 < nc; c0 += CH) {
         const unsigned cn = nc - c0 < CH ? nc - c0 : CH;
@@ -687,22 +692,33 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
             }
         __syncthreads();   /* the chunk's buffer is free for the next one */
     }
-    URF_PHASE_MARK;
+    } else {
+        /* part 2: the counters of part 1 */
+        if (tid < URF_FRONT_LANES) {
+            S.ncurb[tid] = st[tid];
+            S.ring[tid] = a.front_lane_ring[(size_t)s * 64u + tid];
+        }
+        if (tid < 4)
+            S.q[tid] = (int)st[64u + tid];
+        if (tid == 0)
+            S.n_pend = st[68];
+        m_from = st[68];
+        __syncthreads();
+    }
     /* lidar_segmentation.cpp:235-242: the star-shaped hits (the walk reported them as input indices; -1: none or on no ring) */
-    if (dp.p.star_shaped_method)
+    if (part != 1u && dp.p.star_shaped_method)
         for (unsigned k = tid; k < K; k += URF_FINISH_THREADS) {
             const int h = a.star_hit[(size_t)s * K + k];
             if (h >= 0)
                 passed((unsigned)h, 1u);
         }
     __syncthreads();
-    URF_PHASE_MARK;
     /* phase M.  A ring point that has a detector's mark: its record's flag (whoever sets the first one lists the point), the
      * reference's azimuth, its ring's list, ring 1's quadrants (urf_ring_point: lidar_segmentation.cpp:245-269, blind_spots.cpp:
      * 19-56).  The atomic is on its way while the azimuth is worked out.  The list of all curb points (the rings whose own list
      * overflows) takes the places of the entries already read: entry e is rewritten by the thread that read it. */
     const unsigned n_pend = S.n_pend < a.front_cand_cap ? S.n_pend : a.front_cand_cap;
-    for (unsigned e = tid; e < n_pend; e += URF_FINISH_THREADS) {
+    for (unsigned e = m_from + tid; e < n_pend; e += URF_FINISH_THREADS) {
         const urf_u2 pd = pend[e];
         const unsigned idx = pd.x, r = S.ring[idx & 63u];
         const float px = gx[idx], py = gy[idx];
@@ -729,16 +745,16 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
         }
         pend[e] = out;
     }
-    URF_PHASE_MARK;
     __syncthreads();
-    URF_PHASE_MARK;
-#ifdef URF_EXP_PHASE_CLOCK
-    if (threadIdx.x == 0 && blockIdx.x >= 500 && blockIdx.x < 504) {
-        printf("k_front_finish wg %u candidates %u marked %u\n", blockIdx.x, nc, n_pend);
-        for (unsigned ph_i = 1; ph_i < ph_n; ph_i++)
-            printf("k_front_finish wg %u phase %u: %llu cycles\n", blockIdx.x, ph_i, ph_t[ph_i] - ph_t[ph_i - 1]);
+    if (part == 1u) {   /* (uniform) the counters for part 2 */
+        if (tid < URF_FRONT_LANES)
+            st[tid] = S.ncurb[tid];
+        if (tid < 4)
+            st[64u + tid] = (unsigned)S.q[tid];
+        if (tid == 0)
+            st[68] = n_pend;
+        return;
     }
-#endif
     /* what k_beams reads (k_ring's epilogue) */
     if (tid < 4 && dp.p.blind_spots && in.n_rings > 1)
         a.quad[(size_t)s * 4 + tid] = __uint_as_float((unsigned)S.q[tid]);

@@ -266,6 +266,7 @@ struct urf_kargs {
     urf_u2*   front_cand;       /* [S][front_cand_cap] (input index, URF_FC_*): points whose detector decision is pending (k_front -> k_front_finish) */
     urf_u2*   front_all;        /* [S][front_cand_cap] (azimuth bits, ring) of every curb point (k_front_finish: rings whose list overflowed) */
     uint32_t* front_ncand;      /* [S] */
+    uint32_t* front_st;         /* [S][URF_FRONT_ST_WORDS] k_front_finish part 1 -> part 2 */
     uint32_t* front_list;       /* [S] the scans whose flag is clear (k_front_collect; star_count[6] = how many): the list-driven legacy kernels' work */
     uint32_t* front_state;      /* host-mapped: [0] some scan of some call was handed back, [1] every scan of some call was */
     uint32_t  front_lists;      /* this call launches the legacy kernels list-driven (k_split_list, k_ring_list, k_label_list) */
