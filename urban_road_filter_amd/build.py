@@ -24,7 +24,8 @@ LIB_TEST = os.path.join(HERE, "liburf_hip_test.so")
 SOURCES = ["urf_api.hip", "params.cpp", "detector.cpp", "marker.cpp"]
 HOOK_SOURCES = ["synth.cpp"]                 # liburf_hip_test.so only
 HOOK_DEFINES = ["URF_ENABLE_TEST_HOOKS=1"]
-HEADERS = ["urf_internal.hpp", "urf_device.hpp", "urf_kernels.hpp", "urf_front.hpp", "detector.hpp", "marker.hpp",
+HEADERS = ["urf_internal.hpp", "urf_device.hpp", "urf_kernels.hpp", "urf_k_table.hpp", "urf_k_split.hpp", "urf_k_star.hpp", "urf_k_ring.hpp",
+           "urf_k_beams_label.hpp", "urf_k_outputs.hpp", "urf_front.hpp", "detector.hpp", "marker.hpp",
            "../../include/urf.h", "../../include/urf_test_hooks.h", "../../include/urf_libm.h"]
 
 # -ffp-contract=off: the reference is built without FMA contraction and label
