@@ -40,6 +40,9 @@ class DevBuf:
 
     def fill(self, byte):
         assert hip().hipMemset(self.ptr, byte, self.nbytes) == 0
+        # hipMemset runs on the null stream; the library's streams are non-blocking, i.e. NOT ordered behind it: with sixteen fuzz
+        # processes on one GPU the fill has been seen to land after the kernels that wrote the buffer
+        assert hip().hipDeviceSynchronize() == 0
 
     def to_numpy(self, dtype, count=None):
         dtype = np.dtype(dtype)

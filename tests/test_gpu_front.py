@@ -155,7 +155,8 @@ def test_points_on_the_axis_and_too_few_points():
             lb, ib, _ = O.run_b(x, y, z, p)
             assert np.array_equal(labels[k], lb), k
             assert int(np.int32(infos[k][0])) == ib["status"] and all(int(infos[k][j]) == ib[f] for j, f in
-                                                                       ((1, "n_roi"), (4, "n_road"), (5, "n_curb"), (7, "n_nan_azimuth"))), k
+                                                                       ((1, "n_roi"), (3, "n_ring_pts"), (4, "n_road"), (5, "n_curb"), (6, "n_ring10"),
+                                                                        (7, "n_nan_azimuth"))), k
         assert ctx.front_scans() == 2   # (the too-few scan keeps its flag: nothing is published for it either way)
 
 

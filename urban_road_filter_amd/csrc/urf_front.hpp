@@ -514,6 +514,7 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
     if (tid < 64)
         S.ring[tid] = a.front_lane_ring[(size_t)s * 64u + tid];
     if (tid == 0) {
+        st[70] = 0;
         S.q[0] = (int)urf_fbits(0.f);
         S.q[1] = (int)urf_fbits(180.f);
         S.q[2] = (int)urf_fbits(180.f);
@@ -568,10 +569,10 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
             a.maxdist[(size_t)s * C + r] = (float)__builtin_sqrt(__longlong_as_double((long long)m));
             a.vis[(size_t)s * C + r] = urf_vis{ __builtin_inff(), -__builtin_inff() };
             if (r == 10u)
-                a.info[s].n_ring10 = in.n_rings > 10 ? n : 0u;
+                st[70] = n;
         }
         if (tid == 0)
-            a.info[s].n_ring_pts = tot;
+            st[69] = tot;   /* (the summary's two counts are written behind k_index -- below -- which may still find the scan below the 30-point threshold) */
     }
     /* The candidates.  One wave-instruction costs the same with one busy lane as with sixty-four, and every kind of candidate has
      * its own expensive chain (x_zero: three f64 roots and a division; z_zero: ten differences, two roots, a division; a passed
@@ -754,6 +755,11 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
         if (tid == 0)
             st[68] = n_pend;
         return;
+    }
+    /* the scan's summary (lidar_segmentation.cpp:605-608: road_probably = every point of sorted ring 10) */
+    if (tid == 0) {
+        a.info[s].n_ring_pts = st[69];
+        a.info[s].n_ring10 = in.n_rings > 10 ? st[70] : 0u;
     }
     /* what k_beams reads (k_ring's epilogue) */
     if (tid < 4 && dp.p.blind_spots && in.n_rings > 1)
