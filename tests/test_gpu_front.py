@@ -269,3 +269,130 @@ def test_storage_orders_of_sensor_like_sweeps_against_the_oracle(mode):
     with u.Context(N, len(scans)) as ctx:
         labels, infos, nf = fused_batch(ctx, scans, pr, mode=mode)
         check_against_b(labels, infos, scans, pr)
+
+
+# ---- row-major organised sweeps (height = the 64 lasers, width = firings): k_rows_probe, k_transpose, k_label_front's row-major stores ----
+def rows_then_fused(ctx, scans, p, want=None, ragged=False):
+    """A context's first call with such sweeps only sights the layout (legacy kernels, labels already the oracle's); from the second on
+    they take k_transpose and the fused kernels."""
+    labels, infos, nf0 = fused_batch(ctx, scans, p, ragged=ragged)
+    check_against_b(labels, infos, scans, p)
+    labels, infos, nf = fused_batch(ctx, scans, p, ragged=ragged)
+    check_against_b(labels, infos, scans, p)
+    if want is not None:
+        assert nf == want, (nf0, nf)
+    return nf0, nf
+
+
+@pytest.mark.parametrize("name,seeds", [("cfg2", (1, 2, 3, 4)), ("narrow", (1, 2, 3)), ("sensor", (1, 2, 3, 4)), ("sensor_narrow", (1, 2)),
+                                        ("default_roi", (1, 2, 3)), ("sensor_default_roi", (1, 2))])
+def test_row_major_sweeps_take_the_fused_front_end_from_the_second_call(name, seeds):
+    p = O.cfg_params(name)
+    scans = [ring_major(O.cfg_cloud(name, s)) for s in seeds]
+    with u.Context(N, len(scans)) as ctx:
+        nf0, nf = rows_then_fused(ctx, scans, p, want=len(scans))
+        assert nf0 == 0
+        labels, infos, nf = fused_batch(ctx, scans[::-1], p)
+        assert nf == len(scans)
+        check_against_b(labels, infos, scans[::-1], p)
+        labels, infos, nf = fused_batch(ctx, scans, p, mode=0)   # ... and the legacy kernels on the same context
+        assert nf == 0
+        check_against_b(labels, infos, scans, p)
+
+
+def test_row_major_lasers_in_any_order_rear_stored_and_mixed_batches():
+    p = O.cfg_params("sensor")
+    perm = np.random.default_rng(5).permutation(64)
+    scans = [ring_major(permuted(O.cfg_cloud("sensor", s), perm)) for s in (1, 2)] + [ring_major(permuted(O.cfg_cloud("cfg2", 3), perm[::-1].copy()))]
+    with u.Context(N, len(scans)) as ctx:
+        rows_then_fused(ctx, scans, p, want=len(scans))
+    # every row starts outside the reference's default region of interest (the sweep is stored from the rear)
+    pr = O.cfg_params("default_roi")
+    scans = [ring_major(rolled(O.cfg_cloud("default_roi", s), 1024)) for s in (1, 2)] + [ring_major(O.cfg_cloud("default_roi", 3))]
+    with u.Context(N, len(scans)) as ctx:
+        rows_then_fused(ctx, scans, pr, want=len(scans))
+    # row-major, shuffled, firing order and row-major again in one batch
+    p2 = O.cfg_params("cfg2")
+    scans = [ring_major(O.cfg_cloud("cfg2", 1)), shuffled(O.cfg_cloud("cfg2", 3), 1), O.cfg_cloud("sensor", 2), ring_major(O.cfg_cloud("sensor", 4))]
+    with u.Context(N, len(scans)) as ctx:
+        nf0, nf = rows_then_fused(ctx, scans, p2, want=3)
+        assert nf0 == 1
+
+
+@pytest.mark.parametrize("tweak", [{"xDirection": 1}, {"starbeam_filter": 1}, {"star_shaped_method": 0}, {"curbHeight": 0.01},
+                                   {"x_zero_method": 0}, {"z_zero_method": 0}, {"blind_spots": 0}])
+def test_row_major_parameters(tweak):
+    p = O.cfg_params("cfg2")
+    for k, v in tweak.items():
+        setattr(p, k, v)
+    scans = [ring_major(O.cfg_cloud("sensor", 1)), ring_major(O.cfg_cloud("narrow", 2))]
+    with u.Context(N, len(scans)) as ctx:
+        rows_then_fused(ctx, scans, p, want=len(scans))
+
+
+@pytest.mark.parametrize("cols", [96, 40, 33, 8, 2047])
+def test_row_major_widths_that_are_no_multiple_of_a_tile(cols):
+    """F = 96 / 40 / 33 / 8 / 2047 firings: partial last tiles, rows that start at any byte (the labels' 8-byte stores fall back to bytes)."""
+    p = O.cfg_params("cfg2")
+    fir = [u.synth_cloud(64, cols, 1, 7 + k) for k in range(3)]
+    with u.Context(64 * cols, len(fir)) as ctx:
+        nfir = fused_batch(ctx, fir, p)[2]   # (a sweep whose seam falls inside a tile is handed back in either layout)
+        assert nfir >= 1 or cols == 33
+    with u.Context(64 * cols, len(fir)) as ctx:
+        rows_then_fused(ctx, [ring_major(c) for c in fir], p, want=nfir)
+    # ragged: sweeps of different widths in one batch
+    fir = [u.synth_cloud(64, c, 3, 11 + c) for c in (cols, 64, 2048 if cols > 2000 else 130)]
+    with u.Context(max(len(s[0]) for s in fir), len(fir)) as ctx:
+        nfir = fused_batch(ctx, fir, p, ragged=True)[2]
+    with u.Context(max(len(s[0]) for s in fir), len(fir)) as ctx:
+        rows_then_fused(ctx, [ring_major(c) for c in fir], p, want=nfir, ragged=True)
+
+
+def test_a_row_major_sweep_that_is_not_clean_is_handed_back():
+    """One point of a row lifted onto a neighbouring ring's angle: the rows' rule (every point on its row's table entry) fails in k_front,
+    the table is walked the long way (k_table_repair) and the legacy kernels classify the sweep; its neighbours stay fused."""
+    p = O.cfg_params("cfg2")
+    x, y, z = (a.copy() for a in O.cfg_cloud("cfg2", 1))
+    i, j = 20 + 64 * 700, 21 + 64 * 700            # firing 700: laser 20 gets laser 21's point
+    x[i], y[i], z[i] = x[j], y[j], z[j]
+    bad = ring_major((x, y, z))
+    # a point that lies on NO ring of the table (between two rings): it would have become a leader of its own
+    x2, y2, z2 = (a.copy() for a in O.cfg_cloud("cfg2", 2))
+    k0, k1 = 30 + 64 * 900, 31 + 64 * 900
+    z2[k0] = 0.5 * (z2[k0] + z2[k1] * np.hypot(x2[k0], y2[k0]) / max(np.hypot(x2[k1], y2[k1]), 1e-6))
+    bad2 = ring_major((x2, y2, z2))
+    scans = [ring_major(O.cfg_cloud("cfg2", 3)), bad, bad2, ring_major(O.cfg_cloud("sensor", 4))]
+    with u.Context(N, len(scans)) as ctx:
+        nf0, nf = rows_then_fused(ctx, scans, p)
+        assert nf0 == 0 and 2 <= nf <= 3
+        rows_then_fused(ctx, scans, p)   # (the legacy kernels now come as full grids)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_row_major_organised_sweeps_with_holes(seed):
+    """tests/fuzz_organised.py's sweeps (drop-outs, cut rings and firings, random regions of interest and parameters) stored row-major."""
+    sw, p = case(7100000 + seed)
+    scans = [ring_major(sw)]
+    with u.Context(len(sw[0]), 1) as ctx:
+        rows_then_fused(ctx, scans, p)
+
+
+def test_row_major_ring_sorted_results_rerun_the_legacy_kernels():
+    p = O.cfg_params("cfg2")
+    scans = [ring_major(O.cfg_cloud("sensor", 1)), ring_major(O.cfg_cloud("narrow", 2))]
+    with u.Context(N, 2) as ctx:
+        X, Y, Z = (np.concatenate([s[k] for s in scans]) for k in range(3))
+        dx, dy, dz = DevBuf.from_numpy(X), DevBuf.from_numpy(Y), DevBuf.from_numpy(Z)
+        dl = DevBuf(2 * N)
+        ctx.set_params(p)
+        ctx.set_front_mode(2)
+        ctx.classify_batch_soa(dx, dy, dz, N, 2, dl, None)
+        ctx.classify_batch_soa(dx, dy, dz, N, 2, dl, None)
+        assert ctx.front_scans() == 2
+        for k, (x, y, z) in enumerate(scans):
+            lb, ib, st = O.run_b(x, y, z, p, debug=True)
+            road, curb, prob = ctx.ordered_indices(N, scan=k)
+            assert np.array_equal(road, st["road_order"]) and np.array_equal(curb, st["curb_order"]) and np.array_equal(prob, st["ring10_order"])
+            assert np.array_equal(ctx.marker_points(scan=k), st["marker_pts"])
+            assert np.array_equal(dl.to_numpy(np.uint8).reshape(2, N)[k], lb)
+        assert ctx.front_scans() == 0

@@ -71,7 +71,7 @@ def check(name, sweeps, params, ctxs, verbose=True, fresh=False):
                     w = np.nonzero(lab[si] != lb)[0]
                     print("  MISMATCH %s scan %d mode %d: %d labels differ %s first %s gpu %s ref %s" % (
                         name, si, mode, d, di, w[:8], lab[si][w[:8]], lb[w[:8]]))
-    print("%-44s scans %3d fused %3d  %s" % (name, len(sweeps), res[2][2], "ok" if not bad else "FAILED (%d)" % bad), flush=True)
+    print("%-44s scans %3d fused %3d / %3d  %s" % (name, len(sweeps), res[2][2], res[3][2], "ok" if not bad else "FAILED (%d)" % bad), flush=True)
     return bad
 
 
@@ -80,6 +80,11 @@ def permute_lanes(sw, perm):
     for a in sw:
         out.append(np.ascontiguousarray(a.reshape(-1, 64)[:, perm].reshape(-1)))
     return tuple(out)
+
+
+def to_rows(sw):
+    """firing order -> the row-major organised layout (height = 64 lasers, width = firings)"""
+    return tuple(np.ascontiguousarray(a.reshape(-1, 64).T.reshape(-1)) for a in sw)
 
 
 def rotate_cols(sw, k):
@@ -129,18 +134,53 @@ def basic(ctxs):
     return bad
 
 
+def rows(ctxs):
+    """row-major organised sweeps: the first call of a context only sights them (legacy kernels), the second takes k_transpose + the fused kernels"""
+    bad = 0
+    P = oracles.cfg_params
+    R = to_rows
+    bad += check("rows: cfg2 x4", [R(oracles.cfg_cloud("cfg2", s)) for s in (1, 2, 3, 4)], P("cfg2"), ctxs, fresh=True)
+    bad += check("rows: sensor x4 (holes, ties)", [R(oracles.cfg_cloud("sensor", s)) for s in (1, 2, 3, 4)], P("sensor"), ctxs)
+    bad += check("rows: narrow x3", [R(oracles.cfg_cloud("narrow", s)) for s in (1, 2, 3)], P("narrow"), ctxs, fresh=True)
+    bad += check("rows: sensor_narrow x2", [R(oracles.cfg_cloud("sensor_narrow", s)) for s in (1, 2)], P("sensor_narrow"), ctxs, fresh=True)
+    bad += check("rows: default roi x3", [R(oracles.cfg_cloud("default_roi", s)) for s in (1, 2, 3)], P("default_roi"), ctxs, fresh=True)
+    bad += check("rows: sensor default roi x2", [R(oracles.cfg_cloud("sensor_default_roi", s)) for s in (1, 2)], P("sensor_default_roi"), ctxs, fresh=True)
+    sw = [R(rotate_cols(oracles.cfg_cloud("default_roi", s), 1024)) for s in (1, 2)] + [R(oracles.cfg_cloud("default_roi", 3))]
+    bad += check("rows: default roi, rear-stored", sw, P("default_roi"), ctxs, fresh=True)
+    perm = np.random.default_rng(5).permutation(64)
+    bad += check("rows: lasers permuted x3", [R(permute_lanes(oracles.cfg_cloud("sensor", s), perm)) for s in (1, 2, 3)], P("sensor"), ctxs, fresh=True)
+    p = P("cfg2")
+    p.starbeam_filter = 1
+    bad += check("rows: starbeam filter", [R(oracles.cfg_cloud("cfg2", 1)), R(oracles.cfg_cloud("sensor", 2))], p, ctxs, fresh=True)
+    p = P("cfg2")
+    p.curbHeight = 0.01
+    bad += check("rows: rough (lists overflow)", [R(oracles.cfg_cloud("sensor", 1)), R(oracles.cfg_cloud("cfg2", 2))], p, ctxs, fresh=True)
+    x, y, z = oracles.cfg_cloud("cfg2", 3)
+    pm = np.random.default_rng(1).permutation(len(x))
+    sw = [R(oracles.cfg_cloud("cfg2", 1)), (x[pm], y[pm], z[pm]), oracles.cfg_cloud("sensor", 2), R(oracles.cfg_cloud("sensor", 4))]
+    bad += check("rows: mixed batch (rows, shuffled, firings, rows)", sw, P("cfg2"), ctxs, fresh=True)
+    for cols in (96, 40, 33, 8):
+        bad += check("rows: short sweep 64 x %d" % cols, [R(u.synth_cloud(64, cols, 1, 7))], P("cfg2"), ctxs, fresh=True)
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fuzz", type=int, default=0)
     ap.add_argument("--seed0", type=int, default=9000000)
     ap.add_argument("--basic", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=1, help="the row-major cases; with --fuzz: 1 = every case is also run row-major")
     a = ap.parse_args()
     ctxs = {}
     bad = 0
     t0 = time.time()
     if a.basic:
         bad += basic(ctxs)
+        if a.rows:
+            bad += rows(ctxs)
     nfused = 0
+    nrows = 0
+    rctx = {}
     for i in range(a.fuzz):
         seed = a.seed0 + i
         sw, p = fuzz_organised.case(seed)
@@ -159,8 +199,25 @@ def main():
         if d or di:
             bad += 1
             print("  FUZZ MISMATCH seed %d fused %d: %d labels %s" % (seed, nf, d, di), flush=True)
+        if a.rows and n % 64 == 0:
+            # the same sweep row-major (a context of their own: its first call sights the layout, the following ones take it)
+            rs = to_rows(sw)
+            if key not in rctx:
+                rctx[key] = u.Context(n, 1)
+            rc = rctx[key]
+            rc.set_params(p)
+            lbr, ibr, _ = oracles.run_b(rs[0], rs[1], rs[2], p)
+            lab, info, nf = run_batch(rc, [rs], 2)
+            nrows += nf
+            iv = dict(zip(INFO_KEYS, [int(v) for v in info[0]]))
+            iv["status"] = int(np.int32(info[0][0]))
+            d = int(np.count_nonzero(lab[0] != lbr))
+            di = {k: (iv[k], ibr[k]) for k in INFO_KEYS if iv[k] != ibr[k]}
+            if d or di:
+                bad += 1
+                print("  FUZZ MISMATCH (row-major) seed %d fused %d: %d labels %s" % (seed, nf, d, di), flush=True)
     if a.fuzz:
-        print("fuzz: %d cases, %d took the fused front end, %d mismatches, %.0f s" % (a.fuzz, nfused, bad, time.time() - t0))
+        print("fuzz: %d cases, %d took the fused front end, %d of their row-major twins, %d mismatches, %.0f s" % (a.fuzz, nfused, nrows, bad, time.time() - t0))
     print("FRONT CHECK %s" % ("PASSED" if bad == 0 else "FAILED: %d" % bad))
     return 1 if bad else 0
 

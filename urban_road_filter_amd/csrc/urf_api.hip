@@ -131,6 +131,9 @@ struct urf_ctx {
      * scan's flag and leave; after the first such scan (h_spec_failed[2]) they come as full grids, and once a whole batch has been
      * handed back (h_spec_failed[3]: unorganised clouds) the context stops trying.  urf_set_params / urf_set_front_mode start over. */
     bool front_direct = false, front_off = false;
+    /* row-major organised sweeps (k_ring_table's third rule): once one has been sighted (h_spec_failed[4]) the batch calls' sequence
+     * holds k_transpose and k_ring_table may choose the layout */
+    bool front_rows = false, rows_oom = false;
     /* k_front_finish's first part runs on a stream of its own next to the star-shaped search (run_pipeline) */
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -244,6 +247,19 @@ static int upload_params(urf_ctx* c)
     return URF_OK;
 }
 
+/* the firing-order copies of row-major organised sweeps (k_transpose): allocated when the first such sweep has been sighted */
+static int ensure_rows_arrays(urf_ctx* c)
+{
+    if (c->k.tx)
+        return URF_OK;
+    int rc;
+    if ((rc = dev_alloc(c, &c->k.rows_v, (size_t)c->max_batch * 64)) != URF_OK || (rc = dev_alloc(c, &c->k.rows_ok, (size_t)c->max_batch)) != URF_OK ||
+        (rc = dev_alloc(c, &c->k.ty, c->total)) != URF_OK || (rc = dev_alloc(c, &c->k.tz, c->total)) != URF_OK ||
+        (rc = dev_alloc(c, &c->k.tx, c->total)) != URF_OK)   /* (tx last: its pointer says that all of them are there) */
+        return rc;
+    return URF_OK;
+}
+
 static int ensure_capture_arrays(urf_ctx* c)
 {
     if (c->k.valpha)
@@ -335,10 +351,11 @@ extern "C" int urf_create(urf_ctx** out, int device_id, uint32_t max_points, uin
         c->front_tpb = (uint32_t)std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : c->front_tpb;
     {
         void* hp = nullptr;
-        if (hipHostMalloc(&hp, 4 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess)
+        if (hipHostMalloc(&hp, 8 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess)
             return fail(URF_ERR_HIP);
-        c->h_spec_failed = (uint32_t*)hp;   /* [2], [3]: the fused front end's two flags (front_direct, front_off) */
-        c->h_spec_failed[0] = c->h_spec_failed[1] = c->h_spec_failed[2] = c->h_spec_failed[3] = 0;
+        c->h_spec_failed = (uint32_t*)hp;   /* [2], [3]: the fused front end's two flags (front_direct, front_off); [4], [5]: row-major sweeps sighted / failed */
+        for (int i = 0; i < 8; i++)
+            c->h_spec_failed[i] = 0;
         if (hipMemset(k.ring_hint, 0, URF_ASYNC_SLOTS * sizeof(uint32_t)) != hipSuccess)
             return fail(URF_ERR_HIP);
         void* dp_ = nullptr;
@@ -718,6 +735,25 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     /* The fused front end (urf_front.hpp) for batches of sweeps in firing order: k_front tries every scan, the legacy kernels
      * skip the scans it kept.  64 lasers = 64 lanes, the detectors' window of curbPoints == 5 in registers, no stage capture
      * (its values are the legacy kernels'), not for the single sweeps of the callback path (sixteen waves on the whole device). */
+    if (c->front_mode != 0 && !c->front_rows && !c->rows_oom && !on_stream && c->h_spec_failed[4]) {
+        /* An earlier call sighted a row-major organised sweep (k_ring_table's third rule): from here on the sequence holds k_transpose.
+         * Once per context: the calls in flight finish first -- what they handed back (such sweeps, possibly all of them) says nothing
+         * about the calls to come. */
+        URF_HIP(c, hipStreamSynchronize(st));
+        if (ensure_rows_arrays(c) == URF_OK) {
+            c->front_rows = true;
+            c->front_direct = c->front_off = false;
+            c->h_spec_failed[2] = c->h_spec_failed[3] = 0;
+            a.tx = c->k.tx;   /* (row 0: the batch calls') */
+            a.ty = c->k.ty;
+            a.tz = c->k.tz;
+            a.rows_v = c->k.rows_v;
+            a.rows_ok = c->k.rows_ok;
+        } else {
+            c->rows_oom = true;   /* (such sweeps keep to the legacy kernels) */
+            c->last_error.clear();
+        }
+    }
     if (c->h_spec_failed[2])
         c->front_direct = true;
     if (c->h_spec_failed[3] && c->front_mode != 2)
@@ -727,6 +763,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
                   ? 1u : 0u;
     a.front_tpb = c->front_tpb;
     a.front_lists = (a.front && !c->front_direct) ? 1u : 0u;
+    a.front_rows = (a.front && c->front_rows && a.table_lookahead) ? 1u : 0u;
 
     std::vector<hipEvent_t>* ev = nullptr;
     if (c->timing) {
@@ -744,8 +781,12 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         stage++;
     };
     mark();
+    if (a.front_rows)
+        hipLaunchKernelGGL(k_rows_probe, g_scan, dim3(256), 0, st, a, dp);
     hipLaunchKernelGGL(k_ring_table, g_scan, dim3(URF_TABLE_THREADS), 0, st, a, dp);
     mark();
+    if (a.front_rows)
+        hipLaunchKernelGGL(k_transpose, g_tiles, dim3(256), 0, st, a);
     if (a.front)
         hipLaunchKernelGGL(k_front, dim3((a.tiles + a.front_tpb - 1) / a.front_tpb, n_scans), dim3(64), 0, st, a, dp);
     if (a.front_lists) {   /* what k_front handed back (normally nothing) */

@@ -83,6 +83,60 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t urf_buf(const void* p, unsigne
 }
 #define URF_OOB 0xffffffffu
 
+/* the arrays the fused kernels read a scan's points from, indexed by firing * 64 + laser: the caller's for a sweep in firing order,
+ * k_transpose's copy for a row-major one (front_ok[s] == URF_FRONT_ROWS) */
+__device__ __forceinline__ void urf_front_src(const urf_kargs& a, unsigned s, unsigned off, unsigned ok, const float*& gx, const float*& gy, const float*& gz)
+{
+    const bool rows = ok == URF_FRONT_ROWS;   /* (uniform) */
+    const size_t o = rows ? (size_t)urf_sbase(a, s) : (size_t)off;
+    gx = (rows ? (const float*)a.tx : a.x) + o;
+    gy = (rows ? (const float*)a.ty : a.y) + o;
+    gz = (rows ? (const float*)a.tz : a.z) + o;
+}
+
+/* Row-major organised sweep -> firing order: tx[f * 64 + l] = x[l * F + f].  Grid (tiles, scans) x 256 threads, a tile = 32 firings:
+ * 64 rows x 128 bytes in (a cache line per row), LDS, 8 KB out in one stretch; 24 B/point, HBM-bound. */
+__global__ __launch_bounds__(256) void k_transpose(urf_kargs a)
+{
+    __shared__ float T[3][64][33];
+    const unsigned s = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    if (a.front_ok[s] != URF_FRONT_ROWS)
+        return;
+    unsigned off, len;
+    urf_scan_range(a, s, off, len);
+    const unsigned F = len >> 6, f0 = t * URF_FRONT_STEPS;
+    if (f0 >= F)
+        return;
+    const unsigned c = tid & 31u, r8 = tid >> 5;
+    const bool in = f0 + c < F;
+    float vx[8], vy[8], vz[8];
+#pragma unroll
+    for (unsigned j = 0; j < 8; j++) {
+        const size_t i = (size_t)off + (size_t)(j * 8u + r8) * F + f0 + (in ? c : 0u);
+        vx[j] = a.x[i];
+        vy[j] = a.y[i];
+        vz[j] = a.z[i];
+    }
+#pragma unroll
+    for (unsigned j = 0; j < 8; j++) {
+        T[0][j * 8u + r8][c] = vx[j];
+        T[1][j * 8u + r8][c] = vy[j];
+        T[2][j * 8u + r8][c] = vz[j];
+    }
+    __syncthreads();
+    const size_t ob = (size_t)urf_sbase(a, s) + (size_t)f0 * 64u;
+    const unsigned nf = F - f0 < URF_FRONT_STEPS ? F - f0 : URF_FRONT_STEPS;
+#pragma unroll
+    for (unsigned j = 0; j < 8; j++) {
+        const unsigned v = j * 256u + tid, f = v >> 6, l = v & 63u;
+        if (f < nf) {
+            a.tx[ob + v] = T[0][l][f];
+            a.ty[ob + v] = T[1][l][f];
+            a.tz[ob + v] = T[2][l][f];
+        }
+    }
+}
+
 /* What the fast decisions of a firing leave open -- a point that is not SURELY on its lane's table entry, whose sector is within
  * the margin of a border, or that the approximations refuse: the reference's exact sequence (urf_exact_keys).  Returns bit 0: on
  * the lane's ring; bits 1-11: sector + 1 (0: none wanted); bits 12-18 + URF_FO_ADOPT: the lane has no confirmed entry yet and the
@@ -148,7 +202,8 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
     const unsigned t_first = b * TPB;
     if (t_first * URF_TILE >= len)
         return;
-    if (a.front_ok[s] == 0u)
+    const unsigned ok = a.front_ok[s];
+    if (ok == 0u)
         return;
     constexpr unsigned C = URF_FRONT_LANES;
     const unsigned K = (unsigned)dp.p.sectors;
@@ -161,15 +216,15 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
     const bool to_end = Fe == nf;       /* no point of the scan lies behind the march */
     static_assert(URF_FRONT_HPRE % 4u == 0u && URF_FRONT_STEPS % 4u == 0u, "the march runs in groups of four firings");
     const unsigned sb = urf_sbase(a, s);
-    const float* __restrict__ const gx = a.x + off;
-    const float* __restrict__ const gy = a.y + off;
-    const float* __restrict__ const gz = a.z + off;
+    const float *gx, *gy, *gz;
+    urf_front_src(a, s, off, ok, gx, gy, gz);
     const __amdgpu_buffer_rsrc_t brec = urf_buf(a.rec + sb, len * 4u);
     const __amdgpu_buffer_rsrc_t bsr = urf_buf(a.sr + sb, a.tiles * URF_TILE * 4u), bsz = urf_buf(a.sz + sb, a.tiles * URF_TILE * 4u);
     const __amdgpu_buffer_rsrc_t bss = urf_buf(a.sslot + sb, a.tiles * URF_TILE * 2u);
     const unsigned nR = a.info[s].n_rings;
     const unsigned upto_v = a.table_upto[s];
-    const unsigned upto = nR < C ? upto_v : 0xffffffffu;
+    /* (a row-major scan's table rests on EVERY point lying on its row's entry -- k_ring_table's third rule: a point on none asks for the long walk) */
+    const unsigned upto = ok == URF_FRONT_ROWS ? 0u : (nR < C ? upto_v : 0xffffffffu);
     const float* const tab = a.angle + (size_t)s * dp.p.channels;
     const float curbH = dp.p.curbHeight;
     const bool use_x = dp.p.x_zero_method != 0, use_z = dp.p.z_zero_method != 0;
@@ -253,7 +308,7 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
                 failed = failed | (ons & !((rho2 >= 0x1p-90f) & (rho2 <= 0x1p126f)));   /* (outside the shortcut's interval: the legacy kernels) */
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pr), bsr, o4, 0, URF_FRONT_NT);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), bsz, o4, 0, URF_FRONT_NT);
-                __builtin_amdgcn_raw_buffer_store_b16((short)(on ? stp * 64u + lane : URF_SLOT_NONE), bss, ons ? so * 2u : URF_OOB, 0, URF_FRONT_NT);
+                __builtin_amdgcn_raw_buffer_store_b16((short)((stp * 64u + lane) | (on ? 0u : URF_SLOT_OFF)), bss, ons ? so * 2u : URF_OOB, 0, URF_FRONT_NT);
                 stepkey_v = lane == stp ? (int)f0 : stepkey_v;
                 stepcnt_v = lane == stp ? (int)__popcll(psm) : stepcnt_v;
                 tstar += (unsigned)__popcll(psm);
@@ -377,6 +432,8 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
             tile_end(f / URF_FRONT_STEPS);
             if (__ballot(failed | overflow) != 0ull) {   /* (uniform) */
                 a.front_ok[s] = 0u;
+                if (ok == URF_FRONT_ROWS)
+                    a.table_redo[s] = 1u;   /* (nobody has checked the rest of the scan against the rows' table) */
                 return;
             }
         }
@@ -410,8 +467,11 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
         const unsigned o2 = atomicCAS(&a.front_ring_lane[(size_t)s * C + E], 0xffffffffu, lane);
         failed = failed | (o1 != 0xffffffffu && o1 != E) | (o2 != 0xffffffffu && o2 != lane);
     }
-    if (__ballot(failed | overflow) != 0ull)
+    if (__ballot(failed | overflow) != 0ull) {
         a.front_ok[s] = 0u;
+        if (ok == URF_FRONT_ROWS)
+            a.table_redo[s] = 1u;
+    }
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(URF_FRONT_WAVES, URF_FRONT_WAVES))) void k_front(urf_kargs a, urf_dev_params dp)
@@ -479,7 +539,8 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
     __shared__ urf_finish_shared S;
     extern __shared__ unsigned sh_finish[];   /* P[tiles][64] presence words | B[tiles][64] (u16) ring points of the lane in the tiles before */
     const unsigned s = blockIdx.x, tid = threadIdx.x;
-    if (!a.front_ok[s])
+    const unsigned ok = a.front_ok[s];
+    if (!ok)
         return;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
@@ -494,9 +555,8 @@ __global__ __launch_bounds__(URF_FINISH_THREADS) void k_front_finish(urf_kargs a
     unsigned* const st = a.front_st + (size_t)s * URF_FRONT_ST_WORDS;   /* [0..63] ncurb, [64..67] quadrants, [68] list length: part 1 -> part 2 */
     urf_u2* const pend = a.front_all + (size_t)s * a.front_cand_cap;   /* (index, flags) of what phase M has to mark; later the list of all curb points */
     const unsigned sb = urf_sbase(a, s);
-    const float* __restrict__ const gx = a.x + off;
-    const float* __restrict__ const gy = a.y + off;
-    const float* __restrict__ const gz = a.z + off;
+    const float *gx, *gy, *gz;
+    urf_front_src(a, s, off, ok, gx, gy, gz);
     auto passed = [&](unsigned idx, unsigned flag) {
         const unsigned e = atomicAdd(&S.n_pend, 1u);
         if (e < a.front_cand_cap)
@@ -835,6 +895,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
 {
     __shared__ unsigned cnt_road, cnt_curb, n_unsure;
     __shared__ unsigned un_idx[URF_LABEL_UNSURE], un_ring[URF_LABEL_UNSURE];
+    __shared__ __attribute__((aligned(8))) uint8_t lab_t[64][40];   /* (row-major scans) [laser][firing of the tile] */
     unsigned s = blockIdx.y, t = blockIdx.x;
     {   /* the tiles of one scan on one XCD (k_label: the scan's window table is fetched by one L2) */
         const unsigned T = gridDim.x, lin = blockIdx.y * T + blockIdx.x;
@@ -845,13 +906,18 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         }
     }
     const unsigned tid = threadIdx.x;
-    if (!a.front_ok[s])
+    const unsigned ok = a.front_ok[s];
+    if (!ok)
         return;
     unsigned off, len;
     urf_scan_range(a, s, off, len);
     const unsigned tbase = t * URF_TILE;
     if (tbase >= len)
         return;
+    const bool rows = ok == URF_FRONT_ROWS;   /* (uniform) the labels go where the points came from: row l, column f */
+    const unsigned F = len >> 6;
+    const float *gx, *gy, *gz;
+    urf_front_src(a, s, off, ok, gx, gy, gz);
     const unsigned C = (unsigned)dp.p.channels;
     const size_t row = (size_t)s * a.tiles + t;
     const unsigned sb = urf_sbase(a, s);
@@ -863,8 +929,29 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
     const unsigned bits = ((const uint8_t*)(a.roi_bits + row * URF_FRONT_STEPS))[tid] & in_scan;
     uint8_t* const out = a.labels + off + i0;
     const bool whole = tbase + URF_TILE <= len && ((uintptr_t)(a.labels + off + tbase) & 7u) == 0;   /* (uniform) */
+    /* row-major: the tile's 32 firings x 64 lasers through LDS, then 8 columns of a row per thread (32 bytes per row and tile) */
+    auto store_rows = [&](const unsigned (&lb)[8]) {
+        const unsigned stp = tid >> 3, l0 = (tid & 7u) * 8u;
+#pragma unroll
+        for (unsigned e = 0; e < 8; e++)
+            lab_t[l0 + e][stp] = (uint8_t)lb[e];
+        __syncthreads();
+        const unsigned l = tid >> 2, c0 = (tid & 3u) * 8u, f0 = t * URF_FRONT_STEPS + c0;
+        uint8_t* const o = a.labels + off + (size_t)l * F + f0;
+        const uint8_t* const src = &lab_t[l][c0];
+        if (f0 + 8u <= F && ((uintptr_t)o & 7u) == 0) {
+            *(uint2*)o = *(const uint2*)src;
+        } else {
+            for (unsigned e = 0; e < 8; e++)
+                if (f0 + e < F)
+                    o[e] = src[e];
+        }
+    };
     if (in.status != URF_OK || troi == 0) {
-        if (whole) {
+        if (rows) {
+            const unsigned zero[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+            store_rows(zero);
+        } else if (whole) {
             *(uint2*)out = make_uint2(0u, 0u);
         } else {
             for (unsigned e = 0; e < 8; e++)
@@ -930,7 +1017,7 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
             } else {   /* list full (pathological input) */
                 float d2;
                 bool dummy;
-                const float xaz = urf_azimuth(a.x[off + i0 + e], a.y[off + i0 + e], &d2);
+                const float xaz = urf_azimuth(gx[i0 + e], gy[i0 + e], &d2);
                 road = urf_road_test(win + c * URF_DEG_CELLS, xaz, 0.0f, dummy);
             }
         }
@@ -941,7 +1028,9 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         my_road += road ? 1u : 0u;
     }
     }
-    if (whole) {
+    if (rows) {
+        store_rows(lab);
+    } else if (whole) {
         *(uint2*)out = make_uint2(lab[0] | lab[1] << 8 | lab[2] << 16 | lab[3] << 24, lab[4] | lab[5] << 8 | lab[6] << 16 | lab[7] << 24);
     } else {
         for (unsigned e = 0; e < 8; e++)
@@ -954,9 +1043,9 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         const unsigned i = un_idx[tid], c = un_ring[tid];
         bool dummy;
         float d2;
-        const float az = urf_azimuth(a.x[off + i], a.y[off + i], &d2);
+        const float az = urf_azimuth(gx[i], gy[i], &d2);
         if (urf_road_test(win + c * URF_DEG_CELLS, az, 0.0f, dummy)) {
-            a.labels[off + i] = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0) | URF_LABEL_ROAD;
+            a.labels[off + (rows ? (size_t)(i & 63u) * F + (i >> 6) : (size_t)i)] = URF_FLAG_ROI | URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0) | URF_LABEL_ROAD;
             my_road++;
         }
     }

@@ -29,6 +29,7 @@
 #define URF_MAX_TILES       4096    /* tiles per scan (k_ring keeps one table entry per tile in LDS) */
 #define URF_SCAN_PAD        512     /* scratch elements per scan beyond its tiles: rings start at multiples of 4 */
 #define URF_SLOT_NONE       0xFFFFu
+#define URF_SLOT_OFF        0x8000u   /* bit 15 of an sslot entry: the point lies on no ring (URF_SLOT_NONE; the fused front end keeps the point's place in its tile below it) */
 #define URF_TABLE_LOOKAHEAD 8192    /* k_ring_table gives up waiting for a new ring after this many points (speculation) */
 
 /* The record of a ring-sorted slot (k_split -> k_ring -> k_label), ONE word per point:
@@ -229,7 +230,7 @@ struct urf_kargs {
     uint32_t* table_upto;       /* [S] first point a speculative k_ring_table did not look at (0xffffffff: none) */
     uint32_t* table_redo;       /* [S] k_split: the speculative table of the scan is incomplete */
     uint32_t* redo_list;        /* [S] such scans (k_table_repair) */
-    uint32_t* table_cause;      /* [S] which rule ended a speculative walk: 1 the quiet look-ahead, 2 the ring-count hint */
+    uint32_t* table_cause;      /* [S] which rule ended a speculative walk: 1 the quiet look-ahead, 2 the ring-count hint, 3 the rows' first points */
     uint32_t* ring_hint;        /* [1] per scratch row: the largest n_rings of the row's previous call (k_ring_table reads it, k_split
                                  * zeroes it, k_index collects the new one) */
     uint32_t* spec_failed;      /* host-mapped flags: [0] a look-ahead speculation failed, [1] a ring-count hint did */
@@ -268,8 +269,20 @@ struct urf_kargs {
     uint32_t* front_ncand;      /* [S] */
     uint32_t* front_st;         /* [S][URF_FRONT_ST_WORDS] k_front_finish part 1 -> part 2 */
     uint32_t* front_list;       /* [S] the scans whose flag is clear (k_front_collect; star_count[6] = how many): the list-driven legacy kernels' work */
-    uint32_t* front_state;      /* host-mapped: [0] some scan of some call was handed back, [1] every scan of some call was */
+    uint32_t* front_state;      /* host-mapped: [0] some scan of some call was handed back, [1] every scan of some call was, [2] a scan looked
+                                 * row-major (URF_FRONT_ROWS), [3] the row-major speculation failed on one */
     uint32_t  front_lists;      /* this call launches the legacy kernels list-driven (k_split_list, k_ring_list, k_label_list) */
+    /* row-major organised sweeps (height = the sensor's 64 lasers, width = firings: point l * F + f): front_ok[s] == URF_FRONT_ROWS,
+     * k_transpose writes the firing-order copy the fused kernels read instead of x / y / z, k_label_front stores the labels
+     * where the points came from.  Everything in between is indexed by firing * 64 + laser. */
+    uint32_t  front_rows;       /* this call's sequence holds k_rows_probe and k_transpose: k_ring_table may choose the layout (else it only reports
+                                 * that it saw such a scan: front_state[2], the next call's sequence holds the kernels) */
+    float*    rows_v;           /* [S][64] k_rows_probe: the vertical angles of the rows' first region-of-interest points, in row order (the table's leaders) */
+    uint32_t* rows_ok;          /* [S] ... how many + 1; 0: the scan is not row-major */
+    float*    tx;               /* [S * sstride] firing-order copies (scratch stride) */
+    float*    ty;
+    float*    tz;
 };
+#define URF_FRONT_ROWS 2u
 
 #endif /* URF_INTERNAL_HPP */

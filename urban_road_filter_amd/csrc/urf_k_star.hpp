@@ -180,7 +180,7 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
 #pragma unroll
         for (unsigned q = 0; q < MAXB; q++) {
             const bool valid = RUNS ? q < run_cnt : q * 64 + lane < n;
-            sreg[q] = RUNS ? (slv[q] == URF_SLOT_NONE ? 0xffffffffu : (adr[q] & ~(URF_TILE - 1u)) + slv[q]) : q * 64 + lane;
+            sreg[q] = RUNS ? ((slv[q] & URF_SLOT_OFF) ? 0xffffffffu : (adr[q] & ~(URF_TILE - 1u)) + slv[q]) : q * 64 + lane;
             key[q] = valid ? ((unsigned long long)rbv[q] << 32) | adr[q] : ~0ull;
             rmin = valid && rbv[q] < rmin ? rbv[q] : rmin;
             rmax = valid && rbv[q] > rmax ? rbv[q] : rmax;
@@ -335,7 +335,7 @@ __device__ __forceinline__ bool urf_star_sort_sector(const urf_kargs& a, const u
                     /* at most two runs: the position inside the sector from the address */
                     if (RUNS) {
                         const unsigned sl = a.sslot[sb + adr];
-                        sreg[q] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+                        sreg[q] = (sl & URF_SLOT_OFF) ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
                     } else {
                         sreg[q] = (two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0;
                     }
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(URF_STAR_MID_THREADS) __attribute__((amdgpu_waves_p
                     sreg[e] = adr >= two_a1 && two_a1 > two_a0 ? two_c0 + (adr - two_a1) : adr - two_a0;
                 } else {
                     const unsigned sl = a.sslot[sb + adr];
-                    sreg[e] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+                    sreg[e] = (sl & URF_SLOT_OFF) ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
                 }
             }
         URF_PHASE_ACC(2);
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void k_star_sort_big(urf_kargs a, urf_dev_para
             const unsigned sl = a.sslot[adr];
             R[i] = a.sr[adr];
             Z[i] = a.sz[adr];
-            I[i] = sl == URF_SLOT_NONE ? 0xffffffffu : lo * URF_TILE + sl;
+            I[i] = (sl & URF_SLOT_OFF) ? 0xffffffffu : lo * URF_TILE + sl;
             Pq[i] = i;
         }
         __threadfence_block();
@@ -1315,12 +1315,42 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
         }
     }
     MEM::sync();
+    if (a.front && a.front_ok[s] == URF_FRONT_ROWS) {   /* (uniform) */
+        /* a row-major scan (urf_front.hpp): the fused kernels hold the sector in firing order -- (tile, firing, laser) -- and the
+         * reference met its points row by row: (laser, firing).  Rank by that key (a point's place in its tile stands in sslot). */
+        for (unsigned i = lane; i < n; i += 64) {
+            const unsigned adr = P[i];
+            const unsigned sl = (unsigned)a.sslot[sb + adr] & (URF_TILE - 1u);
+            LP[i] = ((sl & 63u) << 16) | ((adr / URF_TILE) * (URF_TILE / 64u) + (sl >> 6));
+        }
+        MEM::sync();
+        for (unsigned i = lane; i < n; i += 64) {
+            const unsigned key = LP[i];
+            unsigned rank = 0;
+            for (unsigned j = 0; j < n; j++)
+                rank += LP[j] < key ? 1u : 0u;
+            RP[i] = rank;
+        }
+        MEM::sync();
+        for (unsigned i = lane; i < n; i += 64)
+            LP[RP[i]] = R[i];
+        MEM::sync();
+        for (unsigned i = lane; i < n; i += 64)
+            R[i] = LP[i];
+        MEM::sync();
+        for (unsigned i = lane; i < n; i += 64)
+            LP[RP[i]] = P[i];
+        MEM::sync();
+        for (unsigned i = lane; i < n; i += 64)
+            P[i] = LP[i];
+        MEM::sync();
+    }
     if constexpr (POST) {
         /* behind the walk: the point std::sort leaves at the index the walk stopped at (urf_walk_report's conversion of a
          * point's address in the sector-sorted arrays into its place in the ring-major ones) */
         const unsigned adr = urf_tie_select<MEM>(n, hit_i, R, P, LP, RP);
         const unsigned sl = a.sslot[sb + adr];
-        const unsigned v = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+        const unsigned v = (sl & URF_SLOT_OFF) ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
         const int hit = urf_walk_slot_to_ring_pos(a, s, (unsigned)dp.p.channels, v);
         if (lane == 0) {
             a.star_hit[sk] = hit;
@@ -1363,7 +1393,7 @@ __device__ __forceinline__ void urf_tie_sector_body(const urf_kargs& a, const ur
                 a.ssrt16[base + i] = (uint16_t)((two.nruns == 2 && adr >= two.a1) ? two.c0 + (adr - two.a1) : adr - two.a0);
             } else {
                 const unsigned sl = a.sslot[sb + adr];
-                a.ssrt[base + i] = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;   /* (RP may BE this stretch of ssrt: own element) */
+                a.ssrt[base + i] = (sl & URF_SLOT_OFF) ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;   /* (RP may BE this stretch of ssrt: own element) */
             }
             a.wsg[base + i] = urf_sg{ slp, g };
         }
@@ -1592,7 +1622,7 @@ __device__ __forceinline__ int urf_walk_report(const urf_kargs& a, unsigned s, u
             const unsigned i0 = a.ssrt16[base + hit_i];
             const unsigned adr = i0 < two.c0 ? two.a0 + i0 : two.a1 + (i0 - two.c0);
             const unsigned sl = a.sslot[urf_sbase(a, s) + adr];
-            v = sl == URF_SLOT_NONE ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
+            v = (sl & URF_SLOT_OFF) ? 0xffffffffu : (adr & ~(URF_TILE - 1u)) + sl;
         } else {
             v = a.ssrt[base + hit_i];
         }

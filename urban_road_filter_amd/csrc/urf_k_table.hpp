@@ -118,6 +118,89 @@ struct urf_table_shared {
     unsigned nL, nmatch, zero, fresh;
     unsigned mins[URF_TABLE_THREADS / 64];
 };
+/* k_ring_table's third rule (below), the search: the first region-of-interest point of every row of a row-major organised sweep ->
+ * their vertical angles, and through the reference's insertion in row order: rows_v[s][0 .. n) the leaders, rows_ok[s] = n + 1.  Given up
+ * (rows_ok[s] = 0) when one of them would not become a leader, or as soon as the 64 points from a row's first one on show a second
+ * ring: a sweep in firing order.  A kernel of its own, in the sequence of a context that has
+ * sighted such a sweep: inside k_ring_table its registers cost that kernel a wave per SIMD (1024 scans no longer resident at once). */
+__global__ __launch_bounds__(256) void k_rows_probe(urf_kargs a, urf_dev_params dp)
+{
+    __shared__ unsigned sh_alive;
+    __shared__ float rowv[64];
+    const unsigned s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned off, len;
+    urf_scan_range(a, s, off, len);
+    if (len < 128u || (len & 63u) != 0u) {
+        if (tid == 0)
+            a.rows_ok[s] = 0u;
+        return;
+    }
+    const unsigned F = len >> 6;
+    volatile unsigned* const alive = &sh_alive;
+    if (tid == 0)
+        sh_alive = 1u;
+    __syncthreads();
+    /* wave w takes rows 16 w .. 16 w + 15, four at a time */
+    const float tol = 2.0f * dp.p.interval * 0.017453292f;
+    for (unsigned g = 0; g < 16u && *alive; g += 4u) {
+        const unsigned r0 = wave * 16u + g;
+        unsigned found = 0;   /* bit q: row r0 + q is settled */
+        for (unsigned c0 = 0; c0 < F && found != 15u && *alive; c0 += 64u) {
+            float px[4], py[4], pz[4];
+            const bool in = c0 + lane < F;
+#pragma unroll
+            for (unsigned q = 0; q < 4; q++) {
+                const size_t i = (size_t)off + (size_t)(r0 + q) * F + c0 + (in ? lane : 0u);
+                px[q] = a.x[i];
+                py[q] = a.y[i];
+                pz[q] = a.z[i];
+            }
+#pragma unroll
+            for (unsigned q = 0; q < 4; q++) {
+                if ((found >> q) & 1u)
+                    continue;   /* (uniform) */
+                const bool roi = in && urf_in_roi(dp.p, px[q], py[q], pz[q]);
+                const unsigned long long m = __ballot(roi);
+                if (m == 0ull)
+                    continue;
+                const int src = (int)__ffsll((long long)m) - 1;
+                /* one ring?  (cot of the vertical angle, to twice the interval: a hint -- k_front is the check) */
+                const float u = -pz[q] * __builtin_amdgcn_rsqf(px[q] * px[q] + py[q] * py[q]), u0 = __shfl(u, src);
+                if (__ballot(roi && !(__builtin_fabsf(u - u0) <= tol * (1.0f + u0 * u0))) != 0ull) {
+                    if (lane == 0)
+                        *alive = 0u;
+                    break;
+                }
+                const float v = urf_vertical_angle(__shfl(px[q], src), __shfl(py[q], src), __shfl(pz[q], src));
+                if (lane == 0)
+                    rowv[r0 + q] = v;
+                found |= 1u << q;
+            }
+        }
+#pragma unroll
+        for (unsigned q = 0; q < 4; q++)
+            if (!((found >> q) & 1u) && lane == 0)
+                rowv[r0 + q] = -1.0f;
+    }
+    __syncthreads();
+    /* (a) of the rule: put through the reference's insertion in row order, every one of them becomes a leader -- none matches an earlier one
+     * (lidar_segmentation.cpp:176-190: |angle[j] - alpha| <= interval), none is the table's end marker 0 (:176) */
+    if (wave == 0) {
+        const float v = rowv[lane];
+        bool bad = v == 0.0f;
+        for (unsigned j = 0; j < 63u; j++) {
+            const float w = rowv[j];
+            bad = bad || (j < lane && v >= 0.0f && w >= 0.0f && __builtin_fabsf(w - v) <= dp.p.interval);
+        }
+        const unsigned long long have = __ballot(v >= 0.0f);
+        const bool ok = sh_alive != 0u && __ballot(bad) == 0ull;
+        if (ok && v >= 0.0f)
+            a.rows_v[(size_t)s * 64u + urf_popc_below(have)] = v;   /* compacted: the reference's angle[] before its sort */
+        if (lane == 0)
+            a.rows_ok[s] = ok ? (unsigned)__popcll(have) + 1u : 0u;
+    }
+}
+
 __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp, unsigned s, unsigned lookahead, urf_table_shared& T)
 {
     float* const L = T.L;
@@ -158,21 +241,8 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
     const unsigned hint = (lookahead && a.table_hint) ? *a.ring_hint : 0u;
     unsigned pos = 0, upto = 0xffffffffu;   /* upto: first point the walk did not look at (speculation) */
     unsigned cause = 0;
-    while (pos < len && sh_nL < C) {
-        if (hint && pos && sh_nL >= hint && !sh_zero) {   /* (uniform: LDS values behind a barrier) */
-            upto = pos;
-            cause = 2;
-            break;
-        }
-        /* ---- serial step: wave 0, points [pos, pos + 64) ---- */
-        if (wave == 0) {
-            const unsigned i = pos + lane;
-            float v = -1.0f;
-            if (i < len) {
-                const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
-                if (urf_in_roi(dp.p, x, y, z))
-                    v = urf_vertical_angle(x, y, z);
-            }
+    /* wave 0: the lanes' angles (-1: none), in lane order, through the reference's insertion */
+    auto insert64 = [&](const float v) {
             unsigned nL = sh_nL, nmatch = sh_nmatch;
             bool zero_seen = sh_zero != 0;
             const unsigned nL0 = nL;
@@ -237,9 +307,61 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
                 sh_zero = zero_seen ? 1u : 0u;
                 sh_new = nL != nL0;
             }
+    };
+    /* Third speculation (r6): a ROW-MAJOR organised sweep -- height = the sensor's lasers, width = firings, point l * F + f: what
+     * the drivers that publish organised clouds deliver.  The walk below meets a new ring every F points (0.7 ms per 1024 sweeps of
+     * 64 x 2048).  Rule: the leaders are the first region-of-interest points of the 64 rows, in row order.  That IS the reference's
+     * table when (a) those points, inserted in row order, all become leaders (checked here, by the reference's own insertion) and
+     * (b) every other region-of-interest point of a row lies on its row's entry (then it matched that leader when the reference
+     * met it: it is behind it in its row): k_front checks (b) point by point for the scan's lanes anyway -- a point on another
+     * entry or on none raises table_redo[s], k_table_repair walks the scan the long way and the legacy kernels take it.  Only
+     * for a scan the fused front end will look at; a call whose sequence lacks k_transpose only reports the sighting.
+     * Tried when the walk's first step (64 points: one row's) has shown at most one ring; given up as soon as the 64 points around
+     * a row's first one show a second ring (a sweep in firing order whose first firing lies outside the region of interest). */
+    bool rows = false;
+    bool rows_try = lookahead && a.front && C == 64u && len >= 128u && (len & 63u) == 0u;
+    if (rows_try && a.front_rows) {
+        /* k_rows_probe has found the rows' first points and put them through the reference's insertion: rows_ok[s] - 1 leaders, in row order */
+        const unsigned nr = a.rows_ok[s];   /* (uniform) */
+        if (nr) {
+            if (tid < nr - 1u)
+                L[tid] = a.rows_v[(size_t)s * 64u + tid];
+            if (tid == 0) {
+                sh_nL = nr - 1u;
+                a.front_ok[s] = URF_FRONT_ROWS;
+            }
+            rows = true;
+            upto = 0;
+            cause = 3;
+            __syncthreads();
+        }
+    }
+    while (!rows && pos < len && sh_nL < C) {
+        if (hint && pos && sh_nL >= hint && !sh_zero) {   /* (uniform: LDS values behind a barrier) */
+            upto = pos;
+            cause = (cause & 4u) | 2u;
+            break;
+        }
+        /* ---- serial step: wave 0, points [pos, pos + 64) ---- */
+        if (wave == 0) {
+            const unsigned i = pos + lane;
+            float v = -1.0f;
+            if (i < len) {
+                const float x = a.x[off + i], y = a.y[off + i], z = a.z[off + i];
+                if (urf_in_roi(dp.p, x, y, z))
+                    v = urf_vertical_angle(x, y, z);
+            }
+            insert64(v);
         }
         __syncthreads();
         pos += 64;
+        if (rows_try && !a.front_rows && __builtin_amdgcn_readfirstlane((int)(sh_nL <= (63u + (len >> 6)) / (len >> 6) && !sh_zero))) {   /* (uniform; pos == 64) as many rings as rows of len / 64 points?  A sighting: */
+            if (tid == 0)
+                a.front_state[2] = 1u;   /* host-visible: the next call's sequence holds k_rows_probe and k_transpose */
+            cause = 4;   /* (a row-major sweep defeats the look-ahead wherever its region of interest drops a few rows in succession: such a
+                          * failure must not switch ALL speculation off, this rule included -- k_table_repair) */
+        }
+        rows_try = false;
         if (sh_new || sh_nL >= C)
             continue;
         /* ---- scan mode: first point in [pos, len) that no leader matches ---- */
@@ -333,7 +455,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
             quiet += URF_TABLE_THREADS * URF_TABLE_SCAN_PPT;
             if (lookahead && quiet >= lookahead && !sh_zero && pos < len) {
                 upto = pos;
-                cause = 1;
+                cause = (cause & 4u) | 1u;
                 break;
             }
         }
@@ -453,7 +575,10 @@ __global__ __launch_bounds__(URF_TABLE_THREADS) void k_table_repair(urf_kargs a,
     if (threadIdx.x == 0) {
         if (!collect)   /* (a collected scan is split by k_split_list) */
             a.redo_list[atomicAdd(&a.star_count[2], 1u)] = s;
-        a.spec_failed[cause == 2u ? 1 : 0] = 1u;   /* host-visible: the context stops using the rule that failed */
+        if (cause == 3u)
+            a.front_state[3] = 1u;   /* (the rows' rule: counted, not switched off -- a failure costs that scan the long walk) */
+        else if (!(cause & 4u))     /* (4: a scan that looked row-major to a call whose sequence lacked the kernels for it) */
+            a.spec_failed[cause == 2u ? 1 : 0] = 1u;   /* host-visible: the context stops using the rule that failed */
     }
 }
 
