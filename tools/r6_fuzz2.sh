@@ -5,5 +5,5 @@ for i in $(seq 0 $((P-1))); do
   ( timeout 1500 python tools/front_check.py --basic 0 --fuzz $NF --seed0 $((9100000 + i*NF)) > gpurun_out/r6_fuzz/front_$i.log 2>&1 ) &
 done
 wait
-grep -h "fuzz:" gpurun_out/r6_fuzz/front_*.log | awk '{c+=$2; f+=$4; m+=$10} END {print "fused front end, organised sweeps with holes:", c, "cases,", f, "took it,", m, "mismatches"}'
+grep -h "fuzz:" gpurun_out/r6_fuzz/front_*.log | awk '{c+=$2; f+=$4; r+=$10; m+=$15} END {print "fused front end, organised sweeps with holes:", c, "cases,", f, "took it in firing order,", r, "of their row-major twins,", m, "mismatches"}'
 grep -h "MISMATCH" gpurun_out/r6_fuzz/front_*.log | head

@@ -90,7 +90,8 @@ def build_variant(name, defines, verbose=False):
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "liburf_hip_%s.so" % name)
     srcs = [os.path.join(CSRC, s) for s in SOURCES + HOOK_SOURCES]
-    _compile_lib(out, HOOK_DEFINES + list(defines), srcs, verbose)
+    raw = [d for d in defines if d.startswith("-")]   # (compiler flags pass through: -mllvm -align-loops=64 ...)
+    _run([_hipcc()] + FLAGS + raw + ["-D" + d for d in HOOK_DEFINES + [d for d in defines if not d.startswith("-")]] + srcs + ["-o", out], verbose)
     return out
 
 
