@@ -61,8 +61,14 @@ extern "C" {
  * (star_shaped_search.cpp:109) and equal azimuths inside a ring as the reference's Lomuto quicksort does
  * (lidar_segmentation.cpp:70-93): "deviation D2" of earlier versions is gone, labels on real sensor data (range ties in
  * every sector) and the published order equal the reference's; urf_callback_path_state reports sequence bit 4.
- * 5 (round 6): urf_set_front_mode / urf_front_scans (the fused front end for batches of sweeps in firing order); the
- * entry points that read ring-sorted intermediate results may run the last batch call again, see there. */
+ * 5 (round 6): urf_set_front_mode / urf_front_scans (the fused front end for batches of organised sweeps: firing order and
+ * row-major); the entry points that read ring-sorted intermediate results may run the last batch call again, see there.
+ * WHICH std::sort (4 above): the one of libstdc++ as shipped with GCC 5 .. 13 (bits/stl_algo.h: __sort = __introsort_loop with
+ * _S_threshold 16, __move_median_to_first on (first + 1, mid, last - 1), __unguarded_partition, depth limit 2 * floor(log2 n),
+ * __partial_sort as the fallback, then __final_insertion_sort); tests/test_stdsort.py pins the restatement against the std::sort
+ * of the build host and FAILS when they disagree.  A reference built against another standard library (libc++) or a future
+ * libstdc++ with another __sort orders equal planar ranges differently, and its labels on tied data then differ from this
+ * library's at the points concerned -- nothing at run time can tell. */
 #define URF_ABI_VERSION 5
 
 /* ---- label byte --------------------------------------------------------- */
@@ -302,6 +308,10 @@ int urf_compact_indices_batch(urf_ctx* ctx, const uint8_t* d_labels, uint32_t n_
  * ring).  Host buffers with room
  * for n_points entries each (any may be NULL); counts[3] = {road, curb,
  * road_probably}.  Synchronous; costs one extra per-ring sort.
+ * COST of bit-identical azimuths: a ring that holds ONE such pair is sorted a second time by the reference's own quicksort, run
+ * literally by a single wave -- the ring is nearly sorted by then, Lomuto's scheme is quadratic on that: about 1 ms per ring of
+ * 2048 points (the same holds for urf_marker_points and for a ring with a NaN azimuth).  A sensor that delivers exact duplicates
+ * (dual returns written twice) in many rings makes these two entry points tens of milliseconds slower; the labels are not affected.
  * LIFETIME: urf_ordered_indices*, urf_marker_points* and urf_read_stage run kernels over the LAST
  * classify call's results, which include the caller's own buffers of that call: d_labels (all three)
  * and, for calls with ragged offsets, nothing else -- the x / y / z these kernels need were copied
@@ -428,6 +438,9 @@ int urf_pc2_to_planes(const uint8_t* data, uint32_t n_points, uint32_t point_ste
  * bit 1 the work-list kernels are part of the sequence, bit 2 so is the kernel for rings with NaN azimuths, bit 3 the ring table also
  * stops at the ring count of the previous sweep (a stream of sweeps from one sensor shows the same rings), bit 4 the kernel that orders
  * equal planar ranges of a star sector as std::sort does is part of the sequence (a real sensor's first sweep switches it on).
+ * A stream from a real sensor therefore pays one sweep run twice at its start (and the sweeps in flight beside it) and two more
+ * near-empty launches per sweep from then on: bench.py's e2e_latency_ms_sensor_like is that steady state, e2e_latency_ms the
+ * tie-free one.
  * Either pointer may be NULL. */
 int urf_callback_path_state(const urf_ctx* ctx, uint32_t* n_rerun, uint32_t* sequence);
 const char* urf_strerror(int status);
