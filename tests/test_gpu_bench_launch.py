@@ -48,6 +48,15 @@ def test_single_rank_line_has_the_contract_keys():
     for name, e in oc.items():
         assert e["scans_per_s"] > 0 and 0 < e["frac"] < 1 and e["parity_checked_scans"], name
     assert oc["cfg5"]["points_per_scan"] == 128 * 4096 and oc["cfg2"]["scans_per_step"] == 1
+    # which storage orders took the fused front end (urf_front.hpp): firing order with the lasers permuted and row-major do, a shuffled cloud does not
+    assert oc["laser_order"]["front_scans"] == 32 and oc["ring_major"]["front_scans"] == 32 and oc["shuffled"]["front_scans"] == 0
+    assert d["front_scans_per_gpu"] == 32
+
+
+def test_row_major_workload():
+    d = run_bench("--workload", "ring_major", "--scans", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e")
+    assert d["front_scans_per_gpu"] == 32 and d["value"] > 0 and "k_front" in d["kernel_ms"]
+    assert "row-major" in d["config"]["workload"]
 
 
 def test_rccl_with_one_rank():

@@ -37,7 +37,9 @@
 #define URF_FRONT_HPP
 
 #define URF_FRONT_HPRE 8u      /* firings in front of a block: 7 fill a window without holes (x_zero's j >= 5 rule) */
+#ifndef URF_FRONT_HPOST
 #define URF_FRONT_HPOST 8u     /* firings behind it: 5 complete the last centre's window */
+#endif
 #define URF_FRONT_LANES 64u
 #define URF_FRONT_STEPS (URF_TILE / URF_FRONT_LANES)   /* firings per tile */
 #define URF_FRONT_MIN_SCANS 32u   /* below: the legacy kernels (a block of k_front is one wave; few scans leave the device empty) */
