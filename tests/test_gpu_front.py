@@ -396,3 +396,23 @@ def test_row_major_ring_sorted_results_rerun_the_legacy_kernels():
             assert np.array_equal(ctx.marker_points(scan=k), st["marker_pts"])
             assert np.array_equal(dl.to_numpy(np.uint8).reshape(2, N)[k], lb)
         assert ctx.front_scans() == 0
+
+
+def test_row_major_after_the_other_speculations_were_switched_off():
+    """A context whose look-ahead speculation has failed (rear-stored default-ROI sweeps in firing order) builds its tables the long way
+    from then on; the rows' rule is independent of that: row-major sweeps still take the fused kernels from their second call."""
+    pr = O.cfg_params("default_roi")
+    rear = [rolled(O.cfg_cloud("default_roi", s), 1024) for s in (1, 2)]
+    with u.Context(N, 2) as ctx:
+        for call in range(4):   # (the first call also SIGHTS a possible row-major layout -- no point of the first firing lies in the region --, which
+            labels, infos, nf = fused_batch(ctx, rear, pr)   # keeps that call's failure from counting: the speculation goes with the next one)
+            check_against_b(labels, infos, rear, pr)
+            if nf == 2:
+                break
+        assert nf == 2 and call >= 1   # no speculation any more: the tables are complete, both fused
+        rows = [ring_major(O.cfg_cloud("default_roi", s)) for s in (3, 4)]
+        rows_then_fused(ctx, rows, pr, want=2)
+        rows = [ring_major(c) for c in rear]
+        labels, infos, nf = fused_batch(ctx, rows, pr)
+        check_against_b(labels, infos, rows, pr)
+        assert nf == 2

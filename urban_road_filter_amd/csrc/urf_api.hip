@@ -763,7 +763,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
                   ? 1u : 0u;
     a.front_tpb = c->front_tpb;
     a.front_lists = (a.front && !c->front_direct) ? 1u : 0u;
-    a.front_rows = (a.front && c->front_rows && a.table_lookahead) ? 1u : 0u;
+    a.front_rows = (a.front && c->front_rows) ? 1u : 0u;   /* (the rows' rule does not depend on the two other speculations: the repair kernels below come with it) */
 
     std::vector<hipEvent_t>* ev = nullptr;
     if (c->timing) {
@@ -795,7 +795,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     } else {
         hipLaunchKernelGGL(k_split, g_tiles, dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
     }
-    if (a.table_lookahead && !(a.optimistic & URF_OPT_NO_REPAIR)) {   /* normally both find nothing to do */
+    if ((a.table_lookahead || a.front_rows) && !(a.optimistic & URF_OPT_NO_REPAIR)) {   /* normally both find nothing to do */
         hipLaunchKernelGGL(k_table_repair, g_scan, dim3(URF_TABLE_THREADS), 0, st, a, dp, 0u);
         hipLaunchKernelGGL(k_split_repair, dim3(c->n_cus), dim3(URF_TILE_THREADS), urf_split_lds_bytes(C, K, star), st, a, dp);
     }

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_rows_probe(urf_kargs a, urf_dev_params 
     }
 }
 
-__device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp, unsigned s, unsigned lookahead, urf_table_shared& T)
+__device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp, unsigned s, unsigned lookahead, urf_table_shared& T, bool first_walk)
 {
     float* const L = T.L;
     float* const SL = T.SL;
@@ -319,7 +319,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
      * Tried when the walk's first step (64 points: one row's) has shown at most one ring; given up as soon as the 64 points around
      * a row's first one show a second ring (a sweep in firing order whose first firing lies outside the region of interest). */
     bool rows = false;
-    bool rows_try = lookahead && a.front && C == 64u && len >= 128u && (len & 63u) == 0u;
+    bool rows_try = first_walk && a.front && C == 64u && len >= 128u && (len & 63u) == 0u;   /* (not k_table_repair's walk: that one follows a failure) */
     if (rows_try && a.front_rows) {
         /* k_rows_probe has found the rows' first points and put them through the reference's insertion: rows_ok[s] - 1 leaders, in row order */
         const unsigned nr = a.rows_ok[s];   /* (uniform) */
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(URF_TABLE_THREADS) void k_ring_table(urf_kargs a, u
                 a.front_ring_lane[(size_t)s * dp.p.channels + tid] = 0xffffffffu;
         }
     }
-    urf_ring_table_scan(a, dp, blockIdx.x, a.table_lookahead, T);
+    urf_ring_table_scan(a, dp, blockIdx.x, a.table_lookahead, T, true);
 }
 
 /* the scans whose speculative table k_split found incomplete: the whole walk, listed for k_split_repair */
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(URF_TABLE_THREADS) void k_table_repair(urf_kargs a,
     if (a.front && threadIdx.x == 0)
         a.front_ok[s] = 0u;   /* k_split_repair splits the scan the legacy way: the legacy kernels take it from here (urf_front.hpp) */
     const unsigned cause = a.table_cause[s];   /* (before the walk below overwrites it) */
-    urf_ring_table_scan(a, dp, s, 0, T);
+    urf_ring_table_scan(a, dp, s, 0, T, false);
     if (threadIdx.x == 0) {
         if (!collect)   /* (a collected scan is split by k_split_list) */
             a.redo_list[atomicAdd(&a.star_count[2], 1u)] = s;
