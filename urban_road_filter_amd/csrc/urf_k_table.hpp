@@ -115,7 +115,7 @@ __device__ __forceinline__ bool urf_leader_match_point(const float* SL, unsigned
 struct urf_table_shared {
     float L[URF_MAX_CHANNELS];    /* leaders in insertion order (the reference's angle[]) */
     float SL[URF_MAX_CHANNELS];   /* the matchable ones, ascending */
-    unsigned nL, nmatch, zero, fresh;
+    unsigned nL, nmatch, zero, fresh, first_nl;
     unsigned mins[URF_TABLE_THREADS / 64];
 };
 /* k_ring_table's third rule (below), the search: the first region-of-interest point of every row of a row-major organised sweep ->
@@ -228,6 +228,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
         sh_nL = 0;
         sh_nmatch = 0;
         sh_zero = 0;
+        T.first_nl = 0;
     }
     if (tid < 4)
         a.nan_mask[(size_t)s * 4 + tid] = 0;   /* (k_table_repair: the bits k_split set against the old table are void) */
@@ -306,6 +307,8 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
                 sh_nmatch = nmatch;
                 sh_zero = zero_seen ? 1u : 0u;
                 sh_new = nL != nL0;
+                if (nL0 == 0u && nL != 0u)
+                    T.first_nl = zero_seen ? 0xffffu : nL;   /* what the first step that met a ring found (the rows' sighting, below) */
             }
     };
     /* Third speculation (r6): a ROW-MAJOR organised sweep -- height = the sensor's lasers, width = firings, point l * F + f: what
@@ -339,7 +342,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
     while (!rows && pos < len && sh_nL < C) {
         if (hint && pos && sh_nL >= hint && !sh_zero) {   /* (uniform: LDS values behind a barrier) */
             upto = pos;
-            cause = (cause & 4u) | 2u;
+            cause = 2;
             break;
         }
         /* ---- serial step: wave 0, points [pos, pos + 64) ---- */
@@ -355,13 +358,6 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
         }
         __syncthreads();
         pos += 64;
-        if (rows_try && !a.front_rows && __builtin_amdgcn_readfirstlane((int)(sh_nL <= (63u + (len >> 6)) / (len >> 6) && !sh_zero))) {   /* (uniform; pos == 64) as many rings as rows of len / 64 points?  A sighting: */
-            if (tid == 0)
-                a.front_state[2] = 1u;   /* host-visible: the next call's sequence holds k_rows_probe and k_transpose */
-            cause = 4;   /* (a row-major sweep defeats the look-ahead wherever its region of interest drops a few rows in succession: such a
-                          * failure must not switch ALL speculation off, this rule included -- k_table_repair) */
-        }
-        rows_try = false;
         if (sh_new || sh_nL >= C)
             continue;
         /* ---- scan mode: first point in [pos, len) that no leader matches ---- */
@@ -455,7 +451,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
             quiet += URF_TABLE_THREADS * URF_TABLE_SCAN_PPT;
             if (lookahead && quiet >= lookahead && !sh_zero && pos < len) {
                 upto = pos;
-                cause = (cause & 4u) | 1u;
+                cause = 1;
                 break;
             }
         }
@@ -463,6 +459,17 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
             break;
     }
     __syncthreads();
+    if (rows_try && !a.front_rows && !rows) {
+        /* The first 64-point step that met a ring: a sweep in firing order shows many at once there (wherever its region of interest
+         * begins), a row-major one as many as rows of len / 64 points fit into the step.  A sighting: */
+        const unsigned nl = T.first_nl;
+        if (nl != 0u && nl * (len >> 6) <= 63u + (len >> 6)) {   /* nl <= ceil(64 / F) */
+            if (tid == 0)
+                a.front_state[2] = 1u;   /* host-visible: the next call's sequence holds k_rows_probe and k_transpose */
+            cause |= 4u;   /* (a row-major sweep defeats the look-ahead wherever its region of interest drops a few rows in succession:
+                            * such a failure must not switch ALL speculation off, this rule included -- k_table_repair) */
+        }
+    }
     if (tid == 0) {
         a.table_upto[s] = upto;
         a.table_redo[s] = 0;
