@@ -10,6 +10,6 @@ for i in $(seq 0 $((P-1))); do
     timeout 1500 python tools/fuzz_organised_more.py $((7600000 + i*NO)) $((7600000 + (i+1)*NO)) > gpurun_out/r6_fuzz/org_$i.log 2>&1 ) &
 done
 wait
-grep -h "fuzz:" gpurun_out/r6_fuzz/front_*.log | awk '{c+=$2; f+=$4; m+=$10} END {print "fused front end, organised sweeps with holes:", c, "cases,", f, "took it,", m, "mismatches"}'
+grep -h "fuzz:" gpurun_out/r6_fuzz/front_*.log | awk '{c+=$2; f+=$4; r+=$10; m+=$15} END {print "fused front end, organised sweeps with holes:", c, "cases,", f, "took it in firing order,", r, "of their row-major twins,", m, "mismatches"}'
 grep -h "mismatches\|MISMATCH" gpurun_out/r6_fuzz/unorg_*.log | tail -$((P+3))
 grep -h "organised fuzz\|MISMATCH" gpurun_out/r6_fuzz/org_*.log | tail -$((P+3))
