@@ -1,5 +1,5 @@
 /*
- * urf_front.hpp -- the fused front end for sweeps that arrive firing by firing (r6).
+ * urf_front.hpp -- the fused front end for organised sweeps (r6): firing by firing, or row-major (height = the lasers) through k_transpose.
  *
  * What it replaces: k_split + k_ring (+ k_label's ring-sorted reads) for a scan whose points come as a spinning
  * LiDAR's driver delivers them -- firing after firing, every firing holding the sensor's 64 lasers in ONE fixed order
@@ -27,6 +27,10 @@
  *                  words, the angle tests of the candidates (f64 chains, all lanes busy), the star-shaped hits, the
  *                  rings' curb lists, largest ranges and quadrants for k_beams.
  *   k_label_front  k_label in input order: record -> label byte, no LDS image.
+ *   k_transpose    (row-major organised sweeps: point l * F + f, front_ok[s] == URF_FRONT_ROWS, decided by k_rows_probe + k_ring_table,
+ *                  urf_k_table.hpp) the firing-order copy of x / y / z the three kernels above read instead of the caller's arrays;
+ *                  everything between input and output is indexed by firing * 64 + laser, k_label_front stores the labels row-major
+ *                  and k_star_ties (urf_k_star.hpp) ranks a sector in the reference's row order before it re-enacts std::sort.
  *
  * A scan that does not have the shape (a lane that meets two rings, two lanes on one ring, a firing in two sectors,
  * sectors that fall inside a tile, a ring point on the sensor's axis, an incomplete speculative ring table) clears
