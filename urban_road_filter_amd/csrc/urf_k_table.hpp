@@ -273,6 +273,33 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
                     un = false;
                 }
             }
+            /* The same for lasers in ANY order inside the firing (r6: a Velodyne's laser numbering interleaves two blocks; the loop below
+             * cost such a batch 0.11 ms): into an empty table all unmatched points become leaders, in lane order, iff no two of them
+             * match each other and none is the end marker.  64 broadcast reads; the sorted copy by rank. */
+            if ((m = __ballot(un)) != 0 && !zero_seen && nmatch == 0 && nL + (unsigned)__popcll(m) <= C) {
+                float* const stage = SL + 64;   /* (the sorted copy is empty: its upper half carries the step's angles) */
+                stage[lane] = un ? v : -1.0f;
+                urf_wave_lds_sync();
+                bool clash = un && v == 0.0f;
+                unsigned srank = 0;
+                for (unsigned j = 0; j < 64; j++) {
+                    const float w = stage[j];
+                    const bool there = w >= 0.0f;
+                    clash = clash || (there && un && j < lane && __builtin_fabsf(w - v) <= interval);
+                    srank += (there && (w < v || (w == v && j < lane))) ? 1u : 0u;
+                }
+                if (__ballot(clash) == 0) {
+                    const unsigned cnt = (unsigned)__popcll(m);
+                    if (un) {
+                        L[nL + urf_popc_below(m)] = v;
+                        SL[srank] = v;
+                    }
+                    nL += cnt;
+                    nmatch += cnt;
+                    un = false;
+                }
+                urf_wave_lds_sync();
+            }
             while ((m = __ballot(un)) != 0 && nL < C) {
                 const unsigned f = (unsigned)__ffsll((long long)m) - 1u;
                 const float lv = __shfl(v, (int)f);
