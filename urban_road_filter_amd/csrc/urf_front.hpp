@@ -239,6 +239,7 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
     bool econf = false;       /* ... and a point of this march has confirmed it */
     urf_front_thr th = urf_front_load_thr(a, s, C, E, nR);
     bool failed = false, overflow = false;
+    unsigned long long failed_m = 0;   /* ... what the hot path finds wrong, as lane masks (wave-uniform) */
     unsigned ncb = 0;         /* candidates in the wave's buffer */
 
     /* the lane's window: w10 = its newest ring point, w0 the one ten before; firing (relative to Fs) of the six newest */
@@ -257,7 +258,7 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
         constexpr unsigned PH = decltype(ph)::value;
         const unsigned stp = f % URF_FRONT_STEPS;
         const unsigned i = f * 64u + lane;
-        const bool roi = (i < len) & urf_in_roi(dp.p, x, y, z);
+        const bool roi = i < len && urf_in_roi(dp.p, x, y, z);
         const unsigned long long roim = __ballot(roi);
         if (PH == 1u && lane == 0u)
             a.roi_bits[((size_t)s * a.tiles + f / URF_FRONT_STEPS) * URF_FRONT_STEPS + stp] = roim;
@@ -275,24 +276,23 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
                 fs = fast ? urf_fast_sector_ranged(fi, dp.Kfi, K, dp.sector_margin) : -1;
         }
         bool on = on_f;
-        const bool open = roi & !(on_f & (PH != 1u || !STAR || fs >= 0));
-        if (__ballot(open) != 0ull) {   /* (uniform) rare: the reference's exact sequence for the lanes that need it */
-            unsigned r = 0;
-            if (open)
-                r = urf_front_open(tab, nR, dp.p.interval, x, y, z, (PH == 1u && STAR) ? K : 0u, dp.Kfi, E, econf ? 1u : 0u);
-            on = open ? (r & 1u) != 0u : on;
-            fs = open ? (int)((r >> 1) & 0x7ffu) - 1 : fs;
-            failed = failed | (open & ((r & URF_FO_FAIL) != 0u));
-            if (PH == 1u && open && (r & URF_FO_NONE) && i >= upto)
+        const bool open = roi && !(on_f && (PH != 1u || !STAR || fs >= 0));
+        /* (r6, vector-issue diet: a ballot of anything but a direct compare costs two vector instructions -- v_cndmask 0 / 1, v_cmp -- to
+         * mask it with exec; a plain divergent branch skips its block when no lane takes it for two SCALAR instructions.  Wave-level
+         * flags (failed, overflow) are OR-ed up as masks, per-lane state that only rare paths read (econf) likewise.) */
+        if (open) {   /* rare: the reference's exact sequence for the lanes that need it */
+            const unsigned r = urf_front_open(tab, nR, dp.p.interval, x, y, z, (PH == 1u && STAR) ? K : 0u, dp.Kfi, E, econf ? 1u : 0u);
+            on = (r & 1u) != 0u;
+            fs = (int)((r >> 1) & 0x7ffu) - 1;
+            if (r & URF_FO_FAIL)
+                failed = true;
+            if (PH == 1u && (r & URF_FO_NONE) && i >= upto)
                 a.table_redo[s] = 1u;   /* the speculative ring table is incomplete (k_table_repair, legacy path) */
-            if (__ballot(open && (r & URF_FO_ADOPT)) != 0ull) {   /* (uniform) this lane's laser sits on another table entry: learned from its first point */
-                if (open && (r & URF_FO_ADOPT)) {
-                    E = (r >> 12) & 0x7fu;
-                    th = urf_front_load_thr(a, s, C, E, nR);
-                }
+            if (r & URF_FO_ADOPT) {   /* this lane's laser sits on another table entry: learned from its first point */
+                E = (r >> 12) & 0x7fu;
+                th = urf_front_load_thr(a, s, C, E, nR);
             }
         }
-        econf = econf | on;
         if (PH == 1u) {
             /* the record, input order: ring | azimuth code (URF_REC_*; detector hits are OR-ed in by k_front_finish) */
             const unsigned azc_v = urf_az_code(urf_fast_azimuth_of(fi));   /* (unconditionally, then a select: a branch around eight instructions costs more) */
@@ -303,15 +303,16 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
                 unsigned sk = (unsigned)fs;
                 if (BEAM && roi && !urf_in_beam(a.beams[fs < 0 ? 0 : fs], x, y))
                     sk = URF_SEC_NONE;
-                const bool ons = roi & (sk != URF_SEC_NONE) & ((int)sk >= 0);
-                const unsigned long long psm = __ballot(ons);
+                /* (every lane is active here: the masks of direct compares need no exec) */
+                const unsigned long long psm = roim & __builtin_amdgcn_ballot_w64(sk != URF_SEC_NONE) & __builtin_amdgcn_ballot_w64((int)sk >= 0);
+                const bool ons = roi && sk != URF_SEC_NONE && (int)sk >= 0;
                 const unsigned src = psm ? (unsigned)__ffsll((long long)psm) - 1u : 0u;
                 const unsigned f0 = psm ? (unsigned)__builtin_amdgcn_readlane((int)sk, (int)src) : URF_SEC_NONE;
-                failed = failed | (ons & (sk != f0));
+                failed_m |= psm & __builtin_amdgcn_ballot_w64(sk != f0);
                 const unsigned so = (f / URF_FRONT_STEPS) * URF_TILE + tstar + urf_popc_below(psm);
                 const unsigned o4 = ons ? so * 4u : URF_OOB;
                 const float pr = urf_sqrt_rn_normal(rho2);   /* star_shaped_search.cpp:164: sqrtf(x * x + y * y) */
-                failed = failed | (ons & !((rho2 >= 0x1p-90f) & (rho2 <= 0x1p126f)));   /* (outside the shortcut's interval: the legacy kernels) */
+                failed_m |= psm & ~(__builtin_amdgcn_ballot_w64(rho2 >= 0x1p-90f) & __builtin_amdgcn_ballot_w64(rho2 <= 0x1p126f));   /* (outside the shortcut's interval: the legacy kernels) */
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pr), bsr, o4, 0, URF_FRONT_NT);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), bsz, o4, 0, URF_FRONT_NT);
                 __builtin_amdgcn_raw_buffer_store_b16((short)((stp * 64u + lane) | (on ? 0u : URF_SLOT_OFF)), bss, ons ? so * 2u : URF_OOB, 0, URF_FRONT_NT);
@@ -320,14 +321,15 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
                 tstar += (unsigned)__popcll(psm);
             }
             troi += (unsigned)__popcll(roim);
-            const double s2 = (double)x * (double)x + (double)y * (double)y;
-            maxs = (on && s2 > maxs) ? s2 : maxs;
-            pw |= (on ? 1u : 0u) << stp;
         }
         /* the lane's window moves on by its new ring point; what has become decidable is decided */
-        if (__ballot(on) == 0ull)
-            return;   /* (uniform) */
         if (on) {
+            if (PH == 1u) {
+                const double s2 = (double)x * (double)x + (double)y * (double)y;
+                maxs = s2 > maxs ? s2 : maxs;
+                pw |= 1u << stp;
+            }
+            econf = true;
             w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8; w8 = w9; w9 = w10;
             w10 = z;
             fwA = __builtin_amdgcn_alignbit(fwB, fwA, 16);
@@ -349,17 +351,33 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
         const bool p_in = on & (tot >= 4u) & (tot - 3u <= nin);
         /* z_zero_method.cpp:39-40, 48-49, 67-69 */
         const float a5 = __builtin_fabsf(w5);
-        const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(w0), __builtin_fabsf(w1)), __builtin_fabsf(w2)),
-                                         __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(w3), __builtin_fabsf(w4)), a5));
-        const float m2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a5, __builtin_fabsf(w6)), __builtin_fabsf(w7)),
-                                         __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(w8), __builtin_fabsf(w9)), __builtin_fabsf(w10)));
+        /* (window values are region-of-interest points' heights, never NaN: v_max3 with |.| modifiers, three instructions per side --
+         * the compiler's fmaxf quiets the first two operands of every chain with a v_max x, x each: five) */
+        float m1, m2, t1, t2;
+        asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t1) : "v"(w0), "v"(w1), "v"(w2));
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(t1) : "v"(t1), "v"(w3), "v"(w4));
+        asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(m1) : "v"(t1), "v"(w5));
+        asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(t2) : "v"(w10), "v"(w9), "v"(w8));
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(t2) : "v"(t2), "v"(w7), "v"(w6));
+        asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(m2) : "v"(t2), "v"(w5));
         const bool hz = ((m1 - a5 >= curbH) | (m2 - a5 >= curbH)) & (__builtin_fabsf(m1 - m2) >= 0.05f);   /* ((double)v >= 0.05 <=> v >= 0.05f: the float above 0.05) */
         /* x_zero_method.cpp:62-64 for the triple (w5, w7, w10) = (j, j + 2, j + 5) */
         const bool hx = ((__builtin_fabsf(w5 - w7) >= curbH) | (__builtin_fabsf(w10 - w7) >= curbH)) & (__builtin_fabsf(w5 - w10) >= 0.05f);
-        const bool zz = use_z & c_in & full & hz, xz = use_x & p_in & full & hx;
+        /* (lane masks combined as masks: `&` on bools mixed with the wave-uniform switches went through 0 / 1 integers in vector
+         * registers -- v_cndmask, v_and, v_cmp per term) */
+        bool zz = false, xz = false, ez = false, ex = false;
         /* a window that began inside this march (a block border with a hole in the halo, a ring that has just entered the
          * region of interest): positions unknown here, k_front_finish decides */
-        const bool ez = use_z & c_in & !full & !from_start, ex = use_x & p_in & !full & !from_start;
+        if (use_z) {   /* (uniform) */
+            zz = c_in && full && hz;
+            if (!from_start)
+                ez = c_in && !full;
+        }
+        if (use_x) {
+            xz = p_in && full && hx;
+            if (!from_start)
+                ex = p_in && !full;
+        }
         if (__ballot(zz | xz | ez | ex) != 0ull) {   /* (uniform) */
             urf_front_push(cbuf, ncb, zz | ez, ((fwA & 0xffffu) + Fs) * 64u + lane, zz ? URF_FC_ZZ : URF_FC_EDGE_Z);
             urf_front_push(cbuf, ncb, xz | ex, ((fwB & 0xffffu) + Fs) * 64u + lane, xz ? URF_FC_XZ : URF_FC_EDGE_X);
@@ -436,7 +454,7 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
         }
         if (((f + 4u) % URF_FRONT_STEPS) == 0u || f + 4u >= F1) {   /* (uniform) the tile is complete */
             tile_end(f / URF_FRONT_STEPS);
-            if (__ballot(failed | overflow) != 0ull) {   /* (uniform) */
+            if (failed_m != 0ull || __ballot(failed | overflow) != 0ull) {   /* (uniform) */
                 a.front_ok[s] = 0u;
                 if (ok == URF_FRONT_ROWS)
                     a.table_redo[s] = 1u;   /* (nobody has checked the rest of the scan against the rows' table) */
@@ -473,7 +491,7 @@ __device__ __forceinline__ void urf_front_body(const urf_kargs& a, const urf_dev
         const unsigned o2 = atomicCAS(&a.front_ring_lane[(size_t)s * C + E], 0xffffffffu, lane);
         failed = failed | (o1 != 0xffffffffu && o1 != E) | (o2 != 0xffffffffu && o2 != lane);
     }
-    if (__ballot(failed | overflow) != 0ull) {
+    if (failed_m != 0ull || __ballot(failed | overflow) != 0ull) {
         a.front_ok[s] = 0u;
         if (ok == URF_FRONT_ROWS)
             a.table_redo[s] = 1u;
