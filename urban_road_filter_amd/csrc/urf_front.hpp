@@ -1032,24 +1032,30 @@ __global__ __launch_bounds__(URF_LABEL_TILE_THREADS) __attribute__((amdgpu_waves
         bool road = az <= whi[q] || az >= wlo[q];
         const bool unsure = az < 0.0f || az - fl <= eps || (fl + 1.0f) - az <= eps || __builtin_fabsf(az - whi[q]) <= eps ||
                             __builtin_fabsf(az - wlo[q]) <= eps;
-        if (unsure && on && !curb) {
-            const unsigned u = atomicAdd(&n_unsure, 1u);
-            if (u < URF_LABEL_UNSURE) {
-                un_idx[u] = i0 + e;
-                un_ring[u] = c;
-                road = false;   /* placeholder, corrected below */
-            } else {   /* list full (pathological input) */
-                float d2;
-                bool dummy;
-                const float xaz = urf_azimuth(gx[i0 + e], gy[i0 + e], &d2);
-                road = urf_road_test(win + c * URF_DEG_CELLS, xaz, 0.0f, dummy);
-            }
-        }
-        road = road && on && !curb;
+        /* (the label first, with a point whose decision is open as "not road"; THEN the branch for such a point: the lane masks above
+         * are dead by then -- they used to live across it, and the compiler parked fourteen scalar registers per point in a vector
+         * register's lanes, v_writelane by v_writelane) */
+        const bool uns = unsure && on && !curb;
+        road = road && on && !curb && !uns;
         lab[e] = !roi ? 0u
                       : (URF_FLAG_ROI | (on ? URF_FLAG_RING | (c == 10 ? URF_FLAG_RING10 : 0) | (curb ? URF_LABEL_CURB : 0) | (road ? URF_LABEL_ROAD : 0) : 0u));
         my_curb += curb ? 1u : 0u;
         my_road += road ? 1u : 0u;
+        if (uns) {
+            const unsigned u = atomicAdd(&n_unsure, 1u);
+            if (u < URF_LABEL_UNSURE) {
+                un_idx[u] = i0 + e;
+                un_ring[u] = c;   /* corrected below */
+            } else {   /* list full (pathological input) */
+                float d2;
+                bool dummy;
+                const float xaz = urf_azimuth(gx[i0 + e], gy[i0 + e], &d2);
+                if (urf_road_test(win + c * URF_DEG_CELLS, xaz, 0.0f, dummy)) {
+                    lab[e] |= URF_LABEL_ROAD;
+                    my_road++;
+                }
+            }
+        }
     }
     }
     if (rows) {
