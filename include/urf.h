@@ -62,7 +62,8 @@ extern "C" {
  * (lidar_segmentation.cpp:70-93): "deviation D2" of earlier versions is gone, labels on real sensor data (range ties in
  * every sector) and the published order equal the reference's; urf_callback_path_state reports sequence bit 4.
  * 5 (round 6): urf_set_front_mode / urf_front_scans (the fused front end for batches of organised sweeps: firing order and
- * row-major); the entry points that read ring-sorted intermediate results may run the last batch call again, see there.
+ * row-major); the entry points that read ring-sorted intermediate results may run the last batch call again, see there;
+ * urf_callback_path_preset.
  * WHICH std::sort (4 above): the one of libstdc++ as shipped with GCC 5 .. 13 (bits/stl_algo.h: __sort = __introsort_loop with
  * _S_threshold 16, __move_median_to_first on (first + 1, mid, last - 1), __unguarded_partition, depth limit 2 * floor(log2 n),
  * __partial_sort as the fallback, then __final_insertion_sort); tests/test_stdsort.py pins the restatement against the std::sort
@@ -443,6 +444,10 @@ int urf_pc2_to_planes(const uint8_t* data, uint32_t n_points, uint32_t point_ste
  * tie-free one.
  * Either pointer may be NULL. */
 int urf_callback_path_state(const urf_ctx* ctx, uint32_t* n_rerun, uint32_t* sequence);
+/* Puts kernels into the callback path's sequence before a sweep has asked for them: sequence_bits = 2 (work lists of large star
+ * sectors) | 4 (rings with NaN azimuths) | 16 (std::sort's order of equal planar ranges) -- a node that knows its sensor (every real
+ * one delivers equal ranges) calls it with 16 once and saves the stream's first sweeps their second run.  Bits are only ever added. */
+int urf_callback_path_preset(urf_ctx* ctx, uint32_t sequence_bits);
 const char* urf_strerror(int status);
 const char* urf_last_error(const urf_ctx* ctx);   /* text of the last HIP failure */
 int urf_abi_version(void);

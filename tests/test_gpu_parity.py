@@ -454,6 +454,20 @@ def test_sensor_like_batch_and_callback_sequence():
         assert ctx.callback_path_state() == (1, 1 | 8 | 16)   # (the first sweep that needed either pass of k_star_ties)
         lg, ig = ctx.classify_xyz(*free)
         assert np.array_equal(lg, O.run_b(*free, p)[0])
+    # urf_callback_path_preset: a node that knows its sensor puts k_star_ties into the sequence ahead of the first sweep -- none is run twice
+    with u.Context(n, 4, params=p) as ctx:
+        ctx.callback_path_preset(16)
+        assert ctx.callback_path_state() == (0, 1 | 8 | 16)
+        for k in range(6):
+            lg, ig = ctx.classify_xyz(*clouds[k])
+            assert np.array_equal(lg, ref[k][0]) and info_equal(ig, ref[k][1])
+        assert ctx.callback_path_state() == (0, 1 | 8 | 16)
+        ctx.callback_path_preset(2 | 4)
+        assert ctx.callback_path_state() == (0, 1 | 2 | 4 | 8 | 16)
+        lg, ig = ctx.classify_xyz(*clouds[0])
+        assert np.array_equal(lg, ref[0][0])
+        with pytest.raises(Exception):
+            ctx.callback_path_preset(1)   # (the speculation bits are not presets)
 
 
 def test_star_sort_paths(ctx_hooks):

@@ -149,6 +149,7 @@ def lib(hooks=False):
         "urf_abi_version": [],
         "urf_set_front_mode": [vp, C.c_int],
         "urf_front_scans": [vp, C.c_void_p],
+        "urf_callback_path_preset": [vp, C.c_uint32],
     }
     for name, args in sig.items():
         if name in HOOK_SYMBOLS and not has_hooks:
@@ -342,6 +343,10 @@ class Context:
     def set_front_mode(self, mode):
         """The fused front end for batches of sweeps in firing order (include/urf.h): 0 never, 1 batches of >= 32 scans, 2 always."""
         self._check(self._lib.urf_set_front_mode(self._h, int(mode)), "urf_set_front_mode")
+
+    def callback_path_preset(self, sequence_bits):
+        """urf_callback_path_preset: 2 work-list kernels | 4 NaN-azimuth rings | 16 std::sort's tie order, ahead of the first sweep that needs them."""
+        self._check(self._lib.urf_callback_path_preset(self._h, int(sequence_bits)), "urf_callback_path_preset")
 
     def front_scans(self):
         """Scans of the last batch call that took the fused front end."""

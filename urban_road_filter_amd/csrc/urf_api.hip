@@ -527,6 +527,20 @@ extern "C" int urf_callback_path_state(const urf_ctx* c, uint32_t* n_rerun, uint
     return URF_OK;
 }
 
+extern "C" int urf_callback_path_preset(urf_ctx* c, uint32_t sequence_bits)
+{
+    if (!c || (sequence_bits & ~(2u | 4u | 16u)))
+        return URF_ERR_INVALID_ARG;
+    const bool lists = c->slot_lists || (sequence_bits & 2u), nan = c->slot_nan || (sequence_bits & 4u), ties = c->slot_ties || (sequence_bits & 16u);
+    if (lists != c->slot_lists || nan != c->slot_nan || ties != c->slot_ties) {
+        c->slot_lists = lists;
+        c->slot_nan = nan;
+        c->slot_ties = ties;
+        c->epoch++;   /* the captured sequences are rebuilt */
+    }
+    return URF_OK;
+}
+
 extern "C" double urf_ring_threshold_cot(double angle_deg)
 {
     return urf_cot_deg(angle_deg);
