@@ -194,3 +194,35 @@ def test_rerun_of_a_voided_sweep_counts_as_the_rows_latest_submission():
             with pytest.raises(u.UrfError) as e:
                 call()
             assert e.value.code == -7
+
+
+def test_classify_batch_pc2_row_major_and_firing_order_take_the_fused_kernels():
+    """PointCloud2 records of organised sweeps through urf_classify_batch_pc2 in front mode 2: the records -> SoA kernel feeds the fused
+    front end like any caller's arrays; the row-major scan (an organised cloud, height = 64) is sighted by the first call and fused from
+    the second; the ring-sorted read-backs afterwards run the call again from the context's own SoA copy."""
+    p = O.cfg_params("cfg2")
+    fir = O.cfg_cloud("sensor", 81)
+    rows = tuple(np.ascontiguousarray(a.reshape(-1, 64).T.reshape(-1)) for a in O.cfg_cloud("cfg2", 82))
+    scans = [fir, rows, O.cfg_cloud("narrow", 83)]
+    step, ox, oy, oz = 32, 0, 4, 8
+    raw = np.concatenate([records(x, y, z, step=step, ox=ox, oy=oy, oz=oz) for x, y, z in scans])
+    d_raw = DevBuf.from_numpy(raw)
+    dl = DevBuf(N * len(scans))
+    di = DevBuf(32 * len(scans))
+    with u.Context(N, len(scans), params=p) as ctx:
+        ctx.set_front_mode(2)
+        fused = []
+        for call in range(3):
+            dl.fill(0xEE)
+            ctx.classify_batch_pc2(d_raw, N, len(scans), step, ox, oy, oz, dl, di)
+            ctx.synchronize()
+            fused.append(ctx.front_scans())
+            L = dl.to_numpy(np.uint8).reshape(len(scans), N)
+            infos = di.to_numpy(np.uint32).reshape(len(scans), 8)
+            check_against_b(list(L), infos, scans, p)
+        assert fused == [2, 3, 3], fused
+        lb, ib, st = O.run_b(*scans[1], p, debug=True)
+        road, curb, prob = ctx.ordered_indices(N, scan=1)
+        assert np.array_equal(road, st["road_order"]) and np.array_equal(curb, st["curb_order"])
+    for b in (d_raw, dl, di):
+        b.free()
