@@ -36,7 +36,7 @@ def test_two_ranks_over_gloo_on_one_device():
 
 
 def test_single_rank_line_has_the_contract_keys():
-    d = run_bench("--scans", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e")
+    d = run_bench("--scans", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--front", "2")   # (mode 1 starts at 192 scans)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "other_configs"):
         assert k in d, k
@@ -54,7 +54,7 @@ def test_single_rank_line_has_the_contract_keys():
 
 
 def test_row_major_workload():
-    d = run_bench("--workload", "ring_major", "--scans", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e")
+    d = run_bench("--workload", "ring_major", "--scans", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--front", "2")
     assert d["front_scans_per_gpu"] == 32 and d["value"] > 0 and "k_front" in d["kernel_ms"]
     assert "row-major" in d["config"]["workload"]
 

@@ -105,7 +105,7 @@ def test_a_batch_of_unorganised_clouds_switches_it_off():
         assert nf == 0
         check_against_b(labels, infos, scans, p)
         ctx.set_front_mode(1)
-        labels, infos = run_batch(ctx, good, p)          # (mode 1: fewer than 32 scans never take it anyway)
+        labels, infos = run_batch(ctx, good, p)          # (mode 1: fewer than 192 scans never take it anyway)
         assert ctx.front_scans() == 0
         check_against_b(labels, infos, good, p)
         labels, infos, nf = fused_batch(ctx, good, p)    # mode 2 again: a new start
@@ -224,20 +224,28 @@ def test_stage_capture_and_other_shapes_keep_the_legacy_kernels():
         check_against_b(labels, infos, [c5], p5)
 
 
-def test_mode_one_takes_batches_of_32_scans():
+def test_mode_one_takes_batches_of_192_scans():
+    """urf_set_front_mode(1), the default: the fused kernels from URF_FRONT_MIN_SCANS = 192 scans per call on (below that the general
+    kernels are faster: tools/r6_min_scans.py); two tiles per block of k_front up to 511 scans, four from 512 on."""
     p = O.cfg_params("cfg2")
     base = [u.synth_cloud(64, 256, 1 + (s % 2) * 2, 50 + s) for s in range(8)]
-    scans = [base[s % 8] for s in range(40)]
-    with u.Context(64 * 256, 40) as ctx:
+    scans = [base[s % 8] for s in range(200)]
+    with u.Context(64 * 256, 520) as ctx:
         ctx.set_front_mode(1)
         labels, infos = run_batch(ctx, scans, p)
-        assert ctx.front_scans() == 40
+        assert ctx.front_scans() == 200
         check_against_b(labels[:8], infos[:8], scans[:8], p)
-        for s in range(8, 40):
+        for s in range(8, 200):
             assert np.array_equal(labels[s], labels[s % 8]) and np.array_equal(infos[s], infos[s % 8])
-        labels, infos = run_batch(ctx, scans[:31], p)
+        labels, infos = run_batch(ctx, scans[:191], p)
         assert ctx.front_scans() == 0
         check_against_b(labels[:8], infos[:8], scans[:8], p)
+        many = [base[s % 8] for s in range(520)]                # (four tiles per block)
+        labels, infos = run_batch(ctx, many, p)
+        assert ctx.front_scans() == 520
+        for s in range(520):
+            assert np.array_equal(labels[s], labels[s % 8]) and np.array_equal(infos[s], infos[s % 8])
+        check_against_b(labels[:8], infos[:8], many[:8], p)
 
 
 def ring_major(cloud):

@@ -124,7 +124,7 @@ struct urf_ctx {
      * urf_ordered_indices*, urf_marker_points*) run the last call again through the legacy kernels when it took the fused ones,
      * and the context keeps to the legacy kernels from then on (want_ring_sorted). */
     int front_mode = 1;
-    uint32_t front_tpb = 4;
+    uint32_t front_tpb = 0;         /* tiles per block of k_front; 0: by batch size (URF_FRONT_TPB_*), else what URF_FRONT_TPB says */
     bool want_ring_sorted = false;
     /* k_front hands a scan without the shape back to the legacy kernels.  As long as no call has done so, those are launched
      * list-driven (a few persistent workgroups that find an empty list) instead of as full grids of workgroups that look at the
@@ -775,7 +775,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     a.front = (c->front_mode != 0 && !c->front_off && !legacy_only && !c->want_ring_sorted && !on_stream && a.capture == 0 && C == URF_FRONT_LANES &&
                dp.p.curbPoints == 5 && a.tiles <= URF_FRONT_MAX_TILES && (c->front_mode == 2 || n_scans >= URF_FRONT_MIN_SCANS))
                   ? 1u : 0u;
-    a.front_tpb = c->front_tpb;
+    a.front_tpb = c->front_tpb ? c->front_tpb : (n_scans >= URF_FRONT_TPB_SCANS ? URF_FRONT_TPB_LARGE : URF_FRONT_TPB_SMALL);
     a.front_lists = (a.front && !c->front_direct) ? 1u : 0u;
     a.front_rows = (a.front && c->front_rows) ? 1u : 0u;   /* (the rows' rule does not depend on the two other speculations: the repair kernels below come with it) */
 

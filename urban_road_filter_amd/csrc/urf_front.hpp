@@ -46,7 +46,12 @@
 #endif
 #define URF_FRONT_LANES 64u
 #define URF_FRONT_STEPS (URF_TILE / URF_FRONT_LANES)   /* firings per tile */
-#define URF_FRONT_MIN_SCANS 32u   /* below: the legacy kernels (a block of k_front is one wave; few scans leave the device empty) */
+#define URF_FRONT_MIN_SCANS 192u  /* below (mode 1): the general kernels.  A block of k_front is ONE wave marching 80-144 dependent steps, k_front_finish one
+                                   * workgroup per scan: with few scans the device is empty and the chains are the time (tools/r6_min_scans.py, general / fused ms per call:
+                                   * 32 sweeps 0.21 / 0.25-0.33, 64: 0.31 / 0.32-0.40, 128: 0.45 / 0.44-0.50, 256: 0.73 / 0.66-0.70, 1024: 2.44 / 2.1) */
+#define URF_FRONT_TPB_SMALL 2u    /* tiles per block of k_front for batches below URF_FRONT_TPB_SCANS scans (more, shorter chains), ... */
+#define URF_FRONT_TPB_LARGE 4u    /* ... and from there on (less halo): 256 sweeps 0.663 / 0.703 ms at 2 / 4, 1024 sweeps 0.829 / 0.820 */
+#define URF_FRONT_TPB_SCANS 512u
 #define URF_FRONT_MAX_TILES 128u   /* k_front_finish keeps a presence word per (tile, lane) in LDS */
 #define URF_FRONT_RING_NONE 0x7fu  /* ring field of an input-order record */
 /* candidate kinds */
