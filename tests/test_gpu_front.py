@@ -425,3 +425,24 @@ def test_row_major_after_the_other_speculations_were_switched_off():
         labels, infos, nf = fused_batch(ctx, rows, pr)
         check_against_b(labels, infos, rows, pr)
         assert nf == 2
+
+
+def test_small_row_major_batches_take_the_fused_kernels_in_the_default_mode():
+    """Mode 1 (the default) starts the fused kernels at 192 sweeps per call -- for sweeps in firing order.  Row-major sweeps gain from them at any
+    batch size: a small batch of them is sighted by its first call (general kernels), and from the second call on the context takes the fused
+    kernels for small batches too; a context that only ever sees small batches in firing order stays with the general kernels."""
+    p = O.cfg_params("cfg2")
+    rows = [ring_major(O.cfg_cloud("cfg2", s)) for s in (1, 2)] + [ring_major(O.cfg_cloud("sensor", 3))]
+    with u.Context(N, 3) as ctx:   # (mode 1 is the default)
+        counts = []
+        for call in range(4):
+            labels, infos = run_batch(ctx, rows, p)
+            check_against_b(labels, infos, rows, p)
+            counts.append(ctx.front_scans())
+        assert counts[0] == 0 and counts[-1] == 3, counts
+    fir = [O.cfg_cloud("cfg2", s) for s in (1, 2, 3)]
+    with u.Context(N, 3) as ctx:
+        for call in range(3):
+            labels, infos = run_batch(ctx, fir, p)
+            check_against_b(labels, infos, fir, p)
+            assert ctx.front_scans() == 0

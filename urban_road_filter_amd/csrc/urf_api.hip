@@ -134,6 +134,10 @@ struct urf_ctx {
     /* row-major organised sweeps (k_ring_table's third rule): once one has been sighted (h_spec_failed[4]) the batch calls' sequence
      * holds k_transpose and k_ring_table may choose the layout */
     bool front_rows = false, rows_oom = false;
+    /* ... and once a scan has really taken the layout (h_spec_failed[6]) -- or for a few calls after the sighting -- batches below mode 1's threshold
+     * take the fused kernels too (row-major sweeps gain from them at any batch size, sweeps in firing order only from 192 per call on) */
+    bool rows_used = false;
+    uint32_t rows_probation = 0;
     /* k_front_finish's first part runs on a stream of its own next to the star-shaped search (run_pipeline) */
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -756,6 +760,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         URF_HIP(c, hipStreamSynchronize(st));
         if (ensure_rows_arrays(c) == URF_OK) {
             c->front_rows = true;
+            c->rows_probation = 16;
             c->front_direct = c->front_off = false;
             c->h_spec_failed[2] = c->h_spec_failed[3] = 0;
             a.tx = c->k.tx;   /* (row 0: the batch calls') */
@@ -772,9 +777,17 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         c->front_direct = true;
     if (c->h_spec_failed[3] && c->front_mode != 2)
         c->front_off = true;
-    a.front = (c->front_mode != 0 && !c->front_off && !legacy_only && !c->want_ring_sorted && !on_stream && a.capture == 0 && C == URF_FRONT_LANES &&
-               dp.p.curbPoints == 5 && a.tiles <= URF_FRONT_MAX_TILES && (c->front_mode == 2 || n_scans >= URF_FRONT_MIN_SCANS))
-                  ? 1u : 0u;
+    /* (a context that has sighted row-major sweeps takes the fused kernels at any batch size: the general kernels need 0.64 ms for four
+     * such sweeps, the fused ones 0.26 -- tools/r6_min_scans.py --rows; sweeps in firing order gain from 192 per call on) */
+    const bool front_shape = c->front_mode != 0 && !c->front_off && !legacy_only && !c->want_ring_sorted && !on_stream && a.capture == 0 &&
+                             C == URF_FRONT_LANES && dp.p.curbPoints == 5 && a.tiles <= URF_FRONT_MAX_TILES;
+    if (c->front_rows && c->h_spec_failed[6])
+        c->rows_used = true;
+    const bool small_ok = c->front_rows && (c->rows_used || c->rows_probation > 0);
+    a.front = (front_shape && (c->front_mode == 2 || small_ok || n_scans >= URF_FRONT_MIN_SCANS)) ? 1u : 0u;
+    if (a.front && c->front_mode != 2 && n_scans < URF_FRONT_MIN_SCANS && !c->rows_used && c->rows_probation)
+        c->rows_probation--;   /* (a sighting that no scan confirms -- a sweep in firing order whose region of interest begins with a single laser -- lapses) */
+    a.front_sight = (front_shape && !a.front && !c->front_rows && !c->rows_oom) ? 1u : 0u;
     a.front_tpb = c->front_tpb ? c->front_tpb : (n_scans >= URF_FRONT_TPB_SCANS ? URF_FRONT_TPB_LARGE : URF_FRONT_TPB_SMALL);
     a.front_lists = (a.front && !c->front_direct) ? 1u : 0u;
     a.front_rows = (a.front && c->front_rows) ? 1u : 0u;   /* (the rows' rule does not depend on the two other speculations: the repair kernels below come with it) */

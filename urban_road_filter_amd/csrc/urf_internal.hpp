@@ -270,13 +270,15 @@ struct urf_kargs {
     uint32_t* front_st;         /* [S][URF_FRONT_ST_WORDS] k_front_finish part 1 -> part 2 */
     uint32_t* front_list;       /* [S] the scans whose flag is clear (k_front_collect; star_count[6] = how many): the list-driven legacy kernels' work */
     uint32_t* front_state;      /* host-mapped: [0] some scan of some call was handed back, [1] every scan of some call was, [2] a scan looked
-                                 * row-major (URF_FRONT_ROWS), [3] the row-major speculation failed on one */
+                                 * row-major (URF_FRONT_ROWS), [3] the row-major speculation failed on one, [4] a scan took the row-major layout */
     uint32_t  front_lists;      /* this call launches the legacy kernels list-driven (k_split_list, k_ring_list, k_label_list) */
     /* row-major organised sweeps (height = the sensor's 64 lasers, width = firings: point l * F + f): front_ok[s] == URF_FRONT_ROWS,
      * k_transpose writes the firing-order copy the fused kernels read instead of x / y / z, k_label_front stores the labels
      * where the points came from.  Everything in between is indexed by firing * 64 + laser. */
     uint32_t  front_rows;       /* this call's sequence holds k_rows_probe and k_transpose: k_ring_table may choose the layout (else it only reports
                                  * that it saw such a scan: front_state[2], the next call's sequence holds the kernels) */
+    uint32_t  front_sight;      /* this call takes the general kernels but k_ring_table still reports a row-major sighting (a batch below mode 1's threshold:
+                                 * row-major sweeps gain from the fused kernels at ANY batch size, tools/r6_min_scans.py --rows) */
     float*    rows_v;           /* [S][64] k_rows_probe: the vertical angles of the rows' first region-of-interest points, in row order (the table's leaders) */
     uint32_t* rows_ok;          /* [S] ... how many + 1; 0: the scan is not row-major */
     float*    tx;               /* [S * sstride] firing-order copies (scratch stride) */

@@ -349,7 +349,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
      * Tried when the walk's first step (64 points: one row's) has shown at most one ring; given up as soon as the 64 points around
      * a row's first one show a second ring (a sweep in firing order whose first firing lies outside the region of interest). */
     bool rows = false;
-    bool rows_try = first_walk && a.front && C == 64u && len >= 128u && (len & 63u) == 0u;   /* (not k_table_repair's walk: that one follows a failure) */
+    bool rows_try = first_walk && (a.front || a.front_sight) && C == 64u && len >= 128u && (len & 63u) == 0u;   /* (not k_table_repair's walk: that one follows a failure) */
     if (rows_try && a.front_rows) {
         /* k_rows_probe has found the rows' first points and put them through the reference's insertion: rows_ok[s] - 1 leaders, in row order */
         const unsigned nr = a.rows_ok[s];   /* (uniform) */
@@ -359,6 +359,7 @@ __device__ void urf_ring_table_scan(const urf_kargs& a, const urf_dev_params& dp
             if (tid == 0) {
                 sh_nL = nr - 1u;
                 a.front_ok[s] = URF_FRONT_ROWS;
+                a.front_state[4] = 1u;   /* host-visible: this context's sweeps DO come row-major (urf_api.hip: the fused kernels at any batch size) */
             }
             rows = true;
             upto = 0;
