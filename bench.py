@@ -275,6 +275,23 @@ def e2e_callback_path(u, O, params, n_sweeps=8, reps=40, stream_reps=160):
         recs, keep = recs_s * n_sweeps, recs
         out["e2e_latency_ms_sensor_like"] = round(latency(ctx), 4)
         recs = keep
+    # a row-major organised sweep (height = the lasers: an Ouster's cloud) on the callback path, in a context of its own: the first sweep
+    # sights the layout (general kernels), the following ones take the fused kernels inside the captured sequences (r6)
+    with u.Context(n, IN_FLIGHT, params=params) as rctx:
+        xr, yr, zr = (np.ascontiguousarray(a.reshape(COLS, RINGS).T.reshape(-1)) for a in u.synth_cloud(RINGS, COLS, 1, 9100))
+        bufr = np.zeros((n, 32), np.uint8)
+        bufr[:, 0:4] = xr.view(np.uint8).reshape(-1, 4)
+        bufr[:, 4:8] = yr.view(np.uint8).reshape(-1, 4)
+        bufr[:, 8:12] = zr.view(np.uint8).reshape(-1, 4)
+        lbr2, _, _ = O.run_b(xr, yr, zr, params)
+        for k in range(4):
+            lgr2, _ = rctx.classify_pc2(bufr.reshape(-1), n, 32, 0, 4, 8)
+            if not np.array_equal(lgr2, lbr2):
+                raise SystemExit("parity failure on the callback path (row-major sweep, call %d)" % k)
+        recs, keep = [bufr.reshape(-1)] * n_sweeps, recs
+        out["e2e_latency_ms_row_major"] = round(latency(rctx), 4)
+        out["e2e_row_major_fused"] = rctx.front_scans()
+        recs = keep
     out["e2e_method"] = ("every e2e_overlapped_* figure: one untimed pass, then the better of two timed passes of %d sweeps; e2e_latency_ms*: median of %d "
                          "synchronous calls after 4 untimed ones (e2e_latency_ms_native_mean: mean of %d).  Library: e2e_latency_ms, *_default_roi latency and the "
                          "*_python_client streams run in liburf_hip.so (the product); the native-loop streams, e2e_latency_ms_native_mean and "

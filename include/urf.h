@@ -400,7 +400,8 @@ int urf_enable_stage_capture(urf_ctx* ctx, int mode);
  * call; labels and summaries are identical either way.  Applies with channels == 64, curbPoints == 5, no stage
  * capture, at most 128 x 2048 points per scan.  mode 0: never; 1 (default): batch calls of at least 192 scans (below that the general kernels are faster: a sweep's fused kernels are
  * a few long dependent chains, which need many sweeps side by side to fill the device; a context whose sweeps have turned out to be
- * row-major takes the fused kernels at any batch size -- the general kernels are 2.3 x slower on that layout even for four sweeps); 2: every
+ * row-major takes the fused kernels at any batch size -- the general kernels are 2.3 x slower on that layout even for four sweeps --
+ * and on the callback path: urf_classify_pc2(_async) of a row-major sweep, from the context's second or third such sweep on); 2: every
  * batch call it applies to.  urf_read_stage / urf_ordered_indices* / urf_marker_points* read ring-sorted intermediate
  * results: after a call that took the fused front end they first run that call again through the general kernels
  * (the call's INPUT arrays must then still be alive, like its label buffer), and the context stays with the general

@@ -446,3 +446,48 @@ def test_small_row_major_batches_take_the_fused_kernels_in_the_default_mode():
             labels, infos = run_batch(ctx, fir, p)
             check_against_b(labels, infos, fir, p)
             assert ctx.front_scans() == 0
+
+
+def test_row_major_sweeps_on_the_callback_path():
+    """One sweep per call (urf_classify_pc2: host message in, labels out).  Sweeps in firing order keep the general kernels there; a context whose
+    sweeps come row-major sights the layout with its first sweep and takes the fused kernels from the second or third on -- inside the captured
+    per-slot sequences, four sweeps in flight -- and the ring-sorted read-backs of such a sweep run it again through the general kernels."""
+    p = O.cfg_params("cfg2")
+    rows = [ring_major(O.cfg_cloud(name, s)) for name, s in (("cfg2", 1), ("sensor", 2), ("narrow", 3), ("cfg2", 4), ("sensor", 5))]
+    ref = [O.run_b(*c, p, debug=True) for c in rows]
+    with u.Context(N, 4, params=p) as ctx:
+        fused = []
+        for rep in range(3):
+            for k, c in enumerate(rows):
+                lab, info = ctx.classify_xyz(*c)
+                assert np.array_equal(lab, ref[k][0]), (rep, k)
+                assert info.n_road == ref[k][1]["n_road"] and info.n_curb == ref[k][1]["n_curb"] and info.n_ring_pts == ref[k][1]["n_ring_pts"]
+                fused.append(ctx.front_scans())
+        assert fused[0] == 0 and fused[-1] == 1 and sum(fused) >= 10, fused
+        # four in flight
+        recs = []
+        for c in rows[:4]:
+            r = np.zeros((N, 4), np.float32)
+            r[:, 0], r[:, 1], r[:, 2] = c
+            recs.append(r)
+        for rep in range(2):
+            tickets = [ctx.classify_pc2_async(r, N, 16, 0, 4, 8) for r in recs]
+            for k, t in enumerate(tickets):
+                lab = np.zeros(N, np.uint8)
+                info = ctx.classify_pc2_wait(t, lab)
+                assert np.array_equal(lab, ref[k][0]) and info.n_road == ref[k][1]["n_road"], (rep, k)
+        # the published order of the last sweep: run again through the general kernels
+        lab, info = ctx.classify_xyz(*rows[1])
+        assert ctx.front_scans() == 1
+        road, curb, prob = ctx.ordered_indices(N)
+        st = ref[1][2]
+        assert np.array_equal(road, st["road_order"]) and np.array_equal(curb, st["curb_order"]) and np.array_equal(prob, st["ring10_order"])
+        assert np.array_equal(ctx.marker_points(), st["marker_pts"])
+        lab, info = ctx.classify_xyz(*rows[2])                # ... and the context stays with them
+        assert np.array_equal(lab, ref[2][0]) and ctx.front_scans() == 0
+    fir = [O.cfg_cloud("cfg2", s) for s in (1, 2)]
+    with u.Context(N, 4, params=p) as ctx:
+        for rep in range(3):
+            for c in fir:
+                lab, info = ctx.classify_xyz(*c)
+                assert np.array_equal(lab, O.run_b(*c, p)[0]) and ctx.front_scans() == 0

@@ -559,6 +559,7 @@ extern "C" int urf_set_front_mode(urf_ctx* c, int mode)
         c->h_spec_failed[2] = c->h_spec_failed[3] = 0;
     }
     c->front_mode = mode;
+    c->epoch++;   /* (the callback path's captured sequences depend on it) */
     if (mode != 0)
         c->want_ring_sorted = false;   /* (a caller that asks for ring-sorted results again pays for them again) */
     return URF_OK;
@@ -569,11 +570,11 @@ extern "C" int urf_front_scans(urf_ctx* c, uint32_t* n_fused)
     if (!c || !n_fused)
         return URF_ERR_INVALID_ARG;
     *n_fused = 0;
-    if (c->last_is_slot || !c->last_a.front || c->last_scans == 0)
+    if (!c->last_a.front || c->last_scans == 0)
         return URF_OK;
     URF_HIP(c, hipSetDevice(c->device));
-    URF_HIP(c, hipStreamSynchronize(c->stream));
-    std::vector<uint32_t> ok(c->last_scans);
+    URF_HIP(c, hipStreamSynchronize(c->stream));   /* (a sweep of the callback path has been waited for: its row is at rest) */
+    std::vector<uint32_t> ok(c->last_is_slot ? 1u : c->last_scans);
     URF_HIP(c, hipMemcpy(ok.data(), c->last_a.front_ok, ok.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (uint32_t v : ok)
         *n_fused += v ? 1u : 0u;
@@ -649,6 +650,9 @@ static urf_kargs kargs_row(const urf_ctx* c, uint32_t row)
     k.win += r * C * URF_DEG_CELLS;
     k.info += r;
     k.front_ok += r; k.front_pres += r * tiles * 64; k.front_maxs += r * tiles * 64; k.front_lane_ring += r * 64; k.front_ring_lane += r * C;
+    if (k.tx) {
+        k.tx += P; k.ty += P; k.tz += P; k.rows_v += r * 64; k.rows_ok += r;
+    }
     k.front_cand += r * (size_t)k.front_cand_cap; k.front_all += r * (size_t)k.front_cand_cap; k.front_ncand += r; k.front_list += r; k.front_st += r * 72;
     return k;
 }
@@ -676,6 +680,33 @@ static int order_row_after_main(urf_ctx* c, uint32_t row, hipStream_t st)
     URF_HIP(c, hipEventRecord(c->ev_main, c->stream));
     URF_HIP(c, hipStreamWaitEvent(st, c->ev_main, 0));
     c->row_seen[row] = c->main_seq;
+    return URF_OK;
+}
+
+/* Row-major organised sweeps (urf_front.hpp, k_ring_table's third rule): what the host makes of the device's flags.  h_spec_failed[4]: a scan
+ * looked row-major (a sighting) -- once per context the firing-order copies are allocated and the launch sequences hold k_rows_probe and
+ * k_transpose from then on; [6]: a scan TOOK the layout.  Everything a captured sequence depends on bumps the epoch.  Never called inside a
+ * stream capture (it synchronises). */
+static int rows_state_update(urf_ctx* c, hipStream_t st)
+{
+    if (c->front_mode != 0 && !c->front_rows && !c->rows_oom && c->h_spec_failed[4]) {
+        /* the calls in flight finish first -- what they handed back (such sweeps, possibly all of them) says nothing about the calls to come */
+        URF_HIP(c, hipStreamSynchronize(st));
+        if (ensure_rows_arrays(c) == URF_OK) {
+            c->front_rows = true;
+            c->rows_probation = 16;
+            c->front_direct = c->front_off = false;
+            c->h_spec_failed[2] = c->h_spec_failed[3] = 0;
+        } else {
+            c->rows_oom = true;   /* (such sweeps keep to the general kernels) */
+            c->last_error.clear();
+        }
+        c->epoch++;
+    }
+    if (c->front_rows && !c->rows_used && c->h_spec_failed[6]) {
+        c->rows_used = true;
+        c->epoch++;
+    }
     return URF_OK;
 }
 
@@ -753,25 +784,17 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
     /* The fused front end (urf_front.hpp) for batches of sweeps in firing order: k_front tries every scan, the legacy kernels
      * skip the scans it kept.  64 lasers = 64 lanes, the detectors' window of curbPoints == 5 in registers, no stage capture
      * (its values are the legacy kernels'), not for the single sweeps of the callback path (sixteen waves on the whole device). */
-    if (c->front_mode != 0 && !c->front_rows && !c->rows_oom && !on_stream && c->h_spec_failed[4]) {
-        /* An earlier call sighted a row-major organised sweep (k_ring_table's third rule): from here on the sequence holds k_transpose.
-         * Once per context: the calls in flight finish first -- what they handed back (such sweeps, possibly all of them) says nothing
-         * about the calls to come. */
-        URF_HIP(c, hipStreamSynchronize(st));
-        if (ensure_rows_arrays(c) == URF_OK) {
-            c->front_rows = true;
-            c->rows_probation = 16;
-            c->front_direct = c->front_off = false;
-            c->h_spec_failed[2] = c->h_spec_failed[3] = 0;
-            a.tx = c->k.tx;   /* (row 0: the batch calls') */
-            a.ty = c->k.ty;
-            a.tz = c->k.tz;
-            a.rows_v = c->k.rows_v;
-            a.rows_ok = c->k.rows_ok;
-        } else {
-            c->rows_oom = true;   /* (such sweeps keep to the legacy kernels) */
-            c->last_error.clear();
-        }
+    if (!on_stream) {   /* (a sweep of the callback path: urf_classify_pc2_async has done it, outside its stream capture) */
+        const int rrc = rows_state_update(c, st);
+        if (rrc != URF_OK)
+            return rrc;
+    }
+    if (c->k.tx && !a.tx) {   /* (allocated after this call's arguments were copied: row 0's) */
+        a.tx = c->k.tx;
+        a.ty = c->k.ty;
+        a.tz = c->k.tz;
+        a.rows_v = c->k.rows_v;
+        a.rows_ok = c->k.rows_ok;
     }
     if (c->h_spec_failed[2])
         c->front_direct = true;
@@ -779,17 +802,18 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
         c->front_off = true;
     /* (a context that has sighted row-major sweeps takes the fused kernels at any batch size: the general kernels need 0.64 ms for four
      * such sweeps, the fused ones 0.26 -- tools/r6_min_scans.py --rows; sweeps in firing order gain from 192 per call on) */
-    const bool front_shape = c->front_mode != 0 && !c->front_off && !legacy_only && !c->want_ring_sorted && !on_stream && a.capture == 0 &&
+    const bool front_shape = c->front_mode != 0 && !c->front_off && !legacy_only && !c->want_ring_sorted && a.capture == 0 &&
                              C == URF_FRONT_LANES && dp.p.curbPoints == 5 && a.tiles <= URF_FRONT_MAX_TILES;
-    if (c->front_rows && c->h_spec_failed[6])
-        c->rows_used = true;
     const bool small_ok = c->front_rows && (c->rows_used || c->rows_probation > 0);
-    a.front = (front_shape && (c->front_mode == 2 || small_ok || n_scans >= URF_FRONT_MIN_SCANS)) ? 1u : 0u;
-    if (a.front && c->front_mode != 2 && n_scans < URF_FRONT_MIN_SCANS && !c->rows_used && c->rows_probation)
-        c->rows_probation--;   /* (a sighting that no scan confirms -- a sweep in firing order whose region of interest begins with a single laser -- lapses) */
+    /* (a single sweep of the callback path: only in a context whose sweeps come row-major -- a sweep in firing order is faster through the
+     * general kernels, tools/r6_single_sweep.py) */
+    a.front = (front_shape && (on_stream ? small_ok : (c->front_mode == 2 || small_ok || n_scans >= URF_FRONT_MIN_SCANS))) ? 1u : 0u;
+    if (a.front && !on_stream && c->front_mode != 2 && n_scans < URF_FRONT_MIN_SCANS && !c->rows_used && c->rows_probation)
+        c->rows_probation--;   /* (a sighting that no scan confirms -- a sweep in firing order whose region of interest begins with a single laser -- lapses;
+                                *  the callback path counts its submissions: urf_classify_pc2_async) */
     a.front_sight = (front_shape && !a.front && !c->front_rows && !c->rows_oom) ? 1u : 0u;
-    a.front_tpb = c->front_tpb ? c->front_tpb : (n_scans >= URF_FRONT_TPB_SCANS ? URF_FRONT_TPB_LARGE : URF_FRONT_TPB_SMALL);
-    a.front_lists = (a.front && !c->front_direct) ? 1u : 0u;
+    a.front_tpb = c->front_tpb ? c->front_tpb : (n_scans >= URF_FRONT_TPB_SCANS ? URF_FRONT_TPB_LARGE : (n_scans >= 16u ? URF_FRONT_TPB_SMALL : 1u));
+    a.front_lists = (a.front && !c->front_direct && !on_stream) ? 1u : 0u;   /* (the callback path's sequence holds the general kernels as grids anyway) */
     a.front_rows = (a.front && c->front_rows) ? 1u : 0u;   /* (the rows' rule does not depend on the two other speculations: the repair kernels below come with it) */
 
     std::vector<hipEvent_t>* ev = nullptr;
@@ -833,7 +857,7 @@ static int run_pipeline(urf_ctx* c, const float* d_x, const float* d_y, const fl
      * stream, so that the brackets add up to the step. */
     bool side = false, part1 = false;
     const size_t finish_lds = (size_t)a.tiles * 384 + 2 * URF_FINISH_CHUNK * sizeof(urf_u2);
-    if (a.front && !ev) {
+    if (a.front && !ev && !on_stream) {
         if (!c->side_stream) {
             if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1219,6 +1243,13 @@ extern "C" int urf_classify_pc2_async(urf_ctx* c, const uint8_t* data, uint32_t 
         c->use_hint = false;
         c->epoch++;
     }
+    /* row-major organised sweeps: sighted by the general kernels, then the fused ones in this path's sequence as well (rows_state_update); a
+     * sighting that no sweep confirms lapses after sixteen submissions */
+    rc = rows_state_update(c, st);
+    if (rc != URF_OK)
+        return rc;
+    if (c->front_rows && !c->rows_used && c->rows_probation && --c->rows_probation == 0)
+        c->epoch++;
     /* the launch sequence of a sweep of this shape is captured once and replayed (one graph launch
      * instead of a dozen kernel launches per callback); anything it depends on bumps the epoch */
     const uint64_t key[3] = { c->epoch, ((uint64_t)n_points << 32) | point_step,
@@ -1385,6 +1416,21 @@ static int last_row_intact(urf_ctx* c)
         c->last_error = "the scratch row of the sweep waited for last has been resubmitted (create the context with max_batch >= "
                         "the number of sweeps in flight, or read its intermediate results before submitting on its row again)";
         return URF_ERR_BUSY;
+    }
+    if (c->last_is_slot && c->last_a.front) {
+        /* ... and so did the sweep of the callback path that was waited for last (a context whose sweeps come row-major): once more on its
+         * row through the general kernels -- the message is still in the slot's device buffer, the row has not been resubmitted (checked
+         * above) --, as a batch call of one scan with every repair kernel in the sequence; the context stays with the general kernels */
+        c->want_ring_sorted = true;
+        c->epoch++;   /* (the captured sequences are rebuilt without the fused kernels) */
+        const urf_kargs a = c->last_a;
+        const urf_dev_params dp = c->last_dp;
+        const int rc = run_pipeline(c, a.x, a.y, a.z, nullptr, a.n_per_scan, a.max_len, 1, a.labels, nullptr, c->last_row, nullptr, nullptr, nullptr, &dp,
+                                    (int)a.capture, true);
+        if (rc != URF_OK)
+            return rc;
+        c->last_is_slot = false;   /* (what the read-backs look at now is that call's) */
+        return URF_OK;
     }
     if (!c->last_is_slot && c->last_a.front) {
         /* the last batch call went through the fused front end (urf_front.hpp), which keeps no ring-sorted copies: once more through

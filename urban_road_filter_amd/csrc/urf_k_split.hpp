@@ -1021,7 +1021,7 @@ __device__ __forceinline__ void urf_index_body(const urf_kargs& a, const urf_dev
         /* the speculative ring table was incomplete and nothing has repaired it (callback path): the scan is void,
          * every later kernel skips it, the host runs it again without the speculation */
         if (tid == 0)
-            a.info[s].status = a.table_cause[s] == 2u ? URF_STATUS_REDO_HINT : URF_STATUS_REDO_TABLE;
+            a.info[s].status = (a.table_cause[s] & 3u) == 2u ? URF_STATUS_REDO_HINT : URF_STATUS_REDO_TABLE;
         return;
     }
     if (a.optimistic & URF_OPT_NO_NAN) {
