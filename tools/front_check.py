@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--seed0", type=int, default=9000000)
     ap.add_argument("--basic", type=int, default=1)
     ap.add_argument("--rows", type=int, default=1, help="the row-major cases; with --fuzz: 1 = every case is also run row-major")
+    ap.add_argument("--callback", type=int, default=0, help="with --fuzz and --rows: every row-major case also as one sweep on the callback path")
     a = ap.parse_args()
     ctxs = {}
     bad = 0
@@ -180,7 +181,9 @@ def main():
             bad += rows(ctxs)
     nfused = 0
     nrows = 0
+    ncb = 0
     rctx = {}
+    cctx = {}
     for i in range(a.fuzz):
         seed = a.seed0 + i
         sw, p = fuzz_organised.case(seed)
@@ -216,8 +219,25 @@ def main():
             if d or di:
                 bad += 1
                 print("  FUZZ MISMATCH (row-major) seed %d fused %d: %d labels %s" % (seed, nf, d, di), flush=True)
+            if a.callback:
+                # ... and as ONE sweep on the callback path (urf_classify_pc2: the fused kernels inside the captured sequence once the
+                # context's sweeps have turned out row-major)
+                if key not in cctx:
+                    cctx[key] = u.Context(n, 4)
+                cc = cctx[key]
+                cc.set_params(p)
+                lab1, info1 = cc.classify_xyz(*rs)
+                ncb += cc.front_scans()
+                iv = {k: int(getattr(info1, k)) for k in INFO_KEYS}
+                d = int(np.count_nonzero(lab1 != lbr))
+                di = {k: (iv[k], ibr[k]) for k in INFO_KEYS if iv[k] != ibr[k]}
+                if d or di:
+                    bad += 1
+                    print("  FUZZ MISMATCH (row-major, callback path) seed %d: %d labels %s" % (seed, d, di), flush=True)
     if a.fuzz:
         print("fuzz: %d cases, %d took the fused front end, %d of their row-major twins, %d mismatches, %.0f s" % (a.fuzz, nfused, nrows, bad, time.time() - t0))
+        if a.callback:
+            print("      %d of the row-major twins took it on the callback path" % ncb)
     print("FRONT CHECK %s" % ("PASSED" if bad == 0 else "FAILED: %d" % bad))
     return 1 if bad else 0
 
